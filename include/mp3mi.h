@@ -1,11 +1,95 @@
+/* libmp3mi -- MI355X-native MPEG-1 Layer III encoding hot path, C ABI.
+ *
+ * Two surfaces:
+ *
+ * 1. The batched API (mp3mi_batch_*): thousands of independent streams per call, device
+ *    pointers in, device pointers out.  This is where the throughput is.
+ *
+ * 2. The reference's own per-frame call surface (section "drop-in symbols" below): the seven
+ *    external-linkage functions that the reference's driver calls for Layer III
+ *    (/root/reference/src/musicin.c:751-786, 803), with identical names, argument meaning and
+ *    in-place side effects, backed by one hidden default stream that runs the same kernels with
+ *    n_streams = 1.  A maintainer links musicin.o + common.o against libmp3mi.so instead of
+ *    l3psy.o encode.o(filterbank part) mdct.o loop.o l3bitstream.o -- see INTEGRATION.md.
+ *
+ * Every function fails loudly (non-zero return / abort with a message for the void drop-in
+ * symbols, like the reference's exit()/abort()) when no gfx950 device is usable: there is no
+ * CPU fallback in this library.
+ */
 #ifndef MP3MI_H
 #define MP3MI_H
+
+#include <stddef.h>
 #include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
-void mp3mi_synth_pcm(int16_t *out, long n_per_ch, int channels, int rate_hz,
-                     uint32_t stream, uint32_t seed);
+
+/* ------------------------------------------------------------------ batched API */
+
+typedef struct mp3mi_batch mp3mi_batch;
+
+enum {
+    MP3MI_OK = 0,
+    MP3MI_ERR_ARG = -1,       /* unsupported rate / bitrate / channel count (what the reference refuses) */
+    MP3MI_ERR_NO_DEVICE = -2, /* no usable GPU */
+    MP3MI_ERR_HIP = -3,       /* a HIP call failed; message on stderr */
+    MP3MI_ERR_NOMEM = -4
+};
+
+/* Creates an encoder for n_streams independent streams that share sample rate and channel
+ * count.  rate_hz in {44100, 48000, 32000}; channels 1 or 2; kbps points to n_streams MPEG-1
+ * Layer III bitrates (32..320) or is NULL, in which case every stream uses kbps_all.
+ * max_frames bounds n_frames of later encode calls.  Replaces the set-up part of
+ * /root/reference/src/musicin.c:456-581 (parse_args defaults, hdr_to_frps, slots per frame). */
+int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz, int channels,
+                       const int *kbps, int kbps_all, int max_frames);
+void mp3mi_batch_destroy(mp3mi_batch *b);
+
+/* Bytes to reserve per stream in the output buffer for n_frames frames. */
+size_t mp3mi_batch_out_stride(const mp3mi_batch *b, int n_frames);
+
+/* Encodes n_frames whole frames of every stream, from a fresh encoder state, including the
+ * final flush (III_FlushBitstream + close_bit_stream_w, musicin.c:802-805).
+ *   pcm_dev     device pointer, int16, [n_streams][n_frames*1152][channels] (WAV sample order)
+ *   out_dev     device pointer, [n_streams][out_stride] bytes
+ *   out_len_dev device pointer, [n_streams] uint32: bytes produced per stream
+ * Work is enqueued on the batch's stream; call mp3mi_batch_sync before reading results. */
+int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev,
+                       size_t out_stride, uint32_t *out_len_dev);
+int mp3mi_batch_sync(mp3mi_batch *b);
+
+/* Milliseconds spent inside the dominant (iteration loop) kernel and inside all kernels during
+ * the last encode call, measured with HIP events on the batch's stream. */
+int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_kernels_ms,
+                            int *loop_kernel_launches);
+
+/* Host-buffer convenience wrapper (tests, smoke): copies PCM up, encodes, copies results back.
+ * pcm: [n_streams][n_frames*1152*channels]; out: [n_streams][out_stride]; out_len: [n_streams]. */
+int mp3mi_encode_host(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,
+                      const int16_t *pcm, int n_frames, uint8_t *out, size_t out_stride,
+                      uint32_t *out_len);
+
+/* Stage seams of the LAST chunk of the last encode call, copied to host memory (parity tests
+ * compare them with oracle/stage_dump.h).  what: 0 = psychoacoustic records (mp3mi_psy_out),
+ * 1 = xr (f64[576] per granule-channel), 2 = quantised values (int16[576]), 3 = side info
+ * (mp3mi_frame_side per frame), 4 = raw subband samples (f64[576], enabled by
+ * mp3mi_batch_debug_enable).  Returns the number of bytes written, or a negative error. */
+long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst, size_t cap);
+void mp3mi_batch_debug_enable(mp3mi_batch *b, int on);
+
+/* Deterministic synthetic PCM (benchmarks / tests): interleaved int16, n_per_ch samples per channel. */
+void mp3mi_synth_pcm(int16_t *out, long n_per_ch, int channels, int rate_hz, uint32_t stream,
+                     uint32_t seed);
+
+/* Self-test hook: evaluates function fn of the device math layer (see csrc/k_debug.hip) on the
+ * GPU for n host-side arguments.  Used by tests to prove device == host bit for bit. */
+int mp3mi_debug_dmath(int fn, const double *x, const double *y, double *out, size_t n);
+
+/* Library / device identification string for logs. */
+const char *mp3mi_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,278 @@
+// Host side of the batched encoder: owns the device buffers, cuts the frames of a call into
+// chunks that fit the scratch budget, and enqueues the five kernels per chunk:
+//
+//   k_fft     (stream, granule, channel)  psy FFTs                 feed-forward
+//   k_psy     (stream, channel)           thresholds / block type  serial over granules
+//   k_fbmdct  (stream, channel, granules) filterbank + MDCT        feed-forward, needs block type
+//   k_loop    (stream)                    iteration loop           serial over frames
+//   k_format  (stream, frame)             bitstream formatting     independent per frame
+//
+// Mirrors the Layer III case of the reference's frame loop (src/musicin.c:708-788) for every
+// stream at once.  No CPU fallback: every entry point returns an error when HIP cannot run.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "mp3mi_host.h"
+#include "mp3mi.h"
+
+size_t mp3mi_psy_state_size(void);
+size_t mp3mi_loop_state_size(void);
+
+#define CHK(call)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            fprintf(stderr, "mp3mi: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MP3MI_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+struct mp3mi_batch {
+    int n_streams, rate_idx, rate_hz, channels, max_frames, chunk_frames;
+    std::vector<int> bits_per_frame_h, bitrate_index_h;
+    int max_frame_bytes;
+    hipStream_t stream;
+    mp3mi_tables *T;
+    int32_t *bits_per_frame, *bitrate_index;
+    float *energy_l, *energy_s, *hist6;
+    double *cw_mid, *xr, *sb_dbg;
+    mp3mi_psy_out *psy;
+    void *psy_state, *loop_state;
+    int16_t *ix;
+    mp3mi_frame_side *side;
+    int debug, last_nf;
+    hipEvent_t ev0, ev1;
+    std::vector<hipEvent_t> loop_ev;
+    int loop_launches;
+};
+
+static const int BITRATES[15] = {0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320}; // src/common.c:124
+
+static int have_device(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    return 1;
+}
+
+extern "C" const char *mp3mi_version(void)
+{
+#if defined(MP3MI_EMU)
+    return "libmp3mi 0.1 (TEST BUILD: wave emulator, not the product)";
+#else
+    return "libmp3mi 0.1 (gfx950 HIP)";
+#endif
+}
+
+extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz, int channels, const int *kbps,
+                                  int kbps_all, int max_frames)
+{
+    static const double s_freq[3] = {44.1, 48, 32}; // src/common.c:113
+    if (!out) return MP3MI_ERR_ARG;
+    *out = NULL;
+    int ri;
+    if (rate_hz == 44100) ri = 0;
+    else if (rate_hz == 48000) ri = 1;
+    else if (rate_hz == 32000) ri = 2;
+    else return MP3MI_ERR_ARG; // the reference's L3psycho_anal exits on anything else (src/l3psy.c:170-176)
+    if (n_streams <= 0 || max_frames <= 0 || (channels != 1 && channels != 2)) return MP3MI_ERR_ARG;
+    if (!have_device()) {
+        fprintf(stderr, "mp3mi: no HIP device available -- this library has no CPU path\n");
+        return MP3MI_ERR_NO_DEVICE;
+    }
+    mp3mi_batch *b = new mp3mi_batch();
+    b->n_streams = n_streams; b->rate_idx = ri; b->rate_hz = rate_hz; b->channels = channels;
+    b->max_frames = max_frames; b->debug = 0; b->last_nf = 0; b->loop_launches = 0;
+    b->bits_per_frame_h.resize(n_streams);
+    b->bitrate_index_h.resize(n_streams);
+    b->max_frame_bytes = 0;
+    for (int s = 0; s < n_streams; s++) {
+        const int k = kbps ? kbps[s] : kbps_all;
+        int bi;
+        for (bi = 1; bi < 15; bi++)
+            if (BITRATES[bi] == k) break;
+        if (bi == 15) { delete b; return MP3MI_ERR_ARG; }
+        // slots per frame, never padded (src/musicin.c:562-581)
+        const int whole_SpF = (int) (((double) 1152 / s_freq[ri]) * ((double) k / 8.0));
+        b->bitrate_index_h[s] = bi;
+        b->bits_per_frame_h[s] = 8 * whole_SpF;
+        if (whole_SpF > b->max_frame_bytes) b->max_frame_bytes = whole_SpF;
+    }
+    // chunk size from a scratch budget (bytes per frame and stream of the per-chunk buffers)
+    const size_t per_gc = MP3MI_HBLK * 4 + 3 * MP3MI_HBLK_S * 4 + 50 * 8 + 12 * 4 + sizeof(mp3mi_psy_out) + 576 * 8 + 576 * 2;
+    const size_t per_frame = per_gc * 2 * (size_t) channels + sizeof(mp3mi_frame_side);
+    const char *env = getenv("MP3MI_SCRATCH_MB");
+    const size_t budget = (env ? (size_t) atol(env) : (size_t) 24576) << 20;
+    long cf = (long) (budget / (per_frame * (size_t) n_streams));
+    if (cf < 1) cf = 1;
+    if (cf > max_frames) cf = max_frames;
+    const char *envc = getenv("MP3MI_CHUNK_FRAMES");
+    if (envc && atol(envc) > 0 && atol(envc) < cf) cf = atol(envc);
+    b->chunk_frames = (int) cf;
+
+    mp3mi_tables *Th = (mp3mi_tables *) malloc(sizeof(mp3mi_tables));
+    if (!Th || mp3mi_build_tables(Th, ri) != 0) { free(Th); delete b; return MP3MI_ERR_ARG; }
+    const size_t ngc = (size_t) n_streams * 2 * (size_t) cf * (size_t) channels;
+    CHK(hipStreamCreate(&b->stream));
+    CHK(hipMalloc((void **) &b->T, sizeof(mp3mi_tables)));
+    CHK(hipMemcpy(b->T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
+    free(Th);
+    CHK(hipMalloc((void **) &b->bits_per_frame, sizeof(int32_t) * n_streams));
+    CHK(hipMalloc((void **) &b->bitrate_index, sizeof(int32_t) * n_streams));
+    CHK(hipMemcpy(b->bits_per_frame, b->bits_per_frame_h.data(), sizeof(int32_t) * n_streams, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(b->bitrate_index, b->bitrate_index_h.data(), sizeof(int32_t) * n_streams, hipMemcpyHostToDevice));
+    CHK(hipMalloc((void **) &b->energy_l, ngc * MP3MI_HBLK * sizeof(float)));
+    CHK(hipMalloc((void **) &b->energy_s, ngc * 3 * MP3MI_HBLK_S * sizeof(float)));
+    CHK(hipMalloc((void **) &b->hist6, ngc * 12 * sizeof(float)));
+    CHK(hipMalloc((void **) &b->cw_mid, ngc * 50 * sizeof(double)));
+    CHK(hipMalloc((void **) &b->xr, ngc * 576 * sizeof(double)));
+    CHK(hipMalloc((void **) &b->psy, ngc * sizeof(mp3mi_psy_out)));
+    CHK(hipMalloc((void **) &b->ix, ngc * 576 * sizeof(int16_t)));
+    CHK(hipMalloc((void **) &b->side, (size_t) n_streams * (size_t) cf * sizeof(mp3mi_frame_side)));
+    CHK(hipMalloc((void **) &b->psy_state, mp3mi_psy_state_size() * (size_t) n_streams * channels));
+    CHK(hipMalloc((void **) &b->loop_state, mp3mi_loop_state_size() * (size_t) n_streams));
+    b->sb_dbg = NULL;
+    CHK(hipEventCreate(&b->ev0));
+    CHK(hipEventCreate(&b->ev1));
+    *out = b;
+    return MP3MI_OK;
+}
+
+extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
+{
+    if (!b) return;
+    hipStreamSynchronize(b->stream);
+    hipFree(b->T); hipFree(b->bits_per_frame); hipFree(b->bitrate_index);
+    hipFree(b->energy_l); hipFree(b->energy_s); hipFree(b->hist6); hipFree(b->cw_mid);
+    hipFree(b->xr); hipFree(b->psy); hipFree(b->ix); hipFree(b->side);
+    hipFree(b->psy_state); hipFree(b->loop_state);
+    if (b->sb_dbg) hipFree(b->sb_dbg);
+    hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
+    for (size_t i = 0; i < b->loop_ev.size(); i++) hipEventDestroy(b->loop_ev[i]);
+    hipStreamDestroy(b->stream);
+    delete b;
+}
+
+extern "C" size_t mp3mi_batch_out_stride(const mp3mi_batch *b, int n_frames)
+{
+    size_t n = (size_t) n_frames * (size_t) b->max_frame_bytes + 1;
+    return (n + 255) & ~(size_t) 255;
+}
+
+extern "C" void mp3mi_batch_debug_enable(mp3mi_batch *b, int on) { b->debug = on; }
+
+extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev,
+                                  size_t out_stride, uint32_t *out_len_dev)
+{
+    if (!b || !pcm_dev || !out_dev || !out_len_dev || n_frames <= 0 || n_frames > b->max_frames) return MP3MI_ERR_ARG;
+    if (out_stride < (size_t) n_frames * (size_t) b->max_frame_bytes + 1) return MP3MI_ERR_ARG;
+    const int S = b->n_streams, C = b->channels;
+    if (b->debug && !b->sb_dbg) {
+        const size_t ngc = (size_t) S * 2 * (size_t) b->chunk_frames * (size_t) C;
+        CHK(hipMalloc((void **) &b->sb_dbg, ngc * 576 * sizeof(double)));
+    }
+    // fresh encoder state for every stream (function statics of the reference start at zero)
+    CHK(hipMemsetAsync(b->psy_state, 0, mp3mi_psy_state_size() * (size_t) S * C, b->stream));
+    CHK(hipMemsetAsync(b->loop_state, 0, mp3mi_loop_state_size() * (size_t) S, b->stream));
+    CHK(hipMemsetAsync(out_dev, 0, out_stride * (size_t) S, b->stream));
+    const int nchunks = (n_frames + b->chunk_frames - 1) / b->chunk_frames;
+    while ((int) b->loop_ev.size() < 2 * nchunks) {
+        hipEvent_t e;
+        CHK(hipEventCreate(&e));
+        b->loop_ev.push_back(e);
+    }
+    b->loop_launches = nchunks;
+    CHK(hipEventRecord(b->ev0, b->stream));
+    for (int c = 0; c < nchunks; c++) {
+        mp3mi_geom g;
+        g.n_streams = S; g.channels = C; g.rate_idx = b->rate_idx; g.n_frames = n_frames;
+        g.f0 = c * b->chunk_frames;
+        g.nf = (n_frames - g.f0 < b->chunk_frames) ? n_frames - g.f0 : b->chunk_frames;
+        mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->stream);
+        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->psy, b->stream);
+        mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy, b->xr, b->debug ? b->sb_dbg : NULL, b->stream);
+        CHK(hipEventRecord(b->loop_ev[2 * c], b->stream));
+        mp3mi_launch_loop(b->T, g, b->xr, b->psy, b->bits_per_frame, b->loop_state, b->ix, b->side, b->stream);
+        CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->stream));
+        mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,
+                            out_len_dev, b->stream);
+        b->last_nf = g.nf;
+    }
+    CHK(hipEventRecord(b->ev1, b->stream));
+    CHK(hipGetLastError());
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
+{
+    if (!b) return MP3MI_ERR_ARG;
+    CHK(hipStreamSynchronize(b->stream));
+    CHK(hipGetLastError());
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_kernels_ms, int *launches)
+{
+    if (!b) return MP3MI_ERR_ARG;
+    CHK(hipEventSynchronize(b->ev1));
+    float tot = 0, loop = 0;
+    CHK(hipEventElapsedTime(&tot, b->ev0, b->ev1));
+    for (int c = 0; c < b->loop_launches; c++) {
+        float ms = 0;
+        CHK(hipEventElapsedTime(&ms, b->loop_ev[2 * c], b->loop_ev[2 * c + 1]));
+        loop += ms;
+    }
+    if (loop_kernel_ms) *loop_kernel_ms = loop;
+    if (all_kernels_ms) *all_kernels_ms = tot;
+    if (launches) *launches = b->loop_launches;
+    return MP3MI_OK;
+}
+
+extern "C" long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst, size_t cap)
+{
+    if (!b || !host_dst) return MP3MI_ERR_ARG;
+    const size_t ngc = (size_t) b->n_streams * 2 * (size_t) b->last_nf * (size_t) b->channels;
+    const void *src = NULL;
+    size_t n = 0;
+    switch (what) {
+    case 0: src = b->psy; n = ngc * sizeof(mp3mi_psy_out); break;
+    case 1: src = b->xr; n = ngc * 576 * sizeof(double); break;
+    case 2: src = b->ix; n = ngc * 576 * sizeof(int16_t); break;
+    case 3: src = b->side; n = (size_t) b->n_streams * (size_t) b->last_nf * sizeof(mp3mi_frame_side); break;
+    case 4: src = b->sb_dbg; n = ngc * 576 * sizeof(double); break;
+    default: return MP3MI_ERR_ARG;
+    }
+    if (!src || n > cap) return MP3MI_ERR_ARG;
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return MP3MI_ERR_HIP;
+    if (hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return MP3MI_ERR_HIP;
+    return (long) n;
+}
+
+extern "C" int mp3mi_encode_host(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,
+                                 const int16_t *pcm, int n_frames, uint8_t *out, size_t out_stride,
+                                 uint32_t *out_len)
+{
+    mp3mi_batch *b = NULL;
+    int rc = mp3mi_batch_create(&b, n_streams, rate_hz, channels, kbps, kbps_all, n_frames);
+    if (rc != MP3MI_OK) return rc;
+    const size_t pcm_bytes = (size_t) n_streams * (size_t) n_frames * 1152 * (size_t) channels * sizeof(int16_t);
+    int16_t *pcm_d = NULL;
+    uint8_t *out_d = NULL;
+    uint32_t *len_d = NULL;
+    rc = MP3MI_ERR_HIP;
+    if (hipMalloc((void **) &pcm_d, pcm_bytes) == hipSuccess && hipMalloc((void **) &out_d, out_stride * n_streams) == hipSuccess &&
+        hipMalloc((void **) &len_d, sizeof(uint32_t) * n_streams) == hipSuccess &&
+        hipMemcpy(pcm_d, pcm, pcm_bytes, hipMemcpyHostToDevice) == hipSuccess) {
+        rc = mp3mi_batch_encode(b, pcm_d, n_frames, out_d, out_stride, len_d);
+        if (rc == MP3MI_OK) rc = mp3mi_batch_sync(b);
+        if (rc == MP3MI_OK && (hipMemcpy(out, out_d, out_stride * n_streams, hipMemcpyDeviceToHost) != hipSuccess ||
+                               hipMemcpy(out_len, len_d, sizeof(uint32_t) * n_streams, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = MP3MI_ERR_HIP;
+    }
+    if (pcm_d) hipFree(pcm_d);
+    if (out_d) hipFree(out_d);
+    if (len_d) hipFree(len_d);
+    mp3mi_batch_destroy(b);
+    return rc;
+}

@@ -1,0 +1,51 @@
+// Device-side self-test entry: evaluates the dmath.h routines (and the hardware f64/f32
+// sqrt/divide the kernels rely on) on the GPU so tests can prove they agree bit for bit with
+// the host build of the same header.  Host buffers in, host buffers out.
+#include "mp3mi_host.h"
+#include "mp3mi.h"
+#include "dmath.h"
+
+__global__ void k_debug_dmath(int fn, const double *__restrict__ x, const double *__restrict__ y,
+                              double *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r = 0.0, s, c;
+    switch (fn) {
+    case 0: r = dm_log(x[i]); break;
+    case 1: r = dm_exp(x[i]); break;
+    case 2: r = dm_sin(x[i]); break;
+    case 3: r = dm_cos(x[i]); break;
+    case 4: r = dm_atan2(x[i], y[i]); break;
+    case 5: r = __builtin_sqrt(x[i]); break;
+    case 6: r = x[i] / y[i]; break;
+    case 7: r = (double) __builtin_sqrtf((float) x[i]); break;
+    case 8: r = (double) ((float) x[i] / (float) y[i]); break;
+    case 9: dm_sincos(x[i], &s, &c); r = s; break;
+    case 10: dm_sincos(x[i], &s, &c); r = c; break;
+    case 11: r = x[i] * y[i] + 1.0; break; /* must NOT be contracted to fma */
+    case 12: r = (double) ((float) x[i] * (float) y[i] + 1.0f); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+extern "C" int mp3mi_debug_dmath(int fn, const double *x, const double *y, double *out, size_t n)
+{
+    double *dx = NULL, *dy = NULL, *dout = NULL;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return MP3MI_ERR_NO_DEVICE;
+    int rc = MP3MI_ERR_HIP;
+    if (hipMalloc((void **) &dx, n * 8) == hipSuccess && hipMalloc((void **) &dy, n * 8) == hipSuccess &&
+        hipMalloc((void **) &dout, n * 8) == hipSuccess &&
+        hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dy, y ? y : x, n * 8, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_dmath, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, fn, dx, dy, dout, n);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            rc = MP3MI_OK;
+    }
+    if (dx) hipFree(dx);
+    if (dy) hipFree(dy);
+    if (dout) hipFree(dout);
+    return rc;
+}

@@ -1,0 +1,286 @@
+// Layer III bitstream formatting: header + side information, scalefactors, Huffman code
+// words, count1 quadruples, stuffing, and placement of each frame's main data behind its
+// back pointer.
+//
+// Replaces III_format_bitstream / encodeSideInfo / encodeMainData / Huffmancodebits
+// (src/l3bitstream.c:67-767), HuffmanCode (src/huffcode.h:16-139), BF_BitstreamFrame /
+// WriteMainDataBits (src/formatBitstream.c:52-270) and putbits (src/common.c:1134-1161).
+//
+// The reference interleaves main data and headers through a queue; because the stream is
+// CBR without padding (src/musicin.c:566-581) the result has a closed form: header n sits at
+// byte n*frame_bytes, and byte k of the concatenated main data sits in slot k / slot_bytes at
+// offset k % slot_bytes behind that slot's header + side info.  Frame n's main data starts at
+// main-data offset n*slot_bytes - main_data_begin[n].  Hence every frame formats independently:
+// one wavefront per (stream, frame); lanes own code words, a wave prefix sum of the code
+// lengths gives each word its bit position, words are OR-ed into an LDS image and the image
+// is scattered to the frame's byte positions.
+#include "mp3mi_host.h"
+
+struct fmt_lds {
+    unsigned words[640];  // main data image, big-endian bit order inside each word
+    unsigned si[12];      // header + side info image (<= 36 bytes)
+    int sfb_l[23], sfb_s[14];
+};
+
+__device__ static const int FMT_SLEN1[16] = {0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
+__device__ static const int FMT_SLEN2[16] = {0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3};
+
+MP3MI_DEVFN void fmt_or(unsigned *w, unsigned v)
+{
+#if defined(MP3MI_EMU)
+    *w |= v;
+#else
+    atomicOr(w, v);
+#endif
+}
+
+// put the low n bits of val at bit position pos (MSB first) of a word image
+MP3MI_DEVFN void fmt_put(unsigned *img, int pos, unsigned val, int n)
+{
+    if (n <= 0) return;
+    if (n < 32) val &= (1u << n) - 1u;
+    const int wi = pos >> 5, off = pos & 31;
+    if (off + n <= 32)
+        fmt_or(&img[wi], val << (32 - off - n));
+    else {
+        const int n2 = off + n - 32;
+        fmt_or(&img[wi], val >> n2);
+        fmt_or(&img[wi + 1], val << (32 - n2));
+    }
+}
+
+// exclusive prefix sum over the wave; *total receives the wave sum
+MP3MI_DEVFN int fmt_scan(int v, int *total)
+{
+    const int lane = wave_lane();
+    int incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, (unsigned) d);
+        if (lane >= d) incl += o;
+    }
+    *total = __shfl(incl, 63);
+    return incl - v;
+}
+
+// code word(s) of one big-value pair (src/huffcode.h:16-139): code/cbits then ext/xbits
+MP3MI_DEVFN void fmt_pair(const mp3mi_tables *T, int t, int x, int y, unsigned *code, int *cbits,
+                          unsigned *ext, int *xbits)
+{
+    *code = 0; *cbits = 0; *ext = 0; *xbits = 0;
+    if (t == 0) return;
+    unsigned signx = 0, signy = 0;
+    if (x < 0) { x = -x; signx = 1; }
+    if (y < 0) { y = -y; signy = 1; }
+    const int ylen = T->ht_ylen[t], linbits = T->ht_linbits[t];
+    if (t > 15) {
+        unsigned lx = 0, ly = 0, e = 0;
+        int xb = 0;
+        const int x0 = x, y0 = y;
+        if (x > 14) { lx = (unsigned) (x - 15); x = 15; }
+        if (y > 14) { ly = (unsigned) (y - 15); y = 15; }
+        const int idx = T->ht_off[t] + x * ylen + y;
+        *code = T->ht_code[idx];
+        *cbits = T->ht_len[idx];
+        if (x0 > 14) { e |= lx; xb += linbits; }
+        if (x0 != 0) { e <<= 1; e |= signx; xb += 1; }
+        if (y0 > 14) { e <<= linbits; e |= ly; xb += linbits; }
+        if (y0 != 0) { e <<= 1; e |= signy; xb += 1; }
+        *ext = e;
+        *xbits = xb;
+    } else {
+        const int idx = T->ht_off[t] + x * ylen + y;
+        unsigned c = T->ht_code[idx];
+        int cb = T->ht_len[idx];
+        if (x != 0) { c = (c << 1) | signx; cb += 1; }
+        if (y != 0) { c = (c << 1) | signy; cb += 1; }
+        *code = c;
+        *cbits = cb;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                               const int16_t *__restrict__ ix_all,
+                                               const mp3mi_frame_side *__restrict__ side_all,
+                                               const int32_t *__restrict__ bits_per_frame,
+                                               const int32_t *__restrict__ bitrate_index,
+                                               uint8_t *__restrict__ out, size_t out_stride,
+                                               uint32_t *__restrict__ out_len)
+{
+    __shared__ fmt_lds L;
+    const int lane = wave_lane();
+    const int C = geo.channels, G = 2 * geo.nf;
+    const int fl = (int) blockIdx.x % geo.nf, s = (int) blockIdx.x / geo.nf;
+    const long n_abs = (long) geo.f0 + fl;
+    const mp3mi_frame_side *sd = &side_all[(size_t) s * geo.nf + fl];
+    const int frame_bytes = bits_per_frame[s] / 8;
+    const int si_bytes = (32 + (C == 2 ? 256 : 136)) / 8;
+    const int slot = frame_bytes - si_bytes;
+    uint8_t *dst = out + (size_t) s * out_stride;
+
+    for (int i = lane; i < 640; i += 64) L.words[i] = 0;
+    if (lane < 12) L.si[lane] = 0;
+    if (lane < 23) L.sfb_l[lane] = T->sfb_l[lane];
+    if (lane < 14) L.sfb_s[lane] = T->sfb_s[lane];
+    __syncthreads();
+
+    // ---- header and side information (src/l3bitstream.c:314-458) ----
+    if (lane == 4) {
+        int pos = 0;
+        fmt_put(L.si, pos, 0xfff, 12); pos += 12;
+        fmt_put(L.si, pos, 1, 1); pos += 1;                       // MPEG-1
+        fmt_put(L.si, pos, 1, 2); pos += 2;                       // 4 - layer
+        fmt_put(L.si, pos, 1, 1); pos += 1;                       // no CRC
+        fmt_put(L.si, pos, (unsigned) bitrate_index[s], 4); pos += 4;
+        fmt_put(L.si, pos, (unsigned) T->rate_idx, 2); pos += 2;
+        pos += 2;                                                 // padding 0, extension 0
+        fmt_put(L.si, pos, (C == 1) ? 3u : 0u, 2); pos += 2;      // mode
+        pos += 6;                                                 // mode_ext, copyright, original, emphasis
+        fmt_put(L.si, pos, (unsigned) sd->main_data_begin, 9); pos += 9;
+        pos += (C == 2) ? 3 : 5;                                  // private_bits 0
+        for (int ch = 0; ch < C; ch++)
+            for (int b = 0; b < 4; b++) { fmt_put(L.si, pos, (unsigned) sd->scfsi[ch][b], 1); pos += 1; }
+    }
+    if (lane < 2 * C) {
+        const int gr = lane / C, ch = lane % C;
+        const mp3mi_gr_side *g = &sd->gr[gr][ch];
+        int pos = 32 + 9 + ((C == 2) ? 3 : 5) + 4 * C + 59 * lane;
+        fmt_put(L.si, pos, (unsigned) g->part2_3_length, 12); pos += 12;
+        fmt_put(L.si, pos, (unsigned) g->big_values, 9); pos += 9;
+        fmt_put(L.si, pos, (unsigned) g->global_gain, 8); pos += 8;
+        fmt_put(L.si, pos, (unsigned) g->scalefac_compress, 4); pos += 4;
+        fmt_put(L.si, pos, (unsigned) g->window_switching_flag, 1); pos += 1;
+        if (g->window_switching_flag) {
+            fmt_put(L.si, pos, (unsigned) g->block_type, 2); pos += 2;
+            pos += 1; // mixed_block_flag 0
+            fmt_put(L.si, pos, (unsigned) g->table_select[0], 5); pos += 5;
+            fmt_put(L.si, pos, (unsigned) g->table_select[1], 5); pos += 5;
+            pos += 9; // subblock_gain 0
+        } else {
+            for (int r = 0; r < 3; r++) { fmt_put(L.si, pos, (unsigned) g->table_select[r], 5); pos += 5; }
+            fmt_put(L.si, pos, (unsigned) g->region0_count, 4); pos += 4;
+            fmt_put(L.si, pos, (unsigned) g->region1_count, 3); pos += 3;
+        }
+        fmt_put(L.si, pos, (unsigned) g->preflag, 1); pos += 1;
+        pos += 1; // scalefac_scale 0
+        fmt_put(L.si, pos, (unsigned) g->count1table_select, 1);
+    }
+
+    // ---- main data (src/l3bitstream.c:174-310, 516-716) ----
+    int gpos = 0; // bit position of the current granule-channel in the image
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < C; ch++) {
+            const mp3mi_gr_side *g = &sd->gr[gr][ch];
+            const size_t rec = ((size_t) s * G + (2 * fl + gr)) * C + ch;
+            const int16_t *ix = ix_all + rec * 576;
+            const bool shortb = g->window_switching_flag && g->block_type == 2;
+            const int slen1 = FMT_SLEN1[g->scalefac_compress], slen2 = FMT_SLEN2[g->scalefac_compress];
+            int pos = gpos, total;
+            { // scalefactors
+                int n = 0;
+                if (shortb) { if (lane < 36) n = (lane < 18) ? slen1 : slen2; }
+                else if (lane < 21) {
+                    const int band = (lane < 6) ? 0 : (lane < 11 ? 1 : (lane < 16 ? 2 : 3));
+                    if (gr == 0 || sd->scfsi[ch][band] == 0) n = (lane < 11) ? slen1 : slen2;
+                }
+                const int ofs = fmt_scan(n, &total);
+                if (n) fmt_put(L.words, pos + ofs, (unsigned) g->scalefac[lane], n);
+                pos += total;
+            }
+            const int bigvalues = g->big_values * 2;
+            if (bigvalues) {
+                const int r1s = shortb ? 0 : L.sfb_l[g->region0_count + 1];
+                const int r2s = shortb ? 0 : L.sfb_l[g->region0_count + g->region1_count + 2];
+                const int npairs = shortb ? 288 : bigvalues / 2;
+                for (int base = 0; base < npairs; base += 64) {
+                    const int e = base + lane;
+                    unsigned code = 0, ext = 0;
+                    int cb = 0, xb = 0;
+                    if (e < npairs) {
+                        int x, y, t;
+                        if (shortb) { // sfb -> window -> line order (src/l3bitstream.c:556-579)
+                            int sfb = 0;
+                            while (3 * L.sfb_s[sfb + 1] / 2 <= e) sfb++;
+                            const int start = L.sfb_s[sfb], half = (L.sfb_s[sfb + 1] - start) / 2;
+                            const int r = e - 3 * start / 2, w = r / half, line = start + 2 * (r - w * half);
+                            x = ix[line * 3 + w];
+                            y = ix[(line + 1) * 3 + w];
+                            t = (start < 12) ? g->table_select[0] : g->table_select[1];
+                        } else {
+                            const int i = 2 * e;
+                            x = ix[i];
+                            y = ix[i + 1];
+                            t = (i < r1s) ? g->table_select[0] : (i < r2s ? g->table_select[1] : g->table_select[2]);
+                        }
+                        fmt_pair(T, t, x, y, &code, &cb, &ext, &xb);
+                    }
+                    const int ofs = fmt_scan(cb + xb, &total);
+                    if (cb) fmt_put(L.words, pos + ofs, code, cb);
+                    if (xb) fmt_put(L.words, pos + ofs + cb, ext, xb);
+                    pos += total;
+                }
+            }
+            { // count1 quadruples (src/l3bitstream.c:727-767)
+                const int toff = T->ht_off[32 + g->count1table_select];
+                for (int base = 0; base < g->count1; base += 64) {
+                    const int qd = base + lane;
+                    unsigned val = 0;
+                    int nb = 0;
+                    if (qd < g->count1) {
+                        const int i = bigvalues + 4 * qd;
+                        int q[4];
+                        unsigned sg[4];
+                        for (int k = 0; k < 4; k++) {
+                            q[k] = ix[i + k];
+                            if (q[k] > 0) sg[k] = 0; else { q[k] = -q[k]; sg[k] = 1; }
+                        }
+                        const int p = q[0] + (q[1] << 1) + (q[2] << 2) + (q[3] << 3);
+                        val = T->ht_code[toff + p];
+                        nb = T->ht_len[toff + p];
+                        for (int k = 0; k < 4; k++)
+                            if (q[k]) { val = (val << 1) | sg[k]; nb += 1; }
+                    }
+                    const int ofs = fmt_scan(nb, &total);
+                    if (nb) fmt_put(L.words, pos + ofs, val, nb);
+                    pos += total;
+                }
+            }
+            { // stuffing with ones up to part2_3_length (src/l3bitstream.c:695-710)
+                const int endpos = gpos + g->part2_3_length;
+                for (int p = pos + lane * 32; p < endpos; p += 64 * 32) {
+                    const int n = (endpos - p < 32) ? endpos - p : 32;
+                    fmt_put(L.words, p, 0xffffffffu, n);
+                }
+                gpos = endpos;
+            }
+        }
+    gpos += sd->resvDrain; // zeros (src/l3bitstream.c:492-509)
+    __syncthreads();
+
+    // ---- scatter: header + side info at n*frame_bytes, main data behind the back pointer ----
+    const size_t hdr = (size_t) n_abs * (size_t) frame_bytes;
+    if (lane < si_bytes) dst[hdr + lane] = (uint8_t) (L.si[lane >> 2] >> (24 - 8 * (lane & 3)));
+    const long m0 = n_abs * (long) slot - sd->main_data_begin;
+    const int nbytes = gpos / 8;
+    for (int k = lane; k < nbytes; k += 64) {
+        const long m = m0 + k;
+        const size_t phys = (size_t) (m / slot) * (size_t) frame_bytes + (size_t) si_bytes + (size_t) (m % slot);
+        dst[phys] = (uint8_t) (L.words[k >> 2] >> (24 - 8 * (k & 3)));
+    }
+    if (n_abs == geo.n_frames - 1 && lane == 0) {
+        // file length (src/formatBitstream.c:87-120 + src/common.c:843-868, 968): the flush stops
+        // short of the last slot by what the current slot still has free, and close writes the
+        // byte under construction as well
+        const long mend = m0 + nbytes;
+        const long rem = ((mend + slot - 1) / slot) * slot - mend;
+        out_len[s] = (uint32_t) ((long) geo.n_frames * frame_bytes - rem + 1);
+    }
+}
+
+void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix, const mp3mi_frame_side *side,
+                         const int32_t *bits_per_frame, const int32_t *bitrate_index, uint8_t *out,
+                         size_t out_stride, uint32_t *out_len, hipStream_t st)
+{
+    const unsigned grid = (unsigned) (g.n_streams * g.nf);
+    hipLaunchKernelGGL(k_format, dim3(grid), dim3(64), 0, st, T, g, ix, side, bits_per_frame, bitrate_index, out,
+                       out_stride, out_len);
+}

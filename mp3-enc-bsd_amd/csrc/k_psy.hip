@@ -1,0 +1,230 @@
+// Psychoacoustic model, threshold part: unpredictability of lines 0..5, partition energies,
+// spreading, tonality, SNR, thresholds with pre-echo control, perceptual entropy, block-type
+// decision and the signal-to-mask ratios per scalefactor band.
+//
+// Replaces src/l3psy.c:452-456, 496-512, 555-739 (and sprdngf1/2, :1062-1084).  The part of
+// L3psycho_anal that carries state from call to call lives here: one wavefront owns one
+// (stream, channel) and walks the chunk's granules in order, keeping in registers/LDS what
+// the reference keeps in function statics (r/phi history of the last two granules, nb_1,
+// nb_2, blocktype_old, the held ratio[] / ratio_s[]).  Lane b handles threshold partition b.
+//
+// Precision map: cb/ecb/nb accumulate in f32 with f64 products rounded
+// at every step, everything else is f64; log/exp/sin/cos come from dmath.h.
+#include "mp3mi_host.h"
+#include "dmath.h"
+
+#define R_LN_TO_LOG10 0.2302585093 /* src/common.h:204 */
+
+typedef struct {
+    float r1[6], p1[6], r2[6], p2[6]; /* r and phi of the previous / second previous granule */
+    double nb_1[MP3MI_CBANDS], nb_2[MP3MI_CBANDS];
+    double ratio_l[21], ratio_s[36];
+    int32_t blocktype_old, pad;
+} mp3mi_psy_state;
+
+struct psy_lds {
+    float el[MP3MI_HBLK];
+    double cwm[50], cwl[6];
+    double eb[MP3MI_CBANDS], thr[MP3MI_CBANDS], pev[MP3MI_CBANDS];
+    float cb[MP3MI_CBANDS];
+    double ebs[MP3MI_CBANDS_S], thrs[MP3MI_CBANDS_S];
+    double held_l[21], held_s[36];
+    double pe;
+};
+
+__global__ void __launch_bounds__(64) k_psy(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                            const float *__restrict__ energy_l, const float *__restrict__ energy_s,
+                                            const double *__restrict__ cw_mid, const float *__restrict__ hist6,
+                                            mp3mi_psy_state *__restrict__ state, mp3mi_psy_out *__restrict__ out)
+{
+    __shared__ psy_lds L;
+    const int lane = wave_lane();
+    const int C = geo.channels, G = 2 * geo.nf;
+    const int ch = (int) blockIdx.x % C, s = (int) blockIdx.x / C;
+    mp3mi_psy_state *st = &state[(size_t) s * C + ch];
+    const int b = lane; // partition owned by this lane (lane 63 idles in partition loops)
+    const bool sparse = (T->rate_idx == 0);
+
+    // restore carried state
+    float r1 = 0, p1 = 0, r2 = 0, p2 = 0;
+    double nb_1 = 0, nb_2 = 0;
+    if (lane < 6) { r1 = st->r1[lane]; p1 = st->p1[lane]; r2 = st->r2[lane]; p2 = st->p2[lane]; }
+    if (b < MP3MI_CBANDS) { nb_1 = st->nb_1[b]; nb_2 = st->nb_2[b]; }
+    if (lane < 21) L.held_l[lane] = st->ratio_l[lane];
+    if (lane < 36) L.held_s[lane] = st->ratio_s[lane];
+    int bt_old = st->blocktype_old;
+    // per-lane constants
+    double minval = 0, qthr_l = 0, norm_l = 0, numl = 0;
+    int pl0 = 0, pl1 = 0, s3lo = 0, s3hi = -1;
+    if (b < MP3MI_CBANDS) {
+        minval = T->minval[b]; qthr_l = T->qthr_l[b]; norm_l = T->norm_l[b];
+        numl = (double) T->numlines_pe[b];
+        pl0 = T->part_l_start[b]; pl1 = T->part_l_start[b + 1];
+        if (sparse) { s3lo = T->s3_lo[b]; s3hi = T->s3_hi[b]; } else { s3lo = 0; s3hi = MP3MI_CBANDS - 1; }
+    }
+    __syncthreads();
+
+    for (int gl = 0; gl < G; gl++) {
+        const size_t rec = ((size_t) s * G + gl) * C + ch;
+        for (int j = lane; j < MP3MI_HBLK; j += 64) L.el[j] = energy_l[rec * MP3MI_HBLK + j];
+        if (lane < 50) L.cwm[lane] = cw_mid[rec * 50 + lane];
+        if (lane < 6) { // unpredictability of the first six lines (src/l3psy.c:496-512)
+            const float rn = hist6[rec * 12 + lane], pn = hist6[rec * 12 + 6 + lane];
+            const double r_prime = 2.0 * (double) r1 - (double) r2;
+            const double phi_prime = 2.0 * (double) p1 - (double) p2;
+            double sn, cn, sp, cp;
+            dm_sincos((double) pn, &sn, &cn);
+            dm_sincos(phi_prime, &sp, &cp);
+            const double t1 = (double) rn * cn - r_prime * cp;
+            const double t2 = (double) rn * sn - r_prime * sp;
+            const double t3 = (double) rn + __builtin_fabs(r_prime);
+            L.cwl[lane] = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
+            r2 = r1; p2 = p1; r1 = rn; p1 = pn;
+        }
+        __syncthreads();
+
+        // partition energy and weighted unpredictability (src/l3psy.c:565-578)
+        if (b < MP3MI_CBANDS) {
+            double eb = 0.0;
+            float cb = 0.0f;
+            for (int pass = 0; pass < 2; pass++) {
+                // second pass: lines beyond the table's coverage fall into partition 0
+                const int j0 = pass ? T->part_l_covered : pl0;
+                const int j1 = pass ? (b == 0 ? MP3MI_HBLK : j0) : pl1;
+                for (int j = j0; j < j1; j++) {
+                    const float e = L.el[j];
+                    const double cw = (j < 6) ? L.cwl[j] : (j < 206 ? L.cwm[(j - 6) >> 2] : 0.4);
+                    eb = eb + (double) e;
+                    cb = (float) ((double) cb + cw * (double) e);
+                }
+            }
+            L.eb[b] = eb;
+            L.cb[b] = cb;
+        }
+        __syncthreads();
+
+        double thr = 0.0, ebv = 0.0;
+        if (b < MP3MI_CBANDS) {
+            // spreading (src/l3psy.c:586-605, 1062-1084)
+            float ecb = 0.0f;
+            double ctb = 0.0;
+            for (int k = s3lo; k <= s3hi; k++) {
+                const double sv = T->s3_l[b][k];
+                if (sparse || sv != 1.0) {
+                    ecb = (float) ((double) ecb + sv * L.eb[k]);
+                    ctb = ctb + sv * (double) L.cb[k];
+                }
+            }
+            // tonality, SNR, threshold (src/l3psy.c:610-636)
+            double cbb, tbb, snr;
+            if ((double) ecb != 0.0) {
+                cbb = ctb / (double) ecb;
+                if (cbb < 0.01) cbb = 0.01;
+                cbb = dm_log(cbb);
+            } else
+                cbb = 0.0;
+            tbb = -0.299 - 0.43 * cbb;
+            tbb = (0.0 > tbb) ? 0.0 : tbb;
+            tbb = (1.0 < tbb) ? 1.0 : tbb;
+            snr = 29.0 * tbb + 6.0 * (1.0 - tbb);
+            snr = (minval > snr) ? minval : snr;
+            const float nb = (float) (((double) ecb * norm_l) * dm_exp(-snr * R_LN_TO_LOG10));
+            const double a2 = 2.0 * nb_1, a16 = 16.0 * nb_2;
+            const double inner = (a2 < a16) ? a2 : a16;
+            const double t1 = ((double) nb < inner) ? (double) nb : inner;
+            thr = (qthr_l > t1) ? qthr_l : t1;
+            nb_2 = nb_1;
+            nb_1 = (double) nb;
+            ebv = L.eb[b];
+            L.thr[b] = thr;
+            // perceptual entropy term (src/l3psy.c:639-645)
+            const double lg = dm_log((thr + 1.0) / (ebv + 1.0));
+            L.pev[b] = numl * ((0.0 < lg) ? 0.0 : lg);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            double pe = 0.0;
+            for (int k = 0; k < MP3MI_CBANDS; k++) pe = pe - L.pev[k];
+            L.pe = pe;
+        }
+        __syncthreads();
+        const double pe = L.pe;
+        const bool attack = !(pe < 1800.0);
+
+        // block type state machine (src/l3psy.c:651-668, 689-694, 732-739)
+        int blocktype, bt_out;
+        if (!attack) {
+            blocktype = (bt_old == 2) ? 3 : 0;
+        } else {
+            blocktype = 2;
+            if (bt_old == 0) bt_old = 1;
+            if (bt_old == 3) bt_old = 2;
+        }
+        bt_out = bt_old;
+        bt_old = blocktype;
+
+        // outputs: ratios are the values held BEFORE this granule updates them (src/l3psy.c:452-456)
+        if (lane < 21) out[rec].ratio_l[lane] = L.held_l[lane];
+        if (lane < 36) out[rec].ratio_s[lane / 3][lane % 3] = L.held_s[lane];
+        if (lane == 0) { out[rec].pe = pe; out[rec].block_type = bt_out; out[rec].pad = 0; }
+        __syncthreads();
+
+        if (!attack) { // long-block ratios (src/l3psy.c:671-684)
+            if (lane < 21) {
+                const int bu = T->bu_l[lane], bo = T->bo_l[lane];
+                const double w1 = T->w1_l[lane], w2 = T->w2_l[lane];
+                double en = w1 * L.eb[bu] + w2 * L.eb[bo];
+                double thm = w1 * L.thr[bu] + w2 * L.thr[bo];
+                for (int k = bu + 1; k < bo; k++) { en = en + L.eb[k]; thm = thm + L.thr[k]; }
+                L.held_l[lane] = (en != 0.0) ? thm / en : 0.0;
+            }
+        } else { // short-block ratios for the three windows (src/l3psy.c:696-729)
+            for (int sblock = 0; sblock < 3; sblock++) {
+                if (b < MP3MI_CBANDS_S) {
+                    const float *es = energy_s + rec * (3 * MP3MI_HBLK_S) + (size_t) sblock * MP3MI_HBLK_S;
+                    double e = 0.0;
+                    for (int j = T->part_s_start[b]; j < T->part_s_start[b + 1]; j++) e = e + (double) es[j];
+                    if (b == 0)
+                        for (int j = T->part_s_covered; j < MP3MI_HBLK_S; j++) e = e + (double) es[j];
+                    L.ebs[b] = e;
+                }
+                __syncthreads();
+                if (b < MP3MI_CBANDS_S) {
+                    float ecb = 0.0f;
+                    for (int k = 0; k < MP3MI_CBANDS_S; k++) ecb = (float) ((double) ecb + T->s3_l[b][k] * L.ebs[k]);
+                    const float nb = (float) (((double) ecb * T->norm_l[b]) * T->exp_snr_s[b]);
+                    const double q = T->qthr_s[b];
+                    L.thrs[b] = (q > (double) nb) ? q : (double) nb;
+                }
+                __syncthreads();
+                if (lane < 12) {
+                    const int bu = T->bu_s[lane], bo = T->bo_s[lane];
+                    const double w1 = T->w1_s[lane], w2 = T->w2_s[lane];
+                    double en = w1 * L.ebs[bu] + w2 * L.ebs[bo];
+                    double thm = w1 * L.thrs[bu] + w2 * L.thrs[bo];
+                    for (int k = bu + 1; k < bo; k++) { en = en + L.ebs[k]; thm = thm + L.thrs[k]; }
+                    L.held_s[lane * 3 + sblock] = (en != 0.0) ? thm / en : 0.0;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+
+    if (lane < 6) { st->r1[lane] = r1; st->p1[lane] = p1; st->r2[lane] = r2; st->p2[lane] = p2; }
+    if (b < MP3MI_CBANDS) { st->nb_1[b] = nb_1; st->nb_2[b] = nb_2; }
+    if (lane < 21) st->ratio_l[lane] = L.held_l[lane];
+    if (lane < 36) st->ratio_s[lane] = L.held_s[lane];
+    if (lane == 0) st->blocktype_old = bt_old;
+}
+
+size_t mp3mi_psy_state_size(void) { return sizeof(mp3mi_psy_state); }
+
+void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l, const float *energy_s,
+                      const double *cw_mid, const float *hist6, void *psy_state, mp3mi_psy_out *out,
+                      hipStream_t st)
+{
+    const unsigned grid = (unsigned) (g.n_streams * g.channels);
+    hipLaunchKernelGGL(k_psy, dim3(grid), dim3(64), 0, st, T, g, energy_l, energy_s, cw_mid, hist6,
+                       (mp3mi_psy_state *) psy_state, out);
+}

@@ -1,0 +1,142 @@
+/* Shared declarations of the device side: table block, per-granule records, wave helpers.
+ *
+ * Layout rule: every inter-kernel buffer is stream-major; within a stream the chunk's
+ * granules are consecutive.  One wavefront (64 lanes) is the unit of work everywhere.
+ */
+#ifndef MP3MI_DEV_H
+#define MP3MI_DEV_H
+
+#include <stdint.h>
+
+#if defined(MP3MI_EMU)
+#include "hipemu.h"
+#define MP3MI_DEVFN static inline
+#else
+#include <hip/hip_runtime.h>
+#define MP3MI_DEVFN static __device__ __forceinline__
+#endif
+
+#define MP3MI_CBANDS 63
+#define MP3MI_CBANDS_S 42
+#define MP3MI_HBLK 513
+#define MP3MI_HBLK_S 129
+#define MP3MI_MAX_FFT_OPS_L 9216
+#define MP3MI_MAX_FFT_OPS_S 2304
+#define MP3MI_MAX_FFT_SEGS 96
+#define MP3MI_POW43_N 8208
+#define MP3MI_STEP_MIN (-400)
+#define MP3MI_STEP_N 801
+
+/* FFT butterfly program (see fft_program.cpp).  One 16-byte record per butterfly. */
+enum {
+    FOP_ADDSUB = 0, /* t=x[a]+x[b]; x[b]=x[a]-x[b]; x[a]=t               (src/subs.c:289-297, 467-472) */
+    FOP_NEG = 1,    /* x[a]=-x[a]                                        (src/subs.c:475-479) */
+    FOP_CROSS = 2,  /* complex step 2 on (r1,r2,i1,i2)=(a,b,c,d)          (src/subs.c:302-311) */
+    FOP_ROT = 3,    /* twiddle rotation of (a,b) by (c,-(s+c),s-c)        (src/subs.c:336-339, 492-495) */
+    FOP_SQ1 = 4,    /* SQHALF rotation, first form                       (src/subs.c:330-332, 487-489) */
+    FOP_SQ2 = 5,    /* SQHALF rotation, second form                      (src/subs.c:333-335) */
+    FOP_SWAPNN = 6, /* t=x[a]; x[a]=-x[b]; x[b]=-t                       (src/subs.c:509-513) */
+    FOP_SWAPN = 7,  /* t=x[a]; x[a]=-x[b]; x[b]=t                        (src/subs.c:516-522) */
+    FOP_SWAP = 8    /* bit-reversal exchange                             (src/subs.c:136-177) */
+};
+
+typedef struct { uint32_t w[4]; } mp3mi_fftop;
+typedef struct { int32_t type, start, count, barrier; } mp3mi_fftseg;
+
+/* All read-only tables, one block in device memory.  Values are produced on the host with
+ * the host's libm exactly as the reference's init code does (tables_host.cpp). */
+typedef struct {
+    int32_t rate_idx;
+    int32_t sfb_l[23], sfb_s[14];
+    uint8_t sfb_of_line_l[576];      /* long sfb index of each line (21 = above sfb 20) */
+    uint8_t sfb_of_line_s[576];      /* short: sfb*3+window of line l*3+w              */
+    /* psy */
+    float window[1024], window_s[256];
+    int32_t numlines_pe[MP3MI_CBANDS];       /* numlines[] as left by L3para_read (quirk) */
+    int32_t part_l_start[MP3MI_CBANDS + 1];  /* lines of long partition b: [start, end)   */
+    int32_t part_s_start[MP3MI_CBANDS_S + 1];
+    int32_t part_l_covered, part_s_covered;  /* lines >= covered belong to partition 0 (quirk) */
+    double minval[MP3MI_CBANDS], qthr_l[MP3MI_CBANDS], norm_l[MP3MI_CBANDS];
+    double qthr_s[MP3MI_CBANDS_S], exp_snr_s[MP3MI_CBANDS_S];
+    double s3_l[MP3MI_CBANDS][MP3MI_CBANDS];
+    int32_t s3_lo[MP3MI_CBANDS], s3_hi[MP3MI_CBANDS];
+    int32_t bu_l[21], bo_l[21], bu_s[12], bo_s[12];
+    double w1_l[21], w2_l[21], w1_s[12], w2_s[12];
+    /* FFT programs */
+    int32_t n_seg_l, n_seg_s;
+    mp3mi_fftseg seg_l[MP3MI_MAX_FFT_SEGS], seg_s[MP3MI_MAX_FFT_SEGS];
+    mp3mi_fftop ops_l[MP3MI_MAX_FFT_OPS_L], ops_s[MP3MI_MAX_FFT_OPS_S];
+    /* filterbank + MDCT */
+    double enwindow[512];
+    double filt[32][32];             /* the 31 used columns per subband: 0..15, 33..47  */
+    double mdct_win[4][36], cos_s[6][12], cos_l[18][36], ca[8], cs[8];
+    /* long-block (type 0) transform, src/mdct.c:199-509, flattened: 36 operands per output.
+       bits 0-5 input index, 6 operand subtracted/negated, 7 first operand of a term,
+       8 last operand of a term, 9-13 cos_l column, 14 coefficient negated, 15 first term */
+    uint16_t mdct_prog[18][36];
+    /* quantiser */
+    double pow_nint_tab[2049];       /* (i-0.4054)^(4/3); [0]=0, [2048]=+inf sentinel   */
+    double pow43[MP3MI_POW43_N];     /* i^(4/3) */
+    double step[MP3MI_STEP_N];       /* 2^(q/4), q = MP3MI_STEP_MIN + i */
+    double pretab_xr[4], pretab_xmin[4]; /* sqrt(2)^n, sqrt(2)^(2n), n = 0..3 */
+    double sqrt2, log2;
+    /* Huffman */
+    uint16_t ht_off[34];
+    uint8_t ht_xlen[34], ht_ylen[34], ht_linbits[34];
+    uint16_t ht_linmax[34];
+    uint8_t ht_len[1440];
+    uint32_t ht_code[1440];
+} mp3mi_tables;
+
+/* Output of the psychoacoustic stage for one (granule, channel); mirrors what
+ * L3psycho_anal hands back to its caller (src/l3psy.h:33). */
+typedef struct {
+    double pe;
+    double ratio_l[21];
+    double ratio_s[12][3];
+    int32_t block_type;
+    int32_t pad;
+} mp3mi_psy_out;
+
+/* Side information of one (granule, channel) as the iteration loop leaves it
+ * (subset of gr_info, src/l3side.h:60-87, that the formatter needs). */
+typedef struct {
+    int32_t part2_3_length, big_values, count1, global_gain, scalefac_compress;
+    int32_t window_switching_flag, block_type, table_select[3];
+    int32_t region0_count, region1_count, preflag, count1table_select, part2_length;
+    int32_t scalefac[39];            /* long: [0..20]; short: [sfb*3+window], sfb<12 (slot 36.. unused) */
+} mp3mi_gr_side;
+
+typedef struct {
+    int32_t main_data_begin, resvDrain, scfsi[2][4];
+    mp3mi_gr_side gr[2][2];
+} mp3mi_frame_side;
+
+/* ---- wave helpers (64 lanes) ---- */
+MP3MI_DEVFN int wave_lane(void) { return (int) (threadIdx.x & 63); }
+
+MP3MI_DEVFN int wave_sum_i32(int v)
+{
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+MP3MI_DEVFN int wave_max_i32(int v)
+{
+    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+MP3MI_DEVFN int wave_min_i32(int v)
+{
+    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
+MP3MI_DEVFN double wave_max_f64(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+MP3MI_DEVFN int wave_bcast_i32(int v, int lane) { return __shfl(v, lane); }
+MP3MI_DEVFN double wave_bcast_f64(double v, int lane) { return __shfl(v, lane); }
+MP3MI_DEVFN int wave_any(int p) { return __ballot(p) != 0ull; }
+
+#endif

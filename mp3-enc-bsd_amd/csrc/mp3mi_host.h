@@ -1,0 +1,41 @@
+/* Internal host-side declarations shared by the translation units of libmp3mi.so. */
+#ifndef MP3MI_HOST_H
+#define MP3MI_HOST_H
+
+#include "mp3mi_dev.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tables_host.cpp: fill the table block for MPEG-1 sampling_frequency code rate_idx
+ * (0 = 44.1 kHz, 1 = 48 kHz, 2 = 32 kHz).  Returns 0 on success. */
+int mp3mi_build_tables(mp3mi_tables *T, int rate_idx);
+
+#ifdef __cplusplus
+}
+
+/* kernel launchers (one per .hip file); all take device pointers */
+struct mp3mi_geom {
+    int n_streams, channels, rate_idx;
+    int n_frames;       /* frames per stream in this call */
+    int f0, nf;         /* frames [f0, f0+nf) form the current chunk */
+};
+
+void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
+                      float *energy_l, float *energy_s, double *cw_mid, float *hist6, hipStream_t st);
+void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l,
+                      const float *energy_s, const double *cw_mid, const float *hist6,
+                      void *psy_state, mp3mi_psy_out *out, hipStream_t st);
+void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
+                         const mp3mi_psy_out *psy, double *xr, double *sb_dbg, hipStream_t st);
+void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
+                       const mp3mi_psy_out *psy, const int32_t *bits_per_frame, void *loop_state,
+                       int16_t *ix, mp3mi_frame_side *side, hipStream_t st);
+void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix,
+                         const mp3mi_frame_side *side, const int32_t *bits_per_frame,
+                         const int32_t *bitrate_index, uint8_t *out, size_t out_stride,
+                         uint32_t *out_len, hipStream_t st);
+#endif
+
+#endif

@@ -1,0 +1,355 @@
+// Host-side construction of the read-only table block (mp3mi_tables).
+//
+// Every value that the reference computes once at start-up with libm is computed here the
+// same way with the host's libm (identical glibc on the GPU box), so the kernels never
+// evaluate an init-time transcendental themselves:
+//   Hann windows            src/l3psy.c:194-195      spreading matrix   src/l3psy.c:818-848
+//   FFT twiddles            src/subs.c:278-286,452-457
+//   analysis filter matrix  src/encode.c:331-345     MDCT windows/cos   src/mdct.c:129-171
+//   alias butterflies       src/mdct.c:37-45         quantiser tables   src/pow_nint.c:13-20,
+//                                                                       src/loop.c:1017-1021
+// plus the FFT butterfly program: the reference's recursive split-radix real FFT
+// (src/subs.c:185-362, 412-523) flattened into barrier-separated segments of independent
+// butterflies so that 64 lanes can execute it with the identical arithmetic DAG.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <algorithm>
+#include <vector>
+#include "mp3mi_host.h"
+#include "mp3mi_tables_gen.h"
+
+#define R_PI 3.14159265358979
+#define R_LN_TO_LOG10 0.2302585093
+#define R_TWOPI 6.28318530717958647692
+
+static const int SFB_L[3][23] = {
+    {0,4,8,12,16,20,24,30,36,44,52,62,74,90,110,134,162,196,238,288,342,418,576},
+    {0,4,8,12,16,20,24,30,36,42,50,60,72,88,106,128,156,190,230,276,330,384,576},
+    {0,4,8,12,16,20,24,30,36,44,54,66,82,102,126,156,194,240,296,364,448,550,576}};
+static const int SFB_S[3][14] = {
+    {0,4,8,12,16,22,30,40,52,66,84,106,136,192},
+    {0,4,8,12,16,22,28,38,50,64,80,100,126,192},
+    {0,4,8,12,16,22,30,42,58,78,104,138,180,192}};
+static const double ALIAS_C[8] = {-0.6,-0.535,-0.33,-0.185,-0.095,-0.041,-0.0142,-0.0037};
+
+namespace {
+
+struct RawOp {
+    int phase, type;
+    unsigned a, b, c, d;
+    float f0, f1, f2;
+};
+
+struct Twiddle { std::vector<float> t; int nel; };
+
+Twiddle make_twiddle(int logm, bool three)
+{
+    int m = 1 << logm, m4 = m / 4, m8 = m / 8, nel = m4 - 2, e = 0;
+    Twiddle tw;
+    tw.nel = nel;
+    tw.t.assign((size_t) (three ? 6 : 3) * (nel > 0 ? nel : 1), 0.0f);
+    for (int n = 1; n < m4; n++) {
+        if (n == m8) continue;
+        float ang = (float) (n * R_TWOPI / m);
+        float c = (float) cos((double) ang), s = (float) sin((double) ang); /* C semantics: double libm on the float angle */
+        tw.t[e] = c;
+        tw.t[nel + e] = -(s + c);
+        tw.t[2 * nel + e] = s - c;
+        if (three) {
+            ang = (float) (3 * n * R_TWOPI / m);
+            c = (float) cos((double) ang);
+            s = (float) sin((double) ang);
+            tw.t[3 * nel + e] = c;
+            tw.t[4 * nel + e] = -(s + c);
+            tw.t[5 * nel + e] = s - c;
+        }
+        e++;
+    }
+    return tw;
+}
+
+struct FftGen {
+    std::vector<RawOp> ops;
+    Twiddle tw_rs[11], tw_sr[11];
+    int post1, post2, brphase;
+
+    void op(int phase, int type, unsigned a, unsigned b = 0, unsigned c = 0, unsigned d = 0,
+            float f0 = 0, float f1 = 0, float f2 = 0)
+    {
+        RawOp o = {phase, type, a, b, c, d, f0, f1, f2};
+        ops.push_back(o);
+    }
+
+    void cplx(int xr, int xi, int logm, int rank)
+    {
+        if (logm <= 0) return;
+        if (logm == 1) {
+            op(3 * rank, FOP_ADDSUB, xr, xr + 1);
+            op(3 * rank, FOP_ADDSUB, xi, xi + 1);
+            return;
+        }
+        int m = 1 << logm, m2 = m / 2, m4 = m2 / 2, m8 = m4 / 2;
+        for (int n = 0; n < m2; n++) {
+            op(3 * rank, FOP_ADDSUB, xr + n, xr + n + m2);
+            op(3 * rank, FOP_ADDSUB, xi + n, xi + n + m2);
+        }
+        for (int n = 0; n < m4; n++)
+            op(3 * rank + 1, FOP_CROSS, xr + m2 + n, xr + m2 + n + m4, xi + m2 + n, xi + m2 + n + m4);
+        const Twiddle &tw = tw_sr[logm];
+        for (int n = 1, e = 0; n < m4; n++) {
+            unsigned r1 = xr + m2 + n, r2 = r1 + m4, i1 = xi + m2 + n, i2 = i1 + m4;
+            if (n == m8) {
+                op(3 * rank + 2, FOP_SQ1, r1, i1);
+                op(3 * rank + 2, FOP_SQ2, r2, i2);
+            } else {
+                op(3 * rank + 2, FOP_ROT, r1, i1, 0, 0, tw.t[e], tw.t[tw.nel + e], tw.t[2 * tw.nel + e]);
+                op(3 * rank + 2, FOP_ROT, r2, i2, 0, 0, tw.t[3 * tw.nel + e], tw.t[4 * tw.nel + e], tw.t[5 * tw.nel + e]);
+                e++;
+            }
+        }
+        cplx(xr, xi, logm - 1, rank + 1);
+        cplx(xr + m2, xi + m2, logm - 2, rank + 1);
+        cplx(xr + 3 * (m / 4), xi + 3 * (m / 4), logm - 2, rank + 1);
+    }
+
+    void real(int o, int logm, int rank)
+    {
+        if (logm <= 0) return;
+        if (logm == 1) {
+            op(3 * rank, FOP_ADDSUB, o, o + 1);
+            return;
+        }
+        int m = 1 << logm, m2 = m / 2, m4 = m2 / 2, m8 = m4 / 2;
+        for (int n = 0; n < m2; n++) op(3 * rank, FOP_ADDSUB, o + n, o + n + m2);
+        for (int n = 0; n < m4; n++) op(3 * rank + 1, FOP_NEG, o + m2 + m4 + n);
+        const Twiddle &tw = tw_rs[logm];
+        for (int n = 1, e = 0; n < m4; n++) {
+            unsigned r1 = o + m2 + n, i1 = r1 + m4;
+            if (n == m8) op(3 * rank + 2, FOP_SQ1, r1, i1);
+            else {
+                op(3 * rank + 2, FOP_ROT, r1, i1, 0, 0, tw.t[e], tw.t[tw.nel + e], tw.t[2 * tw.nel + e]);
+                e++;
+            }
+        }
+        real(o, logm - 1, rank + 1);
+        cplx(o + m2, o + 3 * (m / 4), logm - 2, rank + 1);
+        for (int n = 0; n < m8; n++) op(post1, FOP_SWAPNN, o + m2 + m4 + n, o + m - 1 - n);
+        for (int n = 0; n < m8; n++) op(post2, FOP_SWAPN, o + m2 + 1 + 2 * n, o + m - 2 - 2 * n);
+        if (logm == 2) op(post1, FOP_NEG, o + 3);
+    }
+
+    void build(int logN, mp3mi_fftop *out_ops, int max_ops, mp3mi_fftseg *segs, int32_t *n_seg)
+    {
+        ops.clear();
+        post1 = 3 * logN + 1;
+        post2 = post1 + 1;
+        brphase = post2 + 1;
+        real(0, logN, 0);
+        int N = 1 << logN;
+        for (int i = 0; i < N; i++) {
+            int j = 0;
+            for (int b = 0; b < logN; b++)
+                if (i & (1 << b)) j |= 1 << (logN - 1 - b);
+            if (j > i) op(brphase, FOP_SWAP, i, j);
+        }
+        std::stable_sort(ops.begin(), ops.end(), [](const RawOp &x, const RawOp &y) {
+            return x.phase != y.phase ? x.phase < y.phase : x.type < y.type;
+        });
+        if ((int) ops.size() > max_ops) { fprintf(stderr, "mp3mi: fft program too large (%zu)\n", ops.size()); abort(); }
+        int ns = 0;
+        for (size_t i = 0; i < ops.size(); i++) {
+            const RawOp &o = ops[i];
+            mp3mi_fftop w;
+            w.w[0] = o.a | (o.b << 16);
+            if (o.type == FOP_ROT) {
+                memcpy(&w.w[1], &o.f0, 4);
+                memcpy(&w.w[2], &o.f1, 4);
+                memcpy(&w.w[3], &o.f2, 4);
+            } else {
+                w.w[1] = o.c | (o.d << 16);
+                w.w[2] = w.w[3] = 0;
+            }
+            out_ops[i] = w;
+            if (i == 0 || o.phase != ops[i - 1].phase || o.type != ops[i - 1].type) {
+                if (ns >= MP3MI_MAX_FFT_SEGS) { fprintf(stderr, "mp3mi: too many fft segments\n"); abort(); }
+                if (ns > 0) segs[ns - 1].barrier = (o.phase != ops[i - 1].phase);
+                segs[ns].type = o.type;
+                segs[ns].start = (int) i;
+                segs[ns].count = 0;
+                segs[ns].barrier = 1;
+                ns++;
+            }
+            segs[ns - 1].count++;
+        }
+        *n_seg = ns;
+    }
+};
+
+} // namespace
+
+extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
+{
+    const int ri = rate_idx;
+    if (ri < 0 || ri > 2) return -1;
+    memset(T, 0, sizeof(*T));
+    T->rate_idx = ri;
+    for (int i = 0; i < 23; i++) T->sfb_l[i] = SFB_L[ri][i];
+    for (int i = 0; i < 14; i++) T->sfb_s[i] = SFB_S[ri][i];
+    for (int sfb = 0; sfb < 22; sfb++)
+        for (int l = SFB_L[ri][sfb]; l < SFB_L[ri][sfb + 1]; l++) T->sfb_of_line_l[l] = (uint8_t) sfb;
+    for (int sfb = 0; sfb < 13; sfb++)
+        for (int l = SFB_S[ri][sfb]; l < SFB_S[ri][sfb + 1]; l++)
+            for (int w = 0; w < 3; w++) T->sfb_of_line_s[l * 3 + w] = (uint8_t) (sfb * 3 + w);
+
+    for (unsigned i = 0; i < 1024; i++) T->window[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 1024)));
+    for (unsigned i = 0; i < 256; i++) T->window_s[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 256)));
+
+    const int cb_l = T_PL_COUNT[ri], cb_s = T_PS_COUNT[ri];
+    double bval_l[MP3MI_CBANDS];
+    int k2 = 0;
+    for (int i = 0; i < cb_l; i++) {
+        T->numlines_pe[i] = T_PL_NUMLINES[ri][i];
+        T->part_l_start[i] = k2;
+        k2 += T_PL_NUMLINES[ri][i];
+        T->minval[i] = T_PL_MINVAL[ri][i];
+        T->qthr_l[i] = T_PL_QTHR[ri][i];
+        T->norm_l[i] = T_PL_NORM[ri][i];
+        bval_l[i] = T_PL_BVAL[ri][i];
+    }
+    for (int i = cb_l; i <= MP3MI_CBANDS; i++) T->part_l_start[i] = k2;
+    /* lines the table does not cover keep the reference's zero-initialised partition index,
+       i.e. they are summed into partition 0 after its own lines (src/l3psy.c:131, 808-809) */
+    T->part_l_covered = k2;
+    if (k2 > MP3MI_HBLK) return -2;
+    for (int i = 0; i < cb_l; i++)
+        for (int j = 0; j < cb_l; j++) {
+            double tempx, x, tempy, temp;
+            if (j >= i) tempx = (bval_l[i] - bval_l[j]) * 3.0;
+            else tempx = (bval_l[i] - bval_l[j]) * 1.5;
+            if (tempx >= 0.5 && tempx <= 2.5) { temp = tempx - 0.5; x = 8.0 * (temp * temp - 2.0 * temp); }
+            else x = 0.0;
+            tempx += 0.474;
+            tempy = 15.811389 + 7.5 * tempx - 17.5 * sqrt(1.0 + tempx * tempx);
+            T->s3_l[i][j] = (tempy <= -60.0) ? 0.0 : exp((x + tempy) * R_LN_TO_LOG10);
+        }
+    k2 = 0;
+    for (int i = 0; i < cb_s; i++) {
+        T->numlines_pe[i] = T_PS_NUMLINES[ri][i]; /* the short table overwrites the long one: src/l3psy.c:868 */
+        T->part_s_start[i] = k2;
+        k2 += T_PS_NUMLINES[ri][i];
+        T->qthr_s[i] = T_PS_QTHR[ri][i];
+        T->exp_snr_s[i] = exp((double) T_PS_SNR[ri][i] * R_LN_TO_LOG10);
+    }
+    for (int i = cb_s; i <= MP3MI_CBANDS_S; i++) T->part_s_start[i] = k2;
+    T->part_s_covered = k2;
+    if (k2 > MP3MI_HBLK_S) return -2;
+    /* entries of qthr_s/exp_snr_s beyond cb_s: the reference loops b < 42 over statics that
+       were never written there: qthr_s = 0, SNR_s = 0 -> exp(0) = 1 */
+    for (int i = cb_s; i < MP3MI_CBANDS_S; i++) T->exp_snr_s[i] = exp(0.0 * R_LN_TO_LOG10);
+    for (int i = 0; i < MP3MI_CBANDS; i++) { T->s3_lo[i] = T_S3_LO[i]; T->s3_hi[i] = T_S3_HI[i]; }
+    for (int i = 0; i < 21; i++) {
+        T->bu_l[i] = T_SL_BU[ri][i]; T->bo_l[i] = T_SL_BO[ri][i];
+        T->w1_l[i] = T_SL_W1[ri][i]; T->w2_l[i] = T_SL_W2[ri][i];
+    }
+    for (int i = 0; i < 12; i++) {
+        T->bu_s[i] = T_SS_BU[ri][i]; T->bo_s[i] = T_SS_BO[ri][i];
+        T->w1_s[i] = T_SS_W1[ri][i]; T->w2_s[i] = T_SS_W2[ri][i];
+    }
+
+    {
+        FftGen *g = new FftGen();
+        for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
+        g->build(10, T->ops_l, MP3MI_MAX_FFT_OPS_L, T->seg_l, &T->n_seg_l);
+        g->build(8, T->ops_s, MP3MI_MAX_FFT_OPS_S, T->seg_s, &T->n_seg_s);
+        delete g;
+    }
+
+    for (int i = 0; i < 512; i++) T->enwindow[i] = T_ENWINDOW[i];
+    for (int i = 0; i < 32; i++) {
+        double row[64];
+        for (int k = 0; k < 64; k++) {
+            double f = 1e9 * cos((double) ((2 * i + 1) * (16 - k) * R_PI / 64));
+            if (f >= 0) modf(f + 0.5, &f);
+            else modf(f - 0.5, &f);
+            row[k] = f * 1e-9;
+        }
+        for (int j = 0; j < 16; j++) T->filt[i][j] = row[j];
+        for (int j = 0; j < 15; j++) T->filt[i][16 + j] = row[33 + j];
+        T->filt[i][31] = 0.0;
+    }
+
+    double (*win)[36] = T->mdct_win;
+    for (int i = 0; i < 36; i++) win[0][i] = sin(R_PI / 36 * (i + 0.5));
+    for (int i = 0; i < 18; i++) win[1][i] = sin(R_PI / 36 * (i + 0.5));
+    for (int i = 18; i < 24; i++) win[1][i] = 1.0;
+    for (int i = 24; i < 30; i++) win[1][i] = sin(R_PI / 12 * (i + 0.5 - 18));
+    for (int i = 30; i < 36; i++) win[1][i] = 0.0;
+    for (int i = 0; i < 6; i++) win[3][i] = 0.0;
+    for (int i = 6; i < 12; i++) win[3][i] = sin(R_PI / 12 * (i + 0.5 - 6));
+    for (int i = 12; i < 18; i++) win[3][i] = 1.0;
+    for (int i = 18; i < 36; i++) win[3][i] = sin(R_PI / 36 * (i + 0.5));
+    for (int i = 0; i < 12; i++) win[2][i] = sin(R_PI / 12 * (i + 0.5));
+    for (int i = 12; i < 36; i++) win[2][i] = 0.0;
+    {
+        int N = 12;
+        for (int m = 0; m < N / 2; m++)
+            for (int k = 0; k < N; k++)
+                T->cos_s[m][k] = cos((R_PI / (2 * N)) * (2 * k + 1 + N / 2) * (2 * m + 1)) / (N / 4);
+        N = 36;
+        for (int m = 0; m < N / 2; m++)
+            for (int k = 0; k < N; k++)
+                T->cos_l[m][k] = cos((R_PI / (2 * N)) * (2 * k + 1 + N / 2) * (2 * m + 1)) / (N / 4);
+    }
+    for (int k = 0; k < 8; k++) {
+        double sq = sqrt(1.0 + ALIAS_C[k] * ALIAS_C[k]);
+        T->ca[k] = ALIAS_C[k] / sq;
+        T->cs[k] = 1.0 / sq;
+    }
+    for (int m = 0; m < 18; m++) {
+        int n = 0;
+        for (int t = T_MDCTL_ROW[m]; t < T_MDCTL_ROW[m + 1]; t++) {
+            int o0 = T_MDCTL_TERM_OP[t], o1 = T_MDCTL_TERM_OP[t + 1];
+            for (int o = o0; o < o1; o++) {
+                unsigned e = T_MDCTL_OPS[o] & 0x3f;
+                if (T_MDCTL_OPS[o] & 0x80) e |= 1u << 6;
+                if (o == o0) e |= 1u << 7;
+                if (o == o1 - 1) e |= 1u << 8;
+                e |= (unsigned) (T_MDCTL_TERM_K[t] & 0x1f) << 9;
+                if (T_MDCTL_TERM_K[t] & 0x80) e |= 1u << 14;
+                if (t == T_MDCTL_ROW[m]) e |= 1u << 15;
+                if (n >= 36) return -4;
+                T->mdct_prog[m][n++] = (uint16_t) e;
+            }
+        }
+        if (n != 36) return -4;
+    }
+
+    T->pow_nint_tab[0] = 0.0;
+    for (int i = 1; i < 2048; i++) T->pow_nint_tab[i] = pow((double) i - 0.4054, 4.0 / 3.0);
+    T->pow_nint_tab[2048] = HUGE_VAL;
+    for (int i = 0; i < MP3MI_POW43_N; i++) T->pow43[i] = pow((double) i, 4.0 / 3.0);
+    for (int i = 0; i < MP3MI_STEP_N; i++) T->step[i] = pow(2.0, (double) (MP3MI_STEP_MIN + i) * 0.25);
+    for (int n = 0; n < 4; n++) {
+        T->pretab_xr[n] = pow(sqrt(2.), (double) n);
+        T->pretab_xmin[n] = pow(sqrt(2.), 2.0 * (double) n);
+    }
+    T->sqrt2 = sqrt(2.0);
+    T->log2 = log(2.0);
+
+    size_t n_ht = sizeof(T_HT_PACKED) / sizeof(T_HT_PACKED[0]);
+    if (n_ht > 1440) return -3;
+    for (size_t i = 0; i < n_ht; i++) {
+        T->ht_len[i] = (uint8_t) (T_HT_PACKED[i] & 0xff);
+        T->ht_code[i] = T_HT_PACKED[i] >> 8;
+    }
+    for (int i = 0; i < 34; i++) {
+        T->ht_off[i] = T_HT_OFF[i];
+        T->ht_xlen[i] = T_HT_XLEN[i];
+        T->ht_ylen[i] = T_HT_YLEN[i];
+        T->ht_linbits[i] = T_HT_LINBITS[i];
+        T->ht_linmax[i] = T_HT_LINMAX[i];
+    }
+    return 0;
+}

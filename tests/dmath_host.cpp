@@ -1,0 +1,11 @@
+// CPU build of the product's deterministic math layer for unit tests (no HIP).
+// Exposes each function over plain arrays so python can compare against glibc and mpmath.
+#include <cstddef>
+#include "../mp3-enc-bsd_amd/csrc/dmath.h"
+extern "C" {
+void t_dm_log(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_log(x[i]); }
+void t_dm_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_exp(x[i]); }
+void t_dm_sin(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_sin(x[i]); }
+void t_dm_cos(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_cos(x[i]); }
+void t_dm_atan2(const double *a, const double *b, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2(a[i], b[i]); }
+}

@@ -1,0 +1,130 @@
+"""Shared helpers for the test-suite: ctypes bindings of the product library (libmp3mi.so),
+its CPU-emulated test build (tests/hipemu/_build/libmp3mi_emu.so) and the oracle
+(oracle/_build/liboracle.so), plus numpy views of the records they exchange."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRODUCT_SO = os.path.join(ROOT, "mp3-enc-bsd_amd", "libmp3mi.so")
+EMU_SO = os.path.join(ROOT, "tests", "hipemu", "_build", "libmp3mi_emu.so")
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+SEED = 0x6D70336D
+
+# oracle/stage_dump.h
+STAGE_DT = np.dtype([
+    ("pe", "<f8", (2, 2)), ("ratio_l", "<f8", (2, 2, 21)), ("ratio_s", "<f8", (2, 2, 12, 3)),
+    ("sb", "<f8", (2, 2, 18, 32)), ("xr", "<f8", (2, 2, 576)), ("l3_enc", "<i4", (2, 2, 576)),
+    ("psy_bt", "<i4", (2, 2)), ("main_data_begin", "<i4"), ("resvDrain", "<i4"), ("scfsi", "<i4", (2, 4)),
+    ("gi", "<i4", (2, 2, 20)), ("scalefac_l", "<i4", (2, 2, 22)), ("scalefac_s", "<i4", (2, 2, 13, 3)),
+    ("magic", "<i4"), ("frame_index", "<i4")])
+GI = {n: i for i, n in enumerate([
+    "part2_3_length", "big_values", "count1", "global_gain", "scalefac_compress", "window_switching_flag",
+    "block_type", "mixed_block_flag", "table_select0", "table_select1", "table_select2", "subblock_gain0",
+    "subblock_gain1", "subblock_gain2", "region0_count", "region1_count", "preflag", "scalefac_scale",
+    "count1table_select", "part2_length"])}
+
+# mp3-enc-bsd_amd/csrc/mp3mi_dev.h
+PSY_DT = np.dtype([("pe", "<f8"), ("ratio_l", "<f8", (21,)), ("ratio_s", "<f8", (12, 3)), ("block_type", "<i4"), ("pad", "<i4")])
+GRSIDE_DT = np.dtype([
+    ("part2_3_length", "<i4"), ("big_values", "<i4"), ("count1", "<i4"), ("global_gain", "<i4"),
+    ("scalefac_compress", "<i4"), ("window_switching_flag", "<i4"), ("block_type", "<i4"),
+    ("table_select", "<i4", (3,)), ("region0_count", "<i4"), ("region1_count", "<i4"), ("preflag", "<i4"),
+    ("count1table_select", "<i4"), ("part2_length", "<i4"), ("scalefac", "<i4", (39,))])
+SIDE_DT = np.dtype([("main_data_begin", "<i4"), ("resvDrain", "<i4"), ("scfsi", "<i4", (2, 4)), ("gr", GRSIDE_DT, (2, 2))])
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
+
+
+def build_emu():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu")], check=True)
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        self.lib = ctypes.CDLL(ORACLE_SO)
+        self.lib.mp3o_encode_pcm.restype = ctypes.c_size_t
+        self.lib.mp3o_encode_pcm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int]
+        self.libc = ctypes.CDLL("libc.so.6")
+        self.libc.free.argtypes = [ctypes.c_void_p]
+
+    def encode(self, pcm, rate, kbps, channels, dumps=0):
+        """pcm: int16 array, interleaved.  Returns (mp3 bytes, stage dumps or None)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        out = ctypes.c_void_p()
+        d = np.zeros(dumps, dtype=STAGE_DT) if dumps else None
+        n = self.lib.mp3o_encode_pcm(rate, kbps, channels, pcm.ctypes.data, pcm.size, ctypes.byref(out),
+                                     d.ctypes.data if dumps else None, dumps)
+        if not out.value:
+            raise ValueError("oracle refused configuration")
+        data = ctypes.string_at(out.value, n)
+        self.libc.free(out)
+        return data, d
+
+
+class Mp3mi:
+    """The product library (emu=False) or its emulated CPU test build (emu=True)."""
+
+    def __init__(self, emu=False):
+        path = EMU_SO if emu else PRODUCT_SO
+        if emu and not os.path.exists(path):
+            build_emu()
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        L.mp3mi_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.mp3mi_batch_destroy.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_out_stride.restype = ctypes.c_size_t
+        L.mp3mi_batch_out_stride.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_batch_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_sync.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_debug_fetch.restype = ctypes.c_long
+        L.mp3mi_batch_debug_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+        L.mp3mi_batch_debug_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_batch_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+        L.mp3mi_encode_host.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_synth_pcm.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+        L.mp3mi_version.restype = ctypes.c_char_p
+
+    def synth(self, n_per_ch, channels, rate, stream, seed=SEED):
+        out = np.zeros(n_per_ch * channels, dtype=np.int16)
+        self.lib.mp3mi_synth_pcm(out.ctypes.data, n_per_ch, channels, rate, stream, seed)
+        return out
+
+    def encode_host(self, pcm, rate, channels, kbps, n_frames):
+        """pcm: int16 [n_streams, n_frames*1152*channels]; kbps: int or per-stream list.
+        Returns list of bytes per stream."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        S = pcm.shape[0]
+        assert pcm.shape[1] == n_frames * 1152 * channels
+        if np.isscalar(kbps):
+            karr, kall, kmax = None, int(kbps), int(kbps)
+        else:
+            karr = np.ascontiguousarray(kbps, dtype=np.int32)
+            kall, kmax = 0, int(karr.max())
+        stride = (n_frames * (int(1152 / (rate / 1000.0) * kmax / 8) + 1) + 1 + 255) // 256 * 256
+        out = np.zeros((S, stride), dtype=np.uint8)
+        lens = np.zeros(S, dtype=np.uint32)
+        rc = self.lib.mp3mi_encode_host(S, rate, channels, karr.ctypes.data if karr is not None else None, kall,
+                                        pcm.ctypes.data, n_frames, out.ctypes.data, stride, lens.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("mp3mi_encode_host failed: %d" % rc)
+        return [out[s, :lens[s]].tobytes() for s in range(S)]
+
+
+def pad_frames(pcm, channels):
+    """zero-fill interleaved PCM to whole frames (src/encode.c:162-166)"""
+    per = 1152 * channels
+    n = (len(pcm) + per - 1) // per
+    out = np.zeros(n * per, dtype=np.int16)
+    out[:len(pcm)] = pcm
+    return out, n

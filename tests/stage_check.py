@@ -1,0 +1,98 @@
+"""Compare the stage seams of a batch run (product or emulated) with oracle stage dumps."""
+import ctypes
+
+import numpy as np
+
+from mp3common import GI, PSY_DT, SIDE_DT
+
+
+def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames):
+    """pcm: int16 [S, n_frames*1152*channels].  Returns (bytes per stream, stages dict)."""
+    L = lib.lib
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    S = pcm.shape[0]
+    b = ctypes.c_void_p()
+    karr = None if np.isscalar(kbps) else np.ascontiguousarray(kbps, dtype=np.int32)
+    rc = L.mp3mi_batch_create(ctypes.byref(b), S, rate, channels, karr.ctypes.data if karr is not None else None,
+                              int(kbps) if karr is None else 0, n_frames)
+    assert rc == 0, "mp3mi_batch_create -> %d" % rc
+    try:
+        L.mp3mi_batch_debug_enable(b, 1)
+        stride = L.mp3mi_batch_out_stride(b, n_frames)
+        is_emu = b"emulator" in L.mp3mi_version()
+        if is_emu:
+            out = np.zeros((S, stride), np.uint8)
+            lens = np.zeros(S, np.uint32)
+            rc = L.mp3mi_batch_encode(b, pcm.ctypes.data, n_frames, out.ctypes.data, stride, lens.ctypes.data)
+            assert rc == 0
+        else:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+            hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            hip.hipFree.argtypes = [ctypes.c_void_p]
+            dp, do, dl = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(dp), pcm.nbytes) == 0
+            assert hip.hipMalloc(ctypes.byref(do), S * stride) == 0
+            assert hip.hipMalloc(ctypes.byref(dl), 4 * S) == 0
+            assert hip.hipMemcpy(dp, pcm.ctypes.data, pcm.nbytes, 1) == 0
+            rc = L.mp3mi_batch_encode(b, dp, n_frames, do, stride, dl)
+            assert rc == 0, rc
+            assert L.mp3mi_batch_sync(b) == 0
+            out = np.zeros((S, stride), np.uint8)
+            lens = np.zeros(S, np.uint32)
+            assert hip.hipMemcpy(out.ctypes.data, do, S * stride, 2) == 0
+            assert hip.hipMemcpy(lens.ctypes.data, dl, 4 * S, 2) == 0
+            for p in (dp, do, dl):
+                hip.hipFree(p)
+        G = 2 * n_frames
+        st = {}
+        st["psy"] = np.zeros((S, G, channels), PSY_DT)
+        st["xr"] = np.zeros((S, G, channels, 576))
+        st["ix"] = np.zeros((S, G, channels, 576), np.int16)
+        st["side"] = np.zeros((S, n_frames), SIDE_DT)
+        st["sb"] = np.zeros((S, G, channels, 18, 32))
+        for what, key in ((0, "psy"), (1, "xr"), (2, "ix"), (3, "side"), (4, "sb")):
+            n = L.mp3mi_batch_debug_fetch(b, what, st[key].ctypes.data, st[key].nbytes)
+            assert n == st[key].nbytes, (key, n, st[key].nbytes)
+        return [out[s, :lens[s]].tobytes() for s in range(S)], st
+    finally:
+        L.mp3mi_batch_destroy(b)
+
+
+def compare_stages(st, s, dumps, channels):
+    """Returns a list of mismatch descriptions (empty = identical)."""
+    bad = []
+
+    def chk(where, name, a, b):
+        if not np.array_equal(np.asarray(a), np.asarray(b)):
+            bad.append("%s %s" % (where, name))
+
+    for f in range(len(dumps)):
+        d = dumps[f]
+        for gr in range(2):
+            for c in range(channels):
+                g = 2 * f + gr
+                w = "stream %d frame %d gr %d ch %d" % (s, f, gr, c)
+                p = st["psy"][s, g, c]
+                chk(w, "pe", p["pe"], d["pe"][gr, c])
+                chk(w, "block_type", p["block_type"], d["psy_bt"][gr, c])
+                chk(w, "ratio_l", p["ratio_l"], d["ratio_l"][gr, c])
+                chk(w, "ratio_s", p["ratio_s"], d["ratio_s"][gr, c])
+                chk(w, "subband samples", st["sb"][s, g, c], d["sb"][c, gr])
+                chk(w, "xr", st["xr"][s, g, c], d["xr"][gr, c])
+                chk(w, "|ix|", np.abs(st["ix"][s, g, c].astype(np.int32)), d["l3_enc"][gr, c])
+                sg, gi = st["side"][s, f]["gr"][gr, c], d["gi"][gr, c]
+                for nm in ("part2_3_length", "big_values", "count1", "global_gain", "scalefac_compress",
+                           "window_switching_flag", "block_type", "region0_count", "region1_count", "preflag",
+                           "count1table_select", "part2_length"):
+                    chk(w, nm, sg[nm], gi[GI[nm]])
+                chk(w, "table_select", sg["table_select"], gi[8:11])
+                if sg["window_switching_flag"] and sg["block_type"] == 2:
+                    chk(w, "scalefac_s", sg["scalefac"][:36].reshape(12, 3), d["scalefac_s"][gr, c][:12])
+                else:
+                    chk(w, "scalefac_l", sg["scalefac"][:21], d["scalefac_l"][gr, c][:21])
+        w = "stream %d frame %d" % (s, f)
+        chk(w, "main_data_begin", st["side"][s, f]["main_data_begin"], d["main_data_begin"])
+        chk(w, "resvDrain", st["side"][s, f]["resvDrain"], d["resvDrain"])
+        chk(w, "scfsi", st["side"][s, f]["scfsi"][:channels], d["scfsi"][:channels])
+    return bad
