@@ -1,0 +1,99 @@
+"""mp3-enc-bsd_amd: MI355X-native MPEG-1 Layer III encoding hot path.
+
+The product is the C-ABI shared library next to this file (libmp3mi.so, built from csrc/ by
+`make -C csrc` or `__graft_entry__.build()`); this module is only a thin ctypes binding used by
+bench.py, smoke() and the tests.  There is no Python or CPU implementation of the path here:
+if the library or a GPU is missing, everything fails loudly.
+
+Import with importlib (the directory name carries a hyphen):
+    mp3 = importlib.import_module("mp3-enc-bsd_amd")
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmp3mi.so")
+FRAME_SAMPLES = 1152
+
+
+class Mp3miError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmp3mi.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mp3miError("libmp3mi.so not found at %s -- run __graft_entry__.build()" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.mp3mi_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.mp3mi_batch_destroy.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_out_stride.restype = ctypes.c_size_t
+        L.mp3mi_batch_out_stride.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_batch_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_sync.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+                                              ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+        L.mp3mi_synth_pcm.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+        L.mp3mi_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def frame_bytes(rate_hz, kbps):
+    """slots per frame, never padded (reference: src/musicin.c:562-581)"""
+    return int((1152.0 / (rate_hz / 1000.0)) * (kbps / 8.0))
+
+
+class Batch:
+    """Batched encoder over device memory handed in as torch tensors (device pointers)."""
+
+    def __init__(self, n_streams, rate_hz, channels, kbps, max_frames):
+        import numpy as np
+        self.L = lib()
+        self.n_streams, self.rate_hz, self.channels, self.max_frames = n_streams, rate_hz, channels, max_frames
+        self.h = ctypes.c_void_p()
+        if isinstance(kbps, int):
+            rc = self.L.mp3mi_batch_create(ctypes.byref(self.h), n_streams, rate_hz, channels, None, kbps, max_frames)
+        else:
+            arr = np.ascontiguousarray(kbps, dtype=np.int32)
+            rc = self.L.mp3mi_batch_create(ctypes.byref(self.h), n_streams, rate_hz, channels, arr.ctypes.data, 0, max_frames)
+        if rc != 0:
+            raise Mp3miError("mp3mi_batch_create failed with %d" % rc)
+
+    def out_stride(self, n_frames):
+        return self.L.mp3mi_batch_out_stride(self.h, n_frames)
+
+    def encode(self, pcm, n_frames, out, out_len):
+        """pcm: int16 cuda tensor [S, n_frames*1152*C]; out: uint8 cuda [S, stride]; out_len: int32 cuda [S]."""
+        assert pcm.is_cuda and out.is_cuda and out_len.is_cuda and pcm.is_contiguous() and out.is_contiguous()
+        rc = self.L.mp3mi_batch_encode(self.h, pcm.data_ptr(), n_frames, out.data_ptr(), out.shape[1], out_len.data_ptr())
+        if rc != 0:
+            raise Mp3miError("mp3mi_batch_encode failed with %d" % rc)
+
+    def sync(self):
+        rc = self.L.mp3mi_batch_sync(self.h)
+        if rc != 0:
+            raise Mp3miError("mp3mi_batch_sync failed with %d" % rc)
+
+    def last_timing(self):
+        a, b, n = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
+        self.L.mp3mi_batch_last_timing(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n))
+        return a.value, b.value, n.value
+
+    def close(self):
+        if self.h:
+            self.L.mp3mi_batch_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
