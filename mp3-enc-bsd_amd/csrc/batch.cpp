@@ -185,10 +185,9 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
     b->loop_launches = nchunks;
     CHK(hipEventRecord(b->ev0, b->stream));
     for (int c = 0; c < nchunks; c++) {
-        mp3mi_geom g;
-        g.n_streams = S; g.channels = C; g.rate_idx = b->rate_idx; g.n_frames = n_frames;
-        g.f0 = c * b->chunk_frames;
-        g.nf = (n_frames - g.f0 < b->chunk_frames) ? n_frames - g.f0 : b->chunk_frames;
+        const int f0 = c * b->chunk_frames;
+        const int nf = (n_frames - f0 < b->chunk_frames) ? n_frames - f0 : b->chunk_frames;
+        const mp3mi_geom g = mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
         mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->stream);
         mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->psy, b->stream);
         mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy, b->xr, b->debug ? b->sb_dbg : NULL, b->stream);

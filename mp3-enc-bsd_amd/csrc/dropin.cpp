@@ -1,0 +1,415 @@
+// The reference's per-frame Layer III call surface (include/mp3mi_dropin.h) over the HIP
+// kernels: one hidden default stream, n_streams = 1.  Host code only marshals caller-owned
+// arrays to and from the device and reproduces the caller-visible side effects of each
+// function (savebuf shift, buffer pointer advance, in-place sign flips, back pointer); every
+// number that ends up in the bitstream is computed by the kernels.
+//
+// Error behaviour mirrors the reference: these functions return void, so failures print a
+// message and exit/abort (src/l3psy.c:170-176, src/l3psy.c:665-666, asserts throughout).
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mp3mi_host.h"
+#include "mp3mi.h"
+#include "mp3mi_dropin.h"
+
+size_t mp3mi_psy_state_size(void);
+size_t mp3mi_loop_state_size(void);
+void mp3mi_launch_window_subband(const mp3mi_tables *T, double *ring, int off, const int16_t *new32, double *z, hipStream_t st);
+void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double *s, hipStream_t st);
+void mp3mi_launch_mdct_sub(const mp3mi_tables *T, double *sb, const int32_t *bt, double *xr, int stereo, int mode_gr, hipStream_t st);
+
+#define DIE(...)                                   \
+    do {                                           \
+        fprintf(stderr, "mp3mi (drop-in): ");      \
+        fprintf(stderr, __VA_ARGS__);              \
+        fprintf(stderr, "\n");                     \
+        abort();                                   \
+    } while (0)
+#define HIPOK(call)                                                          \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) DIE("%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+const int WIN_FRAMES = 16; // frames of history kept in the formatter's byte window
+
+// mirrors mp3mi_loop_state in k_loop.hip (all int32)
+struct loop_state_host {
+    int32_t ResvSize;
+    int32_t sc_en_tot[2][2], sc_en[2][2][21], sc_xm[2][2][21], sc_xrmax[2][2];
+    int32_t addr[2][2][3];
+    int32_t pad;
+};
+
+struct DropIn {
+    bool ready = false;
+    int rate_idx = -1;
+    hipStream_t st = 0;
+    mp3mi_tables *T = nullptr;
+    // psy
+    int16_t *pcm_d = nullptr;
+    float *el = nullptr, *es = nullptr, *h6 = nullptr;
+    double *cw = nullptr;
+    void *psy_state = nullptr;
+    mp3mi_psy_out *psy1 = nullptr;
+    // filterbank
+    double *ring = nullptr, *z_d = nullptr, *s_d = nullptr;
+    int16_t *new32 = nullptr;
+    int off[2] = {0, 0};
+    // mdct
+    double *sb_d = nullptr, *xr_d = nullptr;
+    int32_t *bt_d = nullptr;
+    // loop
+    mp3mi_psy_out *psy4 = nullptr;
+    int16_t *ix_d = nullptr;
+    mp3mi_frame_side *side_d = nullptr;
+    void *loop_state = nullptr;
+    int32_t *bits_d = nullptr, *bri_d = nullptr;
+    bool loop_first = true;
+    // format
+    uint8_t *win_d = nullptr;
+    uint32_t *len_d = nullptr;
+    size_t win_bytes = 0;
+    long frames_done = 0, abs_emitted = 0, m_end = 0;
+    int frame_bytes = 0, si_bytes = 0;
+    void (*putbits)(Bit_stream_struc *, unsigned int, int) = nullptr;
+    Bit_stream_struc *bs = nullptr;
+};
+
+DropIn D;
+
+void ensure(int rate_idx)
+{
+    if (D.ready) {
+        if (rate_idx != D.rate_idx) DIE("sampling frequency changed between calls");
+        return;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) DIE("no HIP device available -- this library has no CPU path");
+    mp3mi_tables *Th = (mp3mi_tables *) malloc(sizeof(mp3mi_tables));
+    if (!Th || mp3mi_build_tables(Th, rate_idx) != 0) DIE("cannot build tables for rate index %d", rate_idx);
+    HIPOK(hipStreamCreate(&D.st));
+    HIPOK(hipMalloc((void **) &D.T, sizeof(mp3mi_tables)));
+    HIPOK(hipMemcpy(D.T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
+    free(Th);
+    HIPOK(hipMalloc((void **) &D.pcm_d, 2304 * sizeof(int16_t)));
+    HIPOK(hipMalloc((void **) &D.el, MP3MI_HBLK * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.es, 3 * MP3MI_HBLK_S * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.h6, 12 * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.cw, 50 * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.psy_state, 2 * mp3mi_psy_state_size()));
+    HIPOK(hipMemset(D.psy_state, 0, 2 * mp3mi_psy_state_size()));
+    HIPOK(hipMalloc((void **) &D.psy1, sizeof(mp3mi_psy_out)));
+    HIPOK(hipMalloc((void **) &D.ring, 2 * 512 * sizeof(double)));
+    HIPOK(hipMemset(D.ring, 0, 2 * 512 * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.z_d, 512 * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.s_d, 32 * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.new32, 32 * sizeof(int16_t)));
+    HIPOK(hipMalloc((void **) &D.sb_d, sizeof(L3SBS)));
+    HIPOK(hipMalloc((void **) &D.xr_d, 4 * 576 * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.bt_d, 4 * sizeof(int32_t)));
+    HIPOK(hipMalloc((void **) &D.psy4, 4 * sizeof(mp3mi_psy_out)));
+    HIPOK(hipMalloc((void **) &D.ix_d, 4 * 576 * sizeof(int16_t)));
+    HIPOK(hipMalloc((void **) &D.side_d, sizeof(mp3mi_frame_side)));
+    HIPOK(hipMalloc((void **) &D.loop_state, mp3mi_loop_state_size()));
+    HIPOK(hipMemset(D.loop_state, 0, mp3mi_loop_state_size()));
+    HIPOK(hipMalloc((void **) &D.bits_d, sizeof(int32_t)));
+    HIPOK(hipMalloc((void **) &D.bri_d, sizeof(int32_t)));
+    HIPOK(hipMalloc((void **) &D.len_d, sizeof(uint32_t)));
+    if (sizeof(loop_state_host) != mp3mi_loop_state_size()) DIE("internal: loop state layout mismatch");
+    D.rate_idx = rate_idx;
+    D.ready = true;
+}
+
+int rate_index_of(double sfreq)
+{
+    const unsigned i = (unsigned) (sfreq + 0.5); // src/l3psy.c:168-176
+    switch (i) {
+    case 44100: return 0;
+    case 48000: return 1;
+    case 32000: return 2;
+    default:
+        printf("error, invalid sampling frequency: %d Hz\n", i);
+        exit(-1);
+    }
+}
+
+long emitted_upto(long m, int slot, int frame_bytes, int si_bytes)
+{ // file bytes that are final once m bytes of main data have been written
+    if (m == 0) return 0;
+    return ((m - 1) / slot) * (long) frame_bytes + si_bytes + ((m - 1) % slot) + 1;
+}
+
+void emit(long upto, long base)
+{
+    if (upto <= D.abs_emitted) return;
+    const size_t n = (size_t) (upto - D.abs_emitted);
+    uint8_t *tmp = (uint8_t *) malloc(n);
+    if (D.abs_emitted - base < 0 || (size_t) (upto - base) > D.win_bytes) DIE("internal: formatter window too small");
+    HIPOK(hipMemcpy(tmp, D.win_d + (D.abs_emitted - base), n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) D.putbits(D.bs, tmp[i], 8);
+    free(tmp);
+    D.abs_emitted = upto;
+}
+
+} // namespace
+
+extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int chn, int lay, float snr32[32],
+                              double sfreq, double ratio_d[21], double ratio_ds[12][3], double *pe,
+                              gr_info *cod_info)
+{
+    (void) snr32;
+    if (lay != 3) DIE("L3psycho_anal: layer %d is not served by this library", lay);
+    ensure(rate_index_of(sfreq));
+    // delay line: drop the oldest 576 samples, append the new ones (src/l3psy.c:477-481)
+    memmove(savebuf, savebuf + 576, 768 * sizeof(short));
+    memcpy(savebuf + 768, buffer, 576 * sizeof(short));
+    // present the 1344-sample window to k_fft as granule 2 of a mono pseudo-stream: its window
+    // starts at sample 576*2 - 768 = 384
+    static int16_t host_pcm[2304];
+    memset(host_pcm, 0, sizeof(host_pcm));
+    memcpy(host_pcm + 384, savebuf, 1344 * sizeof(int16_t));
+    HIPOK(hipMemcpyAsync(D.pcm_d, host_pcm, sizeof(host_pcm), hipMemcpyHostToDevice, D.st));
+    mp3mi_geom g = mp3mi_make_geom(1, 1, D.rate_idx, 2, 1, 1);
+    g.g0 = 2;
+    g.n_gran = 1;
+    mp3mi_launch_fft(D.T, g, D.pcm_d, D.el, D.es, D.cw, D.h6, D.st);
+    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.psy1, D.st);
+    mp3mi_psy_out o;
+    HIPOK(hipMemcpyAsync(&o, D.psy1, sizeof(o), hipMemcpyDeviceToHost, D.st));
+    HIPOK(hipStreamSynchronize(D.st));
+    memcpy(ratio_d, o.ratio_l, sizeof(o.ratio_l));
+    memcpy(ratio_ds, o.ratio_s, sizeof(o.ratio_s));
+    *pe = o.pe;
+    cod_info->block_type = (unsigned) o.block_type;
+    cod_info->window_switching_flag = (o.block_type == 0) ? 0 : 1;
+    cod_info->mixed_block_flag = 0;
+}
+
+extern "C" void window_subband(short **buffer, double z[512], int k)
+{
+    if (!D.ready) DIE("window_subband called before L3psycho_anal fixed the sampling frequency");
+    HIPOK(hipMemcpyAsync(D.new32, *buffer, 32 * sizeof(int16_t), hipMemcpyHostToDevice, D.st));
+    *buffer += 32; // src/encode.c:307
+    mp3mi_launch_window_subband(D.T, D.ring + 512 * k, D.off[k], D.new32, D.z_d, D.st);
+    HIPOK(hipMemcpyAsync(z, D.z_d, 512 * sizeof(double), hipMemcpyDeviceToHost, D.st));
+    HIPOK(hipStreamSynchronize(D.st));
+    D.off[k] = (D.off[k] + 480) & 511; // src/encode.c:313-314
+}
+
+extern "C" void filter_subband(double z[512], double s[32])
+{
+    if (!D.ready) DIE("filter_subband called before L3psycho_anal fixed the sampling frequency");
+    HIPOK(hipMemcpyAsync(D.z_d, z, 512 * sizeof(double), hipMemcpyHostToDevice, D.st));
+    mp3mi_launch_filter_subband(D.T, D.z_d, D.s_d, D.st);
+    HIPOK(hipMemcpyAsync(s, D.s_d, 32 * sizeof(double), hipMemcpyDeviceToHost, D.st));
+    HIPOK(hipStreamSynchronize(D.st));
+}
+
+extern "C" void mdct_sub(L3SBS *sb_sample, double (*mdct_freq)[2][576], int stereo, III_side_info_t *l3_side, int mode_gr)
+{
+    if (!D.ready) DIE("mdct_sub called before L3psycho_anal fixed the sampling frequency");
+    if (mode_gr != 2) DIE("mdct_sub: MPEG-2 LSF (mode_gr = %d) is outside this library's scope", mode_gr);
+    int32_t bt[4] = {0, 0, 0, 0};
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < stereo; ch++) bt[gr * 2 + ch] = (int32_t) l3_side->gr[gr].ch[ch].tt.block_type;
+    HIPOK(hipMemcpyAsync(D.sb_d, sb_sample, sizeof(L3SBS), hipMemcpyHostToDevice, D.st));
+    HIPOK(hipMemcpyAsync(D.bt_d, bt, sizeof(bt), hipMemcpyHostToDevice, D.st));
+    mp3mi_launch_mdct_sub(D.T, D.sb_d, D.bt_d, D.xr_d, stereo, mode_gr, D.st);
+    HIPOK(hipMemcpyAsync(sb_sample, D.sb_d, sizeof(L3SBS), hipMemcpyDeviceToHost, D.st));
+    static double xr[2][2][576];
+    HIPOK(hipMemcpyAsync(xr, D.xr_d, sizeof(xr), hipMemcpyDeviceToHost, D.st));
+    HIPOK(hipStreamSynchronize(D.st));
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < stereo; ch++) memcpy(mdct_freq[gr][ch], xr[gr][ch], sizeof(xr[0][0]));
+}
+
+extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy_ratio *ratio, III_side_info_t *l3_side,
+                               int l3_enc[2][2][576], int mean_bits, int stereo, double xr_dec[2][2][576],
+                               III_scalefac_t *scalefac, frame_params *fr_ps, int ancillary_pad, int bitsPerFrame)
+{
+    static unsigned no_partition_table[4] = {0, 0, 0, 0};
+    (void) xr_dec;
+    (void) ancillary_pad;
+    layer *info = fr_ps->header;
+    if (info->version != 1) DIE("iteration_loop: MPEG-2 LSF is outside this library's scope");
+    ensure(info->sampling_frequency);
+    const int C = stereo;
+    if (mean_bits != (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2) DIE("iteration_loop: unexpected mean_bits %d", mean_bits);
+    if (D.loop_first) { // src/loop.c:250-257
+        l3_side->main_data_begin = 0;
+        D.loop_first = false;
+    }
+    // records in the batch layout [gr][ch] for one stream, one frame
+    static mp3mi_psy_out rec[4];
+    static double xr[4][576];
+    memset(rec, 0, sizeof(rec));
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < C; ch++) {
+            mp3mi_psy_out *r = &rec[gr * C + ch];
+            r->pe = pe[gr][ch];
+            memcpy(r->ratio_l, ratio->l[gr][ch], sizeof(r->ratio_l));
+            memcpy(r->ratio_s, ratio->s[gr][ch], sizeof(r->ratio_s));
+            r->block_type = (int32_t) l3_side->gr[gr].ch[ch].tt.block_type;
+            memcpy(xr[gr * C + ch], xr_org[gr][ch], sizeof(xr[0]));
+        }
+    const int32_t bpf = bitsPerFrame;
+    HIPOK(hipMemcpyAsync(D.psy4, rec, sizeof(rec), hipMemcpyHostToDevice, D.st));
+    HIPOK(hipMemcpyAsync(D.xr_d, xr, sizeof(xr), hipMemcpyHostToDevice, D.st));
+    HIPOK(hipMemcpyAsync(D.bits_d, &bpf, sizeof(bpf), hipMemcpyHostToDevice, D.st));
+    const mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1, 0, 1);
+    mp3mi_launch_loop(D.T, g, D.xr_d, D.psy4, D.bits_d, D.loop_state, D.ix_d, D.side_d, D.st);
+    static int16_t ix[4][576];
+    mp3mi_frame_side sd;
+    loop_state_host ls;
+    HIPOK(hipMemcpyAsync(ix, D.ix_d, sizeof(ix), hipMemcpyDeviceToHost, D.st));
+    HIPOK(hipMemcpyAsync(&sd, D.side_d, sizeof(sd), hipMemcpyDeviceToHost, D.st));
+    HIPOK(hipMemcpyAsync(&ls, D.loop_state, sizeof(ls), hipMemcpyDeviceToHost, D.st));
+    HIPOK(hipStreamSynchronize(D.st));
+    l3_side->resvDrain = sd.resvDrain;
+    for (int ch = 0; ch < C; ch++)
+        for (int b = 0; b < 4; b++) l3_side->scfsi[ch][b] = (unsigned) sd.scfsi[ch][b];
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < C; ch++) {
+            const mp3mi_gr_side *s = &sd.gr[gr][ch];
+            gr_info *g2 = &l3_side->gr[gr].ch[ch].tt;
+            const bool shortb = s->window_switching_flag && s->block_type == 2;
+            for (int i = 0; i < 576; i++) { // still non-negative here; signs are applied by III_format_bitstream
+                const int v = ix[gr * C + ch][i];
+                l3_enc[gr][ch][i] = v < 0 ? -v : v;
+            }
+            g2->part2_3_length = (unsigned) s->part2_3_length;
+            g2->big_values = (unsigned) s->big_values;
+            g2->count1 = (unsigned) s->count1;
+            g2->global_gain = (unsigned) s->global_gain;
+            g2->scalefac_compress = (unsigned) s->scalefac_compress;
+            for (int k = 0; k < 3; k++) { g2->table_select[k] = (unsigned) s->table_select[k]; g2->subblock_gain[k] = 0; }
+            g2->region0_count = (unsigned) s->region0_count;
+            g2->region1_count = (unsigned) s->region1_count;
+            g2->preflag = (unsigned) s->preflag;
+            g2->scalefac_scale = 0;
+            g2->count1table_select = (unsigned) s->count1table_select;
+            g2->part2_length = (unsigned) s->part2_length;
+            g2->sfb_lmax = shortb ? 0 : 21; // gr_deco, src/loop.c:2063-2081
+            g2->sfb_smax = shortb ? 0 : 12;
+            g2->address1 = (unsigned) ls.addr[gr][ch][0];
+            g2->address2 = (unsigned) ls.addr[gr][ch][1];
+            g2->address3 = (unsigned) ls.addr[gr][ch][2];
+            g2->quantizerStepSize = (double) (s->global_gain - 210); // global_gain = nint(q + 210), src/loop.c:357
+            g2->sfb_partition_table = no_partition_table;
+            for (int k = 0; k < 4; k++) g2->slen[k] = 0;
+            for (int i = 0; i < 21; i++) scalefac->l[gr][ch][i] = shortb ? 0 : s->scalefac[i];
+            for (int i = 0; i < 13; i++)
+                for (int w = 0; w < 3; w++) scalefac->s[gr][ch][i][w] = (shortb && i < 12) ? s->scalefac[i * 3 + w] : 0;
+        }
+}
+
+extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int l3_enc[2][2][576], III_side_info_t *l3_side,
+                                     III_scalefac_t *scalefac, Bit_stream_struc *bs, double (*xr)[2][576], char *ancillary,
+                                     int anc_bits)
+{
+    (void) ancillary;
+    layer *info = fr_ps->header;
+    if (anc_bits != 0) DIE("III_format_bitstream: ancillary data is not supported");
+    if (info->error_protection) DIE("III_format_bitstream: error protection is not supported (the reference writes a zero CRC)");
+    ensure(info->sampling_frequency);
+    const int C = fr_ps->stereo;
+    if (!D.putbits) {
+        D.putbits = (void (*)(Bit_stream_struc *, unsigned int, int)) dlsym(RTLD_DEFAULT, "putbits");
+        if (!D.putbits) DIE("host program does not export putbits() (link it with -rdynamic)");
+    }
+    D.bs = bs;
+    const int frame_bytes = bitsPerFrame / 8, si_bytes = (32 + (C == 2 ? 256 : 136)) / 8, slot = frame_bytes - si_bytes;
+    if (D.frames_done == 0) {
+        D.frame_bytes = frame_bytes;
+        D.si_bytes = si_bytes;
+        D.win_bytes = (size_t) (WIN_FRAMES + 1) * frame_bytes;
+        if (D.win_d) HIPOK(hipFree(D.win_d));
+        HIPOK(hipMalloc((void **) &D.win_d, D.win_bytes));
+        HIPOK(hipMemset(D.win_d, 0, D.win_bytes));
+        D.abs_emitted = 0;
+        D.m_end = 0;
+    } else if (frame_bytes != D.frame_bytes)
+        DIE("III_format_bitstream: frame length changed (padding is never used by the reference driver)");
+    // signs of the spectrum go onto the quantised values, in place (src/l3bitstream.c:115-125)
+    static int16_t ix[4][576];
+    static mp3mi_frame_side sd;
+    memset(&sd, 0, sizeof(sd));
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < C; ch++) {
+            for (int i = 0; i < 576; i++) {
+                if (xr[gr][ch][i] < 0 && l3_enc[gr][ch][i] > 0) l3_enc[gr][ch][i] *= -1;
+                ix[gr * C + ch][i] = (int16_t) l3_enc[gr][ch][i];
+            }
+            const gr_info *g2 = &l3_side->gr[gr].ch[ch].tt;
+            mp3mi_gr_side *s = &sd.gr[gr][ch];
+            const bool shortb = g2->window_switching_flag && g2->block_type == 2;
+            s->part2_3_length = (int32_t) g2->part2_3_length; s->big_values = (int32_t) g2->big_values;
+            s->count1 = (int32_t) g2->count1; s->global_gain = (int32_t) g2->global_gain;
+            s->scalefac_compress = (int32_t) g2->scalefac_compress;
+            s->window_switching_flag = (int32_t) g2->window_switching_flag; s->block_type = (int32_t) g2->block_type;
+            for (int k = 0; k < 3; k++) s->table_select[k] = (int32_t) g2->table_select[k];
+            s->region0_count = (int32_t) g2->region0_count; s->region1_count = (int32_t) g2->region1_count;
+            s->preflag = (int32_t) g2->preflag; s->count1table_select = (int32_t) g2->count1table_select;
+            s->part2_length = (int32_t) g2->part2_length;
+            if (shortb) for (int i = 0; i < 36; i++) s->scalefac[i] = scalefac->s[gr][ch][i / 3][i % 3];
+            else for (int i = 0; i < 21; i++) s->scalefac[i] = scalefac->l[gr][ch][i];
+        }
+    sd.main_data_begin = l3_side->main_data_begin;
+    sd.resvDrain = l3_side->resvDrain;
+    for (int ch = 0; ch < C; ch++)
+        for (int b = 0; b < 4; b++) sd.scfsi[ch][b] = (int32_t) l3_side->scfsi[ch][b];
+    // slide the byte window so that this frame sits at index widx
+    const long n = D.frames_done;
+    const int widx = (int) (n < WIN_FRAMES ? n : WIN_FRAMES);
+    if (n > WIN_FRAMES) {
+        uint8_t *tmp = NULL;
+        HIPOK(hipMalloc((void **) &tmp, D.win_bytes));
+        HIPOK(hipMemsetAsync(tmp, 0, D.win_bytes, D.st));
+        HIPOK(hipMemcpyAsync(tmp, D.win_d + frame_bytes, D.win_bytes - (size_t) frame_bytes, hipMemcpyDeviceToDevice, D.st));
+        HIPOK(hipStreamSynchronize(D.st));
+        HIPOK(hipFree(D.win_d));
+        D.win_d = tmp;
+    }
+    const long base = (n - widx) * (long) frame_bytes;
+    const int32_t bpf = bitsPerFrame, bri = info->bitrate_index;
+    HIPOK(hipMemcpyAsync(D.ix_d, ix, sizeof(ix), hipMemcpyHostToDevice, D.st));
+    HIPOK(hipMemcpyAsync(D.side_d, &sd, sizeof(sd), hipMemcpyHostToDevice, D.st));
+    HIPOK(hipMemcpyAsync(D.bits_d, &bpf, sizeof(bpf), hipMemcpyHostToDevice, D.st));
+    HIPOK(hipMemcpyAsync(D.bri_d, &bri, sizeof(bri), hipMemcpyHostToDevice, D.st));
+    mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1 << 30, widx, 1);
+    g.hdr_mode = info->mode;
+    g.hdr_flags = ((info->mode_ext & 3) << 4) | ((info->copyright & 1) << 3) | ((info->original & 1) << 2) | (info->emphasis & 3);
+    mp3mi_launch_format(D.T, g, D.ix_d, D.side_d, D.bits_d, D.bri_d, D.win_d, D.win_bytes, D.len_d, D.st);
+    HIPOK(hipStreamSynchronize(D.st));
+    // bytes that are final now = everything up to the end of this frame's main data
+    long bits = sd.resvDrain;
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < C; ch++) bits += sd.gr[gr][ch].part2_3_length;
+    const long m0 = n * (long) slot - l3_side->main_data_begin;
+    if (m0 != D.m_end) DIE("III_format_bitstream: back pointer %d does not match the reservoir", l3_side->main_data_begin);
+    D.m_end = m0 + bits / 8;
+    emit(emitted_upto(D.m_end, slot, frame_bytes, si_bytes), base);
+    D.frames_done = n + 1;
+    // nextBackPtr (src/formatBitstream.c:78-79)
+    l3_side->main_data_begin = (int) (D.frames_done * (long) slot - D.m_end);
+}
+
+extern "C" void III_FlushBitstream(void)
+{
+    if (!D.ready || D.frames_done == 0) return;
+    const int slot = D.frame_bytes - D.si_bytes;
+    const long rem = ((D.m_end + slot - 1) / slot) * slot - D.m_end;
+    const long total = D.frames_done * (long) D.frame_bytes - rem;
+    const long widx = D.frames_done - 1 < WIN_FRAMES ? D.frames_done - 1 : WIN_FRAMES;
+    const long base = (D.frames_done - 1 - widx) * (long) D.frame_bytes;
+    emit(total, base);
+    // src/formatBitstream.c:112-119: the formatter starts over
+    D.frames_done = 0;
+    D.abs_emitted = 0;
+    D.m_end = 0;
+}

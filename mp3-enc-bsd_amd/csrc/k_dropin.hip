@@ -1,0 +1,74 @@
+// Small kernels behind the reference's per-call symbols (include/mp3mi_dropin.h) that have no
+// batched counterpart of the same granularity: window_subband, filter_subband, mdct_sub.  They
+// reuse the device functions of the batched path (fbmdct_dev.h), so the arithmetic is the same
+// code.  L3psycho_anal, iteration_loop and III_format_bitstream reuse k_fft/k_psy, k_loop and
+// k_format directly with n_streams = 1 (dropin.cpp).
+#include "fbmdct_dev.h"
+
+// src/encode.c:287-316: ring[ch] is the 512-entry history x[k][], off the running offset
+__global__ void __launch_bounds__(64) k_window_subband(const mp3mi_tables *__restrict__ T, double *__restrict__ ring,
+                                                       int off, const int16_t *__restrict__ new32,
+                                                       double *__restrict__ z)
+{
+    const int lane = wave_lane();
+    if (lane < 32) ring[(31 - lane + off) & 511] = (double) new32[lane] * (1.0 / 32768.0);
+    __syncthreads();
+    for (int i = lane; i < 512; i += 64) z[i] = ring[(i + off) & 511] * T->enwindow[i];
+}
+
+// src/encode.c:361-409
+__global__ void __launch_bounds__(64) k_filter_subband(const mp3mi_tables *__restrict__ T, const double *__restrict__ z,
+                                                       double *__restrict__ s)
+{
+    __shared__ double y[64];
+    const int lane = wave_lane();
+    double acc = z[lane];
+    for (int k = 1; k < 8; k++) acc = acc + z[lane + 64 * k];
+    y[lane] = acc;
+    __syncthreads();
+    if (lane < 32) {
+        double frow[31];
+        for (int j = 0; j < 31; j++) frow[j] = T->filt[lane][j];
+        s[lane] = fbm_matrix(y, frow);
+    }
+}
+
+// src/mdct.c:25-103: sb is the caller's L3SBS [2][3][18][32]; bt[gr][ch]; xr [gr][ch][576]
+__global__ void __launch_bounds__(64) k_mdct_sub(const mp3mi_tables *__restrict__ T, double *__restrict__ sb,
+                                                 const int32_t *__restrict__ bt, double *__restrict__ xr, int mode_gr)
+{
+    __shared__ fbm_lds L;
+    const int lane = wave_lane(), ch = (int) blockIdx.x;
+    double *sbc = sb + (size_t) ch * 3 * 576;
+    fbm_load_tables(L, T);
+    for (int gr = 0; gr < mode_gr; gr++) {
+        for (int i = lane; i < 576; i += 64) {
+            const int slot = i / 32, sub = i % 32;
+            double v = sbc[(gr + 1) * 576 + i];
+            if ((sub & 1) && (slot & 1)) v = v * -1.0;
+            sbc[(gr + 1) * 576 + i] = v;
+            L.sb[1][slot][sub] = v;
+            L.sb[0][slot][sub] = sbc[gr * 576 + i];
+        }
+        __syncthreads();
+        fbm_mdct_granule(L, T, bt[gr * 2 + ch]);
+        for (int i = lane; i < 576; i += 64) xr[((size_t) gr * 2 + ch) * 576 + i] = L.xr[i];
+        __syncthreads();
+    }
+    for (int i = lane; i < 576; i += 64) sbc[i] = sbc[mode_gr * 576 + i];
+}
+
+void mp3mi_launch_window_subband(const mp3mi_tables *T, double *ring, int off, const int16_t *new32, double *z, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_window_subband, dim3(1), dim3(64), 0, st, T, ring, off, new32, z);
+}
+
+void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double *s, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_filter_subband, dim3(1), dim3(64), 0, st, T, z, s);
+}
+
+void mp3mi_launch_mdct_sub(const mp3mi_tables *T, double *sb, const int32_t *bt, double *xr, int stereo, int mode_gr, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_mdct_sub, dim3((unsigned) stereo), dim3(64), 0, st, T, sb, bt, xr, mode_gr);
+}

@@ -117,13 +117,13 @@ __global__ void __launch_bounds__(64) k_fft(const mp3mi_tables *__restrict__ T, 
 {
     __shared__ fft_lds L;
     const int lane = wave_lane();
-    const int C = geo.channels, G = 2 * geo.nf;
+    const int C = geo.channels, G = geo.n_gran;
     int bid = (int) blockIdx.x;
     const int ch = bid % C; bid /= C;
     const int gl = bid % G;
     const int s = bid / G;
     const size_t rec = ((size_t) s * G + gl) * C + ch;
-    const long gabs = 2L * geo.f0 + gl;
+    const long gabs = (long) geo.g0 + gl;
     const long n_per_ch = (long) geo.n_frames * 1152;
     const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_per_ch * (size_t) C;
     const long t0 = 576 * gabs - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
@@ -184,6 +184,6 @@ __global__ void __launch_bounds__(64) k_fft(const mp3mi_tables *__restrict__ T, 
 void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, float *energy_l,
                       float *energy_s, double *cw_mid, float *hist6, hipStream_t st)
 {
-    const unsigned grid = (unsigned) (g.n_streams * 2 * g.nf * g.channels);
+    const unsigned grid = (unsigned) (g.n_streams * g.n_gran * g.channels);
     hipLaunchKernelGGL(k_fft, dim3(grid), dim3(64), 0, st, T, g, pcm, energy_l, energy_s, cw_mid, hist6);
 }

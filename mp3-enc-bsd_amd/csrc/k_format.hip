@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
 {
     __shared__ fmt_lds L;
     const int lane = wave_lane();
-    const int C = geo.channels, G = 2 * geo.nf;
+    const int C = geo.channels, G = geo.n_gran;
     const int fl = (int) blockIdx.x % geo.nf, s = (int) blockIdx.x / geo.nf;
     const long n_abs = (long) geo.f0 + fl;
     const mp3mi_frame_side *sd = &side_all[(size_t) s * geo.nf + fl];
@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
         fmt_put(L.si, pos, (unsigned) bitrate_index[s], 4); pos += 4;
         fmt_put(L.si, pos, (unsigned) T->rate_idx, 2); pos += 2;
         pos += 2;                                                 // padding 0, extension 0
-        fmt_put(L.si, pos, (C == 1) ? 3u : 0u, 2); pos += 2;      // mode
-        pos += 6;                                                 // mode_ext, copyright, original, emphasis
+        fmt_put(L.si, pos, (unsigned) geo.hdr_mode, 2); pos += 2; // mode
+        fmt_put(L.si, pos, (unsigned) geo.hdr_flags, 6); pos += 6; // mode_ext, copyright, original, emphasis
         fmt_put(L.si, pos, (unsigned) sd->main_data_begin, 9); pos += 9;
         pos += (C == 2) ? 3 : 5;                                  // private_bits 0
         for (int ch = 0; ch < C; ch++)

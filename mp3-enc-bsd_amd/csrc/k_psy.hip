@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64) k_psy(const mp3mi_tables *__restrict__ T, 
 {
     __shared__ psy_lds L;
     const int lane = wave_lane();
-    const int C = geo.channels, G = 2 * geo.nf;
+    const int C = geo.channels, G = geo.n_gran;
     const int ch = (int) blockIdx.x % C, s = (int) blockIdx.x / C;
     mp3mi_psy_state *st = &state[(size_t) s * C + ch];
     const int b = lane; // partition owned by this lane (lane 63 idles in partition loops)

@@ -18,9 +18,22 @@ int mp3mi_build_tables(mp3mi_tables *T, int rate_idx);
 /* kernel launchers (one per .hip file); all take device pointers */
 struct mp3mi_geom {
     int n_streams, channels, rate_idx;
-    int n_frames;       /* frames per stream in this call */
+    int n_frames;       /* frames per stream in this call (PCM extent = n_frames*1152 per channel) */
     int f0, nf;         /* frames [f0, f0+nf) form the current chunk */
+    int g0, n_gran;     /* granules [g0, g0+n_gran) of the chunk: 2*f0, 2*nf for the batch path */
+    int hdr_mode;       /* header mode field (src/common.h:233-236): 0 stereo, 2 dual, 3 mono */
+    int hdr_flags;      /* bit 3 copyright, bit 2 original, bits 1-0 emphasis, bits 5-4 mode_ext */
 };
+
+static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_idx, int n_frames, int f0, int nf)
+{
+    mp3mi_geom g;
+    g.n_streams = n_streams; g.channels = channels; g.rate_idx = rate_idx; g.n_frames = n_frames;
+    g.f0 = f0; g.nf = nf; g.g0 = 2 * f0; g.n_gran = 2 * nf;
+    g.hdr_mode = (channels == 1) ? 3 : 0;
+    g.hdr_flags = 0;
+    return g;
+}
 
 void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
                       float *energy_l, float *energy_s, double *cw_mid, float *hist6, hipStream_t st);

@@ -1,0 +1,58 @@
+"""Drop-in boundary: the reference's UNCHANGED driver objects (musicin.o, common.o, ... compiled
+from /root/reference/src into oracle/_ref/obj here) linked against the product library instead
+of the reference's Layer III objects must produce the reference's MP3 byte for byte.
+
+ * encode_dropin_emu: linked against the emulated CPU test build  -> runs in the CPU suite
+ * encode_dropin:     linked against libmp3mi.so (HIP)            -> runs with -m gpu
+Both binaries are built by `make -C oracle _ref/encode_dropin[_emu]` where the reference exists
+and travel with the repo; the tests skip where they are absent."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from mp3common import ROOT, SEED
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def write_wav(path, pcm, ch, rate):
+    data = pcm.astype("<i2").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " +
+                struct.pack("<IHHIIHH", 16, 1, ch, rate, rate * ch * 2, ch * 2, 16) + b"data" + struct.pack("<I", len(data)) + data)
+
+
+def run_cli(binary, wav, mp3, rate, kbps, mono):
+    args = [os.path.join(REF, binary), "-s", "%g" % (rate / 1000.0), "-b", str(kbps)]
+    if mono:
+        args += ["-m", "m"]
+    subprocess.run(args + [str(wav), str(mp3)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(mp3, "rb").read()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "encode_dropin_emu")), reason="oracle/_ref/encode_dropin_emu not built")
+def test_reference_driver_over_emulated_library(emu, oracle, tmp_path):
+    rate, ch, kbps = 44100, 2, 128
+    pcm = emu.synth(1152 * 6 + 500, ch, rate, 5, SEED)
+    write_wav(tmp_path / "a.wav", pcm, ch, rate)
+    got = run_cli("encode_dropin_emu", tmp_path / "a.wav", tmp_path / "a.mp3", rate, kbps, False)
+    ref, _ = oracle.encode(pcm, rate, kbps, ch)
+    assert got == ref
+    if os.path.exists(os.path.join(REF, "encode")):
+        assert got == run_cli("encode", tmp_path / "a.wav", tmp_path / "r.mp3", rate, kbps, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "encode_dropin")), reason="oracle/_ref/encode_dropin not built")
+@pytest.mark.parametrize("rate,ch,kbps,frames", [(44100, 2, 128, 40), (32000, 1, 64, 30), (48000, 2, 320, 25)])
+def test_reference_driver_over_hip_library(product, oracle, tmp_path, rate, ch, kbps, frames):
+    pcm = product.synth(1152 * frames - 300, ch, rate, 21, SEED)
+    write_wav(tmp_path / "a.wav", pcm, ch, rate)
+    got = run_cli("encode_dropin", tmp_path / "a.wav", tmp_path / "a.mp3", rate, kbps, ch == 1)
+    ref, _ = oracle.encode(pcm, rate, kbps, ch)
+    assert got == ref
+    if os.path.exists(os.path.join(REF, "encode")):
+        assert got == run_cli("encode", tmp_path / "a.wav", tmp_path / "r.mp3", rate, kbps, ch == 1)
