@@ -9,6 +9,15 @@ __global__ void k_debug_dmath(int fn, const double *__restrict__ x, const double
                               double *__restrict__ out, size_t n)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (fn >= 20) { // wave-reduction self-tests: n must be a multiple of 64, every lane active
+        const int v = (int) x[i];
+        int r = 0;
+        if (fn == 20) r = wave_sum_i32(v);
+        else if (fn == 21) r = wave_max_i32(v);
+        else if (fn == 22) r = wave_readlane_i32(v, (int) y[i & ~(size_t) 63]);
+        out[i] = (double) r;
+        return;
+    }
     if (i >= n) return;
     double r = 0.0, s, c;
     switch (fn) {

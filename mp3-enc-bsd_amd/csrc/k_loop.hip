@@ -5,15 +5,19 @@
 // src/pow_nint.h, src/reservoir.c) for a whole batch.  The search is serial per stream (the
 // reservoir size threads through every granule), so ONE WAVEFRONT OWNS ONE STREAM and walks its
 // frames in order; the 64 lanes share each granule's 576 lines (line i lives in lane i%64,
-// register slot i/64), all loop decisions are wave-uniform, bit counts are wave-reduced.
+// register slot i/64), all loop decisions are wave-uniform, bit counts are wave-reduced (DPP).
 //
 // Order-sensitive f64 sums (band energies, noise, the 576-term sums of calc_scfsi and
 // quantanf_init) are formed by ONE lane per band in the reference's index order after the
 // terms were computed in parallel; integer work is order-free.
 //
+// Small tables the search consults with wave-uniform indices (scalefactor band edges, Huffman
+// table geometry, the region subdivision table) live one entry per lane in registers and are
+// read with v_readlane; per-line Huffman code lengths sit in LDS; the quantiser boundary table
+// and i^(4/3) are read through L1/L2.
+//
 // HBM per (granule, channel): 4608 B xr in, 472 B psy record in, 1152 B ix out, ~54 words of
-// side information out.  Tables that are hit per line (Huffman lengths) sit in LDS; the
-// quantiser boundary table and i^(4/3) are read through L1/L2.
+// side information out.
 #include "mp3mi_host.h"
 #include "dmath.h"
 
@@ -38,31 +42,37 @@ struct loop_lds {
     int16_t ix[576 + 8];
     uint8_t hlen[1440];
     int sf[64], sfsave[64], sf_gr0[2][21], ampflag[64];
-    int sfb_l[23], sfb_s[14];
     int ibcast[4];
     mp3mi_loop_state st;
     mp3mi_frame_side side;
 };
 
+// one entry per lane, read with wave_readlane_i32(reg, uniform index)
+struct loop_regs {
+    int sfb_l;   // lane < 23: long scalefactor band edge
+    int sfb_s;   // lane < 14: short scalefactor band edge
+    int subdv;   // lane < 23: region0_count | region1_count << 8 (src/loop.c:1596-1625)
+    int ht;      // lane < 34: ht_off | ylen << 16 | linbits << 24
+};
+
 __device__ static const int LOOP_PRETAB[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 3, 2};
 __device__ static const int LOOP_SLEN1[16] = {0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
 __device__ static const int LOOP_SLEN2[16] = {0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3};
-__device__ static const int LOOP_SUBDV[23][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 1}, {1, 1}, {1, 1},
-    {1, 2}, {2, 2}, {2, 3}, {2, 3}, {3, 4}, {3, 4}, {3, 4}, {4, 5}, {4, 5}, {4, 6}, {5, 6}, {5, 6}, {5, 7}, {6, 7}, {6, 7}};
+__device__ static const unsigned char LOOP_SUBDV0[23] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 6};
+__device__ static const unsigned char LOOP_SUBDV1[23] = {0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6, 7, 7, 7};
 
 MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int) (in + 0.5); } // src/loop.c:2020
 
 // ---- quantiser: ix = max{p in [0,2047] : tab[p] <= x}  (src/pow_nint.h:15-49, src/loop.c:1360-1428) ----
 // A float estimate of x^(3/4)+0.4054 settles every line that is not within 2^-9 of a table
 // boundary; the others are settled against the exact table.  The result never depends on the
-// quality of the estimate.
-MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double xr[9], int q)
+// quality of the estimate.  Leaves the values in p[] and in L.ix (followed by a barrier).
+MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double xr[9], int q, int p[9])
 {
     const int lane = wave_lane();
     const double step = T->step[q - MP3MI_STEP_MIN];
     const double ostep = 1.0 / step;
     const double tab1 = T->pow_nint_tab[1], tab2047 = T->pow_nint_tab[2047];
-    int p[9];
     unsigned need = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
@@ -74,9 +84,10 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double 
             const float f = __builtin_sqrtf(xf * __builtin_sqrtf(xf)) + 0.4054f;
             const float fl = __builtin_floorf(f);
             const float fr = f - fl;
-            p[j] = (int) fl;
-            if (p[j] < 1) p[j] = 1;
-            if (p[j] > 2046) p[j] = 2046;
+            int pj = (int) fl;
+            pj = pj < 1 ? 1 : pj;
+            pj = pj > 2046 ? 2046 : pj;
+            p[j] = pj;
             if (!(fr > 0.002f && fr < 0.998f)) need |= 1u << j;
         }
     }
@@ -97,29 +108,51 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double 
     __syncthreads();
 }
 
-// cost in bits of one (x, y) pair in Huffman table t (src/loop.c:172-225)
-MP3MI_DEVFN int loop_pair_bits(const mp3mi_tables *T, const loop_lds &L, int t, int x, int y)
+// geometry of Huffman table t (wave-uniform t)
+struct loop_ht { int off, ylen, linbits; };
+MP3MI_DEVFN loop_ht loop_table(const loop_regs &R, int t)
+{
+    const int v = wave_readlane_i32(R.ht, t);
+    loop_ht h;
+    h.off = v & 0xffff;
+    h.ylen = (v >> 16) & 0xff;
+    h.linbits = (v >> 24) & 0xff;
+    return h;
+}
+
+// cost in bits of one (x, y) pair in Huffman table t with geometry h (src/loop.c:172-225)
+MP3MI_DEVFN int loop_pair_bits(const loop_lds &L, int t, const loop_ht &h, int x, int y)
 {
     int bits = (x != 0) + (y != 0);
     if (t > 15) {
-        const int lb = T->ht_linbits[t];
-        if (x > 14) { x = 15; bits += lb; }
-        if (y > 14) { y = 15; bits += lb; }
+        if (x > 14) { x = 15; bits += h.linbits; }
+        if (y > 14) { y = 15; bits += h.linbits; }
     }
-    return bits + L.hlen[T->ht_off[t] + x * T->ht_ylen[t] + y];
+    return bits + L.hlen[h.off + x * h.ylen + y];
+}
+
+// first table without / with linbits that can hold `max` (the searches over ht[].xlen and
+// ht[].linmax of src/loop.c:1812-1817, 1872-1888, 1919-1939 written as comparisons)
+MP3MI_DEVFN int loop_first_table(int max)
+{
+    if (max < 15) return max <= 1 ? 1 : (max == 2 ? 2 : (max == 3 ? 5 : (max <= 5 ? 7 : (max <= 7 ? 10 : 13))));
+    const int m = max - 15;
+    return m <= 0 ? 15 : (m <= 1 ? 16 : (m <= 3 ? 17 : (m <= 7 ? 18 : (m <= 15 ? 19 : (m <= 63 ? 20 : (m <= 255 ? 21 : (m <= 1023 ? 22 : 23)))))));
+}
+MP3MI_DEVFN int loop_second_linbits_table(int max)
+{
+    const int m = max - 15;
+    return m <= 15 ? 24 : (m <= 31 ? 25 : (m <= 63 ? 26 : (m <= 127 ? 27 : (m <= 255 ? 28 : (m <= 511 ? 29 : (m <= 2047 ? 30 : 31))))));
 }
 
 // candidate tables of new_choose_table for a region maximum (src/loop.c:1793-1897); returns count
-MP3MI_DEVFN int loop_candidates(const mp3mi_tables *T, int max, int cand[3])
+MP3MI_DEVFN int loop_candidates(int max, int cand[3])
 {
     cand[0] = cand[1] = cand[2] = 0;
     if (max == 0) return 0;
+    cand[0] = loop_first_table(max);
     if (max < 15) {
-        int c = 0;
-        for (int i = 0; i < 14; i++)
-            if ((int) T->ht_xlen[i] > max) { c = i; break; }
-        cand[0] = c;
-        switch (c) {
+        switch (cand[0]) {
         case 2: cand[1] = 3; return 2;
         case 5: cand[1] = 6; return 2;
         case 7: cand[1] = 8; cand[2] = 9; return 3;
@@ -128,11 +161,7 @@ MP3MI_DEVFN int loop_candidates(const mp3mi_tables *T, int max, int cand[3])
         default: return 1;
         }
     }
-    max -= 15;
-    for (int i = 15; i < 24; i++)
-        if ((int) T->ht_linmax[i] >= max) { cand[0] = i; break; }
-    for (int i = 24; i < 32; i++)
-        if ((int) T->ht_linmax[i] >= max) { cand[1] = i; break; }
+    cand[1] = loop_second_linbits_table(max);
     return -2; // linbits pair: strict '<' tie-break
 }
 
@@ -146,23 +175,10 @@ MP3MI_DEVFN int loop_pick(int n, const int cand[3], const int sum[3])
     return choice;
 }
 
-MP3MI_DEVFN int loop_choose_table_short(const mp3mi_tables *T, int max)
-{ // choose_table, src/loop.c:1908-1947
-    if (max == 0) return 0;
-    if (max < 15) {
-        for (int i = 0; i < 15; i++)
-            if ((int) T->ht_xlen[i] > max) return i;
-        return 0;
-    }
-    max -= 15;
-    for (int i = 15; i < 32; i++)
-        if ((int) T->ht_linmax[i] >= max) return i;
-    return 0;
-}
-
-// calc_runlen + count1_bitcount + subdivide + bigv_tab_select + bigv_bitcount on L.ix
-// (src/loop.c:1488-2014).  Returns the Huffman bit count and fills g.
-MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, loop_lds &L, loop_gr &g)
+// calc_runlen + count1_bitcount + subdivide + bigv_tab_select + bigv_bitcount
+// (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
+// Returns the Huffman bit count and fills g.
+MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9])
 {
     const int lane = wave_lane();
     const bool shortb = g.wsf && g.block_type == 2;
@@ -174,9 +190,9 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, loop_lds &L, loop_gr &g)
     } else {
         // highest line with ix != 0 and highest line with ix > 1, via ballots over 64-line rows
         int top_nz = -1, top_big = -1;
+#pragma unroll
         for (int j = 8; j >= 0; j--) {
-            const int v = L.ix[lane + 64 * j];
-            const unsigned long long mnz = __ballot(v != 0), mbig = __ballot(v > 1);
+            const unsigned long long mnz = __ballot(p[j] != 0), mbig = __ballot(p[j] > 1);
             if (top_nz < 0 && mnz) top_nz = 64 * j + 63 - __clzll((long long) mnz);
             if (top_big < 0 && mbig) top_big = 64 * j + 63 - __clzll((long long) mbig);
         }
@@ -185,15 +201,16 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, loop_lds &L, loop_gr &g)
         g.big_values = (i0 - 4 * g.count1) / 2;
         // count1 region: table A vs table B
         int s01 = 0;
+        const int offA = wave_readlane_i32(R.ht, 32) & 0xffff, offB = wave_readlane_i32(R.ht, 33) & 0xffff;
         for (int qd = lane; qd < g.count1; qd += 64) {
             const int i = 2 * g.big_values + 4 * qd;
             const int v = L.ix[i], w = L.ix[i + 1], x = L.ix[i + 2], y = L.ix[i + 3];
-            const int p = v + (w << 1) + (x << 2) + (y << 3);
+            const int pp = v + (w << 1) + (x << 2) + (y << 3);
             const int sg = (v != 0) + (w != 0) + (x != 0) + (y != 0);
-            s01 += (sg + L.hlen[T->ht_off[32] + p]) | ((sg + L.hlen[T->ht_off[33] + p]) << 16);
+            s01 += (sg + L.hlen[offA + pp]) | ((sg + L.hlen[offB + pp]) << 16);
         }
         s01 = wave_sum_i32(s01);
-        const int sum0 = s01 & 0xffff, sum1 = s01 >> 16;
+        const int sum0 = s01 & 0xffff, sum1 = (s01 >> 16) & 0xffff;
         if (sum0 < sum1) { g.count1table_select = 0; bits = sum0; }
         else { g.count1table_select = 1; bits = sum1; }
     }
@@ -204,44 +221,48 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, loop_lds &L, loop_gr &g)
     } else {
         const int bvr = 2 * g.big_values;
         if (g.wsf == 0) {
-            int anz = 0;
-            while (L.sfb_l[anz] < bvr) anz++;
-            int cnt = LOOP_SUBDV[anz][0], idx = cnt + 1;
-            while (cnt && L.sfb_l[idx] > bvr) { cnt--; idx--; }
-            g.region0_count = cnt;
-            cnt = LOOP_SUBDV[anz][1];
-            idx = g.region0_count + cnt + 2;
-            while (cnt && L.sfb_l[idx] > bvr) { cnt--; idx--; }
-            g.region1_count = cnt;
-            g.address1 = L.sfb_l[g.region0_count + 1];
-            g.address2 = L.sfb_l[g.region0_count + g.region1_count + 2];
+            // scfb_anz = number of band edges below bvr; K = last edge not above bvr
+            const int anz = __popcll(__ballot(lane < 23 && R.sfb_l < bvr));
+            const int K = __popcll(__ballot(lane < 23 && R.sfb_l <= bvr)) - 1;
+            const int sd = wave_readlane_i32(R.subdv, anz);
+            int c0 = sd & 0xff, c1 = (sd >> 8) & 0xff;
+            const int lim0 = K - 1 > 0 ? K - 1 : 0;
+            c0 = c0 < lim0 ? c0 : lim0;          // while (cnt && edge[cnt+1] > bvr) cnt--
+            const int lim1 = K - c0 - 2 > 0 ? K - c0 - 2 : 0;
+            c1 = c1 < lim1 ? c1 : lim1;          // while (cnt && edge[r0+cnt+2] > bvr) cnt--
+            g.region0_count = c0;
+            g.region1_count = c1;
+            g.address1 = wave_readlane_i32(R.sfb_l, c0 + 1);
+            g.address2 = wave_readlane_i32(R.sfb_l, c0 + c1 + 2);
             g.address3 = bvr;
         } else if (g.block_type == 2) {
             g.region0_count = 8; g.region1_count = 36;
             g.address1 = 36; g.address2 = bvr; g.address3 = 0;
         } else {
             g.region0_count = 7; g.region1_count = 13;
-            g.address1 = L.sfb_l[8]; g.address2 = bvr; g.address3 = 0;
+            g.address1 = wave_readlane_i32(R.sfb_l, 8); g.address2 = bvr; g.address3 = 0;
         }
     }
     g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
     if (shortb) {
         // region maxima over lines [0,36) and [36,576); pair (6m+w, 6m+3+w), m<96, w<3
         int m1 = 0, m2 = 0;
+#pragma unroll
         for (int j = 0; j < 9; j++) {
-            const int i = lane + 64 * j, v = L.ix[i];
-            if (i < 36) m1 = v > m1 ? v : m1; else m2 = v > m2 ? v : m2;
+            const int i = lane + 64 * j;
+            if (i < 36) m1 = p[j] > m1 ? p[j] : m1; else m2 = p[j] > m2 ? p[j] : m2;
         }
         m1 = wave_max_i32(m1);
         m2 = wave_max_i32(m2);
-        const int t0 = loop_choose_table_short(T, m1), t1 = loop_choose_table_short(T, m2);
+        const int t0 = (m1 == 0) ? 0 : loop_first_table(m1), t1 = (m2 == 0) ? 0 : loop_first_table(m2); // choose_table
         g.table_select[0] = t0;
         g.table_select[1] = t1;
+        const loop_ht h0 = loop_table(R, t0), h1 = loop_table(R, t1);
         int sum = 0;
-        for (int p = lane; p < 288; p += 64) {
-            const int m = p / 3, w = p - 3 * m;
-            const int t = (m < 6) ? t0 : t1;
-            if (t) sum += loop_pair_bits(T, L, t, L.ix[6 * m + w], L.ix[6 * m + 3 + w]);
+        for (int pr = lane; pr < 288; pr += 64) {
+            const int m = pr / 3, w = pr - 3 * m;
+            if (m < 6) { if (t0) sum += loop_pair_bits(L, t0, h0, L.ix[6 * m + w], L.ix[6 * m + 3 + w]); }
+            else if (t1) sum += loop_pair_bits(L, t1, h1, L.ix[6 * m + w], L.ix[6 * m + 3 + w]);
         }
         return wave_sum_i32(sum);
     }
@@ -251,28 +272,35 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, loop_lds &L, loop_gr &g)
     beg[1] = g.address1; end[1] = g.address2; en[1] = g.address2 > g.address1;
     beg[2] = g.address2; end[2] = 2 * g.big_values; en[2] = 2 * g.big_values > g.address2;
     int mx[3] = {0, 0, 0};
+#pragma unroll
     for (int j = 0; j < 9; j++) {
-        const int i = lane + 64 * j, v = L.ix[i];
+        const int i = lane + 64 * j;
 #pragma unroll
         for (int r = 0; r < 3; r++)
-            if (en[r] && i >= beg[r] && i < end[r]) mx[r] = v > mx[r] ? v : mx[r];
+            if (en[r] && i >= beg[r] && i < end[r]) mx[r] = p[j] > mx[r] ? p[j] : mx[r];
     }
     int cand[3][3], nc[3];
+    loop_ht ht[3][3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         mx[r] = en[r] ? wave_max_i32(mx[r]) : 0;
-        nc[r] = loop_candidates(T, mx[r], cand[r]);
+        nc[r] = loop_candidates(mx[r], cand[r]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) ht[r][c] = loop_table(R, cand[r][c]);
     }
-    // cost of every candidate over its region
+    // cost of every candidate over its region; x and y of a pair come as one 32-bit LDS word
     int acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int p = lane; p < 288; p += 64) {
-        const int i = 2 * p, x = L.ix[i], y = L.ix[i + 1];
+    const unsigned *ixw = (const unsigned *) L.ix;
+    for (int pr = lane; pr < 288; pr += 64) {
+        const int i = 2 * pr;
+        const unsigned xy = ixw[pr];
+        const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             if (nc[r] != 0 && i >= beg[r] && i < end[r]) {
 #pragma unroll
                 for (int c = 0; c < 3; c++)
-                    if (cand[r][c]) acc[r][c] += loop_pair_bits(T, L, cand[r][c], x, y);
+                    if (cand[r][c]) acc[r][c] += loop_pair_bits(L, cand[r][c], ht[r][c], x, y);
             }
         }
     }
@@ -281,8 +309,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, loop_lds &L, loop_gr &g)
     for (int r = 0; r < 3; r++) {
         if (nc[r] == 0) continue;
         int sum[3];
-        // two 16-bit fields per reduction where possible
-        const int s01 = wave_sum_i32(acc[r][0] | (acc[r][1] << 16));
+        const int s01 = wave_sum_i32(acc[r][0] | (acc[r][1] << 16)); // two 16-bit fields per reduction
         sum[0] = s01 & 0xffff;
         sum[1] = (s01 >> 16) & 0xffff;
         sum[2] = cand[r][2] ? wave_sum_i32(acc[r][2]) : 0;
@@ -295,11 +322,12 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, loop_lds &L, loop_gr &g)
     if (g.table_select[1]) bits += sel_sum[1];
     if (g.table_select[2]) {
         if (g.address3 == end[2]) bits += sel_sum[2];
-        else { // unreachable for consistent state; count explicitly to stay faithful
+        else { // cannot happen for a consistent state; counted explicitly to stay faithful
+            const loop_ht h2 = loop_table(R, g.table_select[2]);
             int sum = 0;
-            for (int p = lane; p < 288; p += 64) {
-                const int i = 2 * p;
-                if (i >= g.address2 && i < g.address3) sum += loop_pair_bits(T, L, g.table_select[2], L.ix[i], L.ix[i + 1]);
+            for (int pr = lane; pr < 288; pr += 64) {
+                const int i = 2 * pr;
+                if (i >= g.address2 && i < g.address3) sum += loop_pair_bits(L, g.table_select[2], h2, L.ix[i], L.ix[i + 1]);
             }
             bits += wave_sum_i32(sum);
         }
@@ -319,28 +347,48 @@ MP3MI_DEVFN int loop_part2_length(const loop_lds &L, const loop_gr &g, int gr, i
     return bits;
 }
 
-// sequential per-band sum of L.tmp over the band's lines; valid on band lanes only
-MP3MI_DEVFN double loop_band_sum(const loop_lds &L, bool shortb, int lane, double *bw)
+// Sequential sum over L.tmp[first + k*stride], k < count, in index order.  Every lane of the
+// wave runs the same loop with its own range, so the band sums and the 576-term total overlap.
+// Loads are issued eight at a time so that only the add chain is serial.
+MP3MI_DEVFN double loop_seq_sum(const loop_lds &L, int first, int count, int stride)
 {
     double sum = 0.0;
-    if (!shortb) {
-        const int s0 = L.sfb_l[lane], s1 = L.sfb_l[lane + 1];
-        for (int l = s0; l < s1; l++) sum = sum + L.tmp[l];
-        *bw = (double) (s1 - s0);
-    } else {
-        const int sfb = lane / 3, w = lane - 3 * sfb;
-        const int s0 = L.sfb_s[sfb], s1 = L.sfb_s[sfb + 1];
-        for (int l = s0; l < s1; l++) sum = sum + L.tmp[l * 3 + w];
-        *bw = (double) (s1 - s0);
+    int k = 0;
+    for (; k + 8 <= count; k += 8) {
+        const double *q = &L.tmp[first + k * stride];
+        const double t0 = q[0], t1 = q[stride], t2 = q[2 * stride], t3 = q[3 * stride];
+        const double t4 = q[4 * stride], t5 = q[5 * stride], t6 = q[6 * stride], t7 = q[7 * stride];
+        sum = sum + t0; sum = sum + t1; sum = sum + t2; sum = sum + t3;
+        sum = sum + t4; sum = sum + t5; sum = sum + t6; sum = sum + t7;
     }
+    for (; k < count; k++) sum = sum + L.tmp[first + k * stride];
     return sum;
 }
 
-__global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
-                                             const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
-                                             const int32_t *__restrict__ bits_per_frame,
-                                             mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
-                                             mp3mi_frame_side *__restrict__ side_out)
+// range of L.tmp a lane sums: band lanes their band, lane 63 all 576 lines, other lanes nothing
+MP3MI_DEVFN void loop_sum_range(const loop_regs &R, bool shortb, int nband, int *first, int *count, int *stride)
+{
+    const int lane = wave_lane();
+    const int sfb = shortb ? lane / 3 : lane;
+    const int w = shortb ? lane - 3 * sfb : 0;
+    const int src = shortb ? R.sfb_s : R.sfb_l;
+    const int e0 = __shfl(src, sfb < 22 ? sfb : 22), e1 = __shfl(src, sfb + 1 < 23 ? sfb + 1 : 22);
+    if (lane < nband) {
+        *first = shortb ? e0 * 3 + w : e0;
+        *count = e1 - e0;
+        *stride = shortb ? 3 : 1;
+    } else if (lane == 63) {
+        *first = 0; *count = 576; *stride = 1;
+    } else {
+        *first = 0; *count = 0; *stride = 1;
+    }
+}
+
+__global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                                const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
+                                                const int32_t *__restrict__ bits_per_frame,
+                                                mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
+                                                mp3mi_frame_side *__restrict__ side_out)
 {
     __shared__ loop_lds L;
     const int lane = wave_lane();
@@ -348,9 +396,13 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
     const int bitsPerFrame = bits_per_frame[s];
     const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2; // src/musicin.c:729-746
 
+    loop_regs R;
+    R.sfb_l = (lane < 23) ? T->sfb_l[lane] : 576;
+    R.sfb_s = (lane < 14) ? T->sfb_s[lane] : 192;
+    R.subdv = (lane < 23) ? (LOOP_SUBDV0[lane] | (LOOP_SUBDV1[lane] << 8)) : 0;
+    R.ht = (lane < 34) ? ((int) T->ht_off[lane] | ((int) T->ht_ylen[lane] << 16) | ((int) T->ht_linbits[lane] << 24)) : 0;
+
     for (int i = lane; i < 1440; i += 64) L.hlen[i] = T->ht_len[i];
-    if (lane < 23) L.sfb_l[lane] = T->sfb_l[lane];
-    if (lane < 14) L.sfb_s[lane] = T->sfb_s[lane];
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];
     if (lane < 8) L.ix[576 + lane] = 0;
     __syncthreads();
@@ -379,20 +431,16 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                 g.address2 = L.st.addr[gr][ch][1];
                 g.address3 = L.st.addr[gr][ch][2];
                 const int nband = shortb ? 36 : 21;   // band lanes
-                const int bbase = shortb ? 21 : 0;    // slot base in xmin/xfsf/sf
+                const int bbase = shortb ? 21 : 0;    // slot base in xmin/xfsf
                 const bool bandlane = lane < nband;
+                const uint8_t *band_of_line = shortb ? T->sfb_of_line_s : T->sfb_of_line_l;
+                int sfirst, scount, sstride;
+                loop_sum_range(R, shortb, nband, &sfirst, &scount, &sstride);
 
                 double xr[9];
-                int lband[9]; // band slot of each line (or 63 = none)
+                int p[9];
 #pragma unroll
-                for (int j = 0; j < 9; j++) {
-                    const int i = lane + 64 * j;
-                    xr[j] = xr_all[rec * 576 + i];
-                    int bsl;
-                    if (shortb) { bsl = T->sfb_of_line_s[i]; bsl = (bsl < 36) ? 21 + bsl : 63; }
-                    else { bsl = T->sfb_of_line_l[i]; bsl = (bsl < 21) ? bsl : 63; }
-                    lband[j] = bsl;
-                }
+                for (int j = 0; j < 9; j++) xr[j] = xr_all[rec * 576 + lane + 64 * j];
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the sums calc_scfsi / quantanf_init share ----
                 double amax = 0.0;
@@ -404,17 +452,14 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                 }
                 amax = wave_max_f64(amax);
                 __syncthreads();
-                double band_en = 0.0, bw = 1.0;
+                // band energies on the band lanes, total energy (576 terms in index order,
+                // src/loop.c:636-637 and :378-386) on lane 63, in one overlapped loop
+                const double band_en = loop_seq_sum(L, sfirst, scount, sstride);
                 if (bandlane) {
-                    band_en = loop_band_sum(L, shortb, lane, &bw);
                     const double ratio = shortb ? po->ratio_s[lane / 3][lane % 3] : po->ratio_l[lane];
-                    L.xmin[bbase + lane] = ratio * band_en / bw;
+                    L.xmin[bbase + lane] = ratio * band_en / (double) scount;
                 }
-                if (lane == 63) { // total energy, 576 terms in index order (src/loop.c:636-637, 378-386)
-                    double t = 0.0;
-                    for (int i = 0; i < 576; i++) t = t + L.tmp[i];
-                    L.bcast[0] = t;
-                }
+                if (lane == 63) L.bcast[0] = band_en;
                 __syncthreads();
                 const double en_total = L.bcast[0];
 
@@ -447,8 +492,8 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                             const int lo = (band == 0) ? 0 : (band == 1 ? 6 : (band == 2 ? 11 : 16));
                             const int hi = (band == 0) ? 6 : (band == 1 ? 11 : (band == 2 ? 16 : 21));
                             const bool in = lane >= lo && lane < hi;
-                            const int s01 = wave_sum_i32((in ? d : 0) | ((in ? dx : 0) << 16));
-                            const int v = ((s01 & 0xffff) < 10 && (s01 >> 16) < 10) ? 1 : 0;
+                            const int s0 = wave_sum_i32(in ? d : 0), s1 = wave_sum_i32(in ? dx : 0);
+                            const int v = (s0 < 10 && s1 < 10) ? 1 : 0;
                             if (lane == 0) L.side.scfsi[ch][band] = v;
                         }
                     } else if (lane < 4)
@@ -481,6 +526,8 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                 g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
                 g.region0_count = 0; g.region1_count = 0; g.part2_length = 0; g.preflag = 0;
                 g.count1table_select = 0; g.q = 0;
+#pragma unroll
+                for (int j = 0; j < 9; j++) p[j] = 0;
                 __syncthreads();
 
                 if (amax != 0.0) {
@@ -488,16 +535,17 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
 #pragma unroll
                     for (int j = 0; j < 9; j++) L.tmp[lane + 64 * j] = (xr[j] != 0) ? dm_log(xr[j] * xr[j]) : 0.0;
                     __syncthreads();
-                    if (lane == 0) {
-                        double s1 = 0.0;
-                        for (int i = 0; i < 576; i++) s1 = s1 + L.tmp[i];
-                        int tp = 0;
-                        if (en_total != 0.0) {
-                            const double sfm = dm_exp(s1 / 576.0) / (en_total / 576.0);
-                            tp = loop_nint(8.0 * dm_log(sfm));
-                            if (tp < -100) tp = -100;
+                    {
+                        const double s1 = loop_seq_sum(L, 0, lane == 63 ? 576 : 0, 1);
+                        if (lane == 63) {
+                            int tp = 0;
+                            if (en_total != 0.0) {
+                                const double sfm = dm_exp(s1 / 576.0) / (en_total / 576.0);
+                                tp = loop_nint(8.0 * dm_log(sfm));
+                                if (tp < -100) tp = -100;
+                            }
+                            L.ibcast[0] = tp - 70;
                         }
-                        L.ibcast[0] = tp - 70;
                     }
                     __syncthreads();
                     g.q = L.ibcast[0];
@@ -514,8 +562,8 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                                 last = next;
                                 next = (top + bot) / 2;
                                 g.q = next;
-                                loop_quantize(T, L, xr, g.q);
-                                bit = loop_count_bits(T, L, g);
+                                loop_quantize(T, L, xr, g.q, p);
+                                bit = loop_count_bits(R, L, g, p);
                                 __syncthreads();
                                 if (bit > max_bits) top = next; else bot = next;
                             } while (bit != max_bits && abs(last - next) > 1);
@@ -524,8 +572,8 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                         g.q -= 1;
                         do {
                             g.q += 1;
-                            loop_quantize(T, L, xr, g.q);
-                            bits = loop_count_bits(T, L, g);
+                            loop_quantize(T, L, xr, g.q, p);
+                            bits = loop_count_bits(R, L, g, p);
                             __syncthreads();
                         } while (bits > huff_bits);
 
@@ -534,16 +582,12 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                             const double step = T->step[g.q - MP3MI_STEP_MIN];
 #pragma unroll
                             for (int j = 0; j < 9; j++) {
-                                const int i = lane + 64 * j;
-                                const double t = __builtin_fabs(xr[j]) - T->pow43[L.ix[i]] * step;
-                                L.tmp[i] = t * t;
+                                const double t = __builtin_fabs(xr[j]) - T->pow43[p[j]] * step;
+                                L.tmp[lane + 64 * j] = t * t;
                             }
                             __syncthreads();
-                            if (bandlane) {
-                                double bwn;
-                                const double sum = loop_band_sum(L, shortb, lane, &bwn);
-                                L.xfsf[bbase + lane] = sum / bwn;
-                            }
+                            const double sum = loop_seq_sum(L, sfirst, bandlane ? scount : 0, sstride);
+                            if (bandlane) L.xfsf[bbase + lane] = sum / (double) scount;
                         }
                         L.sfsave[lane] = L.sf[lane];
                         save_preflag = g.preflag;
@@ -566,8 +610,10 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                                     __syncthreads();
                                     if (lane < g.sfb_lmax) L.xmin[lane] = L.xmin[lane] * T->pretab_xmin[LOOP_PRETAB[lane]];
 #pragma unroll
-                                    for (int j = 0; j < 9; j++)
-                                        if (lband[j] < g.sfb_lmax) xr[j] = xr[j] * T->pretab_xr[LOOP_PRETAB[lband[j]]];
+                                    for (int j = 0; j < 9; j++) {
+                                        const int b = band_of_line[lane + 64 * j];
+                                        if (b < g.sfb_lmax) xr[j] = xr[j] * T->pretab_xr[LOOP_PRETAB[b]];
+                                    }
                                 }
                             }
                         }
@@ -596,22 +642,23 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                                     L.sf[lane] = L.sf[lane] + 1;
                                 }
                             }
-                            L.ampflag[lane] = 0;
-                            __syncthreads();
-                            if (bandlane) L.ampflag[bbase + lane] = amp;
+                            L.ampflag[lane] = amp; // indexed by band lane for both block kinds
                             over = wave_sum_i32(amp);
                             __syncthreads();
+                            if (over) {
 #pragma unroll
-                            for (int j = 0; j < 9; j++)
-                                if (L.ampflag[lband[j]]) xr[j] = xr[j] * ifqstep;
+                                for (int j = 0; j < 9; j++) {
+                                    const int b = band_of_line[lane + 64 * j];
+                                    if (b < nband && L.ampflag[b]) xr[j] = xr[j] * ifqstep;
+                                }
+                            }
                         }
                         __syncthreads();
 
                         // loop_break (src/loop.c:1131-1152) then scale_bitcount (src/loop.c:792-860)
                         {
                             const int sfv = bandlane ? L.sf[lane] : 1;
-                            const int allamp = !wave_any(sfv == 0);
-                            status = allamp;
+                            status = !wave_any(sfv == 0);
                             if (status == 0) {
                                 int m1, m2;
                                 if (shortb) {
@@ -621,11 +668,10 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                                     m1 = (lane < 11) ? L.sf[lane] : 0;
                                     m2 = (lane >= 11 && lane < 21) ? L.sf[lane] : 0;
                                 }
-                                const int mm = wave_max_i32((m1 << 16) | 0) >> 16;
-                                const int mm2 = wave_max_i32(m2);
+                                const int mm1 = wave_max_i32(m1), mm2 = wave_max_i32(m2);
                                 int ep = 2, k;
                                 for (k = 0; k < 16; k++)
-                                    if (mm < (1 << LOOP_SLEN1[k]) && mm2 < (1 << LOOP_SLEN2[k])) { ep = 0; break; }
+                                    if (mm1 < (1 << LOOP_SLEN1[k]) && mm2 < (1 << LOOP_SLEN2[k])) { ep = 0; break; }
                                 if (ep == 0) g.scalefac_compress = k;
                                 status = ep;
                             }
@@ -638,9 +684,6 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                     __syncthreads();
                     g.part2_length = loop_part2_length(L, g, gr, ch);
                     g.part2_3_length = g.part2_length + bits;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 9; j++) L.ix[lane + 64 * j] = 0;
                 }
 
                 // ResvAdjust (src/reservoir.c:141-145), global_gain (src/loop.c:357)
@@ -648,13 +691,11 @@ __global__ void __launch_bounds__(64) k_loop(const mp3mi_tables *__restrict__ T,
                 const int global_gain = loop_nint((double) g.q + 210.0);
 
                 // ---- hand the granule over: signed ix (src/l3bitstream.c:115-125) and side info ----
-                __syncthreads();
 #pragma unroll
                 for (int j = 0; j < 9; j++) {
-                    const int i = lane + 64 * j;
-                    int v = L.ix[i];
+                    int v = p[j];
                     if (xr[j] < 0 && v > 0) v = -v;
-                    ix_out[rec * 576 + i] = (int16_t) v;
+                    ix_out[rec * 576 + lane + 64 * j] = (int16_t) v;
                 }
                 if (lane == 0) {
                     mp3mi_gr_side *o = &L.side.gr[gr][ch];

@@ -115,6 +115,7 @@ typedef struct {
 /* ---- wave helpers (64 lanes) ---- */
 MP3MI_DEVFN int wave_lane(void) { return (int) (threadIdx.x & 63); }
 
+#if defined(MP3MI_EMU)
 MP3MI_DEVFN int wave_sum_i32(int v)
 {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -125,6 +126,38 @@ MP3MI_DEVFN int wave_max_i32(int v)
     for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o > v ? o : v; }
     return v;
 }
+/* value of v in lane `lane`; lane must be wave-uniform */
+MP3MI_DEVFN int wave_readlane_i32(int v, int lane) { return __shfl(v, lane); }
+#else
+/* DPP reductions (gfx9 family): xor-1 and xor-2 inside each quad, then half-row and row mirrors
+ * give every lane of a 16-lane row the row total; row_bcast15 / row_bcast31 carry the totals
+ * across rows into lane 63, which is read back as a wave-uniform scalar. */
+#define MP3MI_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp(ident, (v), (ctrl), (rmask), 0xf, false)
+MP3MI_DEVFN int wave_sum_i32(int v)
+{
+    const int ident = 0;
+    v += MP3MI_DPP(v, 0xB1, 0xf);  /* quad_perm [1,0,3,2] */
+    v += MP3MI_DPP(v, 0x4E, 0xf);  /* quad_perm [2,3,0,1] */
+    v += MP3MI_DPP(v, 0x141, 0xf); /* row_half_mirror */
+    v += MP3MI_DPP(v, 0x140, 0xf); /* row_mirror */
+    v += MP3MI_DPP(v, 0x142, 0xa); /* row_bcast15 into rows 1 and 3 */
+    v += MP3MI_DPP(v, 0x143, 0xc); /* row_bcast31 into rows 2 and 3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+MP3MI_DEVFN int wave_max_i32(int v) /* values >= 0 */
+{
+    const int ident = 0;
+    int o;
+    o = MP3MI_DPP(v, 0xB1, 0xf); v = o > v ? o : v;
+    o = MP3MI_DPP(v, 0x4E, 0xf); v = o > v ? o : v;
+    o = MP3MI_DPP(v, 0x141, 0xf); v = o > v ? o : v;
+    o = MP3MI_DPP(v, 0x140, 0xf); v = o > v ? o : v;
+    o = MP3MI_DPP(v, 0x142, 0xa); v = o > v ? o : v;
+    o = MP3MI_DPP(v, 0x143, 0xc); v = o > v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+MP3MI_DEVFN int wave_readlane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+#endif
 MP3MI_DEVFN int wave_min_i32(int v)
 {
     for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o < v ? o : v; }

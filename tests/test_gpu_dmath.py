@@ -69,3 +69,18 @@ def test_device_math_equals_host_build(product, tmp_path_factory):
     assert np.array_equal(dev(11, u, v), u * v + 1.0)
     uf, vf = u.astype(np.float32), v.astype(np.float32)
     assert np.array_equal(dev(12, uf.astype(np.float64), vf.astype(np.float64)), (uf * vf + np.float32(1.0)).astype(np.float64))
+
+
+def test_wave_reductions_on_device(product):
+    """the DPP reductions / readlane helpers of mp3mi_dev.h against numpy, every lane active"""
+    L = product.lib
+    L.mp3mi_debug_dmath.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    x = rng.integers(0, 30000, n).astype(np.float64)
+    lanes = np.repeat(rng.integers(0, 64, n // 64), 64).astype(np.float64)
+    out = np.empty(n)
+    for fn, ref in ((20, x.reshape(-1, 64).sum(1)), (21, x.reshape(-1, 64).max(1)),
+                    (22, x.reshape(-1, 64)[np.arange(n // 64), lanes.reshape(-1, 64)[:, 0].astype(int)])):
+        assert L.mp3mi_debug_dmath(fn, x.ctypes.data, lanes.ctypes.data, out.ctypes.data, n) == 0
+        assert np.array_equal(out.reshape(-1, 64), np.repeat(ref[:, None], 64, 1)), fn
