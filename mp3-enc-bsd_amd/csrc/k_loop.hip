@@ -67,31 +67,34 @@ MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int
 // A float estimate of x^(3/4)+0.4054 settles every line that is not within 2^-9 of a table
 // boundary; the others are settled against the exact table.  The result never depends on the
 // quality of the estimate.  Leaves the values in p[] and in L.ix (followed by a barrier).
-MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double xr[9], int q, int p[9])
+// y34[j] = |xr[j]|^(3/4) in float (loop_power34), so that x^(3/4) = y34 * 2^(-3q/16) costs one multiply per pass.
+MP3MI_DEVFN void loop_power34(const double xr[9], float y34[9])
+{
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const float a = (float) __builtin_fabs(xr[j]);
+        y34[j] = __builtin_sqrtf(a * __builtin_sqrtf(a));
+    }
+}
+
+MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double xr[9], const float y34[9], int q, int p[9])
 {
     const int lane = wave_lane();
-    const double step = T->step[q - MP3MI_STEP_MIN];
-    const double ostep = 1.0 / step;
-    const double tab1 = T->pow_nint_tab[1], tab2047 = T->pow_nint_tab[2047];
+    const float cq = __builtin_exp2f(-0.1875f * (float) q);
     unsigned need = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-        const double x = __builtin_fabs(xr[j]) * ostep;
-        if (x < tab1) p[j] = 0;
-        else if (x >= tab2047) p[j] = 2047;
-        else {
-            const float xf = (float) x;
-            const float f = __builtin_sqrtf(xf * __builtin_sqrtf(xf)) + 0.4054f;
-            const float fl = __builtin_floorf(f);
-            const float fr = f - fl;
-            int pj = (int) fl;
-            pj = pj < 1 ? 1 : pj;
-            pj = pj > 2046 ? 2046 : pj;
-            p[j] = pj;
-            if (!(fr > 0.002f && fr < 0.998f)) need |= 1u << j;
-        }
+        float f = y34[j] * cq + 0.4054f;      // estimate of x^(3/4) + 0.4054, abs. error < 1e-3 below 2049
+        f = f > 4000.0f ? 4000.0f : f;
+        const float fl = __builtin_floorf(f);
+        const float fr = f - fl;
+        const int pj = (int) fl;
+        p[j] = pj > 2047 ? 2047 : pj;
+        // near a table boundary (and not saturated, and not plainly zero): settle exactly
+        if (f < 2048.5f && ((fr < 0.002f && pj >= 1) || fr > 0.998f)) need |= 1u << j;
     }
     if (wave_any(need != 0)) {
+        const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
 #pragma unroll
         for (int j = 0; j < 9; j++) {
             if (need & (1u << j)) {
@@ -439,8 +442,10 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
 
                 double xr[9];
                 int p[9];
+                float y34[9];
 #pragma unroll
                 for (int j = 0; j < 9; j++) xr[j] = xr_all[rec * 576 + lane + 64 * j];
+                loop_power34(xr, y34);
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the sums calc_scfsi / quantanf_init share ----
                 double amax = 0.0;
@@ -556,25 +561,33 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         iteration++;
                         g.part2_length = loop_part2_length(L, g, gr, ch);
                         const int huff_bits = max_bits - g.part2_length;
+                        bool have_pass = false; // p[], L.ix and g already describe step size g.q
                         if (iteration == 1) { // bin_search_StepSize (src/loop.c:2119-2140)
                             int top = g.q, bot = 200, next = g.q, last, bit;
                             do {
                                 last = next;
                                 next = (top + bot) / 2;
                                 g.q = next;
-                                loop_quantize(T, L, xr, g.q, p);
+                                loop_quantize(T, L, xr, y34, g.q, p);
                                 bit = loop_count_bits(R, L, g, p);
                                 __syncthreads();
                                 if (bit > max_bits) top = next; else bot = next;
                             } while (bit != max_bits && abs(last - next) > 1);
+                            bits = bit;
+                            have_pass = true;
                         }
-                        // inner_loop (src/loop.c:569-606)
+                        // inner_loop (src/loop.c:569-606): raise the step until the bits fit.  Its first
+                        // pass repeats the last probe of the bisection (same step, same xr), so that one
+                        // is taken over instead of recomputed.
                         g.q -= 1;
                         do {
                             g.q += 1;
-                            loop_quantize(T, L, xr, g.q, p);
-                            bits = loop_count_bits(R, L, g, p);
-                            __syncthreads();
+                            if (!have_pass) {
+                                loop_quantize(T, L, xr, y34, g.q, p);
+                                bits = loop_count_bits(R, L, g, p);
+                                __syncthreads();
+                            }
+                            have_pass = false;
                         } while (bits > huff_bits);
 
                         // calc_noise (src/loop.c:1007-1067)
@@ -614,6 +627,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                         const int b = band_of_line[lane + 64 * j];
                                         if (b < g.sfb_lmax) xr[j] = xr[j] * T->pretab_xr[LOOP_PRETAB[b]];
                                     }
+                                    loop_power34(xr, y34);
                                 }
                             }
                         }
@@ -651,6 +665,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                     const int b = band_of_line[lane + 64 * j];
                                     if (b < nband && L.ampflag[b]) xr[j] = xr[j] * ifqstep;
                                 }
+                                loop_power34(xr, y34);
                             }
                         }
                         __syncthreads();
