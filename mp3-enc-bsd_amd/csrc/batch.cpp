@@ -38,6 +38,7 @@ struct mp3mi_batch {
     float *energy_l, *energy_s, *hist6;
     double *cw_mid, *xr, *sb_dbg;
     mp3mi_psy_out *psy;
+    mp3mi_loop_prep *prep;
     void *psy_state, *loop_state;
     int16_t *ix;
     mp3mi_frame_side *side;
@@ -100,7 +101,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
         if (whole_SpF > b->max_frame_bytes) b->max_frame_bytes = whole_SpF;
     }
     // chunk size from a scratch budget (bytes per frame and stream of the per-chunk buffers)
-    const size_t per_gc = MP3MI_HBLK * 4 + 3 * MP3MI_HBLK_S * 4 + 50 * 8 + 12 * 4 + sizeof(mp3mi_psy_out) + 576 * 8 + 576 * 2;
+    const size_t per_gc = MP3MI_HBLK * 4 + 3 * MP3MI_HBLK_S * 4 + 50 * 8 + 12 * 4 + sizeof(mp3mi_psy_out) + sizeof(mp3mi_loop_prep) + 576 * 8 + 576 * 2;
     const size_t per_frame = per_gc * 2 * (size_t) channels + sizeof(mp3mi_frame_side);
     const char *env = getenv("MP3MI_SCRATCH_MB");
     const size_t budget = (env ? (size_t) atol(env) : (size_t) 24576) << 20;
@@ -128,6 +129,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     CHK(hipMalloc((void **) &b->cw_mid, ngc * 50 * sizeof(double)));
     CHK(hipMalloc((void **) &b->xr, ngc * 576 * sizeof(double)));
     CHK(hipMalloc((void **) &b->psy, ngc * sizeof(mp3mi_psy_out)));
+    CHK(hipMalloc((void **) &b->prep, ngc * sizeof(mp3mi_loop_prep)));
     CHK(hipMalloc((void **) &b->ix, ngc * 576 * sizeof(int16_t)));
     CHK(hipMalloc((void **) &b->side, (size_t) n_streams * (size_t) cf * sizeof(mp3mi_frame_side)));
     CHK(hipMalloc((void **) &b->psy_state, mp3mi_psy_state_size() * (size_t) n_streams * channels));
@@ -145,7 +147,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     hipStreamSynchronize(b->stream);
     hipFree(b->T); hipFree(b->bits_per_frame); hipFree(b->bitrate_index);
     hipFree(b->energy_l); hipFree(b->energy_s); hipFree(b->hist6); hipFree(b->cw_mid);
-    hipFree(b->xr); hipFree(b->psy); hipFree(b->ix); hipFree(b->side);
+    hipFree(b->xr); hipFree(b->psy); hipFree(b->prep); hipFree(b->ix); hipFree(b->side);
     hipFree(b->psy_state); hipFree(b->loop_state);
     if (b->sb_dbg) hipFree(b->sb_dbg);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
@@ -191,8 +193,9 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
         mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->stream);
         mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->psy, b->stream);
         mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy, b->xr, b->debug ? b->sb_dbg : NULL, b->stream);
+        mp3mi_launch_prep(b->T, g, b->xr, b->psy, b->prep, b->stream);
         CHK(hipEventRecord(b->loop_ev[2 * c], b->stream));
-        mp3mi_launch_loop(b->T, g, b->xr, b->psy, b->bits_per_frame, b->loop_state, b->ix, b->side, b->stream);
+        mp3mi_launch_loop(b->T, g, b->xr, b->psy, b->prep, b->bits_per_frame, b->loop_state, b->ix, b->side, b->stream);
         CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->stream));
         mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,
                             out_len_dev, b->stream);

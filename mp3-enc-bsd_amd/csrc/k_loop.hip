@@ -389,6 +389,7 @@ MP3MI_DEVFN void loop_sum_range(const loop_regs &R, bool shortb, int nband, int 
 
 __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
+                                                const mp3mi_loop_prep *__restrict__ prep,
                                                 const int32_t *__restrict__ bits_per_frame,
                                                 mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
                                                 mp3mi_frame_side *__restrict__ side_out)
@@ -447,37 +448,19 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 for (int j = 0; j < 9; j++) xr[j] = xr_all[rec * 576 + lane + 64 * j];
                 loop_power34(xr, y34);
 
-                // ---- calc_xmin (src/loop.c:1085-1118) and the sums calc_scfsi / quantanf_init share ----
-                double amax = 0.0;
-#pragma unroll
-                for (int j = 0; j < 9; j++) {
-                    L.tmp[lane + 64 * j] = xr[j] * xr[j];
-                    const double a = __builtin_fabs(xr[j]);
-                    amax = a > amax ? a : amax;
-                }
-                amax = wave_max_f64(amax);
-                __syncthreads();
-                // band energies on the band lanes, total energy (576 terms in index order,
-                // src/loop.c:636-637 and :378-386) on lane 63, in one overlapped loop
-                const double band_en = loop_seq_sum(L, sfirst, scount, sstride);
-                if (bandlane) {
-                    const double ratio = shortb ? po->ratio_s[lane / 3][lane % 3] : po->ratio_l[lane];
-                    L.xmin[bbase + lane] = ratio * band_en / (double) scount;
-                }
-                if (lane == 63) L.bcast[0] = band_en;
-                __syncthreads();
-                const double en_total = L.bcast[0];
-
-                // ---- calc_scfsi (src/loop.c:615-715) ----
+                // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
+                //      were computed by k_prep; only the stateful decision of calc_scfsi happens here ----
+                const mp3mi_loop_prep *pp = &prep[rec];
+                if (bandlane) L.xmin[bbase + lane] = pp->xmin[lane];
                 if (lane == 0) {
-                    L.st.sc_xrmax[gr][ch] = (int) amax;
-                    L.st.sc_en_tot[gr][ch] = (en_total == 0.0) ? 0 : (int) (dm_log(en_total) / T->log2);
+                    L.st.sc_xrmax[gr][ch] = pp->sc_xrmax;
+                    L.st.sc_en_tot[gr][ch] = pp->sc_en_tot;
                 }
                 if (!shortb && lane < 21) {
-                    L.st.sc_en[gr][ch][lane] = (band_en == 0.0) ? 0 : (int) (dm_log(band_en) / T->log2);
-                    const double xm = L.xmin[lane];
-                    L.st.sc_xm[gr][ch][lane] = (xm == 0.0) ? 0 : (int) (dm_log(xm) / T->log2);
+                    L.st.sc_en[gr][ch][lane] = pp->sc_en[lane];
+                    L.st.sc_xm[gr][ch][lane] = pp->sc_xm[lane];
                 }
+                const int nonzero = pp->nonzero;
                 __syncthreads();
                 if (gr == 1) {
                     int condition = 0;
@@ -535,25 +518,8 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 for (int j = 0; j < 9; j++) p[j] = 0;
                 __syncthreads();
 
-                if (amax != 0.0) {
-                    // ---- quantanf_init (src/loop.c:369-402) ----
-#pragma unroll
-                    for (int j = 0; j < 9; j++) L.tmp[lane + 64 * j] = (xr[j] != 0) ? dm_log(xr[j] * xr[j]) : 0.0;
-                    __syncthreads();
-                    {
-                        const double s1 = loop_seq_sum(L, 0, lane == 63 ? 576 : 0, 1);
-                        if (lane == 63) {
-                            int tp = 0;
-                            if (en_total != 0.0) {
-                                const double sfm = dm_exp(s1 / 576.0) / (en_total / 576.0);
-                                tp = loop_nint(8.0 * dm_log(sfm));
-                                if (tp < -100) tp = -100;
-                            }
-                            L.ibcast[0] = tp - 70;
-                        }
-                    }
-                    __syncthreads();
-                    g.q = L.ibcast[0];
+                if (nonzero) {
+                    g.q = pp->q0; // quantanf_init (src/loop.c:369-402), from k_prep
 
                     // ---- outer_loop (src/loop.c:415-558) ----
                     int iteration = 0, bits = 0, over, status, save_preflag, save_compress;
@@ -771,9 +737,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
 size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
-                       const int32_t *bits_per_frame, void *loop_state, int16_t *ix, mp3mi_frame_side *side,
-                       hipStream_t st)
+                       const mp3mi_loop_prep *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
+                       mp3mi_frame_side *side, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_loop, dim3((unsigned) g.n_streams), dim3(64), 0, st, T, g, xr, psy, bits_per_frame,
+    hipLaunchKernelGGL(k_loop, dim3((unsigned) g.n_streams), dim3(64), 0, st, T, g, xr, psy, prep, bits_per_frame,
                        (mp3mi_loop_state *) loop_state, ix, side);
 }

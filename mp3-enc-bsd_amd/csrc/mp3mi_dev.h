@@ -98,6 +98,16 @@ typedef struct {
     int32_t pad;
 } mp3mi_psy_out;
 
+/* Stateless per-(granule, channel) inputs of the iteration loop, computed for all granules in
+ * parallel by k_prep so that the serial kernel starts from them: allowed distortion
+ * (calc_xmin, src/loop.c:1085), the integer log-energies calc_scfsi stores (src/loop.c:631-667)
+ * and the start value of the quantiser step (quantanf_init, src/loop.c:369). */
+typedef struct {
+    double xmin[36];                 /* long: [sfb], sfb < 21; short: [sfb*3 + window], sfb < 12 */
+    int32_t sc_en[21], sc_xm[21];    /* written for non-short granules only */
+    int32_t sc_en_tot, sc_xrmax, q0, nonzero;
+} mp3mi_loop_prep;
+
 /* Side information of one (granule, channel) as the iteration loop leaves it
  * (subset of gr_info, src/l3side.h:60-87, that the formatter needs). */
 typedef struct {

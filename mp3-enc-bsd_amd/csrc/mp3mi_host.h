@@ -42,9 +42,11 @@ void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *e
                       void *psy_state, mp3mi_psy_out *out, hipStream_t st);
 void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
                          const mp3mi_psy_out *psy, double *xr, double *sb_dbg, hipStream_t st);
+void mp3mi_launch_prep(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
+                       const mp3mi_psy_out *psy, mp3mi_loop_prep *prep, hipStream_t st);
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
-                       const mp3mi_psy_out *psy, const int32_t *bits_per_frame, void *loop_state,
-                       int16_t *ix, mp3mi_frame_side *side, hipStream_t st);
+                       const mp3mi_psy_out *psy, const mp3mi_loop_prep *prep, const int32_t *bits_per_frame,
+                       void *loop_state, int16_t *ix, mp3mi_frame_side *side, hipStream_t st);
 void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix,
                          const mp3mi_frame_side *side, const int32_t *bits_per_frame,
                          const int32_t *bitrate_index, uint8_t *out, size_t out_stride,
