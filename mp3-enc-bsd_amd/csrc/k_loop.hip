@@ -35,14 +35,13 @@ struct loop_gr { // wave-uniform working copy of gr_info (src/l3side.h:60-87)
     int sfb_lmax, sfb_smax, address1, address2, address3, q;
 };
 
+// 9.2 KB per wavefront: 16 single-wave workgroups fit the 160 KB of a CU, i.e. 4 waves per SIMD,
+// which is what 4096 streams on 256 CUs need to be resident all at once.
 struct loop_lds {
     double tmp[576];
-    double xmin[64], xfsf[64];
-    double bcast[4];
     int16_t ix[576 + 8];
     uint8_t hlen[1440];
-    int sf[64], sfsave[64], sf_gr0[2][21], ampflag[64];
-    int ibcast[4];
+    int sf_gr0[2][21];
     mp3mi_loop_state st;
     mp3mi_frame_side side;
 };
@@ -451,7 +450,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
                 //      were computed by k_prep; only the stateful decision of calc_scfsi happens here ----
                 const mp3mi_loop_prep *pp = &prep[rec];
-                if (bandlane) L.xmin[bbase + lane] = pp->xmin[lane];
+                // per-band state lives in the band lanes' registers: allowed distortion, noise, scalefactor
+                double xmin_r = bandlane ? pp->xmin[lane] : 0.0, xfsf_r = 0.0;
+                int sf_r = 0, sfsave_r = 0;
                 if (lane == 0) {
                     L.st.sc_xrmax[gr][ch] = pp->sc_xrmax;
                     L.st.sc_en_tot[gr][ch] = pp->sc_en_tot;
@@ -509,7 +510,6 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 }
 
                 // ---- reset of iteration variables (src/loop.c:318-344) ----
-                L.sf[lane] = 0;
                 g.part2_3_length = 0; g.big_values = 0; g.count1 = 0; g.scalefac_compress = 0;
                 g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
                 g.region0_count = 0; g.region1_count = 0; g.part2_length = 0; g.preflag = 0;
@@ -566,12 +566,13 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             }
                             __syncthreads();
                             const double sum = loop_seq_sum(L, sfirst, bandlane ? scount : 0, sstride);
-                            if (bandlane) L.xfsf[bbase + lane] = sum / (double) scount;
+                            xfsf_r = bandlane ? sum / (double) scount : 0.0;
                         }
-                        L.sfsave[lane] = L.sf[lane];
+                        sfsave_r = sf_r;
                         save_preflag = g.preflag;
                         save_compress = g.scalefac_compress;
-                        __syncthreads();
+                        // bands whose noise exceeds the allowed distortion (bit b = band lane b)
+                        const unsigned long long viol = __ballot(bandlane && xfsf_r > xmin_r);
 
                         // preemphasis (src/loop.c:1161-1214)
                         {
@@ -581,13 +582,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 skip = true;
                             }
                             if (!skip && g.block_type != 2 && g.preflag == 0) {
-                                int ov = 0;
-                                for (int sfb = 17; sfb < 21; sfb++)
-                                    if (L.xfsf[sfb] > L.xmin[sfb]) ov++;
-                                if (ov == 4) {
+                                if ((viol & 0x1E0000ull) == 0x1E0000ull) { // sfb 17..20 all violate
                                     g.preflag = 1;
-                                    __syncthreads();
-                                    if (lane < g.sfb_lmax) L.xmin[lane] = L.xmin[lane] * T->pretab_xmin[LOOP_PRETAB[lane]];
+                                    if (lane < g.sfb_lmax) xmin_r = xmin_r * T->pretab_xmin[LOOP_PRETAB[lane]];
 #pragma unroll
                                     for (int j = 0; j < 9; j++) {
                                         const int b = band_of_line[lane + 64 * j];
@@ -606,48 +603,45 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 if (iteration == 1) copySF = 1; else preventSF = 1;
                             }
                             const double ifqstep = T->sqrt2, ifqstep2 = ifqstep * ifqstep;
-                            int amp = 0;
+                            bool amp = false;
                             if (bandlane) {
                                 bool skipband = false;
                                 if (!shortb && (copySF || preventSF)) {
                                     const int sb4 = (lane < 6) ? 0 : (lane < 11 ? 1 : (lane < 16 ? 2 : 3));
                                     if (L.side.scfsi[ch][sb4]) {
-                                        if (copySF) L.sf[lane] = L.sf_gr0[ch][lane];
+                                        if (copySF) sf_r = L.sf_gr0[ch][lane];
                                         skipband = true;
                                     }
                                 }
-                                if (!skipband && L.xfsf[bbase + lane] > L.xmin[bbase + lane]) {
-                                    amp = 1;
-                                    L.xmin[bbase + lane] = L.xmin[bbase + lane] * ifqstep2;
-                                    L.sf[lane] = L.sf[lane] + 1;
+                                if (!skipband && xfsf_r > xmin_r) {
+                                    amp = true;
+                                    xmin_r = xmin_r * ifqstep2;
+                                    sf_r = sf_r + 1;
                                 }
                             }
-                            L.ampflag[lane] = amp; // indexed by band lane for both block kinds
-                            over = wave_sum_i32(amp);
-                            __syncthreads();
+                            const unsigned long long ampmask = __ballot(amp); // bit b = band lane b amplified
+                            over = __popcll(ampmask);
                             if (over) {
 #pragma unroll
                                 for (int j = 0; j < 9; j++) {
                                     const int b = band_of_line[lane + 64 * j];
-                                    if (b < nband && L.ampflag[b]) xr[j] = xr[j] * ifqstep;
+                                    if (b < nband && ((ampmask >> b) & 1ull)) xr[j] = xr[j] * ifqstep;
                                 }
                                 loop_power34(xr, y34);
                             }
                         }
-                        __syncthreads();
 
                         // loop_break (src/loop.c:1131-1152) then scale_bitcount (src/loop.c:792-860)
                         {
-                            const int sfv = bandlane ? L.sf[lane] : 1;
-                            status = !wave_any(sfv == 0);
+                            status = !wave_any(bandlane && sf_r == 0);
                             if (status == 0) {
                                 int m1, m2;
                                 if (shortb) {
-                                    m1 = (lane < 18) ? L.sf[lane] : 0;
-                                    m2 = (lane >= 18 && lane < 36) ? L.sf[lane] : 0;
+                                    m1 = (lane < 18) ? sf_r : 0;
+                                    m2 = (lane >= 18 && lane < 36) ? sf_r : 0;
                                 } else {
-                                    m1 = (lane < 11) ? L.sf[lane] : 0;
-                                    m2 = (lane >= 11 && lane < 21) ? L.sf[lane] : 0;
+                                    m1 = (lane < 11) ? sf_r : 0;
+                                    m2 = (lane >= 11 && lane < 21) ? sf_r : 0;
                                 }
                                 const int mm1 = wave_max_i32(m1), mm2 = wave_max_i32(m2);
                                 int ep = 2, k;
@@ -660,9 +654,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     } while (status == 0 && over > 0);
                     g.preflag = save_preflag;
                     g.scalefac_compress = save_compress;
-                    __syncthreads();
-                    L.sf[lane] = L.sfsave[lane];
-                    __syncthreads();
+                    sf_r = sfsave_r;
                     g.part2_length = loop_part2_length(L, g, gr, ch);
                     g.part2_3_length = g.part2_length + bits;
                 }
@@ -690,8 +682,8 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     o->part2_length = g.part2_length;
                     L.st.addr[gr][ch][0] = g.address1; L.st.addr[gr][ch][1] = g.address2; L.st.addr[gr][ch][2] = g.address3;
                 }
-                if (lane < 39) L.side.gr[gr][ch].scalefac[lane] = (lane < nband) ? L.sf[lane] : 0;
-                if (gr == 0 && lane < 21) L.sf_gr0[ch][lane] = shortb ? 0 : L.sf[lane];
+                if (lane < 39) L.side.gr[gr][ch].scalefac[lane] = (lane < nband) ? sf_r : 0;
+                if (gr == 0 && lane < 21) L.sf_gr0[ch][lane] = shortb ? 0 : sf_r;
                 __syncthreads();
             }
 
