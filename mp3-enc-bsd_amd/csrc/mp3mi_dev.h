@@ -70,10 +70,13 @@ typedef struct {
     double enwindow[512];
     double filt[32][32];             /* the 31 used columns per subband: 0..15, 33..47  */
     double mdct_win[4][36], cos_s[6][12], cos_l[18][36], ca[8], cs[8];
-    /* long-block (type 0) transform, src/mdct.c:199-509, flattened: 36 operands per output.
-       bits 0-5 input index, 6 operand subtracted/negated, 7 first operand of a term,
-       8 last operand of a term, 9-13 cos_l column, 14 coefficient negated, 15 first term */
-    uint16_t mdct_prog[18][36];
+    /* long-block (type 0) transform, src/mdct.c:199-509, in shared-subexpression form: per band 26
+       values V (0-8: fin[j]-fin[17-j]; 9-17: fin[18+j]+fin[35-j]; 18-23: the six 6-operand groups;
+       24-25: the two 18-operand groups, operand lists below, bit 7 = subtract/negate); output m is
+       the ordered sum over t < mdct_nterm[m] of V[mdct_vidx[m][t]] * mdct_vcoef[m][t] */
+    uint8_t mdct_vidx[18][18], mdct_nterm[18];
+    uint8_t mdct_g_ops[6][18], mdct_h_ops[2][18];
+    double mdct_vcoef[18][18];
     /* quantiser */
     double pow_nint_tab[2049];       /* (i-0.4054)^(4/3); [0]=0, [2048]=+inf sentinel   */
     double pow43[MP3MI_POW43_N];     /* i^(4/3) */

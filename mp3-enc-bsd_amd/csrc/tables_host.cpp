@@ -307,23 +307,54 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
         T->ca[k] = ALIAS_C[k] / sq;
         T->cs[k] = 1.0 / sq;
     }
-    for (int m = 0; m < 18; m++) {
-        int n = 0;
-        for (int t = T_MDCTL_ROW[m]; t < T_MDCTL_ROW[m + 1]; t++) {
-            int o0 = T_MDCTL_TERM_OP[t], o1 = T_MDCTL_TERM_OP[t + 1];
-            for (int o = o0; o < o1; o++) {
-                unsigned e = T_MDCTL_OPS[o] & 0x3f;
-                if (T_MDCTL_OPS[o] & 0x80) e |= 1u << 6;
-                if (o == o0) e |= 1u << 7;
-                if (o == o1 - 1) e |= 1u << 8;
-                e |= (unsigned) (T_MDCTL_TERM_K[t] & 0x1f) << 9;
-                if (T_MDCTL_TERM_K[t] & 0x80) e |= 1u << 14;
-                if (t == T_MDCTL_ROW[m]) e |= 1u << 15;
-                if (n >= 36) return -4;
-                T->mdct_prog[m][n++] = (uint16_t) e;
+    /* Long-block MDCT in shared-subexpression form.  Every bracketed operand group of
+       src/mdct.c:205-508 is one of 26 per-band values V: d1[j] = fin[j]-fin[17-j], s2[j] =
+       fin[18+j]+fin[35-j] (j<9), six 6-operand groups and two 18-operand groups -- or the exact
+       negation of one (rounding is symmetric, so negating every operand negates the sum bit for
+       bit).  A term is then V[idx] * (+-cos_l[m][k]); rows keep the reference's term order. */
+    {
+        int n_g = 0, n_h = 0;
+        for (int m = 0; m < 18; m++) {
+            int nt = 0;
+            for (int t = T_MDCTL_ROW[m]; t < T_MDCTL_ROW[m + 1]; t++, nt++) {
+                const int o0 = T_MDCTL_TERM_OP[t], o1 = T_MDCTL_TERM_OP[t + 1], nops = o1 - o0;
+                const unsigned char *ops = &T_MDCTL_OPS[o0];
+                double coef = T->cos_l[m][T_MDCTL_TERM_K[t] & 0x7f];
+                if (T_MDCTL_TERM_K[t] & 0x80) coef = -coef;
+                int vidx = -1, sgn = 0; /* term value = sgn * V[vidx] */
+                if (nops == 2) {
+                    const int a = ops[0] & 0x3f, b = ops[1] & 0x3f, na = ops[0] >> 7, nb = ops[1] >> 7;
+                    if (a < 9 && b == 17 - a && na != nb) { vidx = a; sgn = na ? -1 : 1; }                 /* +-(fin[a]-fin[17-a]) */
+                    else if (a >= 18 && a < 27 && b == 53 - a && na == nb) { vidx = 9 + (a - 18); sgn = na ? -1 : 1; } /* +-(fin[a]+fin[35-j]) */
+                } else {
+                    uint8_t (*canon)[18] = (nops == 6) ? T->mdct_g_ops : T->mdct_h_ops;
+                    int &ncanon = (nops == 6) ? n_g : n_h;
+                    const int maxc = (nops == 6) ? 6 : 2, base = (nops == 6) ? 18 : 24;
+                    if (nops != 6 && nops != 18) return -4;
+                    for (int c = 0; c < ncanon && vidx < 0; c++) {
+                        bool same = true, neg = true;
+                        for (int o = 0; o < nops; o++) {
+                            if ((canon[c][o] & 0x3f) != (ops[o] & 0x3f)) { same = neg = false; break; }
+                            if ((canon[c][o] >> 7) != (ops[o] >> 7)) same = false; else neg = false;
+                        }
+                        if (same) { vidx = base + c; sgn = 1; }
+                        else if (neg) { vidx = base + c; sgn = -1; }
+                    }
+                    if (vidx < 0) {
+                        if (ncanon >= maxc) return -4;
+                        for (int o = 0; o < nops; o++) canon[ncanon][o] = ops[o];
+                        vidx = base + ncanon++;
+                        sgn = 1;
+                    }
+                }
+                if (vidx < 0 || nt >= 18) return -4;
+                T->mdct_vidx[m][nt] = (uint8_t) vidx;
+                T->mdct_vcoef[m][nt] = (sgn < 0) ? -coef : coef;
             }
+            T->mdct_nterm[m] = (uint8_t) nt;
+            for (; nt < 18; nt++) { T->mdct_vidx[m][nt] = 0; T->mdct_vcoef[m][nt] = 0.0; }
         }
-        if (n != 36) return -4;
+        if (n_g != 6 || n_h != 2) return -4;
     }
 
     T->pow_nint_tab[0] = 0.0;
