@@ -40,7 +40,7 @@ struct loop_gr { // wave-uniform working copy of gr_info (src/l3side.h:60-87)
 struct loop_lds {
     double tmp[576];
     int16_t ix[576 + 8];
-    uint8_t hlen[1440];
+    uint16_t glut[928];
     int sf_gr0[2][21];
     mp3mi_loop_state st;
     mp3mi_frame_side side;
@@ -110,27 +110,51 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double 
     __syncthreads();
 }
 
-// geometry of Huffman table t (wave-uniform t)
-struct loop_ht { int off, ylen, linbits; };
-MP3MI_DEVFN loop_ht loop_table(const loop_regs &R, int t)
+// ---- Huffman code-length look-up, grouped ----
+// new_choose_table (src/loop.c:1793-1897) only ever compares tables of one "group": {1},
+// {2,3}, {5,6}, {7,8,9}, {10,11,12}, {13,15}, {15,24+}, {16+,24+}; within a group all tables have
+// the same geometry.  T->glut holds, per group and (x,y) cell, the code lengths of all its
+// tables packed 5 bits each, so ONE LDS read prices a pair for every candidate.
+#define GL_G1 0
+#define GL_G2 4
+#define GL_G5 13
+#define GL_G7 29
+#define GL_G10 65
+#define GL_G13 129
+#define GL_G15 385
+#define GL_G16 641
+#define GL_C1 897 /* count1 tables A | B << 5 */
+
+struct loop_group { int off, ylen, lb0, lb1; }; // wave-uniform: LUT offset, row length, linbits of candidate 0 / 1
+
+MP3MI_DEVFN loop_group loop_group_of(const loop_regs &R, int c0, int c1)
 {
-    const int v = wave_readlane_i32(R.ht, t);
-    loop_ht h;
-    h.off = v & 0xffff;
-    h.ylen = (v >> 16) & 0xff;
-    h.linbits = (v >> 24) & 0xff;
-    return h;
+    loop_group gp;
+    gp.lb0 = 0;
+    gp.lb1 = 0;
+    switch (c0) {
+    case 1: gp.off = GL_G1; gp.ylen = 2; break;
+    case 2: gp.off = GL_G2; gp.ylen = 3; break;
+    case 5: gp.off = GL_G5; gp.ylen = 4; break;
+    case 7: gp.off = GL_G7; gp.ylen = 6; break;
+    case 10: gp.off = GL_G10; gp.ylen = 8; break;
+    case 13: gp.off = GL_G13; gp.ylen = 16; break;
+    case 15: gp.off = GL_G15; gp.ylen = 16; break;
+    default: gp.off = GL_G16; gp.ylen = 16; gp.lb0 = (wave_readlane_i32(R.ht, c0) >> 24) & 0xff; break;
+    }
+    if (c1 >= 24) gp.lb1 = (wave_readlane_i32(R.ht, c1) >> 24) & 0xff;
+    return gp;
 }
 
-// cost in bits of one (x, y) pair in Huffman table t with geometry h (src/loop.c:172-225)
-MP3MI_DEVFN int loop_pair_bits(const loop_lds &L, int t, const loop_ht &h, int x, int y)
+// code lengths of pair (x, y) for the (up to) three tables of a group, spread to 10-bit fields and
+// with the sign bits and linbits of src/loop.c:172-225 added to every field that has a table
+MP3MI_DEVFN int loop_pair_cost3(const loop_lds &L, const loop_group &gp, int fieldmask, int x, int y)
 {
-    int bits = (x != 0) + (y != 0);
-    if (t > 15) {
-        if (x > 14) { x = 15; bits += h.linbits; }
-        if (y > 14) { y = 15; bits += h.linbits; }
-    }
-    return bits + L.hlen[h.off + x * h.ylen + y];
+    const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
+    const int nesc = (x > 14) + (y > 14), sg = (x != 0) + (y != 0);
+    const int e = L.glut[gp.off + xc * gp.ylen + yc];
+    const int spread = (e & 31) | (((e >> 5) & 31) << 10) | (((e >> 10) & 31) << 20);
+    return spread + sg * fieldmask + nesc * (gp.lb0 | (gp.lb1 << 10));
 }
 
 // first table without / with linbits that can hold `max` (the searches over ht[].xlen and
@@ -184,6 +208,7 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
 {
     const int lane = wave_lane();
     const bool shortb = g.wsf && g.block_type == 2;
+    const unsigned *ixw = (const unsigned *) L.ix; // (x, y) of pair pr as one word: x | y << 16
     int bits = 0;
     if (shortb) {
         g.count1 = 0;
@@ -201,15 +226,14 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         const int i0 = (top_nz < 0) ? 0 : 2 * (top_nz / 2 + 1);
         g.count1 = (i0 - (top_big + 1)) / 4;
         g.big_values = (i0 - 4 * g.count1) / 2;
-        // count1 region: table A vs table B
+        // count1 region: table A vs table B (values are 0/1, so v+2w+4x+8y comes from two words)
         int s01 = 0;
-        const int offA = wave_readlane_i32(R.ht, 32) & 0xffff, offB = wave_readlane_i32(R.ht, 33) & 0xffff;
         for (int qd = lane; qd < g.count1; qd += 64) {
-            const int i = 2 * g.big_values + 4 * qd;
-            const int v = L.ix[i], w = L.ix[i + 1], x = L.ix[i + 2], y = L.ix[i + 3];
-            const int pp = v + (w << 1) + (x << 2) + (y << 3);
-            const int sg = (v != 0) + (w != 0) + (x != 0) + (y != 0);
-            s01 += (sg + L.hlen[offA + pp]) | ((sg + L.hlen[offB + pp]) << 16);
+            const unsigned a = ixw[g.big_values + 2 * qd], b = ixw[g.big_values + 2 * qd + 1];
+            const int pp = (int) ((a & 1u) | ((a >> 15) & 2u) | ((b & 1u) << 2) | ((b >> 13) & 8u));
+            const int sg = __popc((unsigned) pp);
+            const int e = L.glut[GL_C1 + pp];
+            s01 += (sg + (e & 31)) | ((sg + ((e >> 5) & 31)) << 16);
         }
         s01 = wave_sum_i32(s01);
         const int sum0 = s01 & 0xffff, sum1 = (s01 >> 16) & 0xffff;
@@ -259,12 +283,13 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         const int t0 = (m1 == 0) ? 0 : loop_first_table(m1), t1 = (m2 == 0) ? 0 : loop_first_table(m2); // choose_table
         g.table_select[0] = t0;
         g.table_select[1] = t1;
-        const loop_ht h0 = loop_table(R, t0), h1 = loop_table(R, t1);
+        const loop_group g0 = loop_group_of(R, t0, 0), g1 = loop_group_of(R, t1, 0);
         int sum = 0;
         for (int pr = lane; pr < 288; pr += 64) {
             const int m = pr / 3, w = pr - 3 * m;
-            if (m < 6) { if (t0) sum += loop_pair_bits(L, t0, h0, L.ix[6 * m + w], L.ix[6 * m + 3 + w]); }
-            else if (t1) sum += loop_pair_bits(L, t1, h1, L.ix[6 * m + w], L.ix[6 * m + 3 + w]);
+            const int x = L.ix[6 * m + w], y = L.ix[6 * m + 3 + w];
+            if (m < 6) { if (t0) sum += loop_pair_cost3(L, g0, 1, x, y) & 0x3ff; }
+            else if (t1) sum += loop_pair_cost3(L, g1, 1, x, y) & 0x3ff;
         }
         return wave_sum_i32(sum);
     }
@@ -281,40 +306,34 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         for (int r = 0; r < 3; r++)
             if (en[r] && i >= beg[r] && i < end[r]) mx[r] = p[j] > mx[r] ? p[j] : mx[r];
     }
-    int cand[3][3], nc[3];
-    loop_ht ht[3][3];
+    int cand[3][3], nc[3], fmask[3];
+    loop_group grp[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         mx[r] = en[r] ? wave_max_i32(mx[r]) : 0;
         nc[r] = loop_candidates(mx[r], cand[r]);
-#pragma unroll
-        for (int c = 0; c < 3; c++) ht[r][c] = loop_table(R, cand[r][c]);
+        grp[r] = loop_group_of(R, cand[r][0], cand[r][1]);
+        fmask[r] = 1 | (cand[r][1] ? 1 << 10 : 0) | (cand[r][2] ? 1 << 20 : 0);
     }
-    // cost of every candidate over its region; x and y of a pair come as one 32-bit LDS word
-    int acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    const unsigned *ixw = (const unsigned *) L.ix;
+    // cost of every candidate over its region: per lane three 10-bit partial sums per region
+    int acc[3] = {0, 0, 0};
     for (int pr = lane; pr < 288; pr += 64) {
         const int i = 2 * pr;
         const unsigned xy = ixw[pr];
         const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            if (nc[r] != 0 && i >= beg[r] && i < end[r]) {
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    if (cand[r][c]) acc[r][c] += loop_pair_bits(L, cand[r][c], ht[r][c], x, y);
-            }
-        }
+        for (int r = 0; r < 3; r++)
+            if (nc[r] != 0 && i >= beg[r] && i < end[r]) acc[r] += loop_pair_cost3(L, grp[r], fmask[r], x, y);
     }
     int sel_sum[3] = {0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         if (nc[r] == 0) continue;
         int sum[3];
-        const int s01 = wave_sum_i32(acc[r][0] | (acc[r][1] << 16)); // two 16-bit fields per reduction
+        const int s01 = wave_sum_i32((acc[r] & 0x3ff) | (((acc[r] >> 10) & 0x3ff) << 16)); // two fields per reduction
         sum[0] = s01 & 0xffff;
         sum[1] = (s01 >> 16) & 0xffff;
-        sum[2] = cand[r][2] ? wave_sum_i32(acc[r][2]) : 0;
+        sum[2] = cand[r][2] ? wave_sum_i32((acc[r] >> 20) & 0x3ff) : 0;
         const int t = loop_pick(nc[r], cand[r], sum);
         g.table_select[r] = t;
         sel_sum[r] = (t == cand[r][0]) ? sum[0] : (t == cand[r][1] ? sum[1] : sum[2]);
@@ -324,14 +343,8 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
     if (g.table_select[1]) bits += sel_sum[1];
     if (g.table_select[2]) {
         if (g.address3 == end[2]) bits += sel_sum[2];
-        else { // cannot happen for a consistent state; counted explicitly to stay faithful
-            const loop_ht h2 = loop_table(R, g.table_select[2]);
-            int sum = 0;
-            for (int pr = lane; pr < 288; pr += 64) {
-                const int i = 2 * pr;
-                if (i >= g.address2 && i < g.address3) sum += loop_pair_bits(L, g.table_select[2], h2, L.ix[i], L.ix[i + 1]);
-            }
-            bits += wave_sum_i32(sum);
+        else { // cannot happen for a consistent state (address3 == 2*big_values whenever region 2 is on)
+            bits += 100000;
         }
     }
     return bits;
@@ -405,7 +418,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     R.subdv = (lane < 23) ? (LOOP_SUBDV0[lane] | (LOOP_SUBDV1[lane] << 8)) : 0;
     R.ht = (lane < 34) ? ((int) T->ht_off[lane] | ((int) T->ht_ylen[lane] << 16) | ((int) T->ht_linbits[lane] << 24)) : 0;
 
-    for (int i = lane; i < 1440; i += 64) L.hlen[i] = T->ht_len[i];
+    for (int i = lane; i < 928; i += 64) L.glut[i] = T->glut[i];
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];
     if (lane < 8) L.ix[576 + lane] = 0;
     __syncthreads();

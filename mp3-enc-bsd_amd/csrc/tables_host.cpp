@@ -375,6 +375,22 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
         T->ht_len[i] = (uint8_t) (T_HT_PACKED[i] & 0xff);
         T->ht_code[i] = T_HT_PACKED[i] >> 8;
     }
+    {
+        static const int groups[9][5] = { /* offset, cells, table a, table b, table c (0 = none) */
+            {0, 4, 1, 0, 0}, {4, 9, 2, 3, 0}, {13, 16, 5, 6, 0}, {29, 36, 7, 8, 9}, {65, 64, 10, 11, 12},
+            {129, 256, 13, 15, 0}, {385, 256, 15, 24, 0}, {641, 256, 16, 24, 0}, {897, 16, 32, 33, 0}};
+        memset(T->glut, 0, sizeof(T->glut));
+        for (int gi = 0; gi < 9; gi++)
+            for (int c = 0; c < groups[gi][1]; c++) {
+                unsigned e = 0;
+                for (int f = 0; f < 3; f++) {
+                    const int t = groups[gi][2 + f];
+                    if (t && (T_HT_PACKED[T_HT_OFF[t] + c] & 0xff) > 31) return -5;
+                    if (t) e |= (unsigned) (T_HT_PACKED[T_HT_OFF[t] + c] & 0xff) << (5 * f);
+                }
+                T->glut[groups[gi][0] + c] = (uint16_t) e;
+            }
+    }
     for (int i = 0; i < 34; i++) {
         T->ht_off[i] = T_HT_OFF[i];
         T->ht_xlen[i] = T_HT_XLEN[i];

@@ -85,6 +85,7 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long) v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long) v) : 64; }
 
