@@ -60,6 +60,18 @@ __device__ static const int LOOP_SLEN2[16] = {0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1
 __device__ static const unsigned char LOOP_SUBDV0[23] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 6};
 __device__ static const unsigned char LOOP_SUBDV1[23] = {0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6, 7, 7, 7};
 
+// Diagnostic build only (-DMP3MI_LOOP_PROFILE): cycles per phase, summed over all waves.
+#if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
+__device__ unsigned long long g_loop_prof[8];
+#define PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
+#define PROF_END do { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_loop_prof[i_], prof_acc[i_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_END
+#endif
+
 MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int) (in + 0.5); } // src/loop.c:2020
 
 // ---- quantiser: ix = max{p in [0,2047] : tab[p] <= x}  (src/pow_nint.h:15-49, src/loop.c:1360-1428) ----
@@ -67,12 +79,19 @@ MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int
 // boundary; the others are settled against the exact table.  The result never depends on the
 // quality of the estimate.  Leaves the values in p[] and in L.ix (followed by a barrier).
 // y34[j] = |xr[j]|^(3/4) in float (loop_power34), so that x^(3/4) = y34 * 2^(-3q/16) costs one multiply per pass.
+// Only an estimate (the quantiser settles borderline lines exactly), so the raw 1-ulp hardware
+// square root is enough; the correctly rounded expansion costs ~20 instructions per root.
+#if defined(MP3MI_EMU)
+#define LOOP_FAST_SQRTF(x) __builtin_sqrtf(x)
+#else
+#define LOOP_FAST_SQRTF(x) __builtin_amdgcn_sqrtf(x)
+#endif
 MP3MI_DEVFN void loop_power34(const double xr[9], float y34[9])
 {
 #pragma unroll
     for (int j = 0; j < 9; j++) {
         const float a = (float) __builtin_fabs(xr[j]);
-        y34[j] = __builtin_sqrtf(a * __builtin_sqrtf(a));
+        y34[j] = LOOP_FAST_SQRTF(a * LOOP_FAST_SQRTF(a));
     }
 }
 
@@ -89,8 +108,11 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double 
         const float fr = f - fl;
         const int pj = (int) fl;
         p[j] = pj > 2047 ? 2047 : pj;
-        // near a table boundary (and not saturated, and not plainly zero): settle exactly
-        if (f < 2048.5f && ((fr < 0.002f && pj >= 1) || fr > 0.998f)) need |= 1u << j;
+        // near a table boundary (and not saturated, and not plainly zero): settle exactly.  The
+        // estimate's error is relative (< 7e-7 f: two 1-ulp roots, exp2, three roundings), so the
+        // guard band scales with f; small values -- the common case -- are almost never ambiguous.
+        const float tol = 2.5e-6f * f + 2e-6f;
+        if (f < 2048.5f && ((fr < tol && pj >= 1) || fr > 1.0f - tol)) need |= 1u << j;
     }
     if (wave_any(need != 0)) {
         const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
@@ -215,14 +237,14 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         g.big_values = 288;
         g.count1table_select = 1; // count1_bitcount with no quadruples: sum0 == sum1 -> table B
     } else {
-        // highest line with ix != 0 and highest line with ix > 1, via ballots over 64-line rows
-        int top_nz = -1, top_big = -1;
+        // highest line with ix != 0 and highest line with ix > 1 (as line + 1; 0 = none)
+        int hi_nz = 0, hi_big = 0;
 #pragma unroll
-        for (int j = 8; j >= 0; j--) {
-            const unsigned long long mnz = __ballot(p[j] != 0), mbig = __ballot(p[j] > 1);
-            if (top_nz < 0 && mnz) top_nz = 64 * j + 63 - __clzll((long long) mnz);
-            if (top_big < 0 && mbig) top_big = 64 * j + 63 - __clzll((long long) mbig);
+        for (int j = 0; j < 9; j++) {
+            hi_nz = (p[j] != 0) ? 64 * j + lane + 1 : hi_nz;
+            hi_big = (p[j] > 1) ? 64 * j + lane + 1 : hi_big;
         }
+        const int top_nz = wave_max_i32(hi_nz) - 1, top_big = wave_max_i32(hi_big) - 1;
         const int i0 = (top_nz < 0) ? 0 : 2 * (top_nz / 2 + 1);
         g.count1 = (i0 - (top_big + 1)) / 4;
         g.big_values = (i0 - 4 * g.count1) / 2;
@@ -411,6 +433,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     const int s = (int) blockIdx.x, C = geo.channels, G = 2 * geo.nf;
     const int bitsPerFrame = bits_per_frame[s];
     const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2; // src/musicin.c:729-746
+    PROF_DECL;
 
     loop_regs R;
     R.sfb_l = (lane < 23) ? T->sfb_l[lane] : 576;
@@ -449,7 +472,13 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 const int nband = shortb ? 36 : 21;   // band lanes
                 const int bbase = shortb ? 21 : 0;    // slot base in xmin/xfsf
                 const bool bandlane = lane < nband;
-                const uint8_t *band_of_line = shortb ? T->sfb_of_line_s : T->sfb_of_line_l;
+                // band (lane) index of each of this lane's 9 lines, 6 bits each
+                unsigned long long bandpack = 0;
+                {
+                    const uint8_t *band_of_line = shortb ? T->sfb_of_line_s : T->sfb_of_line_l;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) bandpack |= (unsigned long long) band_of_line[lane + 64 * j] << (6 * j);
+                }
                 int sfirst, scount, sstride;
                 loop_sum_range(R, shortb, nband, &sfirst, &scount, &sstride);
 
@@ -462,6 +491,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
                 //      were computed by k_prep; only the stateful decision of calc_scfsi happens here ----
+                PROF(0);
                 const mp3mi_loop_prep *pp = &prep[rec];
                 // per-band state lives in the band lanes' registers: allowed distortion, noise, scalefactor
                 double xmin_r = bandlane ? pp->xmin[lane] : 0.0, xfsf_r = 0.0;
@@ -547,8 +577,11 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 last = next;
                                 next = (top + bot) / 2;
                                 g.q = next;
+                                PROF(1);
                                 loop_quantize(T, L, xr, y34, g.q, p);
+                                PROF(2);
                                 bit = loop_count_bits(R, L, g, p);
+                                PROF(3);
                                 __syncthreads();
                                 if (bit > max_bits) top = next; else bot = next;
                             } while (bit != max_bits && abs(last - next) > 1);
@@ -562,13 +595,17 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         do {
                             g.q += 1;
                             if (!have_pass) {
+                                PROF(1);
                                 loop_quantize(T, L, xr, y34, g.q, p);
+                                PROF(2);
                                 bits = loop_count_bits(R, L, g, p);
+                                PROF(3);
                                 __syncthreads();
                             }
                             have_pass = false;
                         } while (bits > huff_bits);
 
+                        PROF(1);
                         // calc_noise (src/loop.c:1007-1067)
                         {
                             const double step = T->step[g.q - MP3MI_STEP_MIN];
@@ -587,6 +624,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         // bands whose noise exceeds the allowed distortion (bit b = band lane b)
                         const unsigned long long viol = __ballot(bandlane && xfsf_r > xmin_r);
 
+                        PROF(4);
                         // preemphasis (src/loop.c:1161-1214)
                         {
                             bool skip = false;
@@ -600,7 +638,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                     if (lane < g.sfb_lmax) xmin_r = xmin_r * T->pretab_xmin[LOOP_PRETAB[lane]];
 #pragma unroll
                                     for (int j = 0; j < 9; j++) {
-                                        const int b = band_of_line[lane + 64 * j];
+                                        const int b = (int) ((bandpack >> (6 * j)) & 63ull);
                                         if (b < g.sfb_lmax) xr[j] = xr[j] * T->pretab_xr[LOOP_PRETAB[b]];
                                     }
                                     loop_power34(xr, y34);
@@ -637,13 +675,14 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             if (over) {
 #pragma unroll
                                 for (int j = 0; j < 9; j++) {
-                                    const int b = band_of_line[lane + 64 * j];
+                                    const int b = (int) ((bandpack >> (6 * j)) & 63ull);
                                     if (b < nband && ((ampmask >> b) & 1ull)) xr[j] = xr[j] * ifqstep;
                                 }
                                 loop_power34(xr, y34);
                             }
                         }
 
+                        PROF(5);
                         // loop_break (src/loop.c:1131-1152) then scale_bitcount (src/loop.c:792-860)
                         {
                             status = !wave_any(bandlane && sf_r == 0);
@@ -676,6 +715,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 ResvSize += (mean_bits / C) - g.part2_3_length;
                 const int global_gain = loop_nint((double) g.q + 210.0);
 
+                PROF(6);
                 // ---- hand the granule over: signed ix (src/l3bitstream.c:115-125) and side info ----
 #pragma unroll
                 for (int j = 0; j < 9; j++) {
@@ -737,7 +777,19 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
         __syncthreads();
     }
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &state[s])[i] = ((const int *) &L.st)[i];
+    PROF(7);
+    PROF_END;
 }
+
+#if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
+extern "C" void mp3mi_debug_loop_profile(unsigned long long *out)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_prof), sizeof(z));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_loop_prof), z, sizeof(z));
+}
+#endif
 
 size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 

@@ -32,7 +32,8 @@ struct psy_lds {
     double pe;
 };
 
-__global__ void __launch_bounds__(64) k_psy(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+// 8192 single-wave workgroups (4096 stereo streams) = 8 waves per SIMD: ask for that occupancy
+__global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                             const float *__restrict__ energy_l, const float *__restrict__ energy_s,
                                             const double *__restrict__ cw_mid, const float *__restrict__ hist6,
                                             mp3mi_psy_state *__restrict__ state, mp3mi_psy_out *__restrict__ out)
