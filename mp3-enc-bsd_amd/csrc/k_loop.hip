@@ -51,7 +51,8 @@ struct loop_regs {
     int sfb_l;   // lane < 23: long scalefactor band edge
     int sfb_s;   // lane < 14: short scalefactor band edge
     int subdv;   // lane < 23: region0_count | region1_count << 8 (src/loop.c:1596-1625)
-    int ht;      // lane < 34: ht_off | ylen << 16 | linbits << 24
+    int desc_a;  // lane < 27: Huffman group descriptor of region maximum class `lane` (see loop_desc_index)
+    int desc_b;  // lane < 27: offset of that group's cells in glut
 };
 
 __device__ static const int LOOP_PRETAB[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 3, 2};
@@ -132,100 +133,85 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double 
     __syncthreads();
 }
 
-// ---- Huffman code-length look-up, grouped ----
+// ---- Huffman table choice and code-length look-up, grouped ----
 // new_choose_table (src/loop.c:1793-1897) only ever compares tables of one "group": {1},
 // {2,3}, {5,6}, {7,8,9}, {10,11,12}, {13,15}, {15,24+}, {16+,24+}; within a group all tables have
-// the same geometry.  T->glut holds, per group and (x,y) cell, the code lengths of all its
-// tables packed 5 bits each, so ONE LDS read prices a pair for every candidate.
-#define GL_G1 0
-#define GL_G2 4
-#define GL_G5 13
-#define GL_G7 29
-#define GL_G10 65
-#define GL_G13 129
-#define GL_G15 385
-#define GL_G16 641
+// the same geometry.  The group is a function of the region maximum alone:
+//   max < 16        -> entry max        of the descriptor table
+//   max >= 16       -> entry 15 + bit length of (max - 15)   (the ht[].linmax thresholds of
+//                      src/loop.c:1872-1888 are all of the form 2^k - 1)
+// R.desc_a / R.desc_b hold that table one entry per lane (built in tables_host.cpp):
+//   desc_a = c0 | c1 << 5 | c2 << 10 | ylen << 15 | linbits(c0) << 20 | linbits(c1) << 24
+//   desc_b = offset of the group's cells in T->glut
+// T->glut holds, per group and (x,y) cell, the code lengths of all its tables packed 5 bits
+// each, so ONE LDS read prices a pair for every candidate.
 #define GL_C1 897 /* count1 tables A | B << 5 */
 
-struct loop_group { int off, ylen, lb0, lb1; }; // wave-uniform: LUT offset, row length, linbits of candidate 0 / 1
-
-MP3MI_DEVFN loop_group loop_group_of(const loop_regs &R, int c0, int c1)
+MP3MI_DEVFN int loop_desc_index(int max)
 {
-    loop_group gp;
-    gp.lb0 = 0;
-    gp.lb1 = 0;
-    switch (c0) {
-    case 1: gp.off = GL_G1; gp.ylen = 2; break;
-    case 2: gp.off = GL_G2; gp.ylen = 3; break;
-    case 5: gp.off = GL_G5; gp.ylen = 4; break;
-    case 7: gp.off = GL_G7; gp.ylen = 6; break;
-    case 10: gp.off = GL_G10; gp.ylen = 8; break;
-    case 13: gp.off = GL_G13; gp.ylen = 16; break;
-    case 15: gp.off = GL_G15; gp.ylen = 16; break;
-    default: gp.off = GL_G16; gp.ylen = 16; gp.lb0 = (wave_readlane_i32(R.ht, c0) >> 24) & 0xff; break;
+    return max < 16 ? max : 15 + (32 - __clz(max - 15));
+}
+
+// descriptor of class `cls` (run once per wave, lane = cls): the candidate searches over ht[].xlen
+// and ht[].linmax of src/loop.c:1812-1817, 1872-1888, 1919-1939 written as comparisons
+MP3MI_DEVFN void loop_desc_init(const mp3mi_tables *T, int cls, int *desc_a, int *desc_b)
+{
+    *desc_a = 0;
+    *desc_b = 0;
+    if (cls == 0 || cls > 26) return;
+    const int max = cls < 16 ? cls : 15 + (1 << (cls - 16));
+    int c0, c1 = 0, c2 = 0, off, ylen;
+    if (max < 15) {
+        if (max <= 1) { c0 = 1; off = 0; ylen = 2; }
+        else if (max == 2) { c0 = 2; c1 = 3; off = 4; ylen = 3; }
+        else if (max == 3) { c0 = 5; c1 = 6; off = 13; ylen = 4; }
+        else if (max <= 5) { c0 = 7; c1 = 8; c2 = 9; off = 29; ylen = 6; }
+        else if (max <= 7) { c0 = 10; c1 = 11; c2 = 12; off = 65; ylen = 8; }
+        else { c0 = 13; c1 = 15; off = 129; ylen = 16; }
+    } else {
+        const int m = max - 15;
+        c0 = m <= 0 ? 15 : (m <= 1 ? 16 : (m <= 3 ? 17 : (m <= 7 ? 18 : (m <= 15 ? 19 : (m <= 63 ? 20 : (m <= 255 ? 21 : (m <= 1023 ? 22 : 23)))))));
+        c1 = m <= 15 ? 24 : (m <= 31 ? 25 : (m <= 63 ? 26 : (m <= 127 ? 27 : (m <= 255 ? 28 : (m <= 511 ? 29 : (m <= 2047 ? 30 : 31))))));
+        off = c0 == 15 ? 385 : 641;
+        ylen = 16;
     }
-    if (c1 >= 24) gp.lb1 = (wave_readlane_i32(R.ht, c1) >> 24) & 0xff;
-    return gp;
+    *desc_a = c0 | (c1 << 5) | (c2 << 10) | (ylen << 15) | ((int) T->ht_linbits[c0] << 20) | ((int) T->ht_linbits[c1] << 24);
+    *desc_b = off;
 }
 
 // code lengths of pair (x, y) for the (up to) three tables of a group, spread to 10-bit fields and
-// with the sign bits and linbits of src/loop.c:172-225 added to every field that has a table
-MP3MI_DEVFN int loop_pair_cost3(const loop_lds &L, const loop_group &gp, int fieldmask, int x, int y)
+// with the sign bits and linbits of src/loop.c:172-225 added to every field that has a table.
+// da/db: the group's descriptor words (may differ per lane), fieldmask: 1 | 1<<10 | 1<<20 subset.
+MP3MI_DEVFN int loop_pair_cost3(const loop_lds &L, int da, int db, int fieldmask, int x, int y)
 {
     const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
     const int nesc = (x > 14) + (y > 14), sg = (x != 0) + (y != 0);
-    const int e = L.glut[gp.off + xc * gp.ylen + yc];
+    const int ylen = (da >> 15) & 31, lb = ((da >> 20) & 15) | (((da >> 24) & 15) << 10);
+    const int e = L.glut[db + xc * ylen + yc];
     const int spread = (e & 31) | (((e >> 5) & 31) << 10) | (((e >> 10) & 31) << 20);
-    return spread + sg * fieldmask + nesc * (gp.lb0 | (gp.lb1 << 10));
+    return spread + sg * fieldmask + nesc * lb;
 }
 
-// first table without / with linbits that can hold `max` (the searches over ht[].xlen and
-// ht[].linmax of src/loop.c:1812-1817, 1872-1888, 1919-1939 written as comparisons)
-MP3MI_DEVFN int loop_first_table(int max)
+// new_choose_table's decision from the candidates' bit sums (src/loop.c:1819-1897): '<=' moves to
+// the later table among tables without linbits, '<' among the linbits pair
+MP3MI_DEVFN int loop_pick(int da, int s0, int s1, int s2, int *sum)
 {
-    if (max < 15) return max <= 1 ? 1 : (max == 2 ? 2 : (max == 3 ? 5 : (max <= 5 ? 7 : (max <= 7 ? 10 : 13))));
-    const int m = max - 15;
-    return m <= 0 ? 15 : (m <= 1 ? 16 : (m <= 3 ? 17 : (m <= 7 ? 18 : (m <= 15 ? 19 : (m <= 63 ? 20 : (m <= 255 ? 21 : (m <= 1023 ? 22 : 23)))))));
-}
-MP3MI_DEVFN int loop_second_linbits_table(int max)
-{
-    const int m = max - 15;
-    return m <= 15 ? 24 : (m <= 31 ? 25 : (m <= 63 ? 26 : (m <= 127 ? 27 : (m <= 255 ? 28 : (m <= 511 ? 29 : (m <= 2047 ? 30 : 31))))));
-}
-
-// candidate tables of new_choose_table for a region maximum (src/loop.c:1793-1897); returns count
-MP3MI_DEVFN int loop_candidates(int max, int cand[3])
-{
-    cand[0] = cand[1] = cand[2] = 0;
-    if (max == 0) return 0;
-    cand[0] = loop_first_table(max);
-    if (max < 15) {
-        switch (cand[0]) {
-        case 2: cand[1] = 3; return 2;
-        case 5: cand[1] = 6; return 2;
-        case 7: cand[1] = 8; cand[2] = 9; return 3;
-        case 10: cand[1] = 11; cand[2] = 12; return 3;
-        case 13: cand[1] = 15; return 2;
-        default: return 1;
-        }
+    const int c0 = da & 31, c1 = (da >> 5) & 31, c2 = (da >> 10) & 31;
+    int choice = c0, best = s0;
+    if (c0 >= 15) { // maximum >= 15: the two candidates were found through linmax
+        if (s1 < s0) { choice = c1; best = s1; }
+    } else {
+        if (c1 && s1 <= best) { choice = c1; best = s1; }
+        if (c2 && s2 <= best) { choice = c2; best = s2; }
     }
-    cand[1] = loop_second_linbits_table(max);
-    return -2; // linbits pair: strict '<' tie-break
-}
-
-MP3MI_DEVFN int loop_pick(int n, const int cand[3], const int sum[3])
-{
-    if (n == 0) return 0;
-    if (n == -2) return (sum[1] < sum[0]) ? cand[1] : cand[0];
-    int choice = cand[0], best = sum[0];
-    if (n >= 2 && sum[1] <= best) { choice = cand[1]; best = sum[1]; }
-    if (n >= 3 && sum[2] <= best) { choice = cand[2]; }
+    *sum = best;
     return choice;
 }
 
 // calc_runlen + count1_bitcount + subdivide + bigv_tab_select + bigv_bitcount
 // (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
-// Returns the Huffman bit count and fills g.
+// Returns the Huffman bit count and fills g.  Written branch-free over the lanes: region
+// membership is a predicate, never a divergent branch.
 MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9])
 {
     const int lane = wave_lane();
@@ -250,12 +236,17 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         g.big_values = (i0 - 4 * g.count1) / 2;
         // count1 region: table A vs table B (values are 0/1, so v+2w+4x+8y comes from two words)
         int s01 = 0;
-        for (int qd = lane; qd < g.count1; qd += 64) {
-            const unsigned a = ixw[g.big_values + 2 * qd], b = ixw[g.big_values + 2 * qd + 1];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { // at most 144 quadruples
+            const int qd = lane + 64 * k;
+            const bool in = qd < g.count1;
+            const int w0 = in ? g.big_values + 2 * qd : 0;
+            const unsigned a = ixw[w0], b = ixw[w0 + 1];
             const int pp = (int) ((a & 1u) | ((a >> 15) & 2u) | ((b & 1u) << 2) | ((b >> 13) & 8u));
             const int sg = __popc((unsigned) pp);
             const int e = L.glut[GL_C1 + pp];
-            s01 += (sg + (e & 31)) | ((sg + ((e >> 5) & 31)) << 16);
+            const int c = (sg + (e & 31)) | ((sg + ((e >> 5) & 31)) << 16);
+            s01 += in ? c : 0;
         }
         s01 = wave_sum_i32(s01);
         const int sum0 = s01 & 0xffff, sum1 = (s01 >> 16) & 0xffff;
@@ -298,76 +289,86 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
 #pragma unroll
         for (int j = 0; j < 9; j++) {
             const int i = lane + 64 * j;
-            if (i < 36) m1 = p[j] > m1 ? p[j] : m1; else m2 = p[j] > m2 ? p[j] : m2;
+            m1 = (i < 36 && p[j] > m1) ? p[j] : m1;
+            m2 = (i >= 36 && p[j] > m2) ? p[j] : m2;
         }
         m1 = wave_max_i32(m1);
         m2 = wave_max_i32(m2);
-        const int t0 = (m1 == 0) ? 0 : loop_first_table(m1), t1 = (m2 == 0) ? 0 : loop_first_table(m2); // choose_table
+        // choose_table (src/loop.c:1908-1947): the first table that can hold the maximum
+        const int da0 = wave_readlane_i32(R.desc_a, loop_desc_index(m1)), db0 = wave_readlane_i32(R.desc_b, loop_desc_index(m1));
+        const int da1 = wave_readlane_i32(R.desc_a, loop_desc_index(m2)), db1 = wave_readlane_i32(R.desc_b, loop_desc_index(m2));
+        const int t0 = m1 ? (da0 & 31) : 0, t1 = m2 ? (da1 & 31) : 0;
         g.table_select[0] = t0;
         g.table_select[1] = t1;
-        const loop_group g0 = loop_group_of(R, t0, 0), g1 = loop_group_of(R, t1, 0);
         int sum = 0;
-        for (int pr = lane; pr < 288; pr += 64) {
-            const int m = pr / 3, w = pr - 3 * m;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int pr = lane + 64 * k;
+            const bool in = pr < 288;
+            const int m = in ? pr / 3 : 0, w = in ? pr - 3 * m : 0;
             const int x = L.ix[6 * m + w], y = L.ix[6 * m + 3 + w];
-            if (m < 6) { if (t0) sum += loop_pair_cost3(L, g0, 1, x, y) & 0x3ff; }
-            else if (t1) sum += loop_pair_cost3(L, g1, 1, x, y) & 0x3ff;
+            const bool first = m < 6;
+            const int c = loop_pair_cost3(L, first ? da0 : da1, first ? db0 : db1, 1, x, y) & 0x3ff;
+            sum += (in && (first ? t0 : t1)) ? c : 0;
         }
         return wave_sum_i32(sum);
     }
-    // long / start / stop blocks: three regions with the reference's (quirky) bounds
-    int beg[3], end[3], en[3];
-    beg[0] = 0; end[0] = g.address1; en[0] = g.address1 > 0;
-    beg[1] = g.address1; end[1] = g.address2; en[1] = g.address2 > g.address1;
-    beg[2] = g.address2; end[2] = 2 * g.big_values; en[2] = 2 * g.big_values > g.address2;
-    int mx[3] = {0, 0, 0};
+    // long / start / stop blocks: regions [0,a1), [a1,a2), [a2,e2) (src/loop.c:1771-1777).  The
+    // reference's enable tests (a1 > 0, a2 > a1, e2 > a2) are exactly "the range is not empty",
+    // and region 2 is non-empty only right after subdivide set a1 <= a2 <= e2, so the three
+    // ranges never overlap.
+    const int a1 = g.address1, a2 = g.address2, e2 = 2 * g.big_values;
+    int m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
         const int i = lane + 64 * j;
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-            if (en[r] && i >= beg[r] && i < end[r]) mx[r] = p[j] > mx[r] ? p[j] : mx[r];
+        const bool c1 = i < a1, c2 = i < a2, c3 = i < e2;
+        m0 = (c1 && p[j] > m0) ? p[j] : m0;
+        m1 = (!c1 && c2 && p[j] > m1) ? p[j] : m1;
+        m2 = (!c2 && c3 && p[j] > m2) ? p[j] : m2;
     }
-    int cand[3][3], nc[3], fmask[3];
-    loop_group grp[3];
+    m0 = wave_max_i32(m0);
+    m1 = wave_max_i32(m1);
+    m2 = wave_max_i32(m2);
+    int da[3], db[3], fm[3];
+    const int mx[3] = {m0, m1, m2};
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        mx[r] = en[r] ? wave_max_i32(mx[r]) : 0;
-        nc[r] = loop_candidates(mx[r], cand[r]);
-        grp[r] = loop_group_of(R, cand[r][0], cand[r][1]);
-        fmask[r] = 1 | (cand[r][1] ? 1 << 10 : 0) | (cand[r][2] ? 1 << 20 : 0);
+        const int idx = loop_desc_index(mx[r]);
+        da[r] = wave_readlane_i32(R.desc_a, idx);
+        db[r] = wave_readlane_i32(R.desc_b, idx);
+        fm[r] = mx[r] ? (1 | (((da[r] >> 5) & 31) ? 1 << 10 : 0) | (((da[r] >> 10) & 31) ? 1 << 20 : 0)) : 0;
     }
     // cost of every candidate over its region: per lane three 10-bit partial sums per region
-    int acc[3] = {0, 0, 0};
-    for (int pr = lane; pr < 288; pr += 64) {
-        const int i = 2 * pr;
-        const unsigned xy = ixw[pr];
-        const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
+    int acc0 = 0, acc1 = 0, acc2 = 0;
 #pragma unroll
-        for (int r = 0; r < 3; r++)
-            if (nc[r] != 0 && i >= beg[r] && i < end[r]) acc[r] += loop_pair_cost3(L, grp[r], fmask[r], x, y);
+    for (int k = 0; k < 5; k++) {
+        const int pr = lane + 64 * k;          // pair index; k == 4 covers pairs 256..287 only
+        const int prc = pr < 288 ? pr : 287;
+        const int i = 2 * pr;
+        const unsigned xy = ixw[prc];
+        const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
+        const bool c1 = i < a1, c2 = i < a2, c3 = i < e2;
+        const bool in0 = c1, in1 = !c1 && c2, in2 = !c2 && c3 && pr < 288;
+        const int dA = in0 ? da[0] : (in1 ? da[1] : da[2]);
+        const int dB = in0 ? db[0] : (in1 ? db[1] : db[2]);
+        const int fM = in0 ? fm[0] : (in1 ? fm[1] : fm[2]);
+        const int c = loop_pair_cost3(L, dA, dB, fM, x, y);
+        acc0 += (in0 && fM) ? c : 0;
+        acc1 += (in1 && fM) ? c : 0;
+        acc2 += (in2 && fM) ? c : 0;
     }
-    int sel_sum[3] = {0, 0, 0};
+    const int acc[3] = {acc0, acc1, acc2};
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        if (nc[r] == 0) continue;
-        int sum[3];
+        if (mx[r] == 0) continue;
         const int s01 = wave_sum_i32((acc[r] & 0x3ff) | (((acc[r] >> 10) & 0x3ff) << 16)); // two fields per reduction
-        sum[0] = s01 & 0xffff;
-        sum[1] = (s01 >> 16) & 0xffff;
-        sum[2] = cand[r][2] ? wave_sum_i32((acc[r] >> 20) & 0x3ff) : 0;
-        const int t = loop_pick(nc[r], cand[r], sum);
-        g.table_select[r] = t;
-        sel_sum[r] = (t == cand[r][0]) ? sum[0] : (t == cand[r][1] ? sum[1] : sum[2]);
-    }
-    // bigv_bitcount (src/loop.c:1997-2011): regions [0,a1), [a1,a2), [a2,a3)
-    if (g.table_select[0]) bits += sel_sum[0];
-    if (g.table_select[1]) bits += sel_sum[1];
-    if (g.table_select[2]) {
-        if (g.address3 == end[2]) bits += sel_sum[2];
-        else { // cannot happen for a consistent state (address3 == 2*big_values whenever region 2 is on)
-            bits += 100000;
-        }
+        const int s2 = (fm[r] >> 20) ? wave_sum_i32((acc[r] >> 20) & 0x3ff) : 0;
+        int best;
+        g.table_select[r] = loop_pick(da[r], s01 & 0xffff, (s01 >> 16) & 0xffff, s2, &best);
+        // bigv_bitcount (src/loop.c:1997-2011) counts region r over the same range (address3 == e2
+        // whenever region 2 is not empty)
+        bits += best;
     }
     return bits;
 }
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     R.sfb_l = (lane < 23) ? T->sfb_l[lane] : 576;
     R.sfb_s = (lane < 14) ? T->sfb_s[lane] : 192;
     R.subdv = (lane < 23) ? (LOOP_SUBDV0[lane] | (LOOP_SUBDV1[lane] << 8)) : 0;
-    R.ht = (lane < 34) ? ((int) T->ht_off[lane] | ((int) T->ht_ylen[lane] << 16) | ((int) T->ht_linbits[lane] << 24)) : 0;
+    loop_desc_init(T, lane, &R.desc_a, &R.desc_b);
 
     for (int i = lane; i < 928; i += 64) L.glut[i] = T->glut[i];
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];

@@ -87,6 +87,7 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long) v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned) v) : 32; }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long) v) : 64; }
 
 // ---- host runtime shims (memory is plain host memory) ----
