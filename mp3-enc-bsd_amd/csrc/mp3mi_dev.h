@@ -20,14 +20,17 @@
 #define MP3MI_CBANDS_S 42
 #define MP3MI_HBLK 513
 #define MP3MI_HBLK_S 129
-#define MP3MI_MAX_FFT_OPS_L 9216
-#define MP3MI_MAX_FFT_OPS_S 2304
+#define MP3MI_MAX_FFT_GOPS_L 5760
+#define MP3MI_MAX_FFT_GOPS_S 1224
+#define MP3MI_MAX_FFT_ROPS_L 1088
+#define MP3MI_MAX_FFT_ROPS_S 192
 #define MP3MI_MAX_FFT_SEGS 96
 #define MP3MI_POW43_N 8208
 #define MP3MI_STEP_MIN (-400)
 #define MP3MI_STEP_N 801
 
-/* FFT butterfly program (see fft_program.cpp).  One 16-byte record per butterfly. */
+/* FFT butterfly program (see tables_host.cpp).  Rotations carry their three twiddle factors in a
+ * 16-byte record; every other butterfly is one word: a | b << 10 | c << 20 (d = c + b - a). */
 enum {
     FOP_ADDSUB = 0, /* t=x[a]+x[b]; x[b]=x[a]-x[b]; x[a]=t               (src/subs.c:289-297, 467-472) */
     FOP_NEG = 1,    /* x[a]=-x[a]                                        (src/subs.c:475-479) */
@@ -65,7 +68,8 @@ typedef struct {
     /* FFT programs */
     int32_t n_seg_l, n_seg_s;
     mp3mi_fftseg seg_l[MP3MI_MAX_FFT_SEGS], seg_s[MP3MI_MAX_FFT_SEGS];
-    mp3mi_fftop ops_l[MP3MI_MAX_FFT_OPS_L], ops_s[MP3MI_MAX_FFT_OPS_S];
+    uint32_t gops_l[MP3MI_MAX_FFT_GOPS_L], gops_s[MP3MI_MAX_FFT_GOPS_S];   /* start of a segment is into these ... */
+    mp3mi_fftop rops_l[MP3MI_MAX_FFT_ROPS_L], rops_s[MP3MI_MAX_FFT_ROPS_S]; /* ... or, for FOP_ROT segments, into these */
     /* filterbank + MDCT */
     double enwindow[512];
     double filt[32][32];             /* the 31 used columns per subband: 0..15, 33..47  */

@@ -140,48 +140,56 @@ struct FftGen {
         if (logm == 2) op(post1, FOP_NEG, o + 3);
     }
 
-    void build(int logN, mp3mi_fftop *out_ops, int max_ops, mp3mi_fftseg *segs, int32_t *n_seg)
+    void build(int logN, uint32_t *gops, int max_gops, mp3mi_fftop *rops, int max_rops, mp3mi_fftseg *segs, int32_t *n_seg)
     {
         ops.clear();
         post1 = 3 * logN + 1;
         post2 = post1 + 1;
         brphase = post2 + 1;
         real(0, logN, 0);
-        int N = 1 << logN;
-        for (int i = 0; i < N; i++) {
-            int j = 0;
-            for (int b = 0; b < logN; b++)
-                if (i & (1 << b)) j |= 1 << (logN - 1 - b);
-            if (j > i) op(brphase, FOP_SWAP, i, j);
-        }
+        /* bit reversal: exchanges listed so that the 32 lanes of a half wave touch 32 different LDS
+           banks on both sides (i = [h][l] <-> j = [rev l][rev h]: l and h both run over all values) */
+        const int N = 1 << logN, half = logN / 2, hn = 1 << half;
+        if (logN % 2) { fprintf(stderr, "mp3mi: fft size must be a power of four\n"); abort(); }
+        for (int c = 0; c < hn; c++)
+            for (int l = 0; l < hn; l++) {
+                const int i = (((l + c) & (hn - 1)) << half) | l;
+                int j = 0;
+                for (int b = 0; b < logN; b++)
+                    if (i & (1 << b)) j |= 1 << (logN - 1 - b);
+                if (j > i) op(brphase, FOP_SWAP, i, j);
+            }
+        (void) N;
         std::stable_sort(ops.begin(), ops.end(), [](const RawOp &x, const RawOp &y) {
             return x.phase != y.phase ? x.phase < y.phase : x.type < y.type;
         });
-        if ((int) ops.size() > max_ops) { fprintf(stderr, "mp3mi: fft program too large (%zu)\n", ops.size()); abort(); }
-        int ns = 0;
+        int ns = 0, ng = 0, nr = 0;
         for (size_t i = 0; i < ops.size(); i++) {
             const RawOp &o = ops[i];
-            mp3mi_fftop w;
-            w.w[0] = o.a | (o.b << 16);
-            if (o.type == FOP_ROT) {
-                memcpy(&w.w[1], &o.f0, 4);
-                memcpy(&w.w[2], &o.f1, 4);
-                memcpy(&w.w[3], &o.f2, 4);
-            } else {
-                w.w[1] = o.c | (o.d << 16);
-                w.w[2] = w.w[3] = 0;
-            }
-            out_ops[i] = w;
+            const bool rot = o.type == FOP_ROT;
             if (i == 0 || o.phase != ops[i - 1].phase || o.type != ops[i - 1].type) {
                 if (ns >= MP3MI_MAX_FFT_SEGS) { fprintf(stderr, "mp3mi: too many fft segments\n"); abort(); }
                 if (ns > 0) segs[ns - 1].barrier = (o.phase != ops[i - 1].phase);
                 segs[ns].type = o.type;
-                segs[ns].start = (int) i;
+                segs[ns].start = rot ? nr : ng;
                 segs[ns].count = 0;
                 segs[ns].barrier = 1;
                 ns++;
             }
             segs[ns - 1].count++;
+            if (rot) {
+                if (nr >= max_rops) { fprintf(stderr, "mp3mi: fft program too large\n"); abort(); }
+                mp3mi_fftop w;
+                w.w[0] = o.a | (o.b << 16);
+                memcpy(&w.w[1], &o.f0, 4);
+                memcpy(&w.w[2], &o.f1, 4);
+                memcpy(&w.w[3], &o.f2, 4);
+                rops[nr++] = w;
+            } else {
+                if (ng >= max_gops) { fprintf(stderr, "mp3mi: fft program too large\n"); abort(); }
+                if (o.type == FOP_CROSS && o.d != o.c + o.b - o.a) { fprintf(stderr, "mp3mi: fft op encoding\n"); abort(); }
+                gops[ng++] = o.a | (o.b << 10) | (o.c << 20);
+            }
         }
         *n_seg = ns;
     }
@@ -261,8 +269,8 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
     {
         FftGen *g = new FftGen();
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
-        g->build(10, T->ops_l, MP3MI_MAX_FFT_OPS_L, T->seg_l, &T->n_seg_l);
-        g->build(8, T->ops_s, MP3MI_MAX_FFT_OPS_S, T->seg_s, &T->n_seg_s);
+        g->build(10, T->gops_l, MP3MI_MAX_FFT_GOPS_L, T->rops_l, MP3MI_MAX_FFT_ROPS_L, T->seg_l, &T->n_seg_l);
+        g->build(8, T->gops_s, MP3MI_MAX_FFT_GOPS_S, T->rops_s, MP3MI_MAX_FFT_ROPS_S, T->seg_s, &T->n_seg_s);
         delete g;
     }
 
