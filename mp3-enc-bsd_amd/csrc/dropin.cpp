@@ -52,7 +52,7 @@ struct DropIn {
     mp3mi_tables *T = nullptr;
     // psy
     int16_t *pcm_d = nullptr;
-    float *el = nullptr, *es = nullptr, *h6 = nullptr;
+    float *el = nullptr, *es = nullptr, *h6 = nullptr, *bins = nullptr;
     double *cw = nullptr;
     void *psy_state = nullptr;
     mp3mi_psy_out *psy1 = nullptr;
@@ -101,6 +101,7 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.el, MP3MI_HBLK * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.es, 3 * MP3MI_HBLK_S * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.h6, 12 * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.bins, MP3MI_FFT_BINS * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.cw, 50 * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.psy_state, 2 * mp3mi_psy_state_size()));
     HIPOK(hipMemset(D.psy_state, 0, 2 * mp3mi_psy_state_size()));
@@ -179,7 +180,7 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
     mp3mi_geom g = mp3mi_make_geom(1, 1, D.rate_idx, 2, 1, 1);
     g.g0 = 2;
     g.n_gran = 1;
-    mp3mi_launch_fft(D.T, g, D.pcm_d, D.el, D.es, D.cw, D.h6, D.st);
+    mp3mi_launch_fft(D.T, g, D.pcm_d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
     mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.psy1, D.st);
     mp3mi_psy_out o;
     HIPOK(hipMemcpyAsync(&o, D.psy1, sizeof(o), hipMemcpyDeviceToHost, D.st));

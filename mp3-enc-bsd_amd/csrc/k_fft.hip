@@ -17,15 +17,34 @@
 
 #define R_SQHALF 0.707106781186547524401 /* src/subs.c:27 */
 
+// Diagnostic build only (-DMP3MI_FFT_PROFILE): cycles per phase, summed over all waves.
+#if defined(MP3MI_FFT_PROFILE) && !defined(MP3MI_EMU)
+__device__ unsigned long long g_fft_prof[8];
+#define PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
+#define PROF_END do { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_fft_prof[i_], prof_acc[i_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_END
+#endif
+
 // One wavefront transforms all C channels of a granule: every butterfly record is fetched once
 // and applied to the C long (then 3C short) arrays, which also gives each lane C independent
 // dependency chains.  es/ps reuse the long arrays' space once the long spectrum is consumed.
-template <int C> struct fft_lds {
+// A workgroup is W such wavefronts (W granules) sharing ONE copy of the butterfly program in LDS:
+// a record costs an LDS read instead of an L2 round trip per round, which is what the transform
+// was waiting on when the program lived in global memory.
+template <int C> struct fft_wave_lds {
     union {
         float xl[C][1024];
-        struct { float es[C][3][129]; float ps[C][3][52]; } sp;
+        float xs[C][3][256]; // filled (from PCM again) once the long spectrum is consumed
     };
-    float xs[C][3][256];
+};
+template <int C, int W> struct fft_lds {
+    uint32_t prog_g[64 * (MP3MI_FFT_GROUNDS_L + 1)]; // + one round that is read ahead but never used
+    uint4 prog_r[64 * (MP3MI_FFT_RROUNDS_L + 1)];
+    fft_wave_lds<C> w[W];
 };
 
 template <int TYPE, int NARR, int STRIDE>
@@ -83,149 +102,209 @@ MP3MI_DEVFN void fft_apply(float *x, uint32_t w0, uint32_t w1, uint32_t w2, uint
     }
 }
 
-// one segment of independent butterflies; the record of the next round is requested before the
-// current one is applied so that its latency hides behind the LDS work
+// The butterfly records are two streams (one-word records; 16-byte rotation records) laid out in
+// rounds of 64, one record per lane, idle lanes marked by bit 31 (tables_host.cpp).  pg/pr point at
+// this lane's record of the next round; the record of the following round is read ahead.
 template <int TYPE, int NARR, int STRIDE>
-MP3MI_DEVFN void fft_segment(float *x, const uint32_t *gops, const mp3mi_fftop *rops, int start, int count)
+MP3MI_DEVFN void fft_segment(float *x, const uint32_t *&pg, const uint4 *&pr, int rounds)
 {
-    const int lane = wave_lane();
     if (TYPE == FOP_ROT) {
-        const uint4 *rp = (const uint4 *) (rops + start);
-        uint4 cur = rp[lane < count ? lane : 0];
-        for (int e = lane; e < count; e += 64) {
-            const uint4 nxt = rp[e + 64 < count ? e + 64 : 0];
-            fft_apply<TYPE, NARR, STRIDE>(x, cur.x, cur.y, cur.z, cur.w);
+        uint4 cur = *pr;
+        for (int t = 0; t < rounds; t++) {
+            pr += 64;
+            const uint4 nxt = *pr;
+            if (!(cur.x >> 31)) fft_apply<TYPE, NARR, STRIDE>(x, cur.x, cur.y, cur.z, cur.w);
             cur = nxt;
         }
     } else {
-        const uint32_t *gp = gops + start;
-        uint32_t cur = gp[lane < count ? lane : 0];
-        for (int e = lane; e < count; e += 64) {
-            const uint32_t nxt = gp[e + 64 < count ? e + 64 : 0];
-            fft_apply<TYPE, NARR, STRIDE>(x, cur, 0, 0, 0);
+        uint32_t cur = *pg;
+        for (int t = 0; t < rounds; t++) {
+            pg += 64;
+            const uint32_t nxt = *pg;
+            if (!(cur >> 31)) fft_apply<TYPE, NARR, STRIDE>(x, cur, 0, 0, 0);
             cur = nxt;
         }
     }
 }
 
 template <int NARR, int STRIDE>
-MP3MI_DEVFN void fft_run(float *x, const mp3mi_fftseg *segs, int nseg, const uint32_t *gops, const mp3mi_fftop *rops)
+MP3MI_DEVFN void fft_run(float *x, const int32_t *segs, int nseg, const uint32_t *pg, const uint4 *pr)
 {
+    int nxt = segs[0];
     for (int sidx = 0; sidx < nseg; sidx++) {
-        const int type = segs[sidx].type, start = segs[sidx].start, count = segs[sidx].count;
+        const int sw = nxt;
+        nxt = segs[sidx + 1 < nseg ? sidx + 1 : sidx];
+        const int type = sw & 0xff, rounds = (sw >> 8) & 0xff;
         switch (type) {
-        case FOP_ADDSUB: fft_segment<FOP_ADDSUB, NARR, STRIDE>(x, gops, rops, start, count); break;
-        case FOP_NEG: fft_segment<FOP_NEG, NARR, STRIDE>(x, gops, rops, start, count); break;
-        case FOP_CROSS: fft_segment<FOP_CROSS, NARR, STRIDE>(x, gops, rops, start, count); break;
-        case FOP_ROT: fft_segment<FOP_ROT, NARR, STRIDE>(x, gops, rops, start, count); break;
-        case FOP_SQ1: fft_segment<FOP_SQ1, NARR, STRIDE>(x, gops, rops, start, count); break;
-        case FOP_SQ2: fft_segment<FOP_SQ2, NARR, STRIDE>(x, gops, rops, start, count); break;
-        case FOP_SWAPNN: fft_segment<FOP_SWAPNN, NARR, STRIDE>(x, gops, rops, start, count); break;
-        case FOP_SWAPN: fft_segment<FOP_SWAPN, NARR, STRIDE>(x, gops, rops, start, count); break;
-        default: fft_segment<FOP_SWAP, NARR, STRIDE>(x, gops, rops, start, count); break;
+        case FOP_ADDSUB: fft_segment<FOP_ADDSUB, NARR, STRIDE>(x, pg, pr, rounds); break;
+        case FOP_NEG: fft_segment<FOP_NEG, NARR, STRIDE>(x, pg, pr, rounds); break;
+        case FOP_CROSS: fft_segment<FOP_CROSS, NARR, STRIDE>(x, pg, pr, rounds); break;
+        case FOP_ROT: fft_segment<FOP_ROT, NARR, STRIDE>(x, pg, pr, rounds); break;
+        case FOP_SQ1: fft_segment<FOP_SQ1, NARR, STRIDE>(x, pg, pr, rounds); break;
+        case FOP_SQ2: fft_segment<FOP_SQ2, NARR, STRIDE>(x, pg, pr, rounds); break;
+        case FOP_SWAPNN: fft_segment<FOP_SWAPNN, NARR, STRIDE>(x, pg, pr, rounds); break;
+        case FOP_SWAPN: fft_segment<FOP_SWAPN, NARR, STRIDE>(x, pg, pr, rounds); break;
+        default: fft_segment<FOP_SWAP, NARR, STRIDE>(x, pg, pr, rounds); break;
         }
-        if (segs[sidx].barrier) __syncthreads();
+        if (sw >> 16) wave_sync();
     }
 }
 
-// energy and phase of bin i of an N-point transform held as x (src/subs.c:53-123)
-MP3MI_DEVFN void fft_bin(const float *x, int N, int i, bool want_phi, float *energy, float *phi)
+// energy of bin i of an N-point transform held as x (src/subs.c:53-123)
+MP3MI_DEVFN float fft_energy(const float *x, int N, int i)
 {
-    if (i == 0 || i == N / 2) {
-        *energy = x[i] * x[i];
-        *phi = want_phi ? (float) dm_atan2(0.0, (double) x[i]) : 0.0f;
-        return;
-    }
+    if (i == 0 || i == N / 2) return x[i] * x[i];
     const float re = x[i], im = x[N - i];
-    float e = re * re + im * im;
-    if ((double) e < 0.0005) {
-        *energy = (float) 0.0005;
-        *phi = 0.0f;
-    } else {
-        *energy = e;
-        *phi = want_phi ? (float) dm_atan2(-(double) im, (double) re) : 0.0f;
-    }
+    const float e = re * re + im * im;
+    return ((double) e < 0.0005) ? (float) 0.0005 : e;
 }
 
-template <int C>
-__global__ void __launch_bounds__(64) k_fft(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
-                                            const int16_t *__restrict__ pcm_all, float *__restrict__ energy_l,
-                                            float *__restrict__ energy_s, double *__restrict__ cw_mid,
-                                            float *__restrict__ hist6)
+template <int C, int W>
+__global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                                const int16_t *__restrict__ pcm_all, float *__restrict__ energy_l,
+                                                float *__restrict__ energy_s, float *__restrict__ bins)
 {
-    __shared__ fft_lds<C> L;
-    const int lane = wave_lane();
-    const int G = geo.n_gran;
-    const int gl = (int) blockIdx.x % G, s = (int) blockIdx.x / G;
+    __shared__ fft_lds<C, W> LL;
+    const int lane = wave_lane(), tid = (int) threadIdx.x;
+    fft_wave_lds<C> &L = LL.w[tid >> 6];
+    const int G = geo.n_gran, n_task = geo.n_streams * G;
+    int task = (int) blockIdx.x * W + (tid >> 6);
+    const bool valid = task < n_task; // the last workgroup may have idle wavefronts: they compute, but do not store
+    task = valid ? task : n_task - 1;
+    const int gl = task % G, s = task / G;
     const size_t rec0 = ((size_t) s * G + gl) * C;
     const long gabs = (long) geo.g0 + gl;
     const long n_per_ch = (long) geo.n_frames * 1152;
     const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_per_ch * (size_t) C;
     const long t0 = 576 * gabs - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
+    PROF_DECL;
 
-    for (int j = lane; j < 1024; j += 64) {
-        const long t = t0 + j;
-        const bool in = t >= 0 && t < n_per_ch;
-        const float w = T->window[j];
-        int v[C];
-        if (C == 2) {
-            const uint32_t both = in ? ((const uint32_t *) pcm)[t] : 0u;
-            v[0] = (int) (int16_t) (both & 0xffffu);
-            v[C - 1] = (int) (int16_t) (both >> 16);
-        } else {
-            v[0] = in ? (int) pcm[t] : 0;
+    for (int i = tid; i < 64 * MP3MI_FFT_GROUNDS_L; i += 64 * W) LL.prog_g[i] = T->gops_l[i];
+    for (int i = tid; i < 64 * MP3MI_FFT_RROUNDS_L; i += 64 * W) LL.prog_r[i] = ((const uint4 *) T->rops_l)[i];
+
+    // the 1024-sample window of all channels: every load is issued before the first use
+    {
+        float wl[16];
+        uint32_t smp[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const long t = t0 + lane + 64 * k;
+            const bool in = t >= 0 && t < n_per_ch;
+            if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : 0u;
+            else smp[k] = in ? (uint32_t) (uint16_t) pcm[t] : 0u;
+            wl[k] = T->window[lane + 64 * k];
         }
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            L.xl[c][j] = w * (float) v[c];                        // src/l3psy.c:485
-            // short windows: samples 256 + 128 sb + jj, sb < 3 (src/l3psy.c:520-523); the middle 128
-            // samples of every window are also the first 128 of the next
-            if (j >= 256) {
-                const int q = j - 256, sb = q >> 7, jj = q & 127;
-                if (sb < 3) L.xs[c][sb][jj] = T->window_s[jj] * (float) v[c];
-                if (sb >= 1 && sb < 4) L.xs[c][sb - 1][128 + jj] = T->window_s[128 + jj] * (float) v[c];
+        for (int k = 0; k < 16; k++)
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
+                L.xl[c][lane + 64 * k] = wl[k] * v;               // src/l3psy.c:485
             }
-        }
     }
     __syncthreads();
+    PROF(0);
 
-    fft_run<C, 1024>(&L.xl[0][0], T->seg_l, T->n_seg_l, T->gops_l, T->rops_l);
+    fft_run<C, 1024>(&L.xl[0][0], T->seg_l, T->n_seg_l, LL.prog_g + lane, LL.prog_r + lane);
+    PROF(1);
 
-    for (int c = 0; c < C; c++)
+    // the short windows' samples are requested now and land while the long spectrum is consumed
+    uint32_t smp[12];
+    float wsv[4];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const long t = t0 + 256 + lane + 64 * k;
+        const bool in = t >= 0 && t < n_per_ch;
+        if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : 0u;
+        else smp[k] = in ? (uint32_t) (uint16_t) pcm[t] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) wsv[k] = T->window_s[lane + 64 * k];
+
+    for (int c = 0; c < C; c++) {
         for (int i = lane; i < MP3MI_HBLK; i += 64) {
-            float e, p;
-            fft_bin(L.xl[c], 1024, i, i < 6, &e, &p);
-            energy_l[(rec0 + c) * MP3MI_HBLK + i] = e;
-            if (i < 6) {
-                hist6[(rec0 + c) * 12 + i] = (float) __builtin_sqrt((double) e); // r, src/l3psy.c:500
-                hist6[(rec0 + c) * 12 + 6 + i] = p;
-            }
+            const float e = fft_energy(L.xl[c], 1024, i);
+            if (valid) energy_l[(rec0 + c) * MP3MI_HBLK + i] = e;
         }
-    __syncthreads(); // xl is dead from here on: es/ps take its place
+        // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
+        if (lane < 6 && valid) {
+            bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = L.xl[c][lane];
+            bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? L.xl[c][1024 - lane] : -0.0f;
+        }
+    }
+    wave_sync(); // xl is dead from here on
+    // short windows: samples 256 + 128 sb + jj, sb < 3 (src/l3psy.c:520-523); the second half of every
+    // window is also the first half of the next.  Sample 256 + lane + 64 k: sb = k >> 1, jj = lane + 64 (k & 1).
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
+            const int sb = k >> 1, jj = lane + 64 * (k & 1);
+            if (sb < 3) L.xs[c][sb][jj] = wsv[k & 1] * v;
+            if (sb >= 1 && sb < 4) L.xs[c][sb - 1][128 + jj] = wsv[2 + (k & 1)] * v;
+        }
+    __syncthreads(); // every wavefront is done with the long program
+    for (int i = tid; i < 64 * MP3MI_FFT_GROUNDS_S; i += 64 * W) LL.prog_g[i] = T->gops_s[i];
+    for (int i = tid; i < 64 * MP3MI_FFT_RROUNDS_S; i += 64 * W) LL.prog_r[i] = ((const uint4 *) T->rops_s)[i];
+    __syncthreads();
+    PROF(2);
 
-    fft_run<3 * C, 256>(&L.xs[0][0][0], T->seg_s, T->n_seg_s, T->gops_s, T->rops_s);
+    fft_run<3 * C, 256>(&L.xs[0][0][0], T->seg_s, T->n_seg_s, LL.prog_g + lane, LL.prog_r + lane);
+    PROF(3);
 
     for (int i = lane; i < C * 3 * MP3MI_HBLK_S; i += 64) {
         const int csb = i / MP3MI_HBLK_S, k = i % MP3MI_HBLK_S, c = csb / 3, sb = csb % 3;
-        float e, p;
-        fft_bin(L.xs[c][sb], 256, k, false, &e, &p);
-        L.sp.es[c][sb][k] = e;
-        energy_s[(rec0 + c) * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S + k] = e;
+        const float e = fft_energy(L.xs[c][sb], 256, k);
+        if (valid) energy_s[(rec0 + c) * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S + k] = e;
     }
-    for (int i = lane; i < C * 150; i += 64) { // phases of short lines 2..51 (src/l3psy.c:531-549 reads these only)
-        const int csb = i / 50, k = 2 + i % 50, c = csb / 3, sb = csb % 3;
-        float e, p;
-        fft_bin(L.xs[c][sb], 256, k, true, &e, &p);
-        L.sp.ps[c][sb][k] = p;
+    for (int i = lane; i < C * 150; i += 64) { // raw short lines 2..51 for k_cw (src/l3psy.c:531-549 reads these only)
+        const int csb = i / 50, n = i % 50, c = csb / 3, sb = csb % 3;
+        if (valid) {
+            float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + n) * 2;
+            o[0] = L.xs[c][sb][2 + n];
+            o[1] = L.xs[c][sb][254 - n];
+        }
     }
-    __syncthreads();
+    PROF(4);
+    PROF_END;
+}
 
-    for (int i = lane; i < C * 50; i += 64) { // unpredictability of lines 6+4n..9+4n from the three short FFTs (src/l3psy.c:531-549)
-        const int c = i / 50, n = i % 50, k = n + 2;
-        const double r_prime = 2.0 * __builtin_sqrt((double) L.sp.es[c][0][k]) - __builtin_sqrt((double) L.sp.es[c][2][k]);
-        const double phi_prime = 2.0 * (double) L.sp.ps[c][0][k] - (double) L.sp.ps[c][2][k];
-        const double r2 = __builtin_sqrt((double) L.sp.es[c][1][k]);
-        const double phi2 = (double) L.sp.ps[c][1][k];
+// energy, magnitude and phase of a raw bin (src/subs.c:53-123).  Bins below the energy floor have
+// phase 0 and never reach atan2; `exact` marks the real-valued bin 0, which has no floor.
+MP3MI_DEVFN void cw_bin(float re, float im, bool exact, float *energy, float *phi)
+{
+    const float e = re * re + im * im;
+    const bool low = !exact && (double) e < 0.0005;
+    *energy = low ? (float) 0.0005 : e;
+    *phi = low ? 0.0f : (float) dm_atan2(-(double) im, (double) re);
+}
+
+// Phases and the unpredictability measure from the raw FFT bins, one wavefront per (granule, channel):
+// lanes 0..49 the unpredictability of lines 6+4n..9+4n from the three short FFTs (src/l3psy.c:531-549),
+// lanes 50..55 magnitude and phase of long lines 0..5 (src/l3psy.c:497-503).  Kept out of k_fft so that
+// this double-precision chain runs at full occupancy instead of next to 150 KB of LDS.
+__global__ void __launch_bounds__(64) k_cw(const float *__restrict__ bins, double *__restrict__ cw_mid, float *__restrict__ hist6)
+{
+    const int lane = wave_lane();
+    const size_t rec = blockIdx.x;
+    const float *b = bins + rec * MP3MI_FFT_BINS;
+    float re[3] = {1.0f, 1.0f, 1.0f}, im[3] = {0.0f, 0.0f, 0.0f};
+    if (lane < 50) {
+#pragma unroll
+        for (int sb = 0; sb < 3; sb++) { re[sb] = b[(sb * 50 + lane) * 2]; im[sb] = b[(sb * 50 + lane) * 2 + 1]; }
+    } else if (lane < 56) {
+        re[0] = b[300 + lane - 50];
+        im[0] = b[306 + lane - 50];
+    }
+    float e[3], ph[3];
+#pragma unroll
+    for (int sb = 0; sb < 3; sb++) cw_bin(re[sb], im[sb], lane == 50 && sb == 0, &e[sb], &ph[sb]);
+    if (lane < 50) {
+        const double r_prime = 2.0 * __builtin_sqrt((double) e[0]) - __builtin_sqrt((double) e[2]);
+        const double phi_prime = 2.0 * (double) ph[0] - (double) ph[2];
+        const double r2 = __builtin_sqrt((double) e[1]);
+        const double phi2 = (double) ph[1];
         double s2, c2, sp, cp;
         dm_sincos(phi2, &s2, &c2);
         dm_sincos(phi_prime, &sp, &cp);
@@ -234,16 +313,34 @@ __global__ void __launch_bounds__(64) k_fft(const mp3mi_tables *__restrict__ T, 
         const double t3 = r2 + __builtin_fabs(r_prime);
         double cw = 0.0;
         if (t3 != 0.0) cw = __builtin_sqrt(t1 * t1 + t2 * t2) / t3;
-        cw_mid[(rec0 + c) * 50 + n] = cw;
+        cw_mid[rec * 50 + lane] = cw;
+    } else if (lane < 56) {
+        hist6[rec * 12 + lane - 50] = (float) __builtin_sqrt((double) e[0]); // r, src/l3psy.c:500
+        hist6[rec * 12 + 6 + lane - 50] = ph[0];
     }
 }
 
-void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, float *energy_l,
-                      float *energy_s, double *cw_mid, float *hist6, hipStream_t st)
+#if defined(MP3MI_FFT_PROFILE) && !defined(MP3MI_EMU)
+extern "C" void mp3mi_debug_fft_profile(unsigned long long *out)
 {
-    const unsigned grid = (unsigned) (g.n_streams * g.n_gran);
-    if (g.channels == 2)
-        hipLaunchKernelGGL(k_fft<2>, dim3(grid), dim3(64), 0, st, T, g, pcm, energy_l, energy_s, cw_mid, hist6);
-    else
-        hipLaunchKernelGGL(k_fft<1>, dim3(grid), dim3(64), 0, st, T, g, pcm, energy_l, energy_s, cw_mid, hist6);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fft_prof), sizeof(z));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_fft_prof), z, sizeof(z));
+}
+#endif
+
+void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, float *energy_l,
+                      float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st)
+{
+    // W: as many wavefronts as fit the 160 KB of LDS next to the shared program
+    const int n_task = g.n_streams * g.n_gran;
+    if (g.channels == 2) {
+        const int W = 13;
+        hipLaunchKernelGGL((k_fft<2, W>), dim3((unsigned) ((n_task + W - 1) / W)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
+    } else {
+        const int W = 16;
+        hipLaunchKernelGGL((k_fft<1, W>), dim3((unsigned) ((n_task + W - 1) / W)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
+    }
+    hipLaunchKernelGGL(k_cw, dim3((unsigned) (n_task * g.channels)), dim3(64), 0, st, bins, cw_mid, hist6);
 }

@@ -20,10 +20,13 @@
 #define MP3MI_CBANDS_S 42
 #define MP3MI_HBLK 513
 #define MP3MI_HBLK_S 129
-#define MP3MI_MAX_FFT_GOPS_L 5760
-#define MP3MI_MAX_FFT_GOPS_S 1224
-#define MP3MI_MAX_FFT_ROPS_L 1088
-#define MP3MI_MAX_FFT_ROPS_S 192
+/* FFT butterfly programs: rounds of 64 records (one per lane); sizes are checked at table build */
+#define MP3MI_FFT_BINS 312   /* raw bins handed from k_fft to k_cw per (granule, channel): short lines 2..51 of the three
+                                windows as (re, im), then re[6], im[6] of long lines 0..5 */
+#define MP3MI_FFT_GROUNDS_L 113
+#define MP3MI_FFT_RROUNDS_L 20
+#define MP3MI_FFT_GROUNDS_S 40
+#define MP3MI_FFT_RROUNDS_S 5
 #define MP3MI_MAX_FFT_SEGS 96
 #define MP3MI_POW43_N 8208
 #define MP3MI_STEP_MIN (-400)
@@ -44,7 +47,6 @@ enum {
 };
 
 typedef struct { uint32_t w[4]; } mp3mi_fftop;
-typedef struct { int32_t type, start, count, barrier; } mp3mi_fftseg;
 
 /* All read-only tables, one block in device memory.  Values are produced on the host with
  * the host's libm exactly as the reference's init code does (tables_host.cpp). */
@@ -67,9 +69,9 @@ typedef struct {
     double w1_l[21], w2_l[21], w1_s[12], w2_s[12];
     /* FFT programs */
     int32_t n_seg_l, n_seg_s;
-    mp3mi_fftseg seg_l[MP3MI_MAX_FFT_SEGS], seg_s[MP3MI_MAX_FFT_SEGS];
-    uint32_t gops_l[MP3MI_MAX_FFT_GOPS_L], gops_s[MP3MI_MAX_FFT_GOPS_S];   /* start of a segment is into these ... */
-    mp3mi_fftop rops_l[MP3MI_MAX_FFT_ROPS_L], rops_s[MP3MI_MAX_FFT_ROPS_S]; /* ... or, for FOP_ROT segments, into these */
+    int32_t seg_l[MP3MI_MAX_FFT_SEGS], seg_s[MP3MI_MAX_FFT_SEGS];   /* type | rounds << 8 | barrier << 16 */
+    uint32_t gops_l[64 * MP3MI_FFT_GROUNDS_L], gops_s[64 * MP3MI_FFT_GROUNDS_S];   /* one-word records of all segments but FOP_ROT */
+    mp3mi_fftop rops_l[64 * MP3MI_FFT_RROUNDS_L], rops_s[64 * MP3MI_FFT_RROUNDS_S]; /* records of the FOP_ROT segments */
     /* filterbank + MDCT */
     double enwindow[512];
     double filt[32][32];             /* the 31 used columns per subband: 0..15, 33..47  */
@@ -192,5 +194,19 @@ MP3MI_DEVFN double wave_max_f64(double v)
 MP3MI_DEVFN int wave_bcast_i32(int v, int lane) { return __shfl(v, lane); }
 MP3MI_DEVFN double wave_bcast_f64(double v, int lane) { return __shfl(v, lane); }
 MP3MI_DEVFN int wave_any(int p) { return __ballot(p) != 0ull; }
+
+/* Orders the LDS traffic of ONE wavefront: what any lane wrote before is visible to every lane
+ * after.  The hardware executes a wave's LDS instructions in order, so on the device this only has
+ * to stop the compiler from moving accesses across; the emulator needs a real rendezvous. */
+#if defined(MP3MI_EMU)
+MP3MI_DEVFN void wave_sync(void) { __syncthreads(); }
+#else
+MP3MI_DEVFN void wave_sync(void)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
 
 #endif

@@ -36,7 +36,7 @@ static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_i
 }
 
 void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
-                      float *energy_l, float *energy_s, double *cw_mid, float *hist6, hipStream_t st);
+                      float *energy_l, float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st);
 void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l,
                       const float *energy_s, const double *cw_mid, const float *hist6,
                       void *psy_state, mp3mi_psy_out *out, hipStream_t st);

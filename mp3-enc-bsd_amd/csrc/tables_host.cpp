@@ -140,7 +140,7 @@ struct FftGen {
         if (logm == 2) op(post1, FOP_NEG, o + 3);
     }
 
-    void build(int logN, uint32_t *gops, int max_gops, mp3mi_fftop *rops, int max_rops, mp3mi_fftseg *segs, int32_t *n_seg)
+    void build(int logN, uint32_t *gops, int max_gops, mp3mi_fftop *rops, int max_rops, int32_t *segw, int32_t *n_seg)
     {
         ops.clear();
         post1 = 3 * logN + 1;
@@ -163,15 +163,29 @@ struct FftGen {
         std::stable_sort(ops.begin(), ops.end(), [](const RawOp &x, const RawOp &y) {
             return x.phase != y.phase ? x.phase < y.phase : x.type < y.type;
         });
+        /* Every segment is padded to whole rounds of 64 records (bit 31 = idle lane): round t of the
+           g (r) stream is records [64 t, 64 t + 64), one per lane.  The kernel keeps both streams in
+           LDS and walks them in order, so a segment is just (type, rounds, barrier). */
+        struct Seg { int type, count, barrier; };
+        Seg segs[MP3MI_MAX_FFT_SEGS];
         int ns = 0, ng = 0, nr = 0;
+        auto pad = [&](bool rot) {
+            if (rot) {
+                while (nr % 64) { mp3mi_fftop w = {{0x80000000u, 0, 0, 0}}; if (nr >= max_rops) abort(); rops[nr++] = w; }
+            } else {
+                while (ng % 64) { if (ng >= max_gops) abort(); gops[ng++] = 0x80000000u; }
+            }
+        };
         for (size_t i = 0; i < ops.size(); i++) {
             const RawOp &o = ops[i];
             const bool rot = o.type == FOP_ROT;
             if (i == 0 || o.phase != ops[i - 1].phase || o.type != ops[i - 1].type) {
                 if (ns >= MP3MI_MAX_FFT_SEGS) { fprintf(stderr, "mp3mi: too many fft segments\n"); abort(); }
-                if (ns > 0) segs[ns - 1].barrier = (o.phase != ops[i - 1].phase);
+                if (ns > 0) {
+                    segs[ns - 1].barrier = (o.phase != ops[i - 1].phase);
+                    pad(segs[ns - 1].type == FOP_ROT);
+                }
                 segs[ns].type = o.type;
-                segs[ns].start = rot ? nr : ng;
                 segs[ns].count = 0;
                 segs[ns].barrier = 1;
                 ns++;
@@ -191,6 +205,9 @@ struct FftGen {
                 gops[ng++] = o.a | (o.b << 10) | (o.c << 20);
             }
         }
+        pad(segs[ns - 1].type == FOP_ROT);
+        if (ng != max_gops || nr != max_rops) { fprintf(stderr, "mp3mi: fft program size %d/%d, expected %d/%d\n", ng, nr, max_gops, max_rops); abort(); }
+        for (int k = 0; k < ns; k++) segw[k] = segs[k].type | (((segs[k].count + 63) / 64) << 8) | (segs[k].barrier << 16);
         *n_seg = ns;
     }
 };
@@ -269,8 +286,8 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
     {
         FftGen *g = new FftGen();
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
-        g->build(10, T->gops_l, MP3MI_MAX_FFT_GOPS_L, T->rops_l, MP3MI_MAX_FFT_ROPS_L, T->seg_l, &T->n_seg_l);
-        g->build(8, T->gops_s, MP3MI_MAX_FFT_GOPS_S, T->rops_s, MP3MI_MAX_FFT_ROPS_S, T->seg_s, &T->n_seg_s);
+        g->build(10, T->gops_l, 64 * MP3MI_FFT_GROUNDS_L, T->rops_l, 64 * MP3MI_FFT_RROUNDS_L, T->seg_l, &T->n_seg_l);
+        g->build(8, T->gops_s, 64 * MP3MI_FFT_GROUNDS_S, T->rops_s, 64 * MP3MI_FFT_RROUNDS_S, T->seg_s, &T->n_seg_s);
         delete g;
     }
 
