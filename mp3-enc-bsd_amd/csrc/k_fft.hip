@@ -42,7 +42,7 @@ template <int C> struct fft_wave_lds {
     };
 };
 template <int C, int W> struct fft_lds {
-    uint32_t prog_g[64 * (MP3MI_FFT_GROUNDS_L + 1)]; // + one round that is read ahead but never used
+    uint32_t prog_g[64 * (MP3MI_FFT_GROUNDS_L + 2)]; // + two rounds that are read ahead but never used
     uint4 prog_r[64 * (MP3MI_FFT_RROUNDS_L + 1)];
     fft_wave_lds<C> w[W];
 };
@@ -50,11 +50,13 @@ template <int C, int W> struct fft_lds {
 template <int TYPE, int NARR, int STRIDE>
 MP3MI_DEVFN void fft_apply(float *x, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
+    // operand indices are LDS positions (MP3MI_FFT_SWZ applied on the host)
     int a, b, c = 0, d = 0;
     if (TYPE == FOP_ROT) {
         a = (int) (w0 & 0xffffu); b = (int) (w0 >> 16);
     } else {
-        a = (int) (w0 & 1023u); b = (int) ((w0 >> 10) & 1023u); c = (int) (w0 >> 20); d = c + b - a;
+        a = (int) (w0 & 1023u); b = (int) ((w0 >> 10) & 1023u);
+        if (TYPE == FOP_CROSS) { c = (int) (w1 & 1023u); d = (int) ((w1 >> 10) & 1023u); }
     }
 #pragma unroll
     for (int arr = 0; arr < NARR; arr++) {
@@ -116,6 +118,15 @@ MP3MI_DEVFN void fft_segment(float *x, const uint32_t *&pg, const uint4 *&pr, in
             if (!(cur.x >> 31)) fft_apply<TYPE, NARR, STRIDE>(x, cur.x, cur.y, cur.z, cur.w);
             cur = nxt;
         }
+    } else if (TYPE == FOP_CROSS) { // two words per butterfly: the round's second words follow its first words
+        uint32_t cur = pg[0], cur2 = pg[64];
+        for (int t = 0; t < rounds; t++) {
+            pg += 128;
+            const uint32_t nxt = pg[0], nxt2 = pg[64];
+            if (!(cur >> 31)) fft_apply<TYPE, NARR, STRIDE>(x, cur, cur2, 0, 0);
+            cur = nxt;
+            cur2 = nxt2;
+        }
     } else {
         uint32_t cur = *pg;
         for (int t = 0; t < rounds; t++) {
@@ -153,8 +164,8 @@ MP3MI_DEVFN void fft_run(float *x, const int32_t *segs, int nseg, const uint32_t
 // energy of bin i of an N-point transform held as x (src/subs.c:53-123)
 MP3MI_DEVFN float fft_energy(const float *x, int N, int i)
 {
-    if (i == 0 || i == N / 2) return x[i] * x[i];
-    const float re = x[i], im = x[N - i];
+    if (i == 0 || i == N / 2) return x[MP3MI_FFT_SWZ(i)] * x[MP3MI_FFT_SWZ(i)];
+    const float re = x[MP3MI_FFT_SWZ(i)], im = x[MP3MI_FFT_SWZ(N - i)];
     const float e = re * re + im * im;
     return ((double) e < 0.0005) ? (float) 0.0005 : e;
 }
@@ -199,7 +210,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
-                L.xl[c][lane + 64 * k] = wl[k] * v;               // src/l3psy.c:485
+                L.xl[c][MP3MI_FFT_SWZ(lane + 64 * k)] = wl[k] * v; // src/l3psy.c:485
             }
     }
     __syncthreads();
@@ -228,8 +239,8 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         }
         // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
         if (lane < 6 && valid) {
-            bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = L.xl[c][lane];
-            bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? L.xl[c][1024 - lane] : -0.0f;
+            bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = L.xl[c][MP3MI_FFT_SWZ(lane)];
+            bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? L.xl[c][MP3MI_FFT_SWZ(1024 - lane)] : -0.0f;
         }
     }
     wave_sync(); // xl is dead from here on
@@ -241,8 +252,8 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         for (int c = 0; c < C; c++) {
             const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
             const int sb = k >> 1, jj = lane + 64 * (k & 1);
-            if (sb < 3) L.xs[c][sb][jj] = wsv[k & 1] * v;
-            if (sb >= 1 && sb < 4) L.xs[c][sb - 1][128 + jj] = wsv[2 + (k & 1)] * v;
+            if (sb < 3) L.xs[c][sb][MP3MI_FFT_SWZ(jj)] = wsv[k & 1] * v;
+            if (sb >= 1 && sb < 4) L.xs[c][sb - 1][MP3MI_FFT_SWZ(128 + jj)] = wsv[2 + (k & 1)] * v;
         }
     __syncthreads(); // every wavefront is done with the long program
     for (int i = tid; i < 64 * MP3MI_FFT_GROUNDS_S; i += 64 * W) LL.prog_g[i] = T->gops_s[i];
@@ -262,8 +273,8 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         const int csb = i / 50, n = i % 50, c = csb / 3, sb = csb % 3;
         if (valid) {
             float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + n) * 2;
-            o[0] = L.xs[c][sb][2 + n];
-            o[1] = L.xs[c][sb][254 - n];
+            o[0] = L.xs[c][sb][MP3MI_FFT_SWZ(2 + n)];
+            o[1] = L.xs[c][sb][MP3MI_FFT_SWZ(254 - n)];
         }
     }
     PROF(4);

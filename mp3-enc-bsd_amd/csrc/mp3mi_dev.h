@@ -23,9 +23,10 @@
 /* FFT butterfly programs: rounds of 64 records (one per lane); sizes are checked at table build */
 #define MP3MI_FFT_BINS 312   /* raw bins handed from k_fft to k_cw per (granule, channel): short lines 2..51 of the three
                                 windows as (re, im), then re[6], im[6] of long lines 0..5 */
-#define MP3MI_FFT_GROUNDS_L 113
+#define MP3MI_FFT_SWZ(p) ((p) ^ (((p) >> 5) & 31)) /* LDS index of element p of an FFT array */
+#define MP3MI_FFT_GROUNDS_L 124
 #define MP3MI_FFT_RROUNDS_L 20
-#define MP3MI_FFT_GROUNDS_S 40
+#define MP3MI_FFT_GROUNDS_S 45
 #define MP3MI_FFT_RROUNDS_S 5
 #define MP3MI_MAX_FFT_SEGS 96
 #define MP3MI_POW43_N 8208

@@ -147,34 +147,94 @@ struct FftGen {
         post2 = post1 + 1;
         brphase = post2 + 1;
         real(0, logN, 0);
-        /* bit reversal: exchanges listed so that the 32 lanes of a half wave touch 32 different LDS
-           banks on both sides (i = [h][l] <-> j = [rev l][rev h]: l and h both run over all values) */
-        const int N = 1 << logN, half = logN / 2, hn = 1 << half;
-        if (logN % 2) { fprintf(stderr, "mp3mi: fft size must be a power of four\n"); abort(); }
-        for (int c = 0; c < hn; c++)
-            for (int l = 0; l < hn; l++) {
-                const int i = (((l + c) & (hn - 1)) << half) | l;
-                int j = 0;
-                for (int b = 0; b < logN; b++)
-                    if (i & (1 << b)) j |= 1 << (logN - 1 - b);
-                if (j > i) op(brphase, FOP_SWAP, i, j);
-            }
-        (void) N;
+        const int N = 1 << logN;
+        for (int i = 0; i < N; i++) { /* bit reversal */
+            int j = 0;
+            for (int b = 0; b < logN; b++)
+                if (i & (1 << b)) j |= 1 << (logN - 1 - b);
+            if (j > i) op(brphase, FOP_SWAP, i, j);
+        }
         std::stable_sort(ops.begin(), ops.end(), [](const RawOp &x, const RawOp &y) {
             return x.phase != y.phase ? x.phase < y.phase : x.type < y.type;
         });
+        /* the arrays live in LDS with the low five address bits XORed with the next five (MP3MI_FFT_SWZ):
+           the small transforms' operands, which in natural order share a few banks, then spread over all */
+        for (size_t i = 0; i < ops.size(); i++) {
+            RawOp &o = ops[i];
+            o.a = MP3MI_FFT_SWZ(o.a);
+            if (o.type != FOP_NEG) o.b = MP3MI_FFT_SWZ(o.b);
+            if (o.type == FOP_CROSS) { o.c = MP3MI_FFT_SWZ(o.c); o.d = MP3MI_FFT_SWZ(o.d); }
+        }
+        /* The butterflies of a segment are independent, so their order is free: place them so that the
+           32 lanes of a half wave (the unit the LDS serves a 4-byte access in) address 32 different
+           banks with every operand.  Greedy: first the butterflies that fit without any collision, then
+           -- a half wave left partly idle would cost a whole round, a collision costs a cycle -- the
+           ones that collide least. */
+        for (size_t s0 = 0; s0 < ops.size();) {
+            size_t s1 = s0;
+            while (s1 < ops.size() && ops[s1].phase == ops[s0].phase && ops[s1].type == ops[s0].type) s1++;
+            std::vector<RawOp> rest(ops.begin() + s0, ops.begin() + s1), placed;
+            const int type = ops[s0].type;
+            const int nopnd = (type == FOP_NEG) ? 1 : (type == FOP_CROSS ? 4 : 2);
+            while (!rest.empty()) {
+                int used[4][32];
+                memset(used, 0, sizeof(used));
+                std::vector<RawOp> group;
+                auto cost = [&](const RawOp &o) {
+                    const unsigned ad[4] = {o.a, o.b, o.c, o.d};
+                    int c = 0;
+                    for (int k = 0; k < nopnd; k++) c += used[k][ad[k] & 31];
+                    return c;
+                };
+                auto take = [&](size_t idx, bool flip) {
+                    RawOp o = rest[idx];
+                    if (flip) std::swap(o.a, o.b);
+                    const unsigned ad[4] = {o.a, o.b, o.c, o.d};
+                    for (int k = 0; k < nopnd; k++) used[k][ad[k] & 31]++;
+                    group.push_back(o);
+                    rest.erase(rest.begin() + (long) idx);
+                };
+                for (size_t i = 0; i < rest.size() && group.size() < 32;) { /* collision-free candidates, in order */
+                    RawOp f = rest[i];
+                    std::swap(f.a, f.b);
+                    if (cost(rest[i]) == 0) take(i, false);
+                    else if (type == FOP_SWAP && cost(f) == 0) take(i, true); /* an exchange is symmetric */
+                    else i++;
+                }
+                while (group.size() < 32 && !rest.empty()) { /* fill up with the least harmful */
+                    size_t best = 0;
+                    int bc = 1 << 30;
+                    for (size_t i = 0; i < rest.size(); i++) {
+                        const int c = cost(rest[i]);
+                        if (c < bc) { bc = c; best = i; }
+                    }
+                    take(best, false);
+                }
+                placed.insert(placed.end(), group.begin(), group.end());
+            }
+            std::copy(placed.begin(), placed.end(), ops.begin() + (long) s0);
+            s0 = s1;
+        }
         /* Every segment is padded to whole rounds of 64 records (bit 31 = idle lane): round t of the
            g (r) stream is records [64 t, 64 t + 64), one per lane.  The kernel keeps both streams in
            LDS and walks them in order, so a segment is just (type, rounds, barrier). */
         struct Seg { int type, count, barrier; };
         Seg segs[MP3MI_MAX_FFT_SEGS];
         int ns = 0, ng = 0, nr = 0;
-        auto pad = [&](bool rot) {
-            if (rot) {
+        auto pad = [&](int type) {
+            if (type == FOP_ROT) {
                 while (nr % 64) { mp3mi_fftop w = {{0x80000000u, 0, 0, 0}}; if (nr >= max_rops) abort(); rops[nr++] = w; }
             } else {
                 while (ng % 64) { if (ng >= max_gops) abort(); gops[ng++] = 0x80000000u; }
             }
+        };
+        std::vector<uint32_t> second; /* FOP_CROSS: the round's second words (c | d << 10) follow its first words */
+        auto flush_cross = [&]() {
+            if (second.empty()) return;
+            pad(FOP_CROSS);
+            for (size_t k = 0; k < second.size(); k++) { if (ng >= max_gops) abort(); gops[ng++] = second[k]; }
+            pad(FOP_CROSS);
+            second.clear();
         };
         for (size_t i = 0; i < ops.size(); i++) {
             const RawOp &o = ops[i];
@@ -183,7 +243,8 @@ struct FftGen {
                 if (ns >= MP3MI_MAX_FFT_SEGS) { fprintf(stderr, "mp3mi: too many fft segments\n"); abort(); }
                 if (ns > 0) {
                     segs[ns - 1].barrier = (o.phase != ops[i - 1].phase);
-                    pad(segs[ns - 1].type == FOP_ROT);
+                    flush_cross();
+                    pad(segs[ns - 1].type);
                 }
                 segs[ns].type = o.type;
                 segs[ns].count = 0;
@@ -201,11 +262,15 @@ struct FftGen {
                 rops[nr++] = w;
             } else {
                 if (ng >= max_gops) { fprintf(stderr, "mp3mi: fft program too large\n"); abort(); }
-                if (o.type == FOP_CROSS && o.d != o.c + o.b - o.a) { fprintf(stderr, "mp3mi: fft op encoding\n"); abort(); }
-                gops[ng++] = o.a | (o.b << 10) | (o.c << 20);
+                gops[ng++] = o.a | (o.b << 10);
+                if (o.type == FOP_CROSS) {
+                    second.push_back(o.c | (o.d << 10));
+                    if (second.size() == 64) flush_cross();
+                }
             }
         }
-        pad(segs[ns - 1].type == FOP_ROT);
+        flush_cross();
+        pad(segs[ns - 1].type);
         if (ng != max_gops || nr != max_rops) { fprintf(stderr, "mp3mi: fft program size %d/%d, expected %d/%d\n", ng, nr, max_gops, max_rops); abort(); }
         for (int k = 0; k < ns; k++) segw[k] = segs[k].type | (((segs[k].count + 63) / 64) << 8) | (segs[k].barrier << 16);
         *n_seg = ns;

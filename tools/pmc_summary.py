@@ -16,6 +16,8 @@ def main(outdir, dest):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("void "):
+                k = k[5:]
             if not k.startswith("k_"):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
