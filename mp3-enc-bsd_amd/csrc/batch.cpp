@@ -36,7 +36,7 @@ struct mp3mi_batch {
     mp3mi_tables *T;
     int32_t *bits_per_frame, *bitrate_index;
     float *energy_l, *energy_s, *hist6, *fft_bins;
-    double *cw_mid, *xr, *sb_dbg;
+    double *cw_mid, *xr, *sbs, *sb_dbg;
     mp3mi_psy_out *psy;
     mp3mi_loop_prep *prep;
     void *psy_state, *loop_state;
@@ -101,7 +101,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
         if (whole_SpF > b->max_frame_bytes) b->max_frame_bytes = whole_SpF;
     }
     // chunk size from a scratch budget (bytes per frame and stream of the per-chunk buffers)
-    const size_t per_gc = MP3MI_HBLK * 4 + 3 * MP3MI_HBLK_S * 4 + MP3MI_FFT_BINS * 4 + 50 * 8 + 12 * 4 + sizeof(mp3mi_psy_out) + sizeof(mp3mi_loop_prep) + 576 * 8 + 576 * 2;
+    const size_t per_gc = MP3MI_HBLK * 4 + 3 * MP3MI_HBLK_S * 4 + MP3MI_FFT_BINS * 4 + 50 * 8 + 12 * 4 + sizeof(mp3mi_psy_out) + sizeof(mp3mi_loop_prep) + 576 * 8 + 576 * 8 + 576 * 2;
     const size_t per_frame = per_gc * 2 * (size_t) channels + sizeof(mp3mi_frame_side);
     const char *env = getenv("MP3MI_SCRATCH_MB");
     const size_t budget = (env ? (size_t) atol(env) : (size_t) 24576) << 20;
@@ -129,6 +129,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     CHK(hipMalloc((void **) &b->fft_bins, ngc * MP3MI_FFT_BINS * sizeof(float)));
     CHK(hipMalloc((void **) &b->cw_mid, ngc * 50 * sizeof(double)));
     CHK(hipMalloc((void **) &b->xr, ngc * 576 * sizeof(double)));
+    CHK(hipMalloc((void **) &b->sbs, (ngc + (size_t) n_streams * channels) * 576 * sizeof(double)));
     CHK(hipMalloc((void **) &b->psy, ngc * sizeof(mp3mi_psy_out)));
     CHK(hipMalloc((void **) &b->prep, ngc * sizeof(mp3mi_loop_prep)));
     CHK(hipMalloc((void **) &b->ix, ngc * 576 * sizeof(int16_t)));
@@ -148,7 +149,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     hipStreamSynchronize(b->stream);
     hipFree(b->T); hipFree(b->bits_per_frame); hipFree(b->bitrate_index);
     hipFree(b->energy_l); hipFree(b->energy_s); hipFree(b->hist6); hipFree(b->fft_bins); hipFree(b->cw_mid);
-    hipFree(b->xr); hipFree(b->psy); hipFree(b->prep); hipFree(b->ix); hipFree(b->side);
+    hipFree(b->xr); hipFree(b->sbs); hipFree(b->psy); hipFree(b->prep); hipFree(b->ix); hipFree(b->side);
     hipFree(b->psy_state); hipFree(b->loop_state);
     if (b->sb_dbg) hipFree(b->sb_dbg);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
@@ -193,7 +194,7 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
         const mp3mi_geom g = mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
         mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
         mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->psy, b->stream);
-        mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy, b->xr, b->debug ? b->sb_dbg : NULL, b->stream);
+        mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy, b->sbs, b->xr, b->debug ? b->sb_dbg : NULL, b->stream);
         mp3mi_launch_prep(b->T, g, b->xr, b->psy, b->prep, b->stream);
         CHK(hipEventRecord(b->loop_ev[2 * c], b->stream));
         mp3mi_launch_loop(b->T, g, b->xr, b->psy, b->prep, b->bits_per_frame, b->loop_state, b->ix, b->side, b->stream);

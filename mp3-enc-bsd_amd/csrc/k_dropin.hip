@@ -37,21 +37,21 @@ __global__ void __launch_bounds__(64) k_filter_subband(const mp3mi_tables *__res
 __global__ void __launch_bounds__(64) k_mdct_sub(const mp3mi_tables *__restrict__ T, double *__restrict__ sb,
                                                  const int32_t *__restrict__ bt, double *__restrict__ xr, int mode_gr)
 {
-    __shared__ fbm_lds L;
+    __shared__ mdct_lds L;
     const int lane = wave_lane(), ch = (int) blockIdx.x;
     double *sbc = sb + (size_t) ch * 3 * 576;
-    fbm_load_tables(L, T);
+    mdct_regs R;
+    mdct_load_tables(L, R, T);
+    __syncthreads();
     for (int gr = 0; gr < mode_gr; gr++) {
-        for (int i = lane; i < 576; i += 64) {
+        for (int i = lane; i < 576; i += 64) { // mdct_sub negates odd slots of odd subbands in place (src/mdct.c:57-60)
             const int slot = i / 32, sub = i % 32;
-            double v = sbc[(gr + 1) * 576 + i];
-            if ((sub & 1) && (slot & 1)) v = v * -1.0;
-            sbc[(gr + 1) * 576 + i] = v;
-            L.sb[1][slot][sub] = v;
-            L.sb[0][slot][sub] = sbc[gr * 576 + i];
+            if ((sub & 1) && (slot & 1)) sbc[(gr + 1) * 576 + i] = sbc[(gr + 1) * 576 + i] * -1.0;
         }
         __syncthreads();
-        fbm_mdct_granule(L, T, bt[gr * 2 + ch]);
+        const int b = bt[gr * 2 + ch];
+        mdct_load_inputs(L, sbc + gr * 576, sbc + (gr + 1) * 576, b);
+        mdct_granule(L, R, T, b);
         for (int i = lane; i < 576; i += 64) xr[((size_t) gr * 2 + ch) * 576 + i] = L.xr[i];
         __syncthreads();
     }

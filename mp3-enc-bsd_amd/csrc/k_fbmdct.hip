@@ -1,78 +1,137 @@
-// Polyphase analysis filterbank + MDCT + alias reduction.
+// Polyphase analysis filterbank, then MDCT + alias reduction.
 //
 // Replaces, for a whole batch, window_subband/filter_subband (src/encode.c:287-409) and
-// mdct_sub/mdct (src/mdct.c:25-511).  One wavefront handles FBM_GPB consecutive granules of
-// one (stream, channel): it recomputes the 18 subband slots of the granule before its first
-// one (the reference keeps them in l3_sb_sample[ch][0]; the filterbank is feed-forward, so
-// they are a pure function of the PCM) and then walks forward, keeping the previous
-// granule's slots in LDS.  Arithmetic and its ordering: fbmdct_dev.h.
+// mdct_sub/mdct (src/mdct.c:25-511).  Two kernels with the subband samples of the chunk in HBM
+// between them (4.6 KB per granule and channel, written once and read twice):
 //
-// HBM traffic per granule-channel: 1152 B of PCM in (+ the 480-sample tail shared with the
-// neighbour, L2-resident) and 4608 B of xr out; everything else lives in LDS/registers.
+//   k_filter  one wavefront per (stream, granule, channel): the 18 slots of 32 subband samples.
+//             The filterbank is feed-forward -- a pure function of 1056 PCM samples -- so every
+//             granule is independent, including the one BEFORE the chunk, which the reference
+//             would still hold in l3_sb_sample[ch][0] and which is recomputed here (granule slot 0).
+//   k_mdct    one wavefront per (stream, granule, channel): 36 inputs per band from two granules.
+//
+// Arithmetic and its ordering: fbmdct_dev.h.
 #include "fbmdct_dev.h"
 
-__global__ void __launch_bounds__(64) k_fbmdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
-                                               const int16_t *__restrict__ pcm_all,
-                                               const mp3mi_psy_out *__restrict__ psy,
-                                               double *__restrict__ xr_out, double *__restrict__ sb_dbg)
+struct filter_lds {
+    int16_t pcm[1056 + 32];
+    double ud[2][2][32]; // [parity of the slot pair][slot of the pair]: y[16], y[j]+y[32-j] (j<16), y[33+j]-y[63-j] (j<15)
+};
+
+__global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                                  const int16_t *__restrict__ pcm_all, double *__restrict__ sbs,
+                                                  double *__restrict__ sb_dbg)
 {
-    __shared__ fbm_lds L;
-    const int lane = wave_lane();
-    const int C = geo.channels, G = geo.n_gran;
-    const int blocks_per_sc = (G + FBM_GPB - 1) / FBM_GPB;
+    __shared__ filter_lds L;
+    const int lane = wave_lane(), half = lane >> 5, sub = lane & 31;
+    const int C = geo.channels, G1 = geo.n_gran + 1;
     int bid = (int) blockIdx.x;
-    const int gb = bid % blocks_per_sc; bid /= blocks_per_sc;
-    const int ch = bid % C;
-    const int s = bid / C;
+    const int ch = bid % C; bid /= C;
+    const int gi = bid % G1;   // granule slot: 0 is the granule before the chunk
+    const int s = bid / G1;
+    const long gabs = (long) geo.g0 - 1 + gi;
+    double *out = sbs + (((size_t) s * G1 + gi) * C + ch) * 576;
+    if (gabs < 0) { // before the stream: the reference's zero-initialised l3_sb_sample
+        for (int i = lane; i < 576; i += 64) out[i] = 0.0;
+        return;
+    }
     const long n_per_ch = (long) geo.n_frames * 1152;
     const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_per_ch * (size_t) C;
-
-    // per-lane constants: 8 window taps for y[lane], the 31 filter coefficients of subband lane&31
+    // samples [576 g - 480, 576 g + 576) of this channel; outside the stream -> 0
+    {
+        int16_t v[17];
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            const int i = lane + 64 * k;
+            const long t = 576 * gabs - 480 + i;
+            v[k] = (i < 1056 && t >= 0 && t < n_per_ch) ? pcm[t * C + ch] : (int16_t) 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 17; k++)
+            if (lane + 64 * k < 1056) L.pcm[lane + 64 * k] = v[k];
+    }
+    // per-lane constants: 8 window taps for y[lane], the 31 filter coefficients of subband lane & 31
     double enw[8], frow[31];
+#pragma unroll
     for (int k = 0; k < 8; k++) enw[k] = T->enwindow[lane + 64 * k];
-    for (int j = 0; j < 31; j++) frow[j] = T->filt[lane & 31][j];
-    fbm_load_tables(L, T);
-
-    const int gl0 = gb * FBM_GPB;
-    const long gabs0 = (long) geo.g0 + gl0;
-
-    // previous granule's slots
-    fbm_load_pcm(L, pcm, n_per_ch, C, ch, gabs0 - 1);
+#pragma unroll
+    for (int j = 0; j < 31; j++) frow[j] = T->filt[sub][j];
+    // where this lane's y goes in the matrixing step: lane j < 16 forms y[j] + y[32-j], lane 16 passes
+    // y[16] on, lane 33+j (j < 15) forms y[33+j] - y[63-j]; the other lanes only supply operands
+    const int partner = (lane < 16) ? 32 - lane : ((lane >= 33 && lane < 48) ? 96 - lane : lane);
+    const int udi = (lane < 16) ? 1 + lane : (lane == 16 ? 0 : ((lane >= 33 && lane < 48) ? lane - 16 : -1));
     __syncthreads();
-    if (gabs0 == 0) {
-        for (int i = lane; i < 576; i += 64) L.sb[0][i / 32][i % 32] = 0.0;
-        __syncthreads();
-    } else
-        fbm_filter_granule(L, 0, enw, frow);
 
-    for (int gi = 0; gi < FBM_GPB && gl0 + gi < G; gi++) {
-        const int gl = gl0 + gi;
-        const long gabs = gabs0 + gi;
-        const size_t rec = ((size_t) s * G + gl) * C + ch;
-        const int bt = psy[rec].block_type;
-        fbm_load_pcm(L, pcm, n_per_ch, C, ch, gabs);
-        __syncthreads();
-        fbm_filter_granule(L, 1, enw, frow);
-        if (sb_dbg) { // raw subband samples as filter_subband returns them (parity tests)
-            for (int i = lane; i < 576; i += 64) {
-                int slot = i / 32, sub = i % 32;
-                double v = L.sb[1][slot][sub];
-                if ((sub & 1) && (slot & 1)) v = v * -1.0;
-                sb_dbg[rec * 576 + i] = v;
+    for (int pair = 0; pair < 9; pair++) {
+        // y[i] = sum_k z[i+64k], z[i] = pcm[32q+31-i]/32768 * enwindow[i]   (src/encode.c:306-312, 393-397)
+        double y[2];
+        {
+            int16_t tp[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) tp[h][k] = L.pcm[480 + 32 * (pair * 2 + h) + 31 - lane - 64 * k];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                double acc = ((double) tp[h][0] * (1.0 / 32768.0)) * enw[0];
+#pragma unroll
+                for (int k = 1; k < 8; k++) acc = acc + ((double) tp[h][k] * (1.0 / 32768.0)) * enw[k];
+                y[h] = acc;
             }
         }
-        fbm_mdct_granule(L, T, bt);
-        for (int i = lane; i < 576; i += 64) xr_out[rec * 576 + i] = L.xr[i];
-        // current becomes previous (src/mdct.c:99-102)
-        for (int i = lane; i < 576; i += 64) L.sb[0][i / 32][i % 32] = L.sb[1][i / 32][i % 32];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const double yp = __shfl(y[h], partner);
+            const double v = (lane < 16) ? y[h] + yp : (lane == 16 ? y[h] : y[h] - yp);
+            if (udi >= 0) L.ud[pair & 1][h][udi] = v;
+        }
         __syncthreads();
+        // s[sub] = y[16] + sum_j filt[j] (y[j] + y[32-j]) + sum_j filt[16+j] (y[33+j] - y[63-j])   (src/encode.c:398-408)
+        {
+            double u[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) u[j] = L.ud[pair & 1][half][j];
+            double si = u[0];
+#pragma unroll
+            for (int j = 0; j < 31; j++) si = si + frow[j] * u[1 + j];
+            const int slot = pair * 2 + half;
+            if (sb_dbg && gi > 0) // raw subband samples as filter_subband returns them (parity tests)
+                sb_dbg[(((size_t) s * geo.n_gran + gi - 1) * C + ch) * 576 + slot * 32 + sub] = si;
+            // mdct_sub negates odd slots of odd subbands before use (src/mdct.c:57-60)
+            if ((sub & 1) && (slot & 1)) si = si * -1.0;
+            out[slot * 32 + sub] = si;
+        }
+        // the next pair writes the other ud buffer; the barrier above orders its reuse two pairs on
     }
 }
 
-void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
-                         const mp3mi_psy_out *psy, double *xr, double *sb_dbg, hipStream_t st)
+__global__ void __launch_bounds__(64, 4) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                                const double *__restrict__ sbs, const mp3mi_psy_out *__restrict__ psy,
+                                                double *__restrict__ xr_out)
 {
-    const int blocks_per_sc = (g.n_gran + FBM_GPB - 1) / FBM_GPB;
-    const unsigned grid = (unsigned) (g.n_streams * g.channels * blocks_per_sc);
-    hipLaunchKernelGGL(k_fbmdct, dim3(grid), dim3(64), 0, st, T, g, pcm, psy, xr, sb_dbg);
+    __shared__ mdct_lds L;
+    const int lane = wave_lane();
+    const int C = geo.channels, G = geo.n_gran;
+    int bid = (int) blockIdx.x;
+    const int ch = bid % C; bid /= C;
+    const int gl = bid % G;
+    const int s = bid / G;
+    const size_t rec = ((size_t) s * G + gl) * C + ch;
+    const double *prev = sbs + (((size_t) s * (G + 1) + gl) * C + ch) * 576;
+    const int bt = psy[rec].block_type;
+    mdct_regs R;
+    mdct_load_tables(L, R, T);
+    __syncthreads();
+    mdct_load_inputs(L, prev, prev + (size_t) C * 576, bt);
+    mdct_granule(L, R, T, bt);
+    for (int i = lane; i < 576; i += 64) xr_out[rec * 576 + i] = L.xr[i];
+}
+
+size_t mp3mi_sbs_bytes(const mp3mi_geom &g) { return (size_t) g.n_streams * (size_t) (g.n_gran + 1) * (size_t) g.channels * 576 * sizeof(double); }
+
+void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
+                         const mp3mi_psy_out *psy, double *sbs, double *xr, double *sb_dbg, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_filter, dim3((unsigned) (g.n_streams * (g.n_gran + 1) * g.channels)), dim3(64), 0, st, T, g, pcm, sbs, sb_dbg);
+    hipLaunchKernelGGL(k_mdct, dim3((unsigned) (g.n_streams * g.n_gran * g.channels)), dim3(64), 0, st, T, g, sbs, psy, xr);
 }
