@@ -87,33 +87,52 @@ MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int
 #else
 #define LOOP_FAST_SQRTF(x) __builtin_amdgcn_sqrtf(x)
 #endif
-MP3MI_DEVFN void loop_power34(const double xr[9], float y34[9])
+// Returns the largest y34 of the granule (wave-uniform): a step size that quantises it to zero
+// quantises everything to zero.
+MP3MI_DEVFN float loop_power34(const double xr[9], float y34[9])
 {
+    float m = 0.0f;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
         const float a = (float) __builtin_fabs(xr[j]);
         y34[j] = LOOP_FAST_SQRTF(a * LOOP_FAST_SQRTF(a));
+        m = y34[j] > m ? y34[j] : m;
     }
+    return __builtin_bit_cast(float, wave_max_i32(__builtin_bit_cast(int, m))); // non-negative floats order like their bits
 }
 
-MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double xr[9], const float y34[9], int q, int p[9])
+MP3MI_DEVFN float loop_estimate(float y34, float cq) { return __builtin_fmaf(y34, cq, 0.4054f); } // of x^(3/4) + 0.4054
+
+// true: every line quantises to 0 at this step (wave-uniform).  Uses the same estimate as the
+// quantiser, which is monotone in y34, so the quantiser would leave every line at 0 unflagged.
+MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
+{
+    return loop_estimate(y34max, __builtin_exp2f(-0.1875f * (float) q)) < 0.999f;
+}
+
+MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double xr[9], const float y34[9], int q, bool all_zero, int p[9])
 {
     const int lane = wave_lane();
+    if (all_zero) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) { p[j] = 0; L.ix[lane + 64 * j] = 0; }
+        __syncthreads();
+        return;
+    }
     const float cq = __builtin_exp2f(-0.1875f * (float) q);
     unsigned need = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-        float f = y34[j] * cq + 0.4054f;      // estimate of x^(3/4) + 0.4054, abs. error < 1e-3 below 2049
-        f = f > 4000.0f ? 4000.0f : f;
+        // estimate f of x^(3/4) + 0.4054 (>= 0.4054); from 2047.5 on the answer is the table's last entry
+        float f = loop_estimate(y34[j], cq);
+        f = f > 2047.5f ? 2047.5f : f;
         const float fl = __builtin_floorf(f);
-        const float fr = f - fl;
-        const int pj = (int) fl;
-        p[j] = pj > 2047 ? 2047 : pj;
-        // near a table boundary (and not saturated, and not plainly zero): settle exactly.  The
-        // estimate's error is relative (< 7e-7 f: two 1-ulp roots, exp2, three roundings), so the
-        // guard band scales with f; small values -- the common case -- are almost never ambiguous.
-        const float tol = 2.5e-6f * f + 2e-6f;
-        if (f < 2048.5f && ((fr < tol && pj >= 1) || fr > 1.0f - tol)) need |= 1u << j;
+        p[j] = (int) fl;
+        // near a table boundary: settle exactly.  The estimate's error is relative (< 7e-7 f: two 1-ulp
+        // roots, exp2, two roundings), so the guard band 2.5e-6 f + 2e-6 scales with f; small values --
+        // the common case -- are almost never ambiguous.  |frac - 1/2| > 1/2 - band <=> within band of an integer.
+        const float d = __builtin_fabsf((f - fl) - 0.5f);
+        if (d > __builtin_fmaf(-2.5e-6f, f, 0.5f - 2e-6f)) need |= 1u << j;
     }
     if (wave_any(need != 0)) {
         const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
@@ -179,17 +198,17 @@ MP3MI_DEVFN void loop_desc_init(const mp3mi_tables *T, int cls, int *desc_a, int
     *desc_b = off;
 }
 
-// code lengths of pair (x, y) for the (up to) three tables of a group, spread to 10-bit fields and
-// with the sign bits and linbits of src/loop.c:172-225 added to every field that has a table.
-// da/db: the group's descriptor words (may differ per lane), fieldmask: 1 | 1<<10 | 1<<20 subset.
-MP3MI_DEVFN int loop_pair_cost3(const loop_lds &L, int da, int db, int fieldmask, int x, int y)
+// code lengths of pair (x, y), sign bits included (glut) and the linbits of src/loop.c:172-225 added,
+// for the (up to) three tables of a group, spread to 10-bit fields.
+// da/db: the group's descriptor words (may differ per lane).
+MP3MI_DEVFN int loop_pair_cost3(const loop_lds &L, int da, int db, int x, int y)
 {
     const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
-    const int nesc = (x > 14) + (y > 14), sg = (x != 0) + (y != 0);
+    const int nesc = (x > 14) + (y > 14);
     const int ylen = (da >> 15) & 31, lb = ((da >> 20) & 15) | (((da >> 24) & 15) << 10);
     const int e = L.glut[db + xc * ylen + yc];
     const int spread = (e & 31) | (((e >> 5) & 31) << 10) | (((e >> 10) & 31) << 20);
-    return spread + sg * fieldmask + nesc * lb;
+    return spread + nesc * lb;
 }
 
 // new_choose_table's decision from the candidates' bit sums (src/loop.c:1819-1897): '<=' moves to
@@ -212,16 +231,21 @@ MP3MI_DEVFN int loop_pick(int da, int s0, int s1, int s2, int *sum)
 // (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
 // Returns the Huffman bit count and fills g.  Written branch-free over the lanes: region
 // membership is a predicate, never a divergent branch.
-MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9])
+MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9], bool all_zero)
 {
     const int lane = wave_lane();
     const bool shortb = g.wsf && g.block_type == 2;
     const unsigned *ixw = (const unsigned *) L.ix; // (x, y) of pair pr as one word: x | y << 16
-    int bits = 0;
+    int bits = 0, nslot = 9; // nslot: slots (of 64 lines) that can hold a non-zero value
     if (shortb) {
         g.count1 = 0;
         g.big_values = 288;
         g.count1table_select = 1; // count1_bitcount with no quadruples: sum0 == sum1 -> table B
+    } else if (all_zero) {
+        g.count1 = 0;
+        g.big_values = 0;
+        g.count1table_select = 1;
+        nslot = 0;
     } else {
         // highest line with ix != 0 and highest line with ix > 1 (as line + 1; 0 = none)
         int hi_nz = 0, hi_big = 0;
@@ -231,6 +255,7 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
             hi_big = (p[j] > 1) ? 64 * j + lane + 1 : hi_big;
         }
         const int top_nz = wave_max_i32(hi_nz) - 1, top_big = wave_max_i32(hi_big) - 1;
+        nslot = (top_nz + 64) >> 6;
         const int i0 = (top_nz < 0) ? 0 : 2 * (top_nz / 2 + 1);
         g.count1 = (i0 - (top_big + 1)) / 4;
         g.big_values = (i0 - 4 * g.count1) / 2;
@@ -238,14 +263,14 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         int s01 = 0;
 #pragma unroll
         for (int k = 0; k < 3; k++) { // at most 144 quadruples
+            if (64 * k >= g.count1) break;
             const int qd = lane + 64 * k;
             const bool in = qd < g.count1;
             const int w0 = in ? g.big_values + 2 * qd : 0;
             const unsigned a = ixw[w0], b = ixw[w0 + 1];
             const int pp = (int) ((a & 1u) | ((a >> 15) & 2u) | ((b & 1u) << 2) | ((b >> 13) & 8u));
-            const int sg = __popc((unsigned) pp);
-            const int e = L.glut[GL_C1 + pp];
-            const int c = (sg + (e & 31)) | ((sg + ((e >> 5) & 31)) << 16);
+            const int e = L.glut[GL_C1 + pp]; // code length + sign bits: table A | table B << 5
+            const int c = (e & 31) | ((e >> 5) << 16);
             s01 += in ? c : 0;
         }
         s01 = wave_sum_i32(s01);
@@ -283,6 +308,7 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         }
     }
     g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
+    if (nslot == 0) return bits; // nothing but zeros: every region maximum is 0, no table, no bits
     if (shortb) {
         // region maxima over lines [0,36) and [36,576); pair (6m+w, 6m+3+w), m<96, w<3
         int m1 = 0, m2 = 0;
@@ -308,7 +334,7 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
             const int m = in ? pr / 3 : 0, w = in ? pr - 3 * m : 0;
             const int x = L.ix[6 * m + w], y = L.ix[6 * m + 3 + w];
             const bool first = m < 6;
-            const int c = loop_pair_cost3(L, first ? da0 : da1, first ? db0 : db1, 1, x, y) & 0x3ff;
+            const int c = loop_pair_cost3(L, first ? da0 : da1, first ? db0 : db1, x, y) & 0x3ff;
             sum += (in && (first ? t0 : t1)) ? c : 0;
         }
         return wave_sum_i32(sum);
@@ -316,11 +342,14 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
     // long / start / stop blocks: regions [0,a1), [a1,a2), [a2,e2) (src/loop.c:1771-1777).  The
     // reference's enable tests (a1 > 0, a2 > a1, e2 > a2) are exactly "the range is not empty",
     // and region 2 is non-empty only right after subdivide set a1 <= a2 <= e2, so the three
-    // ranges never overlap.
+    // ranges never overlap.  Lines from slot nslot on are zero, so the maxima may skip them; but a
+    // region can reach past big_values (stale or clamped addresses) and a pair of zeros still has a
+    // code length, so the pricing loop runs to the end of the last region.
     const int a1 = g.address1, a2 = g.address2, e2 = 2 * g.big_values;
     int m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
+        if (j >= nslot) break;
         const int i = lane + 64 * j;
         const bool c1 = i < a1, c2 = i < a2, c3 = i < e2;
         m0 = (c1 && p[j] > m0) ? p[j] : m0;
@@ -330,40 +359,41 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
     m0 = wave_max_i32(m0);
     m1 = wave_max_i32(m1);
     m2 = wave_max_i32(m2);
-    int da[3], db[3], fm[3];
+    int da[3], db[3];
     const int mx[3] = {m0, m1, m2};
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const int idx = loop_desc_index(mx[r]);
         da[r] = wave_readlane_i32(R.desc_a, idx);
         db[r] = wave_readlane_i32(R.desc_b, idx);
-        fm[r] = mx[r] ? (1 | (((da[r] >> 5) & 31) ? 1 << 10 : 0) | (((da[r] >> 10) & 31) ? 1 << 20 : 0)) : 0;
     }
     // cost of every candidate over its region: per lane three 10-bit partial sums per region
+    const int end = a2 > e2 ? a2 : e2; // lines from here on are in no region (a1 <= a2 whenever region 1 is not empty)
+    const int endp = (a1 > end ? a1 : end);
     int acc0 = 0, acc1 = 0, acc2 = 0;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
+        if (128 * k >= endp) break;
         const int pr = lane + 64 * k;          // pair index; k == 4 covers pairs 256..287 only
         const int prc = pr < 288 ? pr : 287;
         const int i = 2 * pr;
         const unsigned xy = ixw[prc];
         const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
         const bool c1 = i < a1, c2 = i < a2, c3 = i < e2;
-        const bool in0 = c1, in1 = !c1 && c2, in2 = !c2 && c3 && pr < 288;
+        const bool in0 = c1, in1 = !c1 && c2, in2 = !c2 && c3;
         const int dA = in0 ? da[0] : (in1 ? da[1] : da[2]);
         const int dB = in0 ? db[0] : (in1 ? db[1] : db[2]);
-        const int fM = in0 ? fm[0] : (in1 ? fm[1] : fm[2]);
-        const int c = loop_pair_cost3(L, dA, dB, fM, x, y);
-        acc0 += (in0 && fM) ? c : 0;
-        acc1 += (in1 && fM) ? c : 0;
-        acc2 += (in2 && fM) ? c : 0;
+        const int c = loop_pair_cost3(L, dA, dB, x, y);
+        acc0 += (in0 && m0) ? c : 0;
+        acc1 += (in1 && m1) ? c : 0;
+        acc2 += (in2 && m2) ? c : 0;
     }
     const int acc[3] = {acc0, acc1, acc2};
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         if (mx[r] == 0) continue;
         const int s01 = wave_sum_i32((acc[r] & 0x3ff) | (((acc[r] >> 10) & 0x3ff) << 16)); // two fields per reduction
-        const int s2 = (fm[r] >> 20) ? wave_sum_i32((acc[r] >> 20) & 0x3ff) : 0;
+        const int s2 = ((da[r] >> 10) & 31) ? wave_sum_i32((acc[r] >> 20) & 0x3ff) : 0;
         int best;
         g.table_select[r] = loop_pick(da[r], s01 & 0xffff, (s01 >> 16) & 0xffff, s2, &best);
         // bigv_bitcount (src/loop.c:1997-2011) counts region r over the same range (address3 == e2
@@ -485,10 +515,10 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
 
                 double xr[9];
                 int p[9];
-                float y34[9];
+                float y34[9], y34max;
 #pragma unroll
                 for (int j = 0; j < 9; j++) xr[j] = xr_all[rec * 576 + lane + 64 * j];
-                loop_power34(xr, y34);
+                y34max = loop_power34(xr, y34);
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
                 //      were computed by k_prep; only the stateful decision of calc_scfsi happens here ----
@@ -579,9 +609,10 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 next = (top + bot) / 2;
                                 g.q = next;
                                 PROF(1);
-                                loop_quantize(T, L, xr, y34, g.q, p);
+                                const bool az = loop_all_zero(y34max, g.q);
+                                loop_quantize(T, L, xr, y34, g.q, az, p);
                                 PROF(2);
-                                bit = loop_count_bits(R, L, g, p);
+                                bit = loop_count_bits(R, L, g, p, az);
                                 PROF(3);
                                 __syncthreads();
                                 if (bit > max_bits) top = next; else bot = next;
@@ -597,9 +628,10 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             g.q += 1;
                             if (!have_pass) {
                                 PROF(1);
-                                loop_quantize(T, L, xr, y34, g.q, p);
+                                const bool az = loop_all_zero(y34max, g.q);
+                                loop_quantize(T, L, xr, y34, g.q, az, p);
                                 PROF(2);
-                                bits = loop_count_bits(R, L, g, p);
+                                bits = loop_count_bits(R, L, g, p, az);
                                 PROF(3);
                                 __syncthreads();
                             }
@@ -642,7 +674,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                         const int b = (int) ((bandpack >> (6 * j)) & 63ull);
                                         if (b < g.sfb_lmax) xr[j] = xr[j] * T->pretab_xr[LOOP_PRETAB[b]];
                                     }
-                                    loop_power34(xr, y34);
+                                    y34max = loop_power34(xr, y34);
                                 }
                             }
                         }
@@ -679,7 +711,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                     const int b = (int) ((bandpack >> (6 * j)) & 63ull);
                                     if (b < nband && ((ampmask >> b) & 1ull)) xr[j] = xr[j] * ifqstep;
                                 }
-                                loop_power34(xr, y34);
+                                y34max = loop_power34(xr, y34);
                             }
                         }
 

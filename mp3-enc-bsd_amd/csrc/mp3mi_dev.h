@@ -97,7 +97,7 @@ typedef struct {
     uint8_t ht_len[1440];
     uint32_t ht_code[1440];
     /* code lengths grouped the way new_choose_table compares tables: per group and (x,y) cell
-       the lengths of its tables, 5 bits each.  Groups at offsets 0 {1}, 4 {2,3}, 13 {5,6},
+       the lengths of its tables INCLUDING the cell's sign bits, 5 bits each.  Groups at offsets 0 {1}, 4 {2,3}, 13 {5,6},
        29 {7,8,9}, 65 {10,11,12}, 129 {13,15}, 385 {15,24}, 641 {16,24}, 897 {32,33} */
     uint16_t glut[928];
 } mp3mi_tables;

@@ -472,11 +472,16 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
         memset(T->glut, 0, sizeof(T->glut));
         for (int gi = 0; gi < 9; gi++)
             for (int c = 0; c < groups[gi][1]; c++) {
+                /* sign bits of the cell (src/loop.c:172-225, 1560-1584): one per non-zero value */
+                const int ylen = T_HT_YLEN[groups[gi][2]];
+                const int sg = (gi == 8) ? __builtin_popcount((unsigned) c) : (c / ylen != 0) + (c % ylen != 0);
                 unsigned e = 0;
                 for (int f = 0; f < 3; f++) {
                     const int t = groups[gi][2 + f];
-                    if (t && (T_HT_PACKED[T_HT_OFF[t] + c] & 0xff) > 31) return -5;
-                    if (t) e |= (unsigned) (T_HT_PACKED[T_HT_OFF[t] + c] & 0xff) << (5 * f);
+                    if (!t) continue;
+                    const unsigned len = (T_HT_PACKED[T_HT_OFF[t] + c] & 0xff) + (unsigned) sg;
+                    if (len > 31) return -5;
+                    e |= len << (5 * f);
                 }
                 T->glut[groups[gi][0] + c] = (uint16_t) e;
             }
