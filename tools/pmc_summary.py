@@ -12,7 +12,7 @@ import sys
 def main(outdir, dest):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
-    for f in glob.glob(os.path.join(outdir, "*", "*counter_collection.csv")):
+    for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
@@ -26,7 +26,7 @@ def main(outdir, dest):
                 seen.add(key)
                 calls[k] += 1
         os.remove(f)
-    for f in glob.glob(os.path.join(outdir, "*", "*kernel_trace.csv")):
+    for f in glob.glob(os.path.join(outdir, "**", "*kernel_trace.csv"), recursive=True):
         os.remove(f)
     out = {k: dict(v, dispatches=calls[k]) for k, v in agg.items()}
     json.dump(out, open(dest, "w"), indent=1)
