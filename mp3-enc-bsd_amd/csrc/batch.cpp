@@ -1,5 +1,13 @@
 // Host side of the batched encoder: owns the device buffers, cuts the frames of a call into
-// chunks that fit the scratch budget, and enqueues the five kernels per chunk:
+// chunks that fit the scratch budget, and enqueues the kernels of every chunk on TWO HIP streams:
+//
+//   front stream (low priority):  k_fft k_cw k_psy k_filter k_mdct k_prep   of chunk c+1
+//   loop  stream (high priority): k_loop k_format                          of chunk c
+//
+// k_loop keeps one wavefront per stream resident for a whole chunk and ends when the slowest
+// stream ends (streams differ by up to 1.5x in work), so its tail leaves SIMDs idle; the
+// feed-forward kernels of the next chunk fill them.  The three buffers that cross from the front
+// stream to the loop stream (psy, xr, prep) are double-buffered; events order producer/consumer.
 //
 //   k_fft     (stream, granule, channel)  psy FFTs                 feed-forward
 //   k_psy     (stream, channel)           thresholds / block type  serial over granules
@@ -32,13 +40,21 @@ struct mp3mi_batch {
     int n_streams, rate_idx, rate_hz, channels, max_frames, chunk_frames;
     std::vector<int> bits_per_frame_h, bitrate_index_h;
     int max_frame_bytes;
-    hipStream_t stream;
+    hipStream_t stream;      // front stream: feed-forward kernels (and the initial memsets)
+    hipStream_t lstream;     // loop stream: k_loop + k_format
+    hipEvent_t ev_front[2];  // front kernels of the chunk in slot i are done
+    hipEvent_t ev_loop[2];   // k_loop of the chunk in slot i is done (slot may be overwritten)
+    hipEvent_t ev_done;      // everything of the previous encode call is done
+    bool have_done;
+    unsigned *gate_count, *gate_signal; // residency gate of k_loop (mp3mi_loop_gate); signal == NULL: not available
+    unsigned gate_gen;
+    int last_slot;
     mp3mi_tables *T;
     int32_t *bits_per_frame, *bitrate_index;
     float *energy_l, *energy_s, *hist6, *fft_bins;
-    double *cw_mid, *xr, *sbs, *sb_dbg;
-    mp3mi_psy_out *psy;
-    mp3mi_loop_prep *prep;
+    double *cw_mid, *xr[2], *sbs, *sb_dbg;
+    mp3mi_psy_out *psy[2];
+    mp3mi_loop_prep *prep[2];
     void *psy_state, *loop_state;
     int16_t *ix;
     mp3mi_frame_side *side;
@@ -101,10 +117,11 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
         if (whole_SpF > b->max_frame_bytes) b->max_frame_bytes = whole_SpF;
     }
     // chunk size from a scratch budget (bytes per frame and stream of the per-chunk buffers)
-    const size_t per_gc = MP3MI_HBLK * 4 + 3 * MP3MI_HBLK_S * 4 + MP3MI_FFT_BINS * 4 + 50 * 8 + 12 * 4 + sizeof(mp3mi_psy_out) + sizeof(mp3mi_loop_prep) + 576 * 8 + 576 * 8 + 576 * 2;
+    const size_t per_gc = MP3MI_HBLK * 4 + 3 * MP3MI_HBLK_S * 4 + MP3MI_FFT_BINS * 4 + 50 * 8 + 12 * 4 +
+                          2 * (sizeof(mp3mi_psy_out) + sizeof(mp3mi_loop_prep) + 576 * 8) + 576 * 8 + 576 * 2;
     const size_t per_frame = per_gc * 2 * (size_t) channels + sizeof(mp3mi_frame_side);
     const char *env = getenv("MP3MI_SCRATCH_MB");
-    const size_t budget = (env ? (size_t) atol(env) : (size_t) 24576) << 20;
+    const size_t budget = (env ? (size_t) atol(env) : (size_t) 32768) << 20;
     long cf = (long) (budget / (per_frame * (size_t) n_streams));
     if (cf < 1) cf = 1;
     if (cf > max_frames) cf = max_frames;
@@ -115,7 +132,31 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     mp3mi_tables *Th = (mp3mi_tables *) malloc(sizeof(mp3mi_tables));
     if (!Th || mp3mi_build_tables(Th, ri) != 0) { free(Th); delete b; return MP3MI_ERR_ARG; }
     const size_t ngc = (size_t) n_streams * 2 * (size_t) cf * (size_t) channels;
-    CHK(hipStreamCreate(&b->stream));
+    {
+        int least = 0, greatest = 0;
+        CHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CHK(hipStreamCreateWithPriority(&b->stream, hipStreamDefault, least));
+        CHK(hipStreamCreateWithPriority(&b->lstream, hipStreamDefault, greatest));
+    }
+    for (int i = 0; i < 2; i++) {
+        CHK(hipEventCreateWithFlags(&b->ev_front[i], hipEventDisableTiming));
+        CHK(hipEventCreateWithFlags(&b->ev_loop[i], hipEventDisableTiming));
+    }
+    CHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
+    b->have_done = false;
+    b->last_slot = 0;
+    b->gate_count = NULL; b->gate_signal = NULL; b->gate_gen = 0;
+    {
+        int can = 0, dev = 0;
+        const char *envg = getenv("MP3MI_NO_GATE");
+        CHK(hipGetDevice(&dev));
+        if (!(envg && atoi(envg)) && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can) {
+            CHK(hipMalloc((void **) &b->gate_count, sizeof(unsigned)));
+            CHK(hipMemset(b->gate_count, 0, sizeof(unsigned)));
+            if (hipExtMallocWithFlags((void **) &b->gate_signal, 8, hipMallocSignalMemory) != hipSuccess) b->gate_signal = NULL;
+            else CHK(hipMemset(b->gate_signal, 0, 8));
+        }
+    }
     CHK(hipMalloc((void **) &b->T, sizeof(mp3mi_tables)));
     CHK(hipMemcpy(b->T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
     free(Th);
@@ -128,10 +169,12 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     CHK(hipMalloc((void **) &b->hist6, ngc * 12 * sizeof(float)));
     CHK(hipMalloc((void **) &b->fft_bins, ngc * MP3MI_FFT_BINS * sizeof(float)));
     CHK(hipMalloc((void **) &b->cw_mid, ngc * 50 * sizeof(double)));
-    CHK(hipMalloc((void **) &b->xr, ngc * 576 * sizeof(double)));
+    for (int i = 0; i < 2; i++) {
+        CHK(hipMalloc((void **) &b->xr[i], ngc * 576 * sizeof(double)));
+        CHK(hipMalloc((void **) &b->psy[i], ngc * sizeof(mp3mi_psy_out)));
+        CHK(hipMalloc((void **) &b->prep[i], ngc * sizeof(mp3mi_loop_prep)));
+    }
     CHK(hipMalloc((void **) &b->sbs, (ngc + (size_t) n_streams * channels) * 576 * sizeof(double)));
-    CHK(hipMalloc((void **) &b->psy, ngc * sizeof(mp3mi_psy_out)));
-    CHK(hipMalloc((void **) &b->prep, ngc * sizeof(mp3mi_loop_prep)));
     CHK(hipMalloc((void **) &b->ix, ngc * 576 * sizeof(int16_t)));
     CHK(hipMalloc((void **) &b->side, (size_t) n_streams * (size_t) cf * sizeof(mp3mi_frame_side)));
     CHK(hipMalloc((void **) &b->psy_state, mp3mi_psy_state_size() * (size_t) n_streams * channels));
@@ -147,14 +190,21 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
 {
     if (!b) return;
     hipStreamSynchronize(b->stream);
+    hipStreamSynchronize(b->lstream);
     hipFree(b->T); hipFree(b->bits_per_frame); hipFree(b->bitrate_index);
     hipFree(b->energy_l); hipFree(b->energy_s); hipFree(b->hist6); hipFree(b->fft_bins); hipFree(b->cw_mid);
-    hipFree(b->xr); hipFree(b->sbs); hipFree(b->psy); hipFree(b->prep); hipFree(b->ix); hipFree(b->side);
+    for (int i = 0; i < 2; i++) { hipFree(b->xr[i]); hipFree(b->psy[i]); hipFree(b->prep[i]); }
+    hipFree(b->sbs); hipFree(b->ix); hipFree(b->side);
     hipFree(b->psy_state); hipFree(b->loop_state);
+    if (b->gate_count) hipFree(b->gate_count);
+    if (b->gate_signal) hipFree(b->gate_signal);
     if (b->sb_dbg) hipFree(b->sb_dbg);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
     for (size_t i = 0; i < b->loop_ev.size(); i++) hipEventDestroy(b->loop_ev[i]);
+    for (int i = 0; i < 2; i++) { hipEventDestroy(b->ev_front[i]); hipEventDestroy(b->ev_loop[i]); }
+    hipEventDestroy(b->ev_done);
     hipStreamDestroy(b->stream);
+    hipStreamDestroy(b->lstream);
     delete b;
 }
 
@@ -176,6 +226,8 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
         const size_t ngc = (size_t) S * 2 * (size_t) b->chunk_frames * (size_t) C;
         CHK(hipMalloc((void **) &b->sb_dbg, ngc * 576 * sizeof(double)));
     }
+    // the previous call's kernels may still be running on the loop stream
+    if (b->have_done) CHK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
     // fresh encoder state for every stream (function statics of the reference start at zero)
     CHK(hipMemsetAsync(b->psy_state, 0, mp3mi_psy_state_size() * (size_t) S * C, b->stream));
     CHK(hipMemsetAsync(b->loop_state, 0, mp3mi_loop_state_size() * (size_t) S, b->stream));
@@ -188,22 +240,51 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
     }
     b->loop_launches = nchunks;
     CHK(hipEventRecord(b->ev0, b->stream));
-    for (int c = 0; c < nchunks; c++) {
+    // Two kinds of front-end kernels cannot share the chip with k_loop: k_fft takes a whole CU's LDS
+    // per workgroup, and k_psy's wavefronts live for the whole chunk (serial over granules), so
+    // whichever is in flight when k_loop is launched keeps k_loop's wavefronts from starting.  Both
+    // therefore run one chunk ahead, BEFORE k_loop of the previous chunk starts (stage X); what
+    // overlaps with k_loop(c) is stage Y of chunk c+1: k_filter, k_mdct, k_prep -- short-lived
+    // single-wave workgroups that fit next to k_loop's and yield freed slots to it.
+    auto geom_of = [&](int c) {
         const int f0 = c * b->chunk_frames;
         const int nf = (n_frames - f0 < b->chunk_frames) ? n_frames - f0 : b->chunk_frames;
-        const mp3mi_geom g = mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
+        return mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
+    };
+    auto stage_x = [&](int c) -> int {
+        const mp3mi_geom g = geom_of(c);
         mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
-        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->psy, b->stream);
-        mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy, b->sbs, b->xr, b->debug ? b->sb_dbg : NULL, b->stream);
-        mp3mi_launch_prep(b->T, g, b->xr, b->psy, b->prep, b->stream);
-        CHK(hipEventRecord(b->loop_ev[2 * c], b->stream));
-        mp3mi_launch_loop(b->T, g, b->xr, b->psy, b->prep, b->bits_per_frame, b->loop_state, b->ix, b->side, b->stream);
-        CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->stream));
+        if (c >= 2) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[c & 1], 0)); // k_loop of chunk c-2 has read this slot
+        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->psy[c & 1], b->stream);
+        return MP3MI_OK;
+    };
+    if (stage_x(0) != MP3MI_OK) return MP3MI_ERR_HIP;
+    for (int c = 0; c < nchunks; c++) {
+        const int slot = c & 1;
+        const mp3mi_geom g = geom_of(c);
+        // ---- front stream: everything that does not depend on the bit reservoir ----
+        if (c >= 1 && b->gate_signal) // stage Y of this chunk runs behind k_loop(c-1), once that is resident
+            CHK(hipStreamWaitValue32(b->stream, b->gate_signal, b->gate_gen, hipStreamWaitValueGte, 0xffffffffu));
+        mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy[slot], b->sbs, b->xr[slot], b->debug ? b->sb_dbg : NULL, b->stream);
+        mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->stream);
+        if (c + 1 < nchunks && stage_x(c + 1) != MP3MI_OK) return MP3MI_ERR_HIP;
+        CHK(hipEventRecord(b->ev_front[slot], b->stream));
+        // ---- loop stream: the serial search and the formatter ----
+        CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
+        CHK(hipEventRecord(b->loop_ev[2 * c], b->lstream));
+        mp3mi_loop_gate gate;
+        gate.count = b->gate_count; gate.signal = b->gate_signal; gate.generation = ++b->gate_gen;
+        mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, gate, b->lstream);
+        CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->lstream));
+        CHK(hipEventRecord(b->ev_loop[slot], b->lstream));
         mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,
-                            out_len_dev, b->stream);
+                            out_len_dev, b->lstream);
         b->last_nf = g.nf;
+        b->last_slot = slot;
     }
-    CHK(hipEventRecord(b->ev1, b->stream));
+    CHK(hipEventRecord(b->ev1, b->lstream));
+    CHK(hipEventRecord(b->ev_done, b->lstream));
+    b->have_done = true;
     CHK(hipGetLastError());
     return MP3MI_OK;
 }
@@ -212,6 +293,7 @@ extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
 {
     if (!b) return MP3MI_ERR_ARG;
     CHK(hipStreamSynchronize(b->stream));
+    CHK(hipStreamSynchronize(b->lstream));
     CHK(hipGetLastError());
     return MP3MI_OK;
 }
@@ -240,15 +322,15 @@ extern "C" long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst
     const void *src = NULL;
     size_t n = 0;
     switch (what) {
-    case 0: src = b->psy; n = ngc * sizeof(mp3mi_psy_out); break;
-    case 1: src = b->xr; n = ngc * 576 * sizeof(double); break;
+    case 0: src = b->psy[b->last_slot]; n = ngc * sizeof(mp3mi_psy_out); break;
+    case 1: src = b->xr[b->last_slot]; n = ngc * 576 * sizeof(double); break;
     case 2: src = b->ix; n = ngc * 576 * sizeof(int16_t); break;
     case 3: src = b->side; n = (size_t) b->n_streams * (size_t) b->last_nf * sizeof(mp3mi_frame_side); break;
     case 4: src = b->sb_dbg; n = ngc * 576 * sizeof(double); break;
     default: return MP3MI_ERR_ARG;
     }
     if (!src || n > cap) return MP3MI_ERR_ARG;
-    if (hipStreamSynchronize(b->stream) != hipSuccess) return MP3MI_ERR_HIP;
+    if (hipStreamSynchronize(b->stream) != hipSuccess || hipStreamSynchronize(b->lstream) != hipSuccess) return MP3MI_ERR_HIP;
     if (hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return MP3MI_ERR_HIP;
     return (long) n;
 }

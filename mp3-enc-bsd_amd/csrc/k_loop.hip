@@ -64,9 +64,13 @@ __device__ static const unsigned char LOOP_SUBDV1[23] = {0, 0, 0, 0, 0, 1, 1, 1,
 // Diagnostic build only (-DMP3MI_LOOP_PROFILE): cycles per phase, summed over all waves.
 #if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
 __device__ unsigned long long g_loop_prof[8];
-#define PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+__device__ unsigned long long g_loop_wave[2 * 65536];
+__device__ unsigned long long g_loop_start[65536]; // per stream: cycles from first to last instruction, HW_ID
+#define PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (wave_lane() == 0 && blockIdx.x < 65536) g_loop_start[blockIdx.x] = __builtin_amdgcn_s_memrealtime()
 #define PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
-#define PROF_END do { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_loop_prof[i_], prof_acc[i_]); } while (0)
+#define PROF_END do { if (lane == 0) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_loop_prof[i_], prof_acc[i_]); \
+    if (s < 65536) { unsigned long long tot_ = 0; for (int i_ = 0; i_ < 8; i_++) tot_ += prof_acc[i_]; g_loop_wave[2 * s] = tot_; \
+    g_loop_wave[2 * s + 1] = (unsigned long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long) __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); } } } while (0)
 #else
 #define PROF_DECL
 #define PROF(i)
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                                 const mp3mi_loop_prep *__restrict__ prep,
                                                 const int32_t *__restrict__ bits_per_frame,
                                                 mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
-                                                mp3mi_frame_side *__restrict__ side_out)
+                                                mp3mi_frame_side *__restrict__ side_out, mp3mi_loop_gate gate)
 {
     __shared__ loop_lds L;
     const int lane = wave_lane();
@@ -465,6 +469,22 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     const int bitsPerFrame = bits_per_frame[s];
     const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2; // src/musicin.c:729-746
     PROF_DECL;
+    // Residency gate (batch.cpp): the last wavefront of the grid to start publishes this launch's
+    // generation number; the front stream holds the next chunk's feed-forward kernels back until then,
+    // so that they fill the chip BEHIND this kernel instead of taking its wave slots.  Nothing in this
+    // kernel ever waits on the gate.
+    if (gate.signal && lane == 0) {
+        const unsigned arrived = atomicAdd(gate.count, 1u) + 1u;
+        if (arrived == (unsigned) gridDim.x) {
+            *gate.count = 0;
+            __hip_atomic_store(gate.signal, gate.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+#if !defined(MP3MI_EMU)
+    // this wavefront is on the critical path of the whole batch: let it issue ahead of the
+    // feed-forward kernels of the next chunk that fill the chip behind it (batch.cpp)
+    __builtin_amdgcn_s_setprio(3);
+#endif
 
     loop_regs R;
     R.sfb_l = (lane < 23) ? T->sfb_l[lane] : 576;
@@ -822,14 +842,24 @@ extern "C" void mp3mi_debug_loop_profile(unsigned long long *out)
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_prof), sizeof(z));
     hipMemcpyToSymbol(HIP_SYMBOL(g_loop_prof), z, sizeof(z));
 }
+extern "C" void mp3mi_debug_loop_starts(unsigned long long *out, int n_streams)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_start), sizeof(unsigned long long) * (size_t) n_streams);
+}
+extern "C" void mp3mi_debug_loop_waves(unsigned long long *out, int n_streams)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_wave), sizeof(unsigned long long) * 2 * (size_t) n_streams);
+}
 #endif
 
 size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
                        const mp3mi_loop_prep *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
-                       mp3mi_frame_side *side, hipStream_t st)
+                       mp3mi_frame_side *side, mp3mi_loop_gate gate, hipStream_t st)
 {
     hipLaunchKernelGGL(k_loop, dim3((unsigned) g.n_streams), dim3(64), 0, st, T, g, xr, psy, prep, bits_per_frame,
-                       (mp3mi_loop_state *) loop_state, ix, side);
+                       (mp3mi_loop_state *) loop_state, ix, side, gate);
 }

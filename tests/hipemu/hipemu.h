@@ -83,6 +83,10 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
     int l = (int) (threadIdx.x & 63) - (int) d;
     return __shfl(v, l < 0 ? (int) (threadIdx.x & 63) : l, width);
 }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; } // fibers run one at a time
+#define __ATOMIC_RELEASE_EMU 0
+#define __HIP_MEMORY_SCOPE_SYSTEM 0
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
@@ -102,12 +106,22 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = 0; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 double hipemu_now();
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0}; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emu_event{0}; return hipSuccess; }
+enum { hipDeviceAttributeCanUseStreamWaitValue = 1, hipMallocSignalMemory = 2, hipStreamWaitValueGte = 0 };
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 1; return hipSuccess; }
+static inline hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipStreamWaitValue32(hipStream_t, void *, unsigned, unsigned, unsigned) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = hipemu_now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

@@ -19,3 +19,25 @@ v = np.array(list(prof), dtype=np.float64)
 names = ["setup/load", "other(part2,search ctl)", "quantize", "count_bits", "calc_noise", "preemph+amp", "loop_break+scale", "tail"]
 for n, x in zip(names, v): print("%-26s %6.2f %%   %.3g cycles/(gr,ch)" % (n, 100 * x / v.sum(), x / (S * nf * 4)))
 print("total cycles per (gr,ch) per wave: %.3g" % (v.sum() / (S * nf * 4)), b.last_timing())
+
+w = (ctypes.c_ulonglong * (2 * S))()
+L.mp3mi_debug_loop_waves(w, S)
+a = np.array(list(w), dtype=np.uint64).reshape(S, 2)
+cyc = a[:, 0].astype(np.float64)
+hw = a[:, 1] & np.uint64(0xffffffff)
+xcc = (a[:, 1] >> np.uint64(32)).astype(np.int64)
+# HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
+simd = ((hw >> np.uint64(4)) & np.uint64(3)).astype(np.int64); cu = ((hw >> np.uint64(8)) & np.uint64(15)).astype(np.int64)
+se = ((hw >> np.uint64(13)) & np.uint64(7)).astype(np.int64)
+key = ((xcc * 8 + se) * 16 + cu) * 4 + simd
+print("per-stream cycles: mean %.4g  p50 %.4g  p90 %.4g  p99 %.4g  max %.4g  (max/mean %.3f)" % (cyc.mean(), np.percentile(cyc, 50), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max(), cyc.max() / cyc.mean()))
+u, inv = np.unique(key, return_inverse=True)
+per = np.bincount(inv, weights=cyc); cnt = np.bincount(inv)
+print("SIMDs seen %d, waves/SIMD min %d max %d; per-SIMD summed cycles mean %.4g max %.4g (max/mean %.3f)" % (len(u), cnt.min(), cnt.max(), per.mean(), per.max(), per.max() / per.mean()))
+by = [cyc[(np.arange(S) // 3) % 4 == k].mean() for k in range(4)]
+print("mean cycles by noise class:", ["%.4g" % x for x in by])
+
+st = (ctypes.c_ulonglong * S)()
+L.mp3mi_debug_loop_starts(st, S)
+st = np.array(list(st), dtype=np.float64); st -= st.min()
+print("wave start spread (s_memrealtime ticks, 100 MHz): p50 %.0f p90 %.0f p99 %.0f max %.0f" % (np.percentile(st, 50), np.percentile(st, 90), np.percentile(st, 99), st.max()))
