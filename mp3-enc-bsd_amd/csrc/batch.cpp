@@ -46,8 +46,9 @@ struct mp3mi_batch {
     hipEvent_t ev_loop[2];   // k_loop of the chunk in slot i is done (slot may be overwritten)
     hipEvent_t ev_done;      // everything of the previous encode call is done
     bool have_done;
-    unsigned *gate_count, *gate_signal; // residency gate of k_loop (mp3mi_loop_gate); signal == NULL: not available
-    unsigned gate_gen;
+    unsigned *gate_count;    // start census of k_loop's wavefronts (device memory, only ever grows), NULL = gate off
+    unsigned gate_total;     // census value once every wavefront launched so far has started
+    int prep_exact;          // MP3MI_PREP_EXACT=1: k_prep skips its fast first tier (tests)
     int last_slot;
     mp3mi_tables *T;
     int32_t *bits_per_frame, *bitrate_index;
@@ -145,16 +146,13 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     CHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
     b->have_done = false;
     b->last_slot = 0;
-    b->gate_count = NULL; b->gate_signal = NULL; b->gate_gen = 0;
+    { const char *e = getenv("MP3MI_PREP_EXACT"); b->prep_exact = (e && atoi(e)) ? 1 : 0; }
+    b->gate_count = NULL; b->gate_total = 0;
     {
-        int can = 0, dev = 0;
         const char *envg = getenv("MP3MI_NO_GATE");
-        CHK(hipGetDevice(&dev));
-        if (!(envg && atoi(envg)) && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can) {
+        if (!(envg && atoi(envg))) {
             CHK(hipMalloc((void **) &b->gate_count, sizeof(unsigned)));
             CHK(hipMemset(b->gate_count, 0, sizeof(unsigned)));
-            if (hipExtMallocWithFlags((void **) &b->gate_signal, 8, hipMallocSignalMemory) != hipSuccess) b->gate_signal = NULL;
-            else CHK(hipMemset(b->gate_signal, 0, 8));
         }
     }
     CHK(hipMalloc((void **) &b->T, sizeof(mp3mi_tables)));
@@ -197,7 +195,6 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     hipFree(b->sbs); hipFree(b->ix); hipFree(b->side);
     hipFree(b->psy_state); hipFree(b->loop_state);
     if (b->gate_count) hipFree(b->gate_count);
-    if (b->gate_signal) hipFree(b->gate_signal);
     if (b->sb_dbg) hipFree(b->sb_dbg);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
     for (size_t i = 0; i < b->loop_ev.size(); i++) hipEventDestroy(b->loop_ev[i]);
@@ -246,9 +243,10 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
     // therefore run one chunk ahead, BEFORE k_loop of the previous chunk starts (stage X); what
     // overlaps with k_loop(c) is stage Y of chunk c+1: k_filter, k_mdct, k_prep -- short-lived
     // single-wave workgroups that fit next to k_loop's and yield freed slots to it.
+    const int cfr = (n_frames + nchunks - 1) / nchunks; // equal chunks: a short last one would run without overlap
     auto geom_of = [&](int c) {
-        const int f0 = c * b->chunk_frames;
-        const int nf = (n_frames - f0 < b->chunk_frames) ? n_frames - f0 : b->chunk_frames;
+        const int f0 = c * cfr;
+        const int nf = (n_frames - f0 < cfr) ? n_frames - f0 : cfr;
         return mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
     };
     auto stage_x = [&](int c) -> int {
@@ -263,18 +261,17 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
         const int slot = c & 1;
         const mp3mi_geom g = geom_of(c);
         // ---- front stream: everything that does not depend on the bit reservoir ----
-        if (c >= 1 && b->gate_signal) // stage Y of this chunk runs behind k_loop(c-1), once that is resident
-            CHK(hipStreamWaitValue32(b->stream, b->gate_signal, b->gate_gen, hipStreamWaitValueGte, 0xffffffffu));
+        if (c >= 1 && b->gate_count) // stage Y of this chunk runs behind k_loop(c-1), once that is resident (<= 300 us)
+            mp3mi_launch_gate(b->gate_count, b->gate_total - 16u, 30000u, b->stream);
         mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy[slot], b->sbs, b->xr[slot], b->debug ? b->sb_dbg : NULL, b->stream);
-        mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->stream);
+        mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->prep_exact, b->stream);
         if (c + 1 < nchunks && stage_x(c + 1) != MP3MI_OK) return MP3MI_ERR_HIP;
         CHK(hipEventRecord(b->ev_front[slot], b->stream));
         // ---- loop stream: the serial search and the formatter ----
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
         CHK(hipEventRecord(b->loop_ev[2 * c], b->lstream));
-        mp3mi_loop_gate gate;
-        gate.count = b->gate_count; gate.signal = b->gate_signal; gate.generation = ++b->gate_gen;
-        mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, gate, b->lstream);
+        b->gate_total += (unsigned) S;
+        mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, b->gate_count, b->lstream);
         CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->lstream));
         CHK(hipEventRecord(b->ev_loop[slot], b->lstream));
         mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,

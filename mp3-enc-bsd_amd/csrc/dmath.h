@@ -167,6 +167,34 @@ DM_FN double dm_log(double x)
     return acc.hi + acc.lo;
 }
 
+/* Plain double-precision log of a positive, finite, normal x: same argument reduction and tables
+ * as dm_log, everything after it in double.  Absolute error below 2^-50 * max(1, |log x|)
+ * (tests/test_dmath_host.py measures < 1.5 ulp over 2^20 arguments).  NOT correctly rounded:
+ * only for callers that can tell when their decision does not depend on the last bits and fall
+ * back to dm_log otherwise (k_prep.hip). */
+DM_FN double dm_log_fast(double x)
+{
+    const long long ix = dm_bits(x);
+    int e = (int) (ix >> 52) - 1023;
+    const int i = (int) ((ix >> 45) & 127);
+    double m = dm_from_bits((ix & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    double r, q, ed;
+    if (i >= DM_LOG_SPLIT) { m *= 0.5; e += 1; }
+    r = dm_fma(m, DM_LOG_RCP[i], -1.0);     /* |r| <= 2^-7, at most one rounding */
+    q = -0.125;
+    q = dm_fma(q, r, 0x1.2492492492492p-3);   /*  1/7 */
+    q = dm_fma(q, r, -0x1.5555555555555p-3);  /* -1/6 */
+    q = dm_fma(q, r, 0.2);
+    q = dm_fma(q, r, -0.25);
+    q = dm_fma(q, r, 0x1.5555555555555p-2);   /*  1/3 */
+    q = dm_fma(q, r, -0.5);
+    q = q * r * r;                            /* log1p(r) - r, truncated after r^8/8 (< 2^-59) */
+    ed = (double) e;
+    q = q + dm_fma(ed, DM_LN2_MID, DM_LOG_NLOGC[i][1]);
+    q = q + r;
+    return dm_fma(ed, DM_LN2_HI, DM_LOG_NLOGC[i][0]) + q;   /* e*LN2_HI is exact: 36-bit constant */
+}
+
 /* ------------------------------------------------------------------ exp */
 DM_FN double dm_exp(double x)
 {

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                                 const mp3mi_loop_prep *__restrict__ prep,
                                                 const int32_t *__restrict__ bits_per_frame,
                                                 mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
-                                                mp3mi_frame_side *__restrict__ side_out, mp3mi_loop_gate gate)
+                                                mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count)
 {
     __shared__ loop_lds L;
     const int lane = wave_lane();
@@ -469,17 +469,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     const int bitsPerFrame = bits_per_frame[s];
     const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2; // src/musicin.c:729-746
     PROF_DECL;
-    // Residency gate (batch.cpp): the last wavefront of the grid to start publishes this launch's
-    // generation number; the front stream holds the next chunk's feed-forward kernels back until then,
-    // so that they fill the chip BEHIND this kernel instead of taking its wave slots.  Nothing in this
-    // kernel ever waits on the gate.
-    if (gate.signal && lane == 0) {
-        const unsigned arrived = atomicAdd(gate.count, 1u) + 1u;
-        if (arrived == (unsigned) gridDim.x) {
-            *gate.count = 0;
-            __hip_atomic_store(gate.signal, gate.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    // Residency census (batch.cpp, k_gate): every wavefront counts itself in when it starts.  The
+    // counter only ever grows; nothing in this kernel waits on it.
+    if (gate_count && lane == 0) atomicAdd(gate_count, 1u);
 #if !defined(MP3MI_EMU)
     // this wavefront is on the critical path of the whole batch: let it issue ahead of the
     // feed-forward kernels of the next chunk that fill the chip behind it (batch.cpp)
@@ -858,8 +850,29 @@ size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
                        const mp3mi_loop_prep *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
-                       mp3mi_frame_side *side, mp3mi_loop_gate gate, hipStream_t st)
+                       mp3mi_frame_side *side, unsigned *gate_count, hipStream_t st)
 {
     hipLaunchKernelGGL(k_loop, dim3((unsigned) g.n_streams), dim3(64), 0, st, T, g, xr, psy, prep, bits_per_frame,
-                       (mp3mi_loop_state *) loop_state, ix, side, gate);
+                       (mp3mi_loop_state *) loop_state, ix, side, gate_count);
+}
+
+// Holds the front stream back until the k_loop launch whose census target is `target` has (all but
+// a few of) its wavefronts running, so that the feed-forward kernels queued behind this one fill the
+// chip BEHIND k_loop instead of taking its wave slots.  One wavefront, a BOUNDED wait (max_ticks of
+// the 100 MHz real-time counter): k_loop fills every register file, so the slot this wavefront
+// occupies keeps one k_loop wavefront out until it leaves -- hence "all but a few", and hence short.
+__global__ void __launch_bounds__(64) k_gate(const unsigned *__restrict__ count, unsigned target, unsigned max_ticks)
+{
+#if !defined(MP3MI_EMU)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int) (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long) max_ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+}
+
+void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_ticks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, count, target, max_ticks);
 }

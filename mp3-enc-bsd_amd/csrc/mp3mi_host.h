@@ -44,18 +44,12 @@ void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16
                          const mp3mi_psy_out *psy, double *sbs, double *xr, double *sb_dbg, hipStream_t st);
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g); /* subband samples between k_filter and k_mdct */
 void mp3mi_launch_prep(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
-                       const mp3mi_psy_out *psy, mp3mi_loop_prep *prep, hipStream_t st);
-/* residency gate of k_loop: `count` (device memory, zero between launches) counts started
- * wavefronts, `signal` (signal memory a stream can wait on, or NULL = no gate) receives `generation`
- * once every wavefront of the launch has started */
-struct mp3mi_loop_gate {
-    unsigned *count;
-    unsigned *signal;
-    unsigned generation;
-};
+                       const mp3mi_psy_out *psy, mp3mi_loop_prep *prep, int force_exact, hipStream_t st);
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
                        const mp3mi_psy_out *psy, const mp3mi_loop_prep *prep, const int32_t *bits_per_frame,
-                       void *loop_state, int16_t *ix, mp3mi_frame_side *side, mp3mi_loop_gate gate, hipStream_t st);
+                       void *loop_state, int16_t *ix, mp3mi_frame_side *side, unsigned *gate_count, hipStream_t st);
+/* bounded wait (one wavefront) until k_loop's start census reaches `target` -- see k_loop.hip */
+void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_ticks, hipStream_t st);
 void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix,
                          const mp3mi_frame_side *side, const int32_t *bits_per_frame,
                          const int32_t *bitrate_index, uint8_t *out, size_t out_stride,

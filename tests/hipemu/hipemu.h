@@ -87,6 +87,8 @@ static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *
 #define __ATOMIC_RELEASE_EMU 0
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __HIP_MEMORY_SCOPE_AGENT 0
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }

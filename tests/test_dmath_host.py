@@ -74,3 +74,16 @@ def test_log_exp_special_values(dm):
     assert abs(y[3] - np.log(2.0 ** -1060)) <= abs(np.log(2.0 ** -1060)) * 2 ** -52
     e = call1(dm, "exp", np.array([0.0, 800.0, -800.0, 1.0]))
     assert e[0] == 1.0 and e[1] == np.inf and e[2] == 0.0 and e[3] == np.e
+
+
+def test_log_fast_error_bound(dm):
+    """dm_log_fast (k_prep's first tier) stays within its documented absolute error of the
+    correctly rounded dm_log: 2^-50 * max(1, |log x|)."""
+    rng = np.random.default_rng(13)
+    x = np.concatenate([np.exp(rng.uniform(-60, 60, 1 << 20)), 1.0 + rng.uniform(-1e-3, 1e-3, 1 << 16),
+                        np.ldexp(1.0 + np.arange(128) / 128.0, 3)])
+    exact, fast = call1(dm, "log", x), call1(dm, "log_fast", x)
+    err = np.abs(fast - exact)
+    assert (err <= 2.0 ** -50 * np.maximum(1.0, np.abs(exact))).all()
+    d = ulps(fast[np.abs(exact) > 1e-2], exact[np.abs(exact) > 1e-2])
+    assert d.max() <= 2

@@ -37,3 +37,17 @@ def test_two_streams_mixed_bitrate_and_chunking(emu, oracle, monkeypatch):
     got = emu.encode_host(pcm, rate, ch, [64, 192], nf)
     for s, kb in enumerate([64, 192]):
         assert got[s] == oracle.encode(pcm[s], rate, kb, ch)[0]
+
+
+def test_prep_exact_tier_matches_fast_tier(emu, oracle, monkeypatch):
+    """k_prep decides quantanf_init's integer from plain-double logs and repeats the walk with the
+    correctly rounded log only near a rounding boundary; forcing the second tier must give the
+    same bytes (and more than 64 granules, so that a wavefront carries a ragged tail)."""
+    nf, rate, ch = 9, 44100, 2
+    pcm = np.stack([emu.synth(nf * 1152, ch, rate, 70 + s) for s in range(2)])
+    fast = emu.encode_host(pcm, rate, ch, 128, nf)
+    monkeypatch.setenv("MP3MI_PREP_EXACT", "1")
+    exact = emu.encode_host(pcm, rate, ch, 128, nf)
+    for s in range(2):
+        ref = oracle.encode(pcm[s], rate, 128, ch)[0]
+        assert fast[s] == ref and exact[s] == ref
