@@ -6,9 +6,11 @@
 //
 // Everything here is an ORDER-SENSITIVE f64 sum over the 576 lines of a granule (the total
 // energy, the band energies, the sum of logs), i.e. a serial chain per granule.  So the lanes
-// of a wavefront are 64 different granules, each walking its own 576 lines in index order;
-// the spectra are read from HBM coalesced, 24 lines of 64 granules at a time, and transposed
-// through LDS (row stride 25 doubles: conflict-free column walk).
+// of a wavefront are 64 different granules, each walking its own 576 lines in index order.
+// A lane streams its own 4608-byte spectrum with 16-byte loads issued two groups (12 lines)
+// ahead of their use: every 128-byte line is fetched from HBM once and serves the lane's next
+// seven loads out of L2, no LDS and no transposition pass are needed, and four wavefronts per
+// SIMD hide the latency.
 //
 // quantanf_init needs sum(log(xr^2)) only to round 8*ln(sfm) to an integer.  The first tier
 // uses dm_log_fast (plain double, |error| < 2^-50 max(1,|log|)), which moves 8*ln(sfm) by less
@@ -19,23 +21,74 @@
 #include "mp3mi_host.h"
 #include "dmath.h"
 
-#define PREP_TILE 24 /* lines per LDS tile; a multiple of 3 so that short-block windows stay aligned */
-#define PREP_ROW (PREP_TILE + 1)
+#if defined(MP3MI_EMU)
+#define PREP_SCHED_FENCE()
+#else
+#define PREP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#define PREP_GROUP 6 /* lines per step: three 16-byte loads; a multiple of 3 keeps short-block windows aligned */
 
-struct prep_lds {
-    double x[64][PREP_ROW];
-};
+struct __attribute__((aligned(16))) prep_d2 { double x, y; };
+struct prep_group { prep_d2 v[3]; };
+
+MP3MI_DEVFN prep_group prep_load(const double *row, int k)
+{
+    prep_group g;
+    const prep_d2 *p = (const prep_d2 *) (row + k);
+    g.v[0] = p[0]; g.v[1] = p[1]; g.v[2] = p[2];
+    return g;
+}
 
 MP3MI_DEVFN int prep_ilog2(const mp3mi_tables *T, double v) // (int)(log(v)/log(2)), src/loop.c:633-667
 {
     return (v == 0.0) ? 0 : (int) (dm_log(v) / T->log2);
 }
 
-__global__ void __launch_bounds__(64) k_prep(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
-                                             const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
-                                             mp3mi_loop_prep *__restrict__ prep, int force_exact)
+struct prep_walk_state {
+    double tot, slog, accL, a0, a1, a2, amax;
+    bool amb;
+    int bandL, bandS, edgeL, edgeS; // next band to close and where it ends (wave-uniform)
+};
+
+// One spectral line.  w = line % 3 (the short-block window), line1 = line + 1.  Band energies are
+// parked RAW in out->xmin[] when a band closes; prep_finish turns them into xmin and the log-energies.
+template <bool EXACT>
+MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double x, int w, int line1, bool shortb, bool live,
+                           mp3mi_loop_prep *out)
 {
-    __shared__ prep_lds L;
+    const double sq = x * x, ax = __builtin_fabs(x);
+    S.tot = S.tot + sq;
+    S.accL = S.accL + sq;
+    if (w == 0) S.a0 = S.a0 + sq; else if (w == 1) S.a1 = S.a1 + sq; else S.a2 = S.a2 + sq;
+    S.amax = ax > S.amax ? ax : S.amax;
+    double lg = 0.0;
+    if (x != 0.0) {
+        if (sq < 0x1p-1022) { if (EXACT) lg = dm_log(sq); else S.amb = true; } // below the normal range: only dm_log handles it
+        else lg = EXACT ? dm_log(sq) : dm_log_fast(sq);
+    }
+    S.slog = S.slog + lg;
+    if (line1 == S.edgeL) { // a long scalefactor band ends here
+        if (S.bandL < 21 && !shortb && live) out->xmin[S.bandL] = S.accL;
+        S.accL = 0.0;
+        S.bandL++;
+        S.edgeL = S.bandL < 22 ? T->sfb_l[S.bandL + 1] : 577;
+    }
+    if (w == 2 && line1 == S.edgeS) { // a short scalefactor band ends here for all three windows
+        if (S.bandS < 12 && shortb && live) {
+            out->xmin[S.bandS * 3 + 0] = S.a0;
+            out->xmin[S.bandS * 3 + 1] = S.a1;
+            out->xmin[S.bandS * 3 + 2] = S.a2;
+        }
+        S.a0 = S.a1 = S.a2 = 0.0;
+        S.bandS++;
+        S.edgeS = S.bandS < 13 ? 3 * T->sfb_s[S.bandS + 1] : 577;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_prep(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                                const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
+                                                mp3mi_loop_prep *__restrict__ prep, int force_exact)
+{
     const int lane = wave_lane();
     const size_t n_rec = (size_t) geo.n_streams * (size_t) geo.n_gran * (size_t) geo.channels;
     const size_t rec0 = (size_t) blockIdx.x * 64;
@@ -43,87 +96,70 @@ __global__ void __launch_bounds__(64) k_prep(const mp3mi_tables *__restrict__ T,
     const size_t rec = live ? rec0 + lane : n_rec - 1;
     const mp3mi_psy_out *po = &psy[rec];
     mp3mi_loop_prep *out = &prep[rec];
+    const double *row = xr_all + rec * 576;
     const bool shortb = po->block_type == 2;
-    // transposing copy: lanes 0..23 carry granule 2*it, lanes 24..47 granule 2*it + 1
-    const int cp_g = lane >= PREP_TILE ? 1 : 0, cp_line = lane - PREP_TILE * cp_g;
-    const bool cp_on = lane < 2 * PREP_TILE;
 
+    prep_walk_state S;
+    int tp = 0;
     for (int pass = 0; pass < 2; pass++) {
         const bool exact = pass == 1 || force_exact != 0;
-        double tot = 0.0, slog = 0.0, accL = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0, amax = 0.0;
-        bool amb = false;
-        int bandL = 0, bandS = 0;               // next band to close (wave-uniform)
-        int edgeL = T->sfb_l[1], edgeS = 3 * T->sfb_s[1];
-        for (int t = 0; t < 576 / PREP_TILE; t++) {
-            wave_sync();
-#pragma unroll 8
-            for (int it = 0; it < 32; it++) {
-                const size_t r = rec0 + 2 * it + cp_g;
-                if (cp_on) L.x[2 * it + cp_g][cp_line] = (r < n_rec) ? xr_all[r * 576 + t * PREP_TILE + cp_line] : 0.0;
-            }
-            wave_sync();
-            for (int st = 0; st < PREP_TILE / 3; st++) {
-                const int k = t * PREP_TILE + 3 * st;
-                const double xs[3] = {L.x[lane][3 * st], L.x[lane][3 * st + 1], L.x[lane][3 * st + 2]};
+        S.tot = S.slog = S.accL = S.a0 = S.a1 = S.a2 = S.amax = 0.0;
+        S.amb = false;
+        S.bandL = S.bandS = 0;
+        S.edgeL = T->sfb_l[1];
+        S.edgeS = 3 * T->sfb_s[1];
+        if (!exact) {
+            prep_group g0 = prep_load(row, 0), g1 = prep_load(row, PREP_GROUP);
+            for (int k = 0; k < 576; k += PREP_GROUP) {
+                const prep_group cur = g0;
+                g0 = g1;
+                if (k + 2 * PREP_GROUP < 576) g1 = prep_load(row, k + 2 * PREP_GROUP);
+                const double xs[PREP_GROUP] = {cur.v[0].x, cur.v[0].y, cur.v[1].x, cur.v[1].y, cur.v[2].x, cur.v[2].y};
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const double x = xs[j], sq = x * x, ax = __builtin_fabs(x);
-                    tot = tot + sq;
-                    accL = accL + sq;
-                    if (j == 0) a0 = a0 + sq; else if (j == 1) a1 = a1 + sq; else a2 = a2 + sq;
-                    amax = ax > amax ? ax : amax;
-                    double lg = 0.0;
-                    if (x != 0.0) {
-                        if (sq < 0x1p-1022) amb = true; // below the normal range: only dm_log handles it
-                        else lg = exact ? dm_log(sq) : dm_log_fast(sq);
-                    }
-                    slog = slog + lg;
-                    if (k + j + 1 == edgeL) { // a long scalefactor band ends here (wave-uniform)
-                        if (bandL < 21 && !shortb && live) {
-                            const double en = accL;
-                            const double xmin = po->ratio_l[bandL] * en / (double) (edgeL - T->sfb_l[bandL]);
-                            out->xmin[bandL] = xmin;
-                            out->sc_en[bandL] = prep_ilog2(T, en);   // truncation to int as the reference's statics do
-                            out->sc_xm[bandL] = prep_ilog2(T, xmin);
-                        }
-                        accL = 0.0;
-                        bandL++;
-                        edgeL = bandL < 22 ? T->sfb_l[bandL + 1] : 577;
-                    }
-                }
-                if (k + 3 == edgeS) { // a short scalefactor band ends here for all three windows
-                    if (bandS < 12 && shortb && live) {
-                        const double cnt = (double) (T->sfb_s[bandS + 1] - T->sfb_s[bandS]);
-                        out->xmin[bandS * 3 + 0] = po->ratio_s[bandS][0] * a0 / cnt;
-                        out->xmin[bandS * 3 + 1] = po->ratio_s[bandS][1] * a1 / cnt;
-                        out->xmin[bandS * 3 + 2] = po->ratio_s[bandS][2] * a2 / cnt;
-                    }
-                    a0 = a1 = a2 = 0.0;
-                    bandS++;
-                    edgeS = bandS < 13 ? 3 * T->sfb_s[bandS + 1] : 577;
+                for (int j = 0; j < PREP_GROUP; j++) {
+                    prep_line<false>(T, S, xs[j], j % 3, k + j + 1, shortb, live, out);
+                    PREP_SCHED_FENCE(); // one line at a time: four wavefronts per SIMD hide the latency, not ILP across lines
                 }
             }
+        } else { // second tier, rare: plain line-by-line walk
+#pragma unroll 1
+            for (int k = 0; k < 576; k++) prep_line<true>(T, S, row[k], k % 3, k + 1, shortb, live, out);
         }
         // quantanf_init (src/loop.c:369-402)
-        int tp = 0;
-        if (tot != 0.0) {
-            const double sfm = dm_exp(slog / 576.0) / (tot / 576.0);
+        tp = 0;
+        if (S.tot != 0.0) {
+            const double sfm = dm_exp(S.slog / 576.0) / (S.tot / 576.0);
             const double v = 8.0 * dm_log(sfm);
             tp = (v < 0) ? (int) (v - 0.5) : (int) (v + 0.5); // nint, src/loop.c:2020
             if (tp < -100) tp = -100;
             if (!exact) { // is nint(v) independent of the last bits of the logs?
                 const double av = __builtin_fabs(v), fr = av - __builtin_floor(av);
-                if (!(__builtin_fabs(fr - 0.5) > 1e-9 * (av > 1.0 ? av : 1.0))) amb = true; // also catches NaN
+                if (!(__builtin_fabs(fr - 0.5) > 1e-9 * (av > 1.0 ? av : 1.0))) S.amb = true; // also catches NaN
             }
         } else
-            amb = false;
-        if (live) {
-            out->q0 = tp - 70;
-            out->sc_en_tot = prep_ilog2(T, tot);
-            out->sc_xrmax = (int) amax;
-            out->nonzero = (amax != 0.0) ? 1 : 0;
+            S.amb = false;
+        if (exact || !wave_any(S.amb && live)) break;
+    }
+    if (!live) return;
+    out->q0 = tp - 70;
+    out->sc_en_tot = prep_ilog2(T, S.tot);
+    out->sc_xrmax = (int) S.amax;
+    out->nonzero = (S.amax != 0.0) ? 1 : 0;
+    // calc_xmin (src/loop.c:1085-1118) and calc_scfsi's stored values (src/loop.c:642-667) from the parked energies
+    if (shortb) {
+        for (int b = 0; b < 12; b++) {
+            const double cnt = (double) (T->sfb_s[b + 1] - T->sfb_s[b]);
+            for (int w = 0; w < 3; w++) out->xmin[b * 3 + w] = po->ratio_s[b][w] * out->xmin[b * 3 + w] / cnt;
         }
-        if (exact || !wave_any(amb && live)) break;
+    } else {
+#pragma unroll 1
+        for (int b = 0; b < 21; b++) {
+            const double en = out->xmin[b];
+            const double xmin = po->ratio_l[b] * en / (double) (T->sfb_l[b + 1] - T->sfb_l[b]);
+            out->xmin[b] = xmin;
+            out->sc_en[b] = prep_ilog2(T, en);   // truncation to int as the reference's statics do
+            out->sc_xm[b] = prep_ilog2(T, xmin);
+        }
     }
 }
 
