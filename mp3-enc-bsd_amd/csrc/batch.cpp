@@ -49,6 +49,7 @@ struct mp3mi_batch {
     unsigned *gate_count;    // start census of k_loop's wavefronts (device memory, only ever grows), NULL = gate off
     unsigned gate_total;     // census value once every wavefront launched so far has started
     int prep_exact;          // MP3MI_PREP_EXACT=1: k_prep skips its fast first tier (tests)
+    int test_flags;          // mp3mi_geom::test_flags
     int last_slot;
     mp3mi_tables *T;
     int32_t *bits_per_frame, *bitrate_index;
@@ -147,6 +148,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     b->have_done = false;
     b->last_slot = 0;
     { const char *e = getenv("MP3MI_PREP_EXACT"); b->prep_exact = (e && atoi(e)) ? 1 : 0; }
+    { const char *e = getenv("MP3MI_NOISE_EXACT"); b->test_flags = (e && atoi(e)) ? 1 : 0; }
     b->gate_count = NULL; b->gate_total = 0;
     {
         const char *envg = getenv("MP3MI_NO_GATE");
@@ -247,7 +249,9 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
     auto geom_of = [&](int c) {
         const int f0 = c * cfr;
         const int nf = (n_frames - f0 < cfr) ? n_frames - f0 : cfr;
-        return mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
+        mp3mi_geom g = mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
+        g.test_flags = b->test_flags;
+        return g;
     };
     auto stage_x = [&](int c) -> int {
         const mp3mi_geom g = geom_of(c);

@@ -39,6 +39,7 @@ struct loop_gr { // wave-uniform working copy of gr_info (src/l3side.h:60-87)
 // which is what 4096 streams on 256 CUs need to be resident all at once.
 struct loop_lds {
     double tmp[576];
+    double part[64];
     int16_t ix[576 + 8];
     uint16_t glut[928];
     int sf_gr0[2][21];
@@ -105,6 +106,18 @@ MP3MI_DEVFN float loop_power34(const double xr[9], float y34[9])
     return __builtin_bit_cast(float, wave_max_i32(__builtin_bit_cast(int, m))); // non-negative floats order like their bits
 }
 
+// |xr * sqrt(2)^n|^(3/4) = y34 * 2^(3n/8): when a band is amplified (n = 1) or pre-emphasised (n = pretab)
+// the cached power is rescaled instead of taking two roots again.  One float rounding of the
+// constant and one of the product per call: < 1.2e-7 relative (the quantiser's guard band budgets it).
+MP3MI_DEVFN float loop_rescale34(float y34, int n)
+{
+    const float c = n == 1 ? 1.2968395546510096f : (n == 2 ? 1.681792830507429f : (n == 3 ? 2.1810154653305154f : 1.0f));
+    return y34 * c;
+}
+// upper bound of the largest y34 after such a rescaling (only the all-zero shortcut of the
+// bisection reads it, and that runs before the first amplification)
+#define LOOP_Y34MAX_GROW 2.1810157f
+
 MP3MI_DEVFN float loop_estimate(float y34, float cq) { return __builtin_fmaf(y34, cq, 0.4054f); } // of x^(3/4) + 0.4054
 
 // true: every line quantises to 0 at this step (wave-uniform).  Uses the same estimate as the
@@ -132,11 +145,13 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double 
         f = f > 2047.5f ? 2047.5f : f;
         const float fl = __builtin_floorf(f);
         p[j] = (int) fl;
-        // near a table boundary: settle exactly.  The estimate's error is relative (< 7e-7 f: two 1-ulp
-        // roots, exp2, two roundings), so the guard band 2.5e-6 f + 2e-6 scales with f; small values --
-        // the common case -- are almost never ambiguous.  |frac - 1/2| > 1/2 - band <=> within band of an integer.
+        // near a table boundary: settle exactly.  The estimate's error is relative: < 7e-7 f from the two
+        // 1-ulp roots, exp2 and two roundings, plus < 1.2e-7 f for each of the at most 17 rescalings of
+        // y34 by loop_rescale34 (16 amplifications, one pre-emphasis) = 2.8e-6 f.  The guard band
+        // 3.5e-6 f + 2e-6 scales with f; small values -- the common case -- are almost never ambiguous.
+        // |frac - 1/2| > 1/2 - band <=> within band of an integer.
         const float d = __builtin_fabsf((f - fl) - 0.5f);
-        if (d > __builtin_fmaf(-2.5e-6f, f, 0.5f - 2e-6f)) need |= 1u << j;
+        if (d > __builtin_fmaf(-3.5e-6f, f, 0.5f - 2e-6f)) need |= 1u << j;
     }
     if (wave_any(need != 0)) {
         const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
@@ -437,6 +452,19 @@ MP3MI_DEVFN double loop_seq_sum(const loop_lds &L, int first, int count, int str
     return sum;
 }
 
+// the reference's sequential band sums over the noise terms in L.tmp (src/loop.c:1030-1060)
+MP3MI_DEVFN double loop_noise_exact(const loop_lds &L, bool bandlane, int sfirst, int scount, int sstride)
+{
+    const double sum = loop_seq_sum(L, sfirst, bandlane ? scount : 0, sstride);
+    return bandlane ? sum / (double) scount : 0.0;
+}
+
+// is the partial-sum noise of this band lane too close to its threshold to decide `noise > xmin`?
+MP3MI_DEVFN bool loop_noise_close(bool bandlane, double xfsf, double xmin)
+{
+    return bandlane && xmin > 0.0 && __builtin_fabs(xfsf - xmin) <= 1e-12 * xmin;
+}
+
 // range of L.tmp a lane sums: band lanes their band, lane 63 all 576 lines, other lanes nothing
 MP3MI_DEVFN void loop_sum_range(const loop_regs &R, bool shortb, int nband, int *first, int *count, int *stride)
 {
@@ -524,6 +552,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 }
                 int sfirst, scount, sstride;
                 loop_sum_range(R, shortb, nband, &sfirst, &scount, &sstride);
+                // calc_noise's partial-sum jobs (mp3mi_tables::nj_*): this lane's job, and for band lanes their parts
+                const int jfirst = T->nj_first[shortb][lane], jcount = T->nj_count[shortb][lane];
+                const int pj0 = bandlane ? T->nj_job0[shortb][lane] : 0, pn = bandlane ? T->nj_njobs[shortb][lane] : 0;
 
                 double xr[9];
                 int p[9];
@@ -651,7 +682,13 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         } while (bits > huff_bits);
 
                         PROF(1);
-                        // calc_noise (src/loop.c:1007-1067)
+                        // calc_noise (src/loop.c:1007-1067).  The noise of a band is only ever COMPARED with the
+                        // allowed distortion, and it is a sum of non-negative terms, so any summation order
+                        // agrees with the reference's sequential one to within 2(n-1) ulp (n <= 102 lines:
+                        // < 2.3e-14 relative).  First tier: every band is cut into parts of ~10 lines summed by
+                        // different lanes.  Only if a band lands within 1e-12 of its threshold is the
+                        // reference's order used (loop_noise_exact) -- at both places that compare.
+                        bool xfsf_exact = (geo.test_flags & 1) != 0;
                         {
                             const double step = T->step[g.q - MP3MI_STEP_MIN];
 #pragma unroll
@@ -660,8 +697,15 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 L.tmp[lane + 64 * j] = t * t;
                             }
                             __syncthreads();
-                            const double sum = loop_seq_sum(L, sfirst, bandlane ? scount : 0, sstride);
-                            xfsf_r = bandlane ? sum / (double) scount : 0.0;
+                            if (!xfsf_exact) {
+                                L.part[lane] = loop_seq_sum(L, jfirst, jcount, shortb ? 3 : 1);
+                                __syncthreads();
+                                double sum = 0.0;
+                                for (int i = 0; i < pn; i++) sum = sum + L.part[pj0 + i];
+                                xfsf_r = bandlane ? sum / (double) scount : 0.0;
+                                if (wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) xfsf_exact = true;
+                            }
+                            if (xfsf_exact) xfsf_r = loop_noise_exact(L, bandlane, sfirst, scount, sstride);
                         }
                         sfsave_r = sf_r;
                         save_preflag = g.preflag;
@@ -681,12 +725,20 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 if ((viol & 0x1E0000ull) == 0x1E0000ull) { // sfb 17..20 all violate
                                     g.preflag = 1;
                                     if (lane < g.sfb_lmax) xmin_r = xmin_r * T->pretab_xmin[LOOP_PRETAB[lane]];
+                                    // the thresholds moved: amp_scalefac_bands compares against the new ones
+                                    if (!xfsf_exact && wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) {
+                                        xfsf_exact = true;
+                                        xfsf_r = loop_noise_exact(L, bandlane, sfirst, scount, sstride);
+                                    }
 #pragma unroll
                                     for (int j = 0; j < 9; j++) {
                                         const int b = (int) ((bandpack >> (6 * j)) & 63ull);
-                                        if (b < g.sfb_lmax) xr[j] = xr[j] * T->pretab_xr[LOOP_PRETAB[b]];
+                                        if (b < g.sfb_lmax) {
+                                            xr[j] = xr[j] * T->pretab_xr[LOOP_PRETAB[b]];
+                                            y34[j] = loop_rescale34(y34[j], LOOP_PRETAB[b]);
+                                        }
                                     }
-                                    y34max = loop_power34(xr, y34);
+                                    y34max = y34max * LOOP_Y34MAX_GROW;
                                 }
                             }
                         }
@@ -721,9 +773,12 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
 #pragma unroll
                                 for (int j = 0; j < 9; j++) {
                                     const int b = (int) ((bandpack >> (6 * j)) & 63ull);
-                                    if (b < nband && ((ampmask >> b) & 1ull)) xr[j] = xr[j] * ifqstep;
+                                    if (b < nband && ((ampmask >> b) & 1ull)) {
+                                        xr[j] = xr[j] * ifqstep;
+                                        y34[j] = loop_rescale34(y34[j], 1);
+                                    }
                                 }
-                                y34max = loop_power34(xr, y34);
+                                y34max = y34max * LOOP_Y34MAX_GROW;
                             }
                         }
 

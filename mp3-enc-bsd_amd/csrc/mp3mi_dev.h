@@ -56,6 +56,11 @@ typedef struct {
     int32_t sfb_l[23], sfb_s[14];
     uint8_t sfb_of_line_l[576];      /* long sfb index of each line (21 = above sfb 20) */
     uint8_t sfb_of_line_s[576];      /* short: sfb*3+window of line l*3+w              */
+    /* calc_noise as partial sums (k_loop): job j < 64 adds nj_count elements of the noise terms from
+       element nj_first on (stride 1 for long blocks [0], 3 for short blocks [1]); the parts of band b
+       are the jobs [nj_job0[b], nj_job0[b] + nj_njobs[b]) */
+    int16_t nj_first[2][64];
+    uint8_t nj_count[2][64], nj_job0[2][36], nj_njobs[2][36];
     /* psy */
     float window[1024], window_s[256];
     int32_t numlines_pe[MP3MI_CBANDS];       /* numlines[] as left by L3para_read (quirk) */

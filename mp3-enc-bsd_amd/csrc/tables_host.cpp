@@ -293,6 +293,35 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
         for (int l = SFB_S[ri][sfb]; l < SFB_S[ri][sfb + 1]; l++)
             for (int w = 0; w < 3; w++) T->sfb_of_line_s[l * 3 + w] = (uint8_t) (sfb * 3 + w);
 
+    // noise-sum jobs: split every band into parts of at most `target` elements, smallest target that fits 64 jobs
+    for (int t = 0; t < 2; t++) {
+        const int nb = t ? 36 : 21;
+        for (int target = 4; target <= 192; target++) {
+            int jobs = 0;
+            for (int b = 0; b < nb; b++) {
+                const int w = t ? SFB_S[ri][b / 3 + 1] - SFB_S[ri][b / 3] : SFB_L[ri][b + 1] - SFB_L[ri][b];
+                jobs += (w + target - 1) / target;
+            }
+            if (jobs > 64) continue;
+            int j = 0;
+            for (int b = 0; b < nb; b++) {
+                const int e0 = t ? SFB_S[ri][b / 3] : SFB_L[ri][b];
+                const int w = (t ? SFB_S[ri][b / 3 + 1] : SFB_L[ri][b + 1]) - e0;
+                const int parts = (w + target - 1) / target;
+                T->nj_job0[t][b] = (uint8_t) j;
+                T->nj_njobs[t][b] = (uint8_t) parts;
+                for (int q = 0, off = 0; q < parts; q++) {
+                    const int cnt = (w - off + (parts - q) - 1) / (parts - q); // even split of what is left
+                    T->nj_first[t][j] = (int16_t) (t ? (e0 + off) * 3 + b % 3 : e0 + off);
+                    T->nj_count[t][j] = (uint8_t) cnt;
+                    off += cnt;
+                    j++;
+                }
+            }
+            break;
+        }
+    }
+
     for (unsigned i = 0; i < 1024; i++) T->window[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 1024)));
     for (unsigned i = 0; i < 256; i++) T->window_s[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 256)));
 

@@ -51,3 +51,15 @@ def test_prep_exact_tier_matches_fast_tier(emu, oracle, monkeypatch):
     for s in range(2):
         ref = oracle.encode(pcm[s], rate, 128, ch)[0]
         assert fast[s] == ref and exact[s] == ref
+
+
+def test_noise_exact_tier_matches_partial_sums(emu, oracle, monkeypatch):
+    """k_loop decides `noise > xmin` from partial sums spread over the lanes and takes the reference's
+    sequential order only when a band lands within 1e-12 of its threshold; forcing the sequential
+    sums must give the same bytes.  The input has bursts, so short blocks are covered too."""
+    nf, rate, ch = 8, 44100, 2
+    pcm = np.stack([emu.synth(nf * 1152, ch, rate, 90 + s) for s in range(2)])
+    ref = [oracle.encode(pcm[s], rate, 128, ch)[0] for s in range(2)]
+    assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
+    monkeypatch.setenv("MP3MI_NOISE_EXACT", "1")
+    assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
