@@ -153,8 +153,8 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     {
         const char *envg = getenv("MP3MI_NO_GATE");
         if (!(envg && atoi(envg))) {
-            CHK(hipMalloc((void **) &b->gate_count, sizeof(unsigned)));
-            CHK(hipMemset(b->gate_count, 0, sizeof(unsigned)));
+            CHK(hipMalloc((void **) &b->gate_count, 2 * sizeof(unsigned))); // [0] start census, [1] frames finished in this launch
+            CHK(hipMemset(b->gate_count, 0, 2 * sizeof(unsigned)));
         }
     }
     CHK(hipMalloc((void **) &b->T, sizeof(mp3mi_tables)));
@@ -275,6 +275,7 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
         CHK(hipEventRecord(b->loop_ev[2 * c], b->lstream));
         b->gate_total += (unsigned) S;
+        if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
         mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, b->gate_count, b->lstream);
         CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->lstream));
         CHK(hipEventRecord(b->ev_loop[slot], b->lstream));

@@ -502,8 +502,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     if (gate_count && lane == 0) atomicAdd(gate_count, 1u);
 #if !defined(MP3MI_EMU)
     // this wavefront is on the critical path of the whole batch: let it issue ahead of the
-    // feed-forward kernels of the next chunk that fill the chip behind it (batch.cpp)
-    __builtin_amdgcn_s_setprio(3);
+    // feed-forward kernels of the next chunk that fill the chip behind it (batch.cpp); adjusted
+    // per frame by the pacing below
+    __builtin_amdgcn_s_setprio(2);
 #endif
 
     loop_regs R;
@@ -875,6 +876,20 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
             for (int i = lane; i < (int) (sizeof(mp3mi_frame_side) / 4); i += 64) dst[i] = ((const int *) &L.side)[i];
         }
         __syncthreads();
+#if !defined(MP3MI_EMU)
+        // Pacing: the kernel ends when its slowest stream ends, and streams differ by up to 1.5x in
+        // work.  gate_count[1] counts the frames finished by all streams of this launch; a stream
+        // behind the average raises its wave priority (it then issues ahead of the three other
+        // wavefronts of its SIMD), a stream ahead of it lowers it.  Purely a scheduling hint.
+        if (gate_count) {
+            const unsigned done_all = __builtin_amdgcn_readfirstlane((int) (lane == 0 ? atomicAdd(gate_count + 1, 1u) + 1u : 0u));
+            const float lead = (float) (fl + 1) - (float) done_all / (float) gridDim.x;
+            if (lead < -1.0f) __builtin_amdgcn_s_setprio(3);
+            else if (lead < 0.0f) __builtin_amdgcn_s_setprio(2);
+            else if (lead < 1.0f) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
     }
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &state[s])[i] = ((const int *) &L.st)[i];
     PROF(7);
