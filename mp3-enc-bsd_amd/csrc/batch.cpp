@@ -48,6 +48,9 @@ struct mp3mi_batch {
     bool have_done;
     unsigned *gate_count;    // start census of k_loop's wavefronts (device memory, only ever grows), NULL = gate off
     unsigned gate_total;     // census value once every wavefront launched so far has started
+    int *place_order, *place_cost; // k_loop stream placement (mp3mi_loop_place), NULL = off
+    unsigned *place_zero;    // taken[n] + simd_slots + simd_idx + ticket + scan, zeroed before every k_loop
+    int n_simd;
     int prep_exact;          // MP3MI_PREP_EXACT=1: k_prep skips its fast first tier (tests)
     int test_flags;          // mp3mi_geom::test_flags
     int last_slot;
@@ -157,6 +160,20 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
             CHK(hipMemset(b->gate_count, 0, 2 * sizeof(unsigned)));
         }
     }
+    b->place_order = NULL; b->place_cost = NULL; b->place_zero = NULL; b->n_simd = 0;
+    {
+        const char *envp = getenv("MP3MI_NO_PLACE");
+        hipDeviceProp_t prop;
+        int dev = 0;
+        CHK(hipGetDevice(&dev));
+        CHK(hipGetDeviceProperties(&prop, dev));
+        b->n_simd = prop.multiProcessorCount * 4;
+        if (!(envp && atoi(envp)) && n_streams >= 2 * b->n_simd) { // placement only matters when SIMDs hold several streams
+            CHK(hipMalloc((void **) &b->place_order, sizeof(int) * n_streams));
+            CHK(hipMalloc((void **) &b->place_cost, sizeof(int) * n_streams));
+            CHK(hipMalloc((void **) &b->place_zero, sizeof(unsigned) * ((size_t) n_streams + 2 * MP3MI_PLACE_KEYS + 2)));
+        }
+    }
     CHK(hipMalloc((void **) &b->T, sizeof(mp3mi_tables)));
     CHK(hipMemcpy(b->T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
     free(Th);
@@ -197,6 +214,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     hipFree(b->sbs); hipFree(b->ix); hipFree(b->side);
     hipFree(b->psy_state); hipFree(b->loop_state);
     if (b->gate_count) hipFree(b->gate_count);
+    if (b->place_order) { hipFree(b->place_order); hipFree(b->place_cost); hipFree(b->place_zero); }
     if (b->sb_dbg) hipFree(b->sb_dbg);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
     for (size_t i = 0; i < b->loop_ev.size(); i++) hipEventDestroy(b->loop_ev[i]);
@@ -230,6 +248,7 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
     // fresh encoder state for every stream (function statics of the reference start at zero)
     CHK(hipMemsetAsync(b->psy_state, 0, mp3mi_psy_state_size() * (size_t) S * C, b->stream));
     CHK(hipMemsetAsync(b->loop_state, 0, mp3mi_loop_state_size() * (size_t) S, b->stream));
+    if (b->place_cost) CHK(hipMemsetAsync(b->place_cost, 0, sizeof(int) * (size_t) S, b->stream)); // first chunk: order = identity
     CHK(hipMemsetAsync(out_dev, 0, out_stride * (size_t) S, b->stream));
     const int nchunks = (n_frames + b->chunk_frames - 1) / b->chunk_frames;
     while ((int) b->loop_ev.size() < 2 * nchunks) {
@@ -275,8 +294,17 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
         CHK(hipEventRecord(b->loop_ev[2 * c], b->lstream));
         b->gate_total += (unsigned) S;
+        mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
+        if (b->place_order) { // rank the streams by their cost in the previous chunk, hand the tables to k_loop
+            mp3mi_launch_rank(b->place_cost, b->place_order, S, b->lstream);
+            CHK(hipMemsetAsync(b->place_zero, 0, sizeof(unsigned) * ((size_t) S + 2 * MP3MI_PLACE_KEYS + 2), b->lstream));
+            place.order = b->place_order; place.cost = b->place_cost; place.taken = b->place_zero;
+            place.simd_slots = b->place_zero + S; place.simd_idx = place.simd_slots + MP3MI_PLACE_KEYS;
+            place.ticket = place.simd_idx + MP3MI_PLACE_KEYS; place.scan = place.ticket + 1;
+            place.n_simd = b->n_simd;
+        }
         if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
-        mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, b->gate_count, b->lstream);
+        mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, b->gate_count, place, b->lstream);
         CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->lstream));
         CHK(hipEventRecord(b->ev_loop[slot], b->lstream));
         mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,

@@ -266,7 +266,7 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
     HIPOK(hipMemcpyAsync(D.bits_d, &bpf, sizeof(bpf), hipMemcpyHostToDevice, D.st));
     const mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1, 0, 1);
     mp3mi_launch_prep(D.T, g, D.xr_d, D.psy4, D.prep4, 0, D.st);
-    mp3mi_launch_loop(D.T, g, D.xr_d, D.psy4, D.prep4, D.bits_d, D.loop_state, D.ix_d, D.side_d, NULL, D.st);
+    mp3mi_launch_loop(D.T, g, D.xr_d, D.psy4, D.prep4, D.bits_d, D.loop_state, D.ix_d, D.side_d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
     static int16_t ix[4][576];
     mp3mi_frame_side sd;
     loop_state_host ls;

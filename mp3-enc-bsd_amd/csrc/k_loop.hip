@@ -66,7 +66,8 @@ __device__ static const unsigned char LOOP_SUBDV1[23] = {0, 0, 0, 0, 0, 1, 1, 1,
 #if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
 __device__ unsigned long long g_loop_prof[8];
 __device__ unsigned long long g_loop_wave[2 * 65536];
-__device__ unsigned long long g_loop_start[65536]; // per stream: cycles from first to last instruction, HW_ID
+__device__ unsigned long long g_loop_start[65536];
+__device__ unsigned long long g_loop_work[65536]; // per stream: cycles from first to last instruction, HW_ID
 #define PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (wave_lane() == 0 && blockIdx.x < 65536) g_loop_start[blockIdx.x] = __builtin_amdgcn_s_memrealtime()
 #define PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
 #define PROF_END do { if (lane == 0) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_loop_prof[i_], prof_acc[i_]); \
@@ -484,16 +485,84 @@ MP3MI_DEVFN void loop_sum_range(const loop_regs &R, bool shortb, int nband, int 
     }
 }
 
+// ---- placement: which stream does this wavefront take? ----
+// The kernel ends when its most loaded SIMD ends.  The hardware decides where a workgroup runs,
+// so instead of stream = blockIdx a wavefront looks at where it landed (HW_ID / XCC_ID) and takes a
+// stream from the list sorted by the previous chunk's cost such that every SIMD gets a heavy, a
+// light and two middle streams: the r-th wavefront to arrive on the SIMD with arrival ticket i
+// takes sorted position r*NS + i (r even) or (r+1)*NS - 1 - i (r odd), NS = place.n_simd.
+// Any wavefront that finds its position missing or taken (more streams than slots, an uneven
+// spread) takes the next free one from a scan counter, so every stream is taken exactly once.
+MP3MI_DEVFN int loop_place_stream(const mp3mi_loop_place &pl, int n_streams, int block)
+{
+#if defined(MP3MI_EMU)
+    return pl.order ? pl.order[block] : block;
+#else
+    if (!pl.order) return block;
+    int pos = -1;
+    if (wave_lane() == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // XCC_ID
+        // simd_id[5:4] cu_id[11:8] sh_id[12] se_id[15:13]
+        const unsigned key = ((xcc & 7u) << 10) | (((hw >> 13) & 7u) << 7) | (((hw >> 12) & 1u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
+        const unsigned r = atomicAdd(&pl.simd_slots[key], 1u);
+        unsigned idx = 0xffffffffu;
+        if (r == 0) {
+            idx = atomicAdd(pl.ticket, 1u);
+            __hip_atomic_store(&pl.simd_idx[key], idx + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (r < 4) {
+            for (int spin = 0; spin < 20000; spin++) { // the first arrival on this SIMD publishes within microseconds
+                const unsigned v = __hip_atomic_load(&pl.simd_idx[key], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (v) { idx = v - 1u; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (r < 4 && idx < (unsigned) pl.n_simd) {
+            const int p = (r & 1u) ? (int) ((r + 1u) * pl.n_simd - 1u - idx) : (int) (r * pl.n_simd + idx);
+            if (p < n_streams && atomicExch(&pl.taken[p], 1u) == 0u) pos = p;
+        }
+        while (pos < 0) { // n_streams wavefronts claim n_streams positions: this always finds one
+            const unsigned p = atomicAdd(pl.scan, 1u);
+            if (p >= (unsigned) n_streams) { pos = block; break; } // cannot happen; never spin forever
+            if (atomicExch(&pl.taken[p], 1u) == 0u) pos = (int) p;
+        }
+        pos = pl.order[pos];
+    }
+    return __builtin_amdgcn_readfirstlane(pos);
+#endif
+}
+
+// order[rank] = stream, streams ranked by cost (descending, ties by index): one thread per stream.
+__global__ void __launch_bounds__(256) k_rank(const int *__restrict__ cost, int *__restrict__ order, int n)
+{
+    const int i = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int ci = cost[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+        const int cj = cost[j];
+        rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0;
+    }
+    order[rank] = i;
+}
+
+void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rank, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, cost, order, n);
+}
+
 __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
                                                 const mp3mi_loop_prep *__restrict__ prep,
                                                 const int32_t *__restrict__ bits_per_frame,
                                                 mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
-                                                mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count)
+                                                mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
+                                                mp3mi_loop_place place)
 {
     __shared__ loop_lds L;
     const int lane = wave_lane();
-    const int s = (int) blockIdx.x, C = geo.channels, G = 2 * geo.nf;
+    const int s = loop_place_stream(place, (int) gridDim.x, (int) blockIdx.x), C = geo.channels, G = 2 * geo.nf;
+    int work = 0; // cost of this stream in this launch: 4 per quantise+count pass, 5 per distortion-loop iteration
     const int bitsPerFrame = bits_per_frame[s];
     const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2; // src/musicin.c:729-746
     PROF_DECL;
@@ -643,6 +712,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     int iteration = 0, bits = 0, over, status, save_preflag, save_compress;
                     do {
                         iteration++;
+                        work += 5;
                         g.part2_length = loop_part2_length(L, g, gr, ch);
                         const int huff_bits = max_bits - g.part2_length;
                         bool have_pass = false; // p[], L.ix and g already describe step size g.q
@@ -654,6 +724,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 g.q = next;
                                 PROF(1);
                                 const bool az = loop_all_zero(y34max, g.q);
+                                work += 4;
                                 loop_quantize(T, L, xr, y34, g.q, az, p);
                                 PROF(2);
                                 bit = loop_count_bits(R, L, g, p, az);
@@ -673,6 +744,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             if (!have_pass) {
                                 PROF(1);
                                 const bool az = loop_all_zero(y34max, g.q);
+                                work += 4;
                                 loop_quantize(T, L, xr, y34, g.q, az, p);
                                 PROF(2);
                                 bits = loop_count_bits(R, L, g, p, az);
@@ -892,6 +964,10 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
 #endif
     }
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &state[s])[i] = ((const int *) &L.st)[i];
+    if (place.cost && lane == 0) place.cost[s] = work;
+#if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
+    if (lane == 0 && s < 65536) g_loop_work[s] = (unsigned long long) work | ((unsigned long long) __builtin_amdgcn_s_memrealtime() << 20);
+#endif
     PROF(7);
     PROF_END;
 }
@@ -903,6 +979,11 @@ extern "C" void mp3mi_debug_loop_profile(unsigned long long *out)
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_prof), sizeof(z));
     hipMemcpyToSymbol(HIP_SYMBOL(g_loop_prof), z, sizeof(z));
+}
+extern "C" void mp3mi_debug_loop_work(unsigned long long *out, int n_streams)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_work), sizeof(unsigned long long) * (size_t) n_streams);
 }
 extern "C" void mp3mi_debug_loop_starts(unsigned long long *out, int n_streams)
 {
@@ -920,10 +1001,10 @@ size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
                        const mp3mi_loop_prep *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
-                       mp3mi_frame_side *side, unsigned *gate_count, hipStream_t st)
+                       mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place, hipStream_t st)
 {
     hipLaunchKernelGGL(k_loop, dim3((unsigned) g.n_streams), dim3(64), 0, st, T, g, xr, psy, prep, bits_per_frame,
-                       (mp3mi_loop_state *) loop_state, ix, side, gate_count);
+                       (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
 }
 
 // Holds the front stream back until the k_loop launch whose census target is `target` has (all but

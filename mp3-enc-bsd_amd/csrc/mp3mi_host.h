@@ -47,9 +47,22 @@ void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g); /* subband samples between k_filter and k_mdct */
 void mp3mi_launch_prep(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
                        const mp3mi_psy_out *psy, mp3mi_loop_prep *prep, int force_exact, hipStream_t st);
+/* stream placement of k_loop (k_loop.hip: loop_place_stream); all pointers NULL = stream == blockIdx */
+#define MP3MI_PLACE_KEYS 8192
+struct mp3mi_loop_place {
+    const int *order;      /* [n_streams] sorted position -> stream (k_rank) */
+    int *cost;             /* [n_streams] cost of each stream in this launch (input of the next k_rank) */
+    unsigned *taken;       /* [n_streams] zero before the launch */
+    unsigned *simd_slots;  /* [MP3MI_PLACE_KEYS] zero before the launch: arrivals per SIMD */
+    unsigned *simd_idx;    /* [MP3MI_PLACE_KEYS] zero before the launch: arrival ticket of the SIMD + 1 */
+    unsigned *ticket, *scan; /* zero before the launch */
+    int n_simd;            /* SIMDs of the device */
+};
+void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st);
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
                        const mp3mi_psy_out *psy, const mp3mi_loop_prep *prep, const int32_t *bits_per_frame,
-                       void *loop_state, int16_t *ix, mp3mi_frame_side *side, unsigned *gate_count, hipStream_t st);
+                       void *loop_state, int16_t *ix, mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place,
+                       hipStream_t st);
 /* bounded wait (one wavefront) until k_loop's start census reaches `target` -- see k_loop.hip */
 void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_ticks, hipStream_t st);
 void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix,

@@ -120,6 +120,8 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0}; 
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emu_event{0}; return hipSuccess; }
 enum { hipDeviceAttributeCanUseStreamWaitValue = 1, hipMallocSignalMemory = 2, hipStreamWaitValueGte = 0 };
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 1; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 1; return hipSuccess; }
 static inline hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
 static inline hipError_t hipStreamWaitValue32(hipStream_t, void *, unsigned, unsigned, unsigned) { return hipSuccess; }

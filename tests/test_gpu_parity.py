@@ -80,3 +80,23 @@ def test_full_length_stream_matches_golden_md5(product, oracle):
     ref, _ = oracle.encode(pcm, rate, 128, ch)
     assert len(got) == len(ref)
     assert hashlib.md5(got).hexdigest() == hashlib.md5(ref).hexdigest()
+
+
+def test_full_chip_batch_with_placement_and_overlap(product, oracle, monkeypatch):
+    """More streams than the chip has SIMDs x 2: k_loop places streams on SIMDs by the previous
+    chunk's cost (every stream must be taken exactly once), paces them by wave priority, and the
+    next chunk's feed-forward kernels overlap with it.  Three chunks, mixed bitrates; EVERY stream
+    is checked against the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    monkeypatch.setenv("MP3MI_CHUNK_FRAMES", "2")
+    S, nf, rate, ch = 2304, 6, 44100, 2
+    base = np.stack([product.synth(nf * 1152, ch, rate, 500 + s) for s in range(48)])
+    # 48 distinct signals at 48 gains each: all streams differ, the oracle work stays small
+    gains = (np.arange(S) // 48 + 1).astype(np.float64) / 48.0
+    pcm = np.round(base[np.arange(S) % 48].astype(np.float64) * gains[:, None]).astype(np.int16)
+    kb = [(96, 128, 160)[s % 3] for s in range(S)]
+    got = product.encode_host(pcm, rate, ch, kb, nf)
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        refs = list(ex.map(lambda s: oracle.encode(pcm[s], rate, kb[s], ch)[0], range(S)))
+    bad = [s for s in range(S) if got[s] != refs[s]]
+    assert not bad, "streams differ: %s" % bad[:10]

@@ -41,3 +41,13 @@ st = (ctypes.c_ulonglong * S)()
 L.mp3mi_debug_loop_starts(st, S)
 st = np.array(list(st), dtype=np.float64); st -= st.min()
 print("wave start spread (s_memrealtime ticks, 100 MHz): p50 %.0f p90 %.0f p99 %.0f max %.0f" % (np.percentile(st, 50), np.percentile(st, 90), np.percentile(st, 99), st.max()))
+
+wk = (ctypes.c_ulonglong * S)()
+L.mp3mi_debug_loop_work(wk, S)
+wk = np.array(list(wk), dtype=np.uint64)
+work = (wk & np.uint64((1 << 20) - 1)).astype(np.float64); tend = (wk >> np.uint64(20)).astype(np.float64)
+tend -= tend.min()
+perw = np.bincount(inv, weights=work)
+print("work units per stream: mean %.0f max %.0f (max/mean %.3f); per-SIMD work sum max/mean %.3f min/mean %.3f" % (work.mean(), work.max(), work.max() / work.mean(), perw.max() / perw.mean(), perw.min() / perw.mean()))
+print("stream end times (100 MHz ticks after the first end): p10 %.0f p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile(tend, [10, 50, 90, 100])))
+print("corr(work, cycles) = %.3f" % np.corrcoef(work, cyc)[0, 1])
