@@ -47,94 +47,128 @@ template <int C, int W> struct fft_lds {
     fft_wave_lds<C> w[W];
 };
 
-template <int TYPE, int NARR, int STRIDE>
-MP3MI_DEVFN void fft_apply(float *x, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+// A butterfly is applied in two steps -- fetch the operands of all arrays, then compute and store --
+// so that the rounds of a segment (which are independent of each other) can be taken two at a time:
+// both rounds' LDS reads are in flight together and only one LDS latency is exposed per pair.
+struct fft_idx { int a, b, c, d; bool on; };
+
+template <int TYPE>
+MP3MI_DEVFN fft_idx fft_decode(uint32_t w0, uint32_t w1)
 {
-    // operand indices are LDS positions (MP3MI_FFT_SWZ applied on the host)
-    int a, b, c = 0, d = 0;
+    // operand indices are LDS positions (MP3MI_FFT_SWZ applied on the host); an idle lane (bit 31)
+    // decodes to position 0, reads it and stores nothing
+    fft_idx i;
+    i.on = !(w0 >> 31);
+    i.c = 0; i.d = 0;
     if (TYPE == FOP_ROT) {
-        a = (int) (w0 & 0xffffu); b = (int) (w0 >> 16);
+        i.a = (int) (w0 & 0x3ffu); i.b = (int) ((w0 >> 16) & 0x3ffu);
     } else {
-        a = (int) (w0 & 1023u); b = (int) ((w0 >> 10) & 1023u);
-        if (TYPE == FOP_CROSS) { c = (int) (w1 & 1023u); d = (int) ((w1 >> 10) & 1023u); }
+        i.a = (int) (w0 & 1023u); i.b = (int) ((w0 >> 10) & 1023u);
+        if (TYPE == FOP_CROSS) { i.c = (int) (w1 & 1023u); i.d = (int) ((w1 >> 10) & 1023u); }
     }
+    return i;
+}
+
+template <int TYPE, int NARR, int STRIDE>
+MP3MI_DEVFN void fft_fetch(const float *x, const fft_idx &i, float (&v)[NARR][4])
+{
 #pragma unroll
     for (int arr = 0; arr < NARR; arr++) {
-        float *v = x + arr * STRIDE;
+        const float *p = x + arr * STRIDE;
+        v[arr][0] = p[i.a];
+        if (TYPE != FOP_NEG) v[arr][1] = p[i.b];
+        if (TYPE == FOP_CROSS) { v[arr][2] = p[i.c]; v[arr][3] = p[i.d]; }
+    }
+}
+
+template <int TYPE, int NARR, int STRIDE>
+MP3MI_DEVFN void fft_finish(float *x, const fft_idx &i, const float (&v)[NARR][4], uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    if (!i.on) return;
+#pragma unroll
+    for (int arr = 0; arr < NARR; arr++) {
+        float *p = x + arr * STRIDE;
+        const float va = v[arr][0], vb = v[arr][1];
         if (TYPE == FOP_ADDSUB) {
-            const float t = v[a] + v[b];
-            v[b] = v[a] - v[b];
-            v[a] = t;
+            p[i.b] = va - vb;
+            p[i.a] = va + vb;
         } else if (TYPE == FOP_NEG) {
-            v[a] = -v[a];
+            p[i.a] = -va;
         } else if (TYPE == FOP_CROSS) {
-            const float r1 = v[a], r2 = v[b], i1 = v[c], i2 = v[d];
-            v[c] = i1 - r2;
-            v[b] = r1 - i2;
-            v[a] = r1 + i2;
-            v[d] = i1 + r2;
+            const float r1 = va, r2 = vb, i1 = v[arr][2], i2 = v[arr][3];
+            p[i.c] = i1 - r2;
+            p[i.b] = r1 - i2;
+            p[i.a] = r1 + i2;
+            p[i.d] = i1 + r2;
         } else if (TYPE == FOP_ROT) {
             const float cn = __builtin_bit_cast(float, w1), spc = __builtin_bit_cast(float, w2), smc = __builtin_bit_cast(float, w3);
-            const float r1 = v[a], i1 = v[b];
+            const float r1 = va, i1 = vb;
             const float t2 = cn * (r1 + i1);
             const float t1 = spc * r1 + t2;
-            v[a] = smc * i1 + t2;
-            v[b] = t1;
+            p[i.a] = smc * i1 + t2;
+            p[i.b] = t1;
         } else if (TYPE == FOP_SQ1) {
-            const float r1 = v[a], i1 = v[b];
-            v[a] = (float) (R_SQHALF * (double) (r1 + i1));
-            v[b] = (float) (R_SQHALF * (double) (i1 - r1));
+            p[i.a] = (float) (R_SQHALF * (double) (va + vb));
+            p[i.b] = (float) (R_SQHALF * (double) (vb - va));
         } else if (TYPE == FOP_SQ2) {
-            const float r2 = v[a], i2 = v[b];
-            v[a] = (float) (R_SQHALF * (double) (i2 - r2));
-            v[b] = (float) (-R_SQHALF * (double) (r2 + i2));
+            p[i.a] = (float) (R_SQHALF * (double) (vb - va));
+            p[i.b] = (float) (-R_SQHALF * (double) (va + vb));
         } else if (TYPE == FOP_SWAPNN) {
-            const float t = v[a];
-            v[a] = -v[b];
-            v[b] = -t;
+            p[i.a] = -vb;
+            p[i.b] = -va;
         } else if (TYPE == FOP_SWAPN) {
-            const float t = v[a];
-            v[a] = -v[b];
-            v[b] = t;
+            p[i.a] = -vb;
+            p[i.b] = va;
         } else { // FOP_SWAP
-            const float t = v[a];
-            v[a] = v[b];
-            v[b] = t;
+            p[i.a] = vb;
+            p[i.b] = va;
         }
     }
 }
 
 // The butterfly records are two streams (one-word records; 16-byte rotation records) laid out in
 // rounds of 64, one record per lane, idle lanes marked by bit 31 (tables_host.cpp).  pg/pr point at
-// this lane's record of the next round; the record of the following round is read ahead.
+// this lane's record of the segment's first round and are left at the next segment's.  The records
+// of the following pair of rounds are read while the current pair's operands are in flight.
 template <int TYPE, int NARR, int STRIDE>
 MP3MI_DEVFN void fft_segment(float *x, const uint32_t *&pg, const uint4 *&pr, int rounds)
 {
-    if (TYPE == FOP_ROT) {
-        uint4 cur = *pr;
-        for (int t = 0; t < rounds; t++) {
-            pr += 64;
-            const uint4 nxt = *pr;
-            if (!(cur.x >> 31)) fft_apply<TYPE, NARR, STRIDE>(x, cur.x, cur.y, cur.z, cur.w);
-            cur = nxt;
+    const int gstep = (TYPE == FOP_CROSS) ? 128 : 64; // FOP_CROSS: the round's second words follow its first words
+    uint4 c0 = {0x80000000u, 0, 0, 0}, c1 = c0;
+    if (TYPE == FOP_ROT) { c0 = pr[0]; if (rounds > 1) c1 = pr[64]; }
+    else {
+        c0.x = pg[0];
+        if (TYPE == FOP_CROSS) c0.y = pg[64];
+        if (rounds > 1) { c1.x = pg[gstep]; if (TYPE == FOP_CROSS) c1.y = pg[gstep + 64]; }
+    }
+    int t = 0;
+    for (; t + 1 < rounds; t += 2) {
+        const fft_idx i0 = fft_decode<TYPE>(c0.x, c0.y), i1 = fft_decode<TYPE>(c1.x, c1.y);
+        float v0[NARR][4], v1[NARR][4];
+        fft_fetch<TYPE, NARR, STRIDE>(x, i0, v0);
+        fft_fetch<TYPE, NARR, STRIDE>(x, i1, v1);
+        uint4 n0 = {0x80000000u, 0, 0, 0}, n1 = n0;
+        if (TYPE == FOP_ROT) {
+            pr += 128;
+            if (t + 2 < rounds) { n0 = pr[0]; n1 = pr[64]; } // the second may belong to what follows: never used then
+        } else {
+            pg += 2 * gstep;
+            if (t + 2 < rounds) {
+                n0.x = pg[0]; n1.x = pg[gstep];
+                if (TYPE == FOP_CROSS) { n0.y = pg[64]; n1.y = pg[gstep + 64]; }
+            }
         }
-    } else if (TYPE == FOP_CROSS) { // two words per butterfly: the round's second words follow its first words
-        uint32_t cur = pg[0], cur2 = pg[64];
-        for (int t = 0; t < rounds; t++) {
-            pg += 128;
-            const uint32_t nxt = pg[0], nxt2 = pg[64];
-            if (!(cur >> 31)) fft_apply<TYPE, NARR, STRIDE>(x, cur, cur2, 0, 0);
-            cur = nxt;
-            cur2 = nxt2;
-        }
-    } else {
-        uint32_t cur = *pg;
-        for (int t = 0; t < rounds; t++) {
-            pg += 64;
-            const uint32_t nxt = *pg;
-            if (!(cur >> 31)) fft_apply<TYPE, NARR, STRIDE>(x, cur, 0, 0, 0);
-            cur = nxt;
-        }
+        fft_finish<TYPE, NARR, STRIDE>(x, i0, v0, c0.y, c0.z, c0.w);
+        fft_finish<TYPE, NARR, STRIDE>(x, i1, v1, c1.y, c1.z, c1.w);
+        c0 = n0;
+        c1 = n1;
+    }
+    if (t < rounds) { // odd round count: the last round alone
+        const fft_idx i0 = fft_decode<TYPE>(c0.x, c0.y);
+        float v0[NARR][4];
+        fft_fetch<TYPE, NARR, STRIDE>(x, i0, v0);
+        fft_finish<TYPE, NARR, STRIDE>(x, i0, v0, c0.y, c0.z, c0.w);
+        if (TYPE == FOP_ROT) pr += 64; else pg += gstep;
     }
 }
 
