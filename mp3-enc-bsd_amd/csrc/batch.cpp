@@ -57,7 +57,8 @@ struct mp3mi_batch {
     mp3mi_tables *T;
     int32_t *bits_per_frame, *bitrate_index;
     float *energy_l, *energy_s, *hist6, *fft_bins;
-    double *cw_mid, *xr[2], *sbs, *sb_dbg;
+    double *cw_mid, *xr[2], *sbs, *sb_dbg, *part_eb;
+    float *part_cb;
     mp3mi_psy_out *psy[2];
     mp3mi_loop_prep *prep[2];
     void *psy_state, *loop_state;
@@ -122,7 +123,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
         if (whole_SpF > b->max_frame_bytes) b->max_frame_bytes = whole_SpF;
     }
     // chunk size from a scratch budget (bytes per frame and stream of the per-chunk buffers)
-    const size_t per_gc = MP3MI_HBLK * 4 + 3 * MP3MI_HBLK_S * 4 + MP3MI_FFT_BINS * 4 + 50 * 8 + 12 * 4 +
+    const size_t per_gc = MP3MI_HBLK_P * 4 + MP3MI_PART_P * 12 + 3 * MP3MI_HBLK_S * 4 + MP3MI_FFT_BINS * 4 + 50 * 8 + 12 * 4 +
                           2 * (sizeof(mp3mi_psy_out) + sizeof(mp3mi_loop_prep) + 576 * 8) + 576 * 8 + 576 * 2;
     const size_t per_frame = per_gc * 2 * (size_t) channels + sizeof(mp3mi_frame_side);
     const char *env = getenv("MP3MI_SCRATCH_MB");
@@ -181,7 +182,9 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     CHK(hipMalloc((void **) &b->bitrate_index, sizeof(int32_t) * n_streams));
     CHK(hipMemcpy(b->bits_per_frame, b->bits_per_frame_h.data(), sizeof(int32_t) * n_streams, hipMemcpyHostToDevice));
     CHK(hipMemcpy(b->bitrate_index, b->bitrate_index_h.data(), sizeof(int32_t) * n_streams, hipMemcpyHostToDevice));
-    CHK(hipMalloc((void **) &b->energy_l, ngc * MP3MI_HBLK * sizeof(float)));
+    CHK(hipMalloc((void **) &b->energy_l, ngc * MP3MI_HBLK_P * sizeof(float)));
+    CHK(hipMalloc((void **) &b->part_eb, ngc * MP3MI_PART_P * sizeof(double)));
+    CHK(hipMalloc((void **) &b->part_cb, ngc * MP3MI_PART_P * sizeof(float)));
     CHK(hipMalloc((void **) &b->energy_s, ngc * 3 * MP3MI_HBLK_S * sizeof(float)));
     CHK(hipMalloc((void **) &b->hist6, ngc * 12 * sizeof(float)));
     CHK(hipMalloc((void **) &b->fft_bins, ngc * MP3MI_FFT_BINS * sizeof(float)));
@@ -210,6 +213,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     hipStreamSynchronize(b->lstream);
     hipFree(b->T); hipFree(b->bits_per_frame); hipFree(b->bitrate_index);
     hipFree(b->energy_l); hipFree(b->energy_s); hipFree(b->hist6); hipFree(b->fft_bins); hipFree(b->cw_mid);
+    hipFree(b->part_eb); hipFree(b->part_cb);
     for (int i = 0; i < 2; i++) { hipFree(b->xr[i]); hipFree(b->psy[i]); hipFree(b->prep[i]); }
     hipFree(b->sbs); hipFree(b->ix); hipFree(b->side);
     hipFree(b->psy_state); hipFree(b->loop_state);
@@ -276,7 +280,7 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
         const mp3mi_geom g = geom_of(c);
         mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
         if (c >= 2) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[c & 1], 0)); // k_loop of chunk c-2 has read this slot
-        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->psy[c & 1], b->stream);
+        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->part_eb, b->part_cb, b->psy[c & 1], b->stream);
         return MP3MI_OK;
     };
     if (stage_x(0) != MP3MI_OK) return MP3MI_ERR_HIP;

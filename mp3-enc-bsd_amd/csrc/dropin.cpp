@@ -52,7 +52,8 @@ struct DropIn {
     mp3mi_tables *T = nullptr;
     // psy
     int16_t *pcm_d = nullptr;
-    float *el = nullptr, *es = nullptr, *h6 = nullptr, *bins = nullptr;
+    float *el = nullptr, *es = nullptr, *h6 = nullptr, *bins = nullptr, *part_cb = nullptr;
+    double *part_eb = nullptr;
     double *cw = nullptr;
     void *psy_state = nullptr;
     mp3mi_psy_out *psy1 = nullptr;
@@ -98,7 +99,9 @@ void ensure(int rate_idx)
     HIPOK(hipMemcpy(D.T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
     free(Th);
     HIPOK(hipMalloc((void **) &D.pcm_d, 2304 * sizeof(int16_t)));
-    HIPOK(hipMalloc((void **) &D.el, MP3MI_HBLK * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.el, MP3MI_HBLK_P * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.part_eb, MP3MI_PART_P * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.part_cb, MP3MI_PART_P * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.es, 3 * MP3MI_HBLK_S * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.h6, 12 * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.bins, MP3MI_FFT_BINS * sizeof(float)));
@@ -181,7 +184,7 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
     g.g0 = 2;
     g.n_gran = 1;
     mp3mi_launch_fft(D.T, g, D.pcm_d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
-    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.psy1, D.st);
+    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.part_eb, D.part_cb, D.psy1, D.st);
     mp3mi_psy_out o;
     HIPOK(hipMemcpyAsync(&o, D.psy1, sizeof(o), hipMemcpyDeviceToHost, D.st));
     HIPOK(hipStreamSynchronize(D.st));

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     for (int c = 0; c < C; c++) {
         for (int i = lane; i < MP3MI_HBLK; i += 64) {
             const float e = fft_energy(L.xl[c], 1024, i);
-            if (valid) energy_l[(rec0 + c) * MP3MI_HBLK + i] = e;
+            if (valid) energy_l[(rec0 + c) * MP3MI_HBLK_P + i] = e;
         }
         // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
         if (lane < 6 && valid) {

@@ -23,8 +23,6 @@ typedef struct {
 } mp3mi_psy_state;
 
 struct psy_lds {
-    float el[MP3MI_HBLK];
-    double cwm[50], cwl[6];
     double eb[MP3MI_CBANDS], thr[MP3MI_CBANDS], pev[MP3MI_CBANDS];
     float cb[MP3MI_CBANDS];
     double ebs[MP3MI_CBANDS_S], thrs[MP3MI_CBANDS_S];
@@ -32,10 +30,117 @@ struct psy_lds {
     double pe;
 };
 
+// ---- k_part: partition energy and weighted unpredictability (src/l3psy.c:496-512, 565-578) ----
+// eb[b] and cb[b] are ORDER-SENSITIVE sums over the lines of partition b (cb even rounds to float
+// at every step), i.e. serial chains; they depend on nothing but this granule's spectrum and the
+// r/phi of the two granules before it.  So, as in k_prep, the lanes of a wavefront are 64
+// different (granule, channel) records, each walking its own 513 lines in index order (16-byte
+// loads issued ahead of use), closing partitions as it passes their last line; lines beyond the
+// table's coverage continue partition 0's chain.  k_psy then starts every granule from eb/cb.
+struct __attribute__((aligned(16))) psy_f4 { float x, y, z, w; };
+
+struct part_walk {
+    double eb, eb0;
+    float cb, cb0;
+    int b, pend; // open partition and the line after its last (wave-uniform)
+};
+
+MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, int j, float ef, double cw, bool live,
+                           double *__restrict__ eb_row, float *__restrict__ cb_row)
+{
+    const double e = (double) ef;
+    if (j < T->part_l_covered) {
+        W.eb = W.eb + e;
+        W.cb = (float) ((double) W.cb + cw * e);
+        while (W.b < MP3MI_CBANDS && j + 1 == W.pend) { // closes this partition and any empty ones after it
+            if (W.b == 0) { W.eb0 = W.eb; W.cb0 = W.cb; }
+            else if (live) { eb_row[W.b] = W.eb; cb_row[W.b] = W.cb; }
+            W.eb = 0.0; W.cb = 0.0f;
+            W.b++;
+            W.pend = W.b < MP3MI_CBANDS ? T->part_l_start[W.b + 1] : -1;
+        }
+    } else { // lines beyond the table's coverage fall into partition 0 (src/l3psy.c:572-577 with partition_l == 0)
+        W.eb0 = W.eb0 + e;
+        W.cb0 = (float) ((double) W.cb0 + cw * e);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                             const float *__restrict__ energy_l, const double *__restrict__ cw_mid,
+                                             const float *__restrict__ hist6, const mp3mi_psy_state *__restrict__ state,
+                                             double *__restrict__ eb_all, float *__restrict__ cb_all)
+{
+    const int lane = wave_lane();
+    const int C = geo.channels, G = geo.n_gran;
+    const size_t n_rec = (size_t) geo.n_streams * (size_t) G * (size_t) C;
+    const size_t rec0 = (size_t) blockIdx.x * 64;
+    const bool live = rec0 + lane < n_rec;
+    const size_t rec = live ? rec0 + lane : n_rec - 1;
+    const int ch = (int) (rec % C), gl = (int) ((rec / C) % G);
+    const size_t s = rec / ((size_t) C * G);
+    const mp3mi_psy_state *st = &state[s * C + ch];
+    const float *er = energy_l + rec * MP3MI_HBLK_P;
+    const double *cwr = cw_mid + rec * 50;
+    double *eb_row = eb_all + rec * MP3MI_PART_P;
+    float *cb_row = cb_all + rec * MP3MI_PART_P;
+
+    part_walk W;
+    W.eb = W.eb0 = 0.0; W.cb = W.cb0 = 0.0f;
+    W.b = 0; W.pend = T->part_l_start[1];
+    while (W.b < MP3MI_CBANDS && W.pend == 0) { W.b++; W.pend = W.b < MP3MI_CBANDS ? T->part_l_start[W.b + 1] : -1; } // (never: partition 0 has lines)
+
+    // lines 0..5: unpredictability from this granule's r/phi and the two granules before it (src/l3psy.c:496-512)
+#pragma unroll 1
+    for (int j = 0; j < 6; j++) {
+        const float rn = hist6[rec * 12 + j], pn = hist6[rec * 12 + 6 + j];
+        const float r1 = gl >= 1 ? hist6[(rec - C) * 12 + j] : st->r1[j], p1 = gl >= 1 ? hist6[(rec - C) * 12 + 6 + j] : st->p1[j];
+        const float r2 = gl >= 2 ? hist6[(rec - 2 * C) * 12 + j] : (gl == 1 ? st->r1[j] : st->r2[j]);
+        const float p2 = gl >= 2 ? hist6[(rec - 2 * C) * 12 + 6 + j] : (gl == 1 ? st->p1[j] : st->p2[j]);
+        const double r_prime = 2.0 * (double) r1 - (double) r2;
+        const double phi_prime = 2.0 * (double) p1 - (double) p2;
+        double sn, cn, sp, cp;
+        dm_sincos((double) pn, &sn, &cn);
+        dm_sincos(phi_prime, &sp, &cp);
+        const double t1 = (double) rn * cn - r_prime * cp;
+        const double t2 = (double) rn * sn - r_prime * sp;
+        const double t3 = (double) rn + __builtin_fabs(r_prime);
+        const double cw = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
+        part_line(T, W, j, er[j], cw, live, eb_row, cb_row);
+    }
+    // lines 6, 7 reach the 16-byte grid of the energy row; cw of lines 6+4n..9+4n is cw_mid[n] (src/l3psy.c:531-549)
+    double cwa = cwr[0];
+    part_line(T, W, 6, er[6], cwa, live, eb_row, cb_row);
+    part_line(T, W, 7, er[7], cwa, live, eb_row, cb_row);
+    // groups of four lines j0..j0+3, j0 = 8, 12, ..., 508; lines j0, j0+1 use cw_mid[(j0-8)/4], j0+2, j0+3 the next;
+    // from line 206 on the unpredictability is the constant 0.4 (src/l3psy.c:555-556)
+    psy_f4 e0 = *(const psy_f4 *) (er + 8), e1 = *(const psy_f4 *) (er + 12);
+    double cwn0 = cwr[1], cwn1 = cwr[2];
+    for (int j0 = 8; j0 < 512; j0 += 4) {
+        const psy_f4 e = e0;
+        const double cwb = cwn0;
+        e0 = e1;
+        cwn0 = cwn1;
+        if (j0 + 8 < 512) e1 = *(const psy_f4 *) (er + j0 + 8);
+        const int mnext = (j0 - 8) / 4 + 3;
+        if (mnext < 50) cwn1 = cwr[mnext];
+        part_line(T, W, j0, e.x, j0 < 206 ? cwa : 0.4, live, eb_row, cb_row);
+        part_line(T, W, j0 + 1, e.y, j0 + 1 < 206 ? cwa : 0.4, live, eb_row, cb_row);
+        part_line(T, W, j0 + 2, e.z, j0 + 2 < 206 ? cwb : 0.4, live, eb_row, cb_row);
+        part_line(T, W, j0 + 3, e.w, j0 + 3 < 206 ? cwb : 0.4, live, eb_row, cb_row);
+        cwa = cwb;
+    }
+    part_line(T, W, 512, er[512], 0.4, live, eb_row, cb_row);
+    if (live) {
+        eb_row[0] = W.eb0;
+        cb_row[0] = W.cb0;
+        for (int b = W.b < 1 ? 1 : W.b; b < MP3MI_CBANDS; b++) { eb_row[b] = 0.0; cb_row[b] = 0.0f; } // partitions without lines
+    }
+}
+
 // 8192 single-wave workgroups (4096 stereo streams) = 8 waves per SIMD: ask for that occupancy
 __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
-                                            const float *__restrict__ energy_l, const float *__restrict__ energy_s,
-                                            const double *__restrict__ cw_mid, const float *__restrict__ hist6,
+                                            const double *__restrict__ eb_all, const float *__restrict__ cb_all,
+                                            const float *__restrict__ energy_s, const float *__restrict__ hist6,
                                             mp3mi_psy_state *__restrict__ state, mp3mi_psy_out *__restrict__ out)
 {
     __shared__ psy_lds L;
@@ -67,40 +172,15 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
 
     for (int gl = 0; gl < G; gl++) {
         const size_t rec = ((size_t) s * G + gl) * C + ch;
-        for (int j = lane; j < MP3MI_HBLK; j += 64) L.el[j] = energy_l[rec * MP3MI_HBLK + j];
-        if (lane < 50) L.cwm[lane] = cw_mid[rec * 50 + lane];
-        if (lane < 6) { // unpredictability of the first six lines (src/l3psy.c:496-512)
+        // partition energy and weighted unpredictability come from k_part; r/phi of lines 0..5 are only
+        // carried along so that the state handed to the next chunk holds the last two granules'
+        if (lane < 6) {
             const float rn = hist6[rec * 12 + lane], pn = hist6[rec * 12 + 6 + lane];
-            const double r_prime = 2.0 * (double) r1 - (double) r2;
-            const double phi_prime = 2.0 * (double) p1 - (double) p2;
-            double sn, cn, sp, cp;
-            dm_sincos((double) pn, &sn, &cn);
-            dm_sincos(phi_prime, &sp, &cp);
-            const double t1 = (double) rn * cn - r_prime * cp;
-            const double t2 = (double) rn * sn - r_prime * sp;
-            const double t3 = (double) rn + __builtin_fabs(r_prime);
-            L.cwl[lane] = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
             r2 = r1; p2 = p1; r1 = rn; p1 = pn;
         }
-        __syncthreads();
-
-        // partition energy and weighted unpredictability (src/l3psy.c:565-578)
         if (b < MP3MI_CBANDS) {
-            double eb = 0.0;
-            float cb = 0.0f;
-            for (int pass = 0; pass < 2; pass++) {
-                // second pass: lines beyond the table's coverage fall into partition 0
-                const int j0 = pass ? T->part_l_covered : pl0;
-                const int j1 = pass ? (b == 0 ? MP3MI_HBLK : j0) : pl1;
-                for (int j = j0; j < j1; j++) {
-                    const float e = L.el[j];
-                    const double cw = (j < 6) ? L.cwl[j] : (j < 206 ? L.cwm[(j - 6) >> 2] : 0.4);
-                    eb = eb + (double) e;
-                    cb = (float) ((double) cb + cw * (double) e);
-                }
-            }
-            L.eb[b] = eb;
-            L.cb[b] = cb;
+            L.eb[b] = eb_all[rec * MP3MI_PART_P + b];
+            L.cb[b] = cb_all[rec * MP3MI_PART_P + b];
         }
         __syncthreads();
 
@@ -222,10 +302,13 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
 size_t mp3mi_psy_state_size(void) { return sizeof(mp3mi_psy_state); }
 
 void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l, const float *energy_s,
-                      const double *cw_mid, const float *hist6, void *psy_state, mp3mi_psy_out *out,
-                      hipStream_t st)
+                      const double *cw_mid, const float *hist6, void *psy_state, double *eb_all, float *cb_all,
+                      mp3mi_psy_out *out, hipStream_t st)
 {
+    const size_t n_rec = (size_t) g.n_streams * (size_t) g.n_gran * (size_t) g.channels;
+    hipLaunchKernelGGL(k_part, dim3((unsigned) ((n_rec + 63) / 64)), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6,
+                       (const mp3mi_psy_state *) psy_state, eb_all, cb_all);
     const unsigned grid = (unsigned) (g.n_streams * g.channels);
-    hipLaunchKernelGGL(k_psy, dim3(grid), dim3(64), 0, st, T, g, energy_l, energy_s, cw_mid, hist6,
+    hipLaunchKernelGGL(k_psy, dim3(grid), dim3(64), 0, st, T, g, eb_all, cb_all, energy_s, hist6,
                        (mp3mi_psy_state *) psy_state, out);
 }

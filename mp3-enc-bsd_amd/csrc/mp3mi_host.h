@@ -41,7 +41,7 @@ void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t 
                       float *energy_l, float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st);
 void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l,
                       const float *energy_s, const double *cw_mid, const float *hist6,
-                      void *psy_state, mp3mi_psy_out *out, hipStream_t st);
+                      void *psy_state, double *eb_all, float *cb_all, mp3mi_psy_out *out, hipStream_t st);
 void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
                          const mp3mi_psy_out *psy, double *sbs, double *xr, double *sb_dbg, hipStream_t st);
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g); /* subband samples between k_filter and k_mdct */
