@@ -7,10 +7,10 @@
 // Everything here is an ORDER-SENSITIVE f64 sum over the 576 lines of a granule (the total
 // energy, the band energies, the sum of logs), i.e. a serial chain per granule.  So the lanes
 // of a wavefront are 64 different granules, each walking its own 576 lines in index order.
-// A lane streams its own 4608-byte spectrum with 16-byte loads issued two groups (12 lines)
-// ahead of their use: every 128-byte line is fetched from HBM once and serves the lane's next
-// seven loads out of L2, no LDS and no transposition pass are needed, and four wavefronts per
-// SIMD hide the latency.
+// A lane streams its own 4608-byte spectrum one whole 128-byte line (16 values) at a time and uses
+// it up before touching the next: with 64 lanes x 12 wavefronts x 32 CUs walking different rows,
+// lines fetched 16 bytes at a time were evicted from the 4 MB L2 between uses (3x over-fetch
+// measured).  No LDS and no transposition pass are needed; three wavefronts per SIMD hide the latency.
 //
 // quantanf_init needs sum(log(xr^2)) only to round 8*ln(sfm) to an integer.  The first tier
 // uses dm_log_fast (plain double, |error| < 2^-50 max(1,|log|)), which moves 8*ln(sfm) by less
@@ -26,18 +26,9 @@
 #else
 #define PREP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#define PREP_GROUP 6 /* lines per step: three 16-byte loads; a multiple of 3 keeps short-block windows aligned */
+#define PREP_BLOCK 16 /* lines per step: one 128-byte line of the spectrum */
 
 struct __attribute__((aligned(16))) prep_d2 { double x, y; };
-struct prep_group { prep_d2 v[3]; };
-
-MP3MI_DEVFN prep_group prep_load(const double *row, int k)
-{
-    prep_group g;
-    const prep_d2 *p = (const prep_d2 *) (row + k);
-    g.v[0] = p[0]; g.v[1] = p[1]; g.v[2] = p[2];
-    return g;
-}
 
 MP3MI_DEVFN int prep_ilog2(const mp3mi_tables *T, double v) // (int)(log(v)/log(2)), src/loop.c:633-667
 {
@@ -85,7 +76,19 @@ MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double x, 
     }
 }
 
-__global__ void __launch_bounds__(64) k_prep(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+template <int PH>
+MP3MI_DEVFN void prep_block(const mp3mi_tables *T, prep_walk_state &S, const prep_d2 (&v)[PREP_BLOCK / 2], int k, bool shortb,
+                            bool live, mp3mi_loop_prep *out)
+{
+#pragma unroll
+    for (int j = 0; j < PREP_BLOCK; j++) {
+        const double x = (j & 1) ? v[j >> 1].y : v[j >> 1].x;
+        prep_line<false>(T, S, x, (PH + j) % 3, k + j + 1, shortb, live, out);
+        PREP_SCHED_FENCE(); // one line at a time: the wavefronts of the SIMD hide the latency, not ILP across lines
+    }
+}
+
+__global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
                                                 mp3mi_loop_prep *__restrict__ prep, int force_exact)
 {
@@ -109,17 +112,16 @@ __global__ void __launch_bounds__(64) k_prep(const mp3mi_tables *__restrict__ T,
         S.edgeL = T->sfb_l[1];
         S.edgeS = 3 * T->sfb_s[1];
         if (!exact) {
-            prep_group g0 = prep_load(row, 0), g1 = prep_load(row, PREP_GROUP);
-            for (int k = 0; k < 576; k += PREP_GROUP) {
-                const prep_group cur = g0;
-                g0 = g1;
-                if (k + 2 * PREP_GROUP < 576) g1 = prep_load(row, k + 2 * PREP_GROUP);
-                const double xs[PREP_GROUP] = {cur.v[0].x, cur.v[0].y, cur.v[1].x, cur.v[1].y, cur.v[2].x, cur.v[2].y};
+#pragma unroll 1
+            for (int k = 0; k < 576; k += PREP_BLOCK) {
+                prep_d2 v[PREP_BLOCK / 2];
 #pragma unroll
-                for (int j = 0; j < PREP_GROUP; j++) {
-                    prep_line<false>(T, S, xs[j], j % 3, k + j + 1, shortb, live, out);
-                    PREP_SCHED_FENCE(); // one line at a time: four wavefronts per SIMD hide the latency, not ILP across lines
-                }
+                for (int q = 0; q < PREP_BLOCK / 2; q++) v[q] = *(const prep_d2 *) (row + k + 2 * q);
+                // 16 = 1 mod 3: the short-block window of the block's first line cycles 0, 1, 2 (wave-uniform)
+                const int ph = k % 3;
+                if (ph == 0) prep_block<0>(T, S, v, k, shortb, live, out);
+                else if (ph == 1) prep_block<1>(T, S, v, k, shortb, live, out);
+                else prep_block<2>(T, S, v, k, shortb, live, out);
             }
         } else { // second tier, rare: plain line-by-line walk
 #pragma unroll 1

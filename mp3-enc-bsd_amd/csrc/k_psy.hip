@@ -34,9 +34,12 @@ struct psy_lds {
 // eb[b] and cb[b] are ORDER-SENSITIVE sums over the lines of partition b (cb even rounds to float
 // at every step), i.e. serial chains; they depend on nothing but this granule's spectrum and the
 // r/phi of the two granules before it.  So, as in k_prep, the lanes of a wavefront are 64
-// different (granule, channel) records, each walking its own 513 lines in index order (16-byte
-// loads issued ahead of use), closing partitions as it passes their last line; lines beyond the
-// table's coverage continue partition 0's chain.  k_psy then starts every granule from eb/cb.
+// different (granule, channel) records, each walking its own 513 lines in index order, closing
+// partitions as it passes their last line; lines beyond the table's coverage continue partition
+// 0's chain.  A lane fetches one whole 128-byte line (32 energies) of its row at a time and uses it
+// up before touching the next: with 64 lanes x 20 wavefronts x 32 CUs walking different rows, lines
+// fetched 16 bytes at a time were evicted from the 4 MB L2 between uses (8x over-fetch measured).
+// k_psy then starts every granule from eb/cb.
 struct __attribute__((aligned(16))) psy_f4 { float x, y, z, w; };
 
 struct part_walk {
@@ -107,27 +110,36 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
         const double cw = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
         part_line(T, W, j, er[j], cw, live, eb_row, cb_row);
     }
-    // lines 6, 7 reach the 16-byte grid of the energy row; cw of lines 6+4n..9+4n is cw_mid[n] (src/l3psy.c:531-549)
-    double cwa = cwr[0];
-    part_line(T, W, 6, er[6], cwa, live, eb_row, cb_row);
-    part_line(T, W, 7, er[7], cwa, live, eb_row, cb_row);
-    // groups of four lines j0..j0+3, j0 = 8, 12, ..., 508; lines j0, j0+1 use cw_mid[(j0-8)/4], j0+2, j0+3 the next;
-    // from line 206 on the unpredictability is the constant 0.4 (src/l3psy.c:555-556)
-    psy_f4 e0 = *(const psy_f4 *) (er + 8), e1 = *(const psy_f4 *) (er + 12);
-    double cwn0 = cwr[1], cwn1 = cwr[2];
-    for (int j0 = 8; j0 < 512; j0 += 4) {
-        const psy_f4 e = e0;
-        const double cwb = cwn0;
-        e0 = e1;
-        cwn0 = cwn1;
-        if (j0 + 8 < 512) e1 = *(const psy_f4 *) (er + j0 + 8);
-        const int mnext = (j0 - 8) / 4 + 3;
-        if (mnext < 50) cwn1 = cwr[mnext];
-        part_line(T, W, j0, e.x, j0 < 206 ? cwa : 0.4, live, eb_row, cb_row);
-        part_line(T, W, j0 + 1, e.y, j0 + 1 < 206 ? cwa : 0.4, live, eb_row, cb_row);
-        part_line(T, W, j0 + 2, e.z, j0 + 2 < 206 ? cwb : 0.4, live, eb_row, cb_row);
-        part_line(T, W, j0 + 3, e.w, j0 + 3 < 206 ? cwb : 0.4, live, eb_row, cb_row);
-        cwa = cwb;
+    // lines 6..511 in blocks of 32 = one 128-byte line of the energy row; the unpredictability of lines
+    // 6+4n..9+4n is cw_mid[n] (src/l3psy.c:531-549), from line 206 on the constant 0.4 (src/l3psy.c:555-556).
+    // Line l of block k uses cw_mid[8k - 2 + ((l - 6) >> 2) + 2]: nine values per block.
+#pragma unroll 1
+    for (int k = 0; k < 16; k++) {
+        psy_f4 blk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) blk[q] = *(const psy_f4 *) (er + 32 * k + 4 * q);
+        double cwv[9];
+        if (32 * k < 206) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                const int m = 8 * k - 2 + q;
+                cwv[q] = (m >= 0 && m < 50) ? cwr[m] : 0.4;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; q++) cwv[q] = 0.4;
+        }
+        const float ev[32] = {blk[0].x, blk[0].y, blk[0].z, blk[0].w, blk[1].x, blk[1].y, blk[1].z, blk[1].w,
+                              blk[2].x, blk[2].y, blk[2].z, blk[2].w, blk[3].x, blk[3].y, blk[3].z, blk[3].w,
+                              blk[4].x, blk[4].y, blk[4].z, blk[4].w, blk[5].x, blk[5].y, blk[5].z, blk[5].w,
+                              blk[6].x, blk[6].y, blk[6].z, blk[6].w, blk[7].x, blk[7].y, blk[7].z, blk[7].w};
+#pragma unroll
+        for (int l = 0; l < 32; l++) {
+            const int jj = 32 * k + l;
+            if (jj < 6) continue; // done above (only in block 0; wave-uniform)
+            const int q = ((l - 6) >> 2) + 2; // arithmetic shift: l < 6 never reaches here with k == 0
+            part_line(T, W, jj, ev[l], jj < 206 ? cwv[q] : 0.4, live, eb_row, cb_row);
+        }
     }
     part_line(T, W, 512, er[512], 0.4, live, eb_row, cb_row);
     if (live) {

@@ -20,7 +20,7 @@
 #define MP3MI_CBANDS_S 42
 #define MP3MI_HBLK 513
 #define MP3MI_HBLK_S 129
-#define MP3MI_HBLK_P 516      /* row pitch of energy_l in floats: 16-byte aligned rows for k_part's streaming loads */
+#define MP3MI_HBLK_P 544      /* row pitch of energy_l in floats: rows start on a 128-byte line (k_part reads whole lines) */
 #define MP3MI_PART_P 64       /* row pitch of the partition energies eb / cb handed from k_part to k_psy */
 /* FFT butterfly programs: rounds of 64 records (one per lane); sizes are checked at table build */
 #define MP3MI_FFT_BINS 312   /* raw bins handed from k_fft to k_cw per (granule, channel): short lines 2..51 of the three
