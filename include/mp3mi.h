@@ -60,6 +60,19 @@ int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uin
                        size_t out_stride, uint32_t *out_len_dev);
 int mp3mi_batch_sync(mp3mi_batch *b);
 
+/* Ragged batch: stream s has n_samples_dev[s] valid samples per channel (0 <= n <= n_frames*1152) in
+ * its row of pcm_dev (row pitch n_frames*1152*channels as above).  As the reference's get_audio /
+ * read_samples do (/root/reference/src/encode.c:123-269, zero fill :162-166), the last partial frame
+ * is zero-filled and the stream ends after ceil(n/1152) frames; out_len_dev[s] is its own file
+ * length (0 for a stream without samples). */
+int mp3mi_batch_encode_ragged(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames,
+                              uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev);
+
+/* Header bits the reference's driver sets from -c, -o and -d (/root/reference/src/musicin.c:263-275,
+ * written at src/l3bitstream.c:330-334): copyright 0/1, original 0/1, emphasis 0..3.  Applies to later
+ * encode calls of this batch. */
+int mp3mi_batch_set_header(mp3mi_batch *b, int copyright, int original, int emphasis);
+
 /* Milliseconds spent inside the dominant (iteration loop) kernel and inside all kernels during
  * the last encode call, measured with HIP events on the batch's stream. */
 int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_kernels_ms,
@@ -70,6 +83,12 @@ int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_ke
 int mp3mi_encode_host(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,
                       const int16_t *pcm, int n_frames, uint8_t *out, size_t out_stride,
                       uint32_t *out_len);
+
+/* The same with per-stream sample counts (n_samples, host, may be NULL) and header bits
+ * (mp3mi_batch_encode_ragged, mp3mi_batch_set_header). */
+int mp3mi_encode_host_ex(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,
+                         const int16_t *pcm, const int32_t *n_samples, int n_frames, int copyright,
+                         int original, int emphasis, uint8_t *out, size_t out_stride, uint32_t *out_len);
 
 /* Stage seams of the LAST chunk of the last encode call, copied to host memory (parity tests
  * compare them with oracle/stage_dump.h).  what: 0 = psychoacoustic records (mp3mi_psy_out),

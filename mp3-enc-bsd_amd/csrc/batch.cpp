@@ -53,6 +53,7 @@ struct mp3mi_batch {
     int n_simd;
     int prep_exact;          // MP3MI_PREP_EXACT=1: k_prep skips its fast first tier (tests)
     int test_flags;          // mp3mi_geom::test_flags
+    int hdr_flags;           // copyright << 3 | original << 2 | emphasis (src/l3bitstream.c:330-334)
     int last_slot;
     mp3mi_tables *T;
     int32_t *bits_per_frame, *bitrate_index;
@@ -153,6 +154,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     b->last_slot = 0;
     { const char *e = getenv("MP3MI_PREP_EXACT"); b->prep_exact = (e && atoi(e)) ? 1 : 0; }
     { const char *e = getenv("MP3MI_NOISE_EXACT"); b->test_flags = (e && atoi(e)) ? 1 : 0; }
+    b->hdr_flags = 0;
     b->gate_count = NULL; b->gate_total = 0;
     {
         const char *envg = getenv("MP3MI_NO_GATE");
@@ -237,8 +239,31 @@ extern "C" size_t mp3mi_batch_out_stride(const mp3mi_batch *b, int n_frames)
 
 extern "C" void mp3mi_batch_debug_enable(mp3mi_batch *b, int on) { b->debug = on; }
 
+extern "C" int mp3mi_batch_set_header(mp3mi_batch *b, int copyright, int original, int emphasis)
+{
+    if (!b || (copyright & ~1) || (original & ~1) || (emphasis & ~3)) return MP3MI_ERR_ARG;
+    b->hdr_flags = (copyright << 3) | (original << 2) | emphasis;
+    return MP3MI_OK;
+}
+
+static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames, uint8_t *out_dev,
+                       size_t out_stride, uint32_t *out_len_dev);
+
 extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev,
                                   size_t out_stride, uint32_t *out_len_dev)
+{
+    return encode_impl(b, pcm_dev, NULL, n_frames, out_dev, out_stride, out_len_dev);
+}
+
+extern "C" int mp3mi_batch_encode_ragged(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames,
+                                         uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev)
+{
+    if (!n_samples_dev) return MP3MI_ERR_ARG;
+    return encode_impl(b, pcm_dev, n_samples_dev, n_frames, out_dev, out_stride, out_len_dev);
+}
+
+static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames, uint8_t *out_dev,
+                       size_t out_stride, uint32_t *out_len_dev)
 {
     if (!b || !pcm_dev || !out_dev || !out_len_dev || n_frames <= 0 || n_frames > b->max_frames) return MP3MI_ERR_ARG;
     if (out_stride < (size_t) n_frames * (size_t) b->max_frame_bytes + 1) return MP3MI_ERR_ARG;
@@ -274,6 +299,8 @@ extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_
         const int nf = (n_frames - f0 < cfr) ? n_frames - f0 : cfr;
         mp3mi_geom g = mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
         g.test_flags = b->test_flags;
+        g.n_samples = n_samples_dev;
+        g.hdr_flags |= b->hdr_flags;
         return g;
     };
     auto stage_x = [&](int c) -> int {
@@ -369,22 +396,27 @@ extern "C" long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst
     return (long) n;
 }
 
-extern "C" int mp3mi_encode_host(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,
-                                 const int16_t *pcm, int n_frames, uint8_t *out, size_t out_stride,
-                                 uint32_t *out_len)
+static int encode_host_impl(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all, const int16_t *pcm,
+                            const int32_t *n_samples, int n_frames, int hdr, uint8_t *out, size_t out_stride, uint32_t *out_len)
 {
     mp3mi_batch *b = NULL;
     int rc = mp3mi_batch_create(&b, n_streams, rate_hz, channels, kbps, kbps_all, n_frames);
     if (rc != MP3MI_OK) return rc;
+    if (hdr >= 0) rc = mp3mi_batch_set_header(b, (hdr >> 3) & 1, (hdr >> 2) & 1, hdr & 3);
     const size_t pcm_bytes = (size_t) n_streams * (size_t) n_frames * 1152 * (size_t) channels * sizeof(int16_t);
     int16_t *pcm_d = NULL;
     uint8_t *out_d = NULL;
     uint32_t *len_d = NULL;
-    rc = MP3MI_ERR_HIP;
-    if (hipMalloc((void **) &pcm_d, pcm_bytes) == hipSuccess && hipMalloc((void **) &out_d, out_stride * n_streams) == hipSuccess &&
+    int32_t *ns_d = NULL;
+    if (rc == MP3MI_OK) rc = MP3MI_ERR_HIP;
+    if (rc == MP3MI_ERR_HIP && hipMalloc((void **) &pcm_d, pcm_bytes) == hipSuccess &&
+        hipMalloc((void **) &out_d, out_stride * n_streams) == hipSuccess &&
         hipMalloc((void **) &len_d, sizeof(uint32_t) * n_streams) == hipSuccess &&
-        hipMemcpy(pcm_d, pcm, pcm_bytes, hipMemcpyHostToDevice) == hipSuccess) {
-        rc = mp3mi_batch_encode(b, pcm_d, n_frames, out_d, out_stride, len_d);
+        hipMalloc((void **) &ns_d, sizeof(int32_t) * n_streams) == hipSuccess &&
+        hipMemcpy(pcm_d, pcm, pcm_bytes, hipMemcpyHostToDevice) == hipSuccess &&
+        (!n_samples || hipMemcpy(ns_d, n_samples, sizeof(int32_t) * n_streams, hipMemcpyHostToDevice) == hipSuccess)) {
+        rc = n_samples ? mp3mi_batch_encode_ragged(b, pcm_d, ns_d, n_frames, out_d, out_stride, len_d)
+                       : mp3mi_batch_encode(b, pcm_d, n_frames, out_d, out_stride, len_d);
         if (rc == MP3MI_OK) rc = mp3mi_batch_sync(b);
         if (rc == MP3MI_OK && (hipMemcpy(out, out_d, out_stride * n_streams, hipMemcpyDeviceToHost) != hipSuccess ||
                                hipMemcpy(out_len, len_d, sizeof(uint32_t) * n_streams, hipMemcpyDeviceToHost) != hipSuccess))
@@ -393,6 +425,23 @@ extern "C" int mp3mi_encode_host(int n_streams, int rate_hz, int channels, const
     if (pcm_d) hipFree(pcm_d);
     if (out_d) hipFree(out_d);
     if (len_d) hipFree(len_d);
+    if (ns_d) hipFree(ns_d);
     mp3mi_batch_destroy(b);
     return rc;
+}
+
+extern "C" int mp3mi_encode_host(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,
+                                 const int16_t *pcm, int n_frames, uint8_t *out, size_t out_stride,
+                                 uint32_t *out_len)
+{
+    return encode_host_impl(n_streams, rate_hz, channels, kbps, kbps_all, pcm, NULL, n_frames, -1, out, out_stride, out_len);
+}
+
+extern "C" int mp3mi_encode_host_ex(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,
+                                    const int16_t *pcm, const int32_t *n_samples, int n_frames, int copyright,
+                                    int original, int emphasis, uint8_t *out, size_t out_stride, uint32_t *out_len)
+{
+    if ((copyright & ~1) || (original & ~1) || (emphasis & ~3)) return MP3MI_ERR_ARG;
+    return encode_host_impl(n_streams, rate_hz, channels, kbps, kbps_all, pcm, n_samples, n_frames,
+                            (copyright << 3) | (original << 2) | emphasis, out, out_stride, out_len);
 }

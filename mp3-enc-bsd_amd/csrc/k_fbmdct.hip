@@ -35,8 +35,9 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
         for (int i = lane; i < 576; i += 64) out[i] = 0.0;
         return;
     }
-    const long n_per_ch = (long) geo.n_frames * 1152;
-    const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_per_ch * (size_t) C;
+    const long n_pitch = (long) geo.n_frames * 1152; // row pitch of the PCM buffer
+    const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch; // valid samples: the rest reads as zero (src/encode.c:162-166)
+    const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
     // samples [576 g - 480, 576 g + 576) of this channel; outside the stream -> 0
     {
         int16_t v[17];

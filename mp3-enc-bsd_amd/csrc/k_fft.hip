@@ -219,8 +219,9 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     const int gl = task % G, s = task / G;
     const size_t rec0 = ((size_t) s * G + gl) * C;
     const long gabs = (long) geo.g0 + gl;
-    const long n_per_ch = (long) geo.n_frames * 1152;
-    const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_per_ch * (size_t) C;
+    const long n_pitch = (long) geo.n_frames * 1152; // row pitch of the PCM buffer
+    const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch; // valid samples: the rest reads as zero (src/encode.c:162-166)
+    const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
     const long t0 = 576 * gabs - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
     PROF_DECL;
 

@@ -111,6 +111,12 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
     const int C = geo.channels, G = geo.n_gran;
     const int fl = (int) blockIdx.x % geo.nf, s = (int) blockIdx.x / geo.nf;
     const long n_abs = (long) geo.f0 + fl;
+    // ragged batch: this stream's frame count; frames beyond it were not encoded and emit nothing
+    const long n_frames_s = geo.n_samples ? ((long) geo.n_samples[s] + 1151) / 1152 : (long) geo.n_frames;
+    if (n_abs >= n_frames_s) {
+        if (n_frames_s == 0 && n_abs == 0 && wave_lane() == 0) out_len[s] = 0; // no samples, no file body
+        return;
+    }
     const mp3mi_frame_side *sd = &side_all[(size_t) s * geo.nf + fl];
     const int frame_bytes = bits_per_frame[s] / 8;
     const int si_bytes = (32 + (C == 2 ? 256 : 136)) / 8;
@@ -266,13 +272,13 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
         const size_t phys = (size_t) (m / slot) * (size_t) frame_bytes + (size_t) si_bytes + (size_t) (m % slot);
         dst[phys] = (uint8_t) (L.words[k >> 2] >> (24 - 8 * (k & 3)));
     }
-    if (n_abs == geo.n_frames - 1 && lane == 0) {
+    if (n_abs == n_frames_s - 1 && lane == 0) {
         // file length (src/formatBitstream.c:87-120 + src/common.c:843-868, 968): the flush stops
         // short of the last slot by what the current slot still has free, and close writes the
         // byte under construction as well
         const long mend = m0 + nbytes;
         const long rem = ((mend + slot - 1) / slot) * slot - mend;
-        out_len[s] = (uint32_t) ((long) geo.n_frames * frame_bytes - rem + 1);
+        out_len[s] = (uint32_t) (n_frames_s * frame_bytes - rem + 1);
     }
 }
 

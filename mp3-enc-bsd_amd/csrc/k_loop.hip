@@ -485,6 +485,13 @@ MP3MI_DEVFN void loop_sum_range(const loop_regs &R, bool shortb, int nband, int 
     }
 }
 
+// frames of the chunk [f0, f0 + nf) that a stream with n valid samples per channel still has
+MP3MI_DEVFN int loop_frames_here(const mp3mi_geom &geo, int n)
+{
+    const int total = (n + 1151) / 1152, left = total - geo.f0;
+    return left < 0 ? 0 : (left < geo.nf ? left : geo.nf);
+}
+
 // ---- placement: which stream does this wavefront take? ----
 // The kernel ends when its most loaded SIMD ends.  The hardware decides where a workgroup runs,
 // so instead of stream = blockIdx a wavefront looks at where it landed (HW_ID / XCC_ID) and takes a
@@ -587,7 +594,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     if (lane < 8) L.ix[576 + lane] = 0;
     __syncthreads();
 
-    for (int fl = 0; fl < geo.nf; fl++) {
+    // ragged batch: frames of this stream beyond its last (zero-filled) one are not encoded
+    const int nf_s = geo.n_samples ? loop_frames_here(geo, geo.n_samples[s]) : geo.nf;
+    for (int fl = 0; fl < nf_s; fl++) {
         // ResvFrameBegin (src/reservoir.c:45-93); main_data_begin*8 == ResvSize by construction
         int ResvSize = L.st.ResvSize;
         int ResvMax = (bitsPerFrame > 7680) ? 0 : 7680 - bitsPerFrame;

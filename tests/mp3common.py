@@ -92,6 +92,9 @@ class Mp3mi:
         L.mp3mi_batch_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
         L.mp3mi_encode_host.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_encode_host_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_synth_pcm.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_version.restype = ctypes.c_char_p
 
@@ -119,6 +122,22 @@ class Mp3mi:
         if rc != 0:
             raise RuntimeError("mp3mi_encode_host failed: %d" % rc)
         return [out[s, :lens[s]].tobytes() for s in range(S)]
+
+
+def encode_host_ex(mp, pcm, n_samples, rate, channels, kbps, n_frames, copyright=0, original=0, emphasis=0):
+    """Ragged batch through the host wrapper: pcm int16 [S, n_frames*1152*channels], n_samples per channel
+    per stream (or None).  Returns list of bytes per stream."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    S = pcm.shape[0]
+    ns = None if n_samples is None else np.ascontiguousarray(n_samples, dtype=np.int32)
+    stride = (n_frames * (int(1152 / (rate / 1000.0) * kbps / 8) + 1) + 1 + 255) // 256 * 256
+    out = np.zeros((S, stride), dtype=np.uint8)
+    lens = np.zeros(S, dtype=np.uint32)
+    rc = mp.lib.mp3mi_encode_host_ex(S, rate, channels, None, int(kbps), pcm.ctypes.data, ns.ctypes.data if ns is not None else None,
+                                     n_frames, copyright, original, emphasis, out.ctypes.data, stride, lens.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("mp3mi_encode_host_ex failed: %d" % rc)
+    return [out[s, :lens[s]].tobytes() for s in range(S)]
 
 
 def pad_frames(pcm, channels):
