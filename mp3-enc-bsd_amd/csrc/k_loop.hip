@@ -35,10 +35,12 @@ struct loop_gr { // wave-uniform working copy of gr_info (src/l3side.h:60-87)
     int sfb_lmax, sfb_smax, address1, address2, address3, q;
 };
 
-// 9.2 KB per wavefront: 16 single-wave workgroups fit the 160 KB of a CU, i.e. 4 waves per SIMD,
+// 9.7 KB per wavefront: 16 single-wave workgroups fit the 160 KB of a CU, i.e. 4 waves per SIMD,
 // which is what 4096 streams on 256 CUs need to be resident all at once.
 struct loop_lds {
-    double tmp[576];
+    double xr[576];   // the granule's spectrum (amplified in place): kept here, not in registers, because the
+                      // quantise/count passes only need |xr|^(3/4) (registers) and the 18 VGPRs decide
+                      // between 4 wavefronts per SIMD with and without scratch spills
     double part[64];
     int16_t ix[576 + 8];
     uint16_t glut[928];
@@ -128,9 +130,9 @@ MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
     return loop_estimate(y34max, __builtin_exp2f(-0.1875f * (float) q)) < 0.999f;
 }
 
-MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double xr[9], const float y34[9], int q, bool all_zero, int p[9])
+MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], int q, bool all_zero, int p[9])
 {
-    const int lane = wave_lane();
+    const int lane = wave_lane_here();
     if (all_zero) {
 #pragma unroll
         for (int j = 0; j < 9; j++) { p[j] = 0; L.ix[lane + 64 * j] = 0; }
@@ -159,7 +161,7 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const double 
 #pragma unroll
         for (int j = 0; j < 9; j++) {
             if (need & (1u << j)) {
-                const double x = __builtin_fabs(xr[j]) * ostep;
+                const double x = __builtin_fabs(L.xr[lane + 64 * j]) * ostep;
                 int pp = p[j];
                 while (pp > 0 && x < T->pow_nint_tab[pp]) pp--;
                 while (pp < 2047 && x >= T->pow_nint_tab[pp + 1]) pp++;
@@ -253,7 +255,7 @@ MP3MI_DEVFN int loop_pick(int da, int s0, int s1, int s2, int *sum)
 // membership is a predicate, never a divergent branch.
 MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9], bool all_zero)
 {
-    const int lane = wave_lane();
+    const int lane = wave_lane_here();
     const bool shortb = g.wsf && g.block_type == 2;
     const unsigned *ixw = (const unsigned *) L.ix; // (x, y) of pair pr as one word: x | y << 16
     int bits = 0, nslot = 9; // nslot: slots (of 64 lines) that can hold a non-zero value
@@ -298,34 +300,39 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         if (sum0 < sum1) { g.count1table_select = 0; bits = sum0; }
         else { g.count1table_select = 1; bits = sum1; }
     }
-    // subdivide (src/loop.c:1638-1706); address1..3 keep their old values when big_values == 0
-    if (g.big_values == 0) {
-        g.region0_count = 0;
-        g.region1_count = 0;
-    } else {
-        const int bvr = 2 * g.big_values;
-        if (g.wsf == 0) {
-            // scfb_anz = number of band edges below bvr; K = last edge not above bvr
-            const int anz = __popcll(__ballot(lane < 23 && R.sfb_l < bvr));
-            const int K = __popcll(__ballot(lane < 23 && R.sfb_l <= bvr)) - 1;
-            const int sd = wave_readlane_i32(R.subdv, anz);
-            int c0 = sd & 0xff, c1 = (sd >> 8) & 0xff;
-            const int lim0 = K - 1 > 0 ? K - 1 : 0;
-            c0 = c0 < lim0 ? c0 : lim0;          // while (cnt && edge[cnt+1] > bvr) cnt--
-            const int lim1 = K - c0 - 2 > 0 ? K - c0 - 2 : 0;
-            c1 = c1 < lim1 ? c1 : lim1;          // while (cnt && edge[r0+cnt+2] > bvr) cnt--
-            g.region0_count = c0;
-            g.region1_count = c1;
-            g.address1 = wave_readlane_i32(R.sfb_l, c0 + 1);
-            g.address2 = wave_readlane_i32(R.sfb_l, c0 + c1 + 2);
-            g.address3 = bvr;
-        } else if (g.block_type == 2) {
-            g.region0_count = 8; g.region1_count = 36;
-            g.address1 = 36; g.address2 = bvr; g.address3 = 0;
-        } else {
-            g.region0_count = 7; g.region1_count = 13;
-            g.address1 = wave_readlane_i32(R.sfb_l, 8); g.address2 = bvr; g.address3 = 0;
+    // subdivide (src/loop.c:1638-1706); address1..3 keep their old values when big_values == 0.
+    // (Results go through plain locals and are assigned once: stores to the fields from several branches
+    // made the compiler keep them in scratch memory.)
+    {
+        int r0c = 0, r1c = 0, ad1 = g.address1, ad2 = g.address2, ad3 = g.address3;
+        if (g.big_values != 0) {
+            const int bvr = 2 * g.big_values;
+            if (g.wsf == 0) {
+                // scfb_anz = number of band edges below bvr; K = last edge not above bvr
+                const int anz = __popcll(__ballot(lane < 23 && R.sfb_l < bvr));
+                const int K = __popcll(__ballot(lane < 23 && R.sfb_l <= bvr)) - 1;
+                const int sd = wave_readlane_i32(R.subdv, anz);
+                int c0 = sd & 0xff, c1 = (sd >> 8) & 0xff;
+                const int lim0 = K - 1 > 0 ? K - 1 : 0;
+                c0 = c0 < lim0 ? c0 : lim0;          // while (cnt && edge[cnt+1] > bvr) cnt--
+                const int lim1 = K - c0 - 2 > 0 ? K - c0 - 2 : 0;
+                c1 = c1 < lim1 ? c1 : lim1;          // while (cnt && edge[r0+cnt+2] > bvr) cnt--
+                r0c = c0;
+                r1c = c1;
+                ad1 = wave_readlane_i32(R.sfb_l, c0 + 1);
+                ad2 = wave_readlane_i32(R.sfb_l, c0 + c1 + 2);
+                ad3 = bvr;
+            } else {
+                const bool sb = g.block_type == 2;
+                r0c = sb ? 8 : 7;
+                r1c = sb ? 36 : 13;
+                ad1 = sb ? 36 : wave_readlane_i32(R.sfb_l, 8);
+                ad2 = bvr;
+                ad3 = 0;
+            }
         }
+        g.region0_count = r0c; g.region1_count = r1c;
+        g.address1 = ad1; g.address2 = ad2; g.address3 = ad3;
     }
     g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
     if (nslot == 0) return bits; // nothing but zeros: every region maximum is 0, no table, no bits
@@ -365,49 +372,58 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
     // ranges never overlap.  Lines from slot nslot on are zero, so the maxima may skip them; but a
     // region can reach past big_values (stale or clamped addresses) and a pair of zeros still has a
     // code length, so the pricing loop runs to the end of the last region.
-    const int a1 = g.address1, a2 = g.address2, e2 = 2 * g.big_values;
-    int m0 = 0, m1 = 0, m2 = 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-        if (j >= nslot) break;
-        const int i = lane + 64 * j;
-        const bool c1 = i < a1, c2 = i < a2, c3 = i < e2;
-        m0 = (c1 && p[j] > m0) ? p[j] : m0;
-        m1 = (!c1 && c2 && p[j] > m1) ? p[j] : m1;
-        m2 = (!c2 && c3 && p[j] > m2) ? p[j] : m2;
-    }
-    m0 = wave_max_i32(m0);
-    m1 = wave_max_i32(m1);
-    m2 = wave_max_i32(m2);
-    int da[3], db[3];
+    // (the addresses may come out of LDS: make their uniformity explicit, they bound the loops below)
+    const int a1 = __builtin_amdgcn_readfirstlane(g.address1), a2 = __builtin_amdgcn_readfirstlane(g.address2);
+    const int e2 = __builtin_amdgcn_readfirstlane(2 * g.big_values);
+    // Region 0 = lines [0, a1), 1 = [a1, a2), 2 = [a2, e2).  Each region is walked on its own, 64
+    // consecutive lines (32 pairs: one word each) per step straight out of L.ix, so a line is visited once,
+    // by the region it belongs to, with that region's wave-uniform descriptor; lines from slot nslot on are
+    // zero.  (Written out per region: arrays indexed by the region would live in scratch memory.)
+    const int nzend = 64 * nslot;
+    auto region_max = [&](int lo, int hi) {
+        hi = hi < nzend ? hi : nzend; // both even
+        int m = 0;
+        for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // pair index of lane 0
+            const int w = w0 + lane;
+            const unsigned xy = 2 * w < hi ? ixw[w] : 0u;
+            const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
+            const int v = x > y ? x : y;
+            m = v > m ? v : m;
+        }
+        return wave_max_i32(m);
+    };
+    const int m0 = region_max(0, a1), m1 = region_max(a1, a2), m2 = region_max(a2, e2);
     const int mx[3] = {m0, m1, m2};
+    int da[3], db[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const int idx = loop_desc_index(mx[r]);
         da[r] = wave_readlane_i32(R.desc_a, idx);
         db[r] = wave_readlane_i32(R.desc_b, idx);
     }
-    // cost of every candidate over its region: per lane three 10-bit partial sums per region
-    const int end = a2 > e2 ? a2 : e2; // lines from here on are in no region (a1 <= a2 whenever region 1 is not empty)
-    const int endp = (a1 > end ? a1 : end);
-    int acc0 = 0, acc1 = 0, acc2 = 0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        if (128 * k >= endp) break;
-        const int pr = lane + 64 * k;          // pair index; k == 4 covers pairs 256..287 only
-        const int prc = pr < 288 ? pr : 287;
-        const int i = 2 * pr;
-        const unsigned xy = ixw[prc];
-        const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
-        const bool c1 = i < a1, c2 = i < a2, c3 = i < e2;
-        const bool in0 = c1, in1 = !c1 && c2, in2 = !c2 && c3;
-        const int dA = in0 ? da[0] : (in1 ? da[1] : da[2]);
-        const int dB = in0 ? db[0] : (in1 ? db[1] : db[2]);
-        const int c = loop_pair_cost3(L, dA, dB, x, y);
-        acc0 += (in0 && m0) ? c : 0;
-        acc1 += (in1 && m1) ? c : 0;
-        acc2 += (in2 && m2) ? c : 0;
-    }
+    // cost of every candidate over its region: per lane three 10-bit partial sums per region.  A region can
+    // reach past big_values (stale or clamped addresses) and a pair of zeros still has a code length, so the
+    // pricing walks to the end of the region, not only over the non-zero slots.
+    auto region_cost = [&](int lo, int hi, int m, int dA, int dB) {
+        int a = 0;
+        if (m == 0) return a;
+        const int ylen = (dA >> 15) & 31, lb = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 10);
+        for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) {
+            const int w = w0 + lane;
+            const bool in = 2 * w < hi;
+            const unsigned xy = ixw[in ? w : 0];
+            const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
+            const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
+            const int nesc = (x > 14) + (y > 14);
+            const int e = L.glut[dB + xc * ylen + yc];
+            const int c = ((e & 31) | (((e >> 5) & 31) << 10) | (((e >> 10) & 31) << 20)) + nesc * lb;
+            a += in ? c : 0;
+        }
+        return a;
+    };
+    const int acc0 = region_cost(0, a1, m0, da[0], db[0]);
+    const int acc1 = region_cost(a1, a2, m1, da[1], db[1]);
+    const int acc2 = region_cost(a2, e2, m2, da[2], db[2]);
     const int acc[3] = {acc0, acc1, acc2};
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -435,28 +451,35 @@ MP3MI_DEVFN int loop_part2_length(const loop_lds &L, const loop_gr &g, int gr, i
     return bits;
 }
 
-// Sequential sum over L.tmp[first + k*stride], k < count, in index order.  Every lane of the
-// wave runs the same loop with its own range, so the band sums and the 576-term total overlap.
-// Loads are issued eight at a time so that only the add chain is serial.
-MP3MI_DEVFN double loop_seq_sum(const loop_lds &L, int first, int count, int stride)
+// Sequential sum of the noise terms (|xr| - ix^(4/3) step)^2 of lines first + k*stride, k < count, in index
+// order (src/loop.c:1030-1060); xr and ix come from LDS, i^(4/3) from the table.  Every lane runs the
+// same loop with its own range (a partial-sum job, or a whole band for the exact tier).
+MP3MI_DEVFN double loop_noise_sum(const mp3mi_tables *T, const loop_lds &L, double step, int first, int count, int stride)
 {
     double sum = 0.0;
     int k = 0;
-    for (; k + 8 <= count; k += 8) {
-        const double *q = &L.tmp[first + k * stride];
-        const double t0 = q[0], t1 = q[stride], t2 = q[2 * stride], t3 = q[3 * stride];
-        const double t4 = q[4 * stride], t5 = q[5 * stride], t6 = q[6 * stride], t7 = q[7 * stride];
-        sum = sum + t0; sum = sum + t1; sum = sum + t2; sum = sum + t3;
-        sum = sum + t4; sum = sum + t5; sum = sum + t6; sum = sum + t7;
+    for (; k + 4 <= count; k += 4) { // four terms in flight, added in order
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int line = first + (k + u) * stride;
+            t[u] = __builtin_fabs(L.xr[line]) - T->pow43[L.ix[line]] * step;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) sum = sum + t[u] * t[u];
     }
-    for (; k < count; k++) sum = sum + L.tmp[first + k * stride];
+    for (; k < count; k++) {
+        const int line = first + k * stride;
+        const double t = __builtin_fabs(L.xr[line]) - T->pow43[L.ix[line]] * step;
+        sum = sum + t * t;
+    }
     return sum;
 }
 
-// the reference's sequential band sums over the noise terms in L.tmp (src/loop.c:1030-1060)
-MP3MI_DEVFN double loop_noise_exact(const loop_lds &L, bool bandlane, int sfirst, int scount, int sstride)
+// the reference's sequential band sums (src/loop.c:1030-1060)
+MP3MI_DEVFN double loop_noise_exact(const mp3mi_tables *T, const loop_lds &L, double step, bool bandlane, int sfirst, int scount, int sstride)
 {
-    const double sum = loop_seq_sum(L, sfirst, bandlane ? scount : 0, sstride);
+    const double sum = loop_noise_sum(T, L, step, sfirst, bandlane ? scount : 0, sstride);
     return bandlane ? sum / (double) scount : 0.0;
 }
 
@@ -466,7 +489,7 @@ MP3MI_DEVFN bool loop_noise_close(bool bandlane, double xfsf, double xmin)
     return bandlane && xmin > 0.0 && __builtin_fabs(xfsf - xmin) <= 1e-12 * xmin;
 }
 
-// range of L.tmp a lane sums: band lanes their band, lane 63 all 576 lines, other lanes nothing
+// range of lines a band lane sums (lane 63: all 576 lines, other lanes nothing)
 MP3MI_DEVFN void loop_sum_range(const loop_regs &R, bool shortb, int nband, int *first, int *count, int *stride)
 {
     const int lane = wave_lane();
@@ -607,6 +630,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
 
         for (int gr = 0; gr < 2; gr++)
             for (int ch = 0; ch < C; ch++) {
+                const int lane = wave_lane_here(); // nothing derived from the lane index outlives this granule
                 const int gl = 2 * fl + gr;
                 const size_t rec = ((size_t) s * G + gl) * C + ch;
                 const mp3mi_psy_out *po = &psy[rec];
@@ -635,12 +659,16 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 const int jfirst = T->nj_first[shortb][lane], jcount = T->nj_count[shortb][lane];
                 const int pj0 = bandlane ? T->nj_job0[shortb][lane] : 0, pn = bandlane ? T->nj_njobs[shortb][lane] : 0;
 
-                double xr[9];
                 int p[9];
                 float y34[9], y34max;
+                {
+                    double xr[9];
 #pragma unroll
-                for (int j = 0; j < 9; j++) xr[j] = xr_all[rec * 576 + lane + 64 * j];
-                y34max = loop_power34(xr, y34);
+                    for (int j = 0; j < 9; j++) xr[j] = xr_all[rec * 576 + lane + 64 * j];
+                    y34max = loop_power34(xr, y34);
+#pragma unroll
+                    for (int j = 0; j < 9; j++) L.xr[lane + 64 * j] = xr[j];
+                }
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
                 //      were computed by k_prep; only the stateful decision of calc_scfsi happens here ----
@@ -711,7 +739,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 g.region0_count = 0; g.region1_count = 0; g.part2_length = 0; g.preflag = 0;
                 g.count1table_select = 0; g.q = 0;
 #pragma unroll
-                for (int j = 0; j < 9; j++) p[j] = 0;
+                for (int j = 0; j < 9; j++) { p[j] = 0; L.ix[lane + 64 * j] = 0; }
                 __syncthreads();
 
                 if (nonzero) {
@@ -720,6 +748,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     // ---- outer_loop (src/loop.c:415-558) ----
                     int iteration = 0, bits = 0, over, status, save_preflag, save_compress;
                     do {
+                        const int lane = wave_lane_here(); // ... nor an iteration of the distortion loop
                         iteration++;
                         work += 5;
                         g.part2_length = loop_part2_length(L, g, gr, ch);
@@ -734,7 +763,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 PROF(1);
                                 const bool az = loop_all_zero(y34max, g.q);
                                 work += 4;
-                                loop_quantize(T, L, xr, y34, g.q, az, p);
+                                loop_quantize(T, L, y34, g.q, az, p);
                                 PROF(2);
                                 bit = loop_count_bits(R, L, g, p, az);
                                 PROF(3);
@@ -754,7 +783,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 PROF(1);
                                 const bool az = loop_all_zero(y34max, g.q);
                                 work += 4;
-                                loop_quantize(T, L, xr, y34, g.q, az, p);
+                                loop_quantize(T, L, y34, g.q, az, p);
                                 PROF(2);
                                 bits = loop_count_bits(R, L, g, p, az);
                                 PROF(3);
@@ -771,23 +800,18 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         // different lanes.  Only if a band lands within 1e-12 of its threshold is the
                         // reference's order used (loop_noise_exact) -- at both places that compare.
                         bool xfsf_exact = (geo.test_flags & 1) != 0;
+                        double noise_step;
                         {
-                            const double step = T->step[g.q - MP3MI_STEP_MIN];
-#pragma unroll
-                            for (int j = 0; j < 9; j++) {
-                                const double t = __builtin_fabs(xr[j]) - T->pow43[p[j]] * step;
-                                L.tmp[lane + 64 * j] = t * t;
-                            }
-                            __syncthreads();
+                            noise_step = T->step[g.q - MP3MI_STEP_MIN];
                             if (!xfsf_exact) {
-                                L.part[lane] = loop_seq_sum(L, jfirst, jcount, shortb ? 3 : 1);
+                                L.part[lane] = loop_noise_sum(T, L, noise_step, jfirst, jcount, shortb ? 3 : 1);
                                 __syncthreads();
                                 double sum = 0.0;
                                 for (int i = 0; i < pn; i++) sum = sum + L.part[pj0 + i];
                                 xfsf_r = bandlane ? sum / (double) scount : 0.0;
                                 if (wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) xfsf_exact = true;
                             }
-                            if (xfsf_exact) xfsf_r = loop_noise_exact(L, bandlane, sfirst, scount, sstride);
+                            if (xfsf_exact) xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, sfirst, scount, sstride);
                         }
                         sfsave_r = sf_r;
                         save_preflag = g.preflag;
@@ -810,13 +834,13 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                     // the thresholds moved: amp_scalefac_bands compares against the new ones
                                     if (!xfsf_exact && wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) {
                                         xfsf_exact = true;
-                                        xfsf_r = loop_noise_exact(L, bandlane, sfirst, scount, sstride);
+                                        xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, sfirst, scount, sstride);
                                     }
 #pragma unroll
                                     for (int j = 0; j < 9; j++) {
                                         const int b = (int) ((bandpack >> (6 * j)) & 63ull);
                                         if (b < g.sfb_lmax) {
-                                            xr[j] = xr[j] * T->pretab_xr[LOOP_PRETAB[b]];
+                                            L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * T->pretab_xr[LOOP_PRETAB[b]];
                                             y34[j] = loop_rescale34(y34[j], LOOP_PRETAB[b]);
                                         }
                                     }
@@ -856,13 +880,14 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 for (int j = 0; j < 9; j++) {
                                     const int b = (int) ((bandpack >> (6 * j)) & 63ull);
                                     if (b < nband && ((ampmask >> b) & 1ull)) {
-                                        xr[j] = xr[j] * ifqstep;
+                                        L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * ifqstep;
                                         y34[j] = loop_rescale34(y34[j], 1);
                                     }
                                 }
                                 y34max = y34max * LOOP_Y34MAX_GROW;
                             }
                         }
+                        __syncthreads(); // amplified lines in L.xr are read by other lanes' noise sums
 
                         PROF(5);
                         // loop_break (src/loop.c:1131-1152) then scale_bitcount (src/loop.c:792-860)
@@ -901,8 +926,8 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 // ---- hand the granule over: signed ix (src/l3bitstream.c:115-125) and side info ----
 #pragma unroll
                 for (int j = 0; j < 9; j++) {
-                    int v = p[j];
-                    if (xr[j] < 0 && v > 0) v = -v;
+                    int v = L.ix[lane + 64 * j]; // what the last pass (or the reset) left
+                    if (L.xr[lane + 64 * j] < 0 && v > 0) v = -v;
                     ix_out[rec * 576 + lane + 64 * j] = (int16_t) v;
                 }
                 if (lane == 0) {

@@ -145,6 +145,17 @@ typedef struct {
 
 /* ---- wave helpers (64 lanes) ---- */
 MP3MI_DEVFN int wave_lane(void) { return (int) (threadIdx.x & 63); }
+/* The lane index behind an optimisation barrier: everything derived from it (addresses, masks) is
+ * recomputed where it is used instead of being hoisted to the top of a long kernel and kept alive
+ * (in registers, then in scratch) across all of it. */
+MP3MI_DEVFN int wave_lane_here(void)
+{
+    int l = (int) (threadIdx.x & 63);
+#if !defined(MP3MI_EMU)
+    asm volatile("" : "+v"(l));
+#endif
+    return l;
+}
 
 #if defined(MP3MI_EMU)
 MP3MI_DEVFN int wave_sum_i32(int v)
