@@ -259,6 +259,7 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
     const bool shortb = g.wsf && g.block_type == 2;
     const unsigned *ixw = (const unsigned *) L.ix; // (x, y) of pair pr as one word: x | y << 16
     int bits = 0, nslot = 9; // nslot: slots (of 64 lines) that can hold a non-zero value
+    int c1part = 0;          // this lane's part of the count1 region's bits: table A | table B << 16
     if (shortb) {
         g.count1 = 0;
         g.big_values = 288;
@@ -276,7 +277,9 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
             hi_nz = (p[j] != 0) ? 64 * j + lane + 1 : hi_nz;
             hi_big = (p[j] > 1) ? 64 * j + lane + 1 : hi_big;
         }
-        const int top_nz = wave_max_i32(hi_nz) - 1, top_big = wave_max_i32(hi_big) - 1;
+        int hh[2] = {hi_nz, hi_big};
+        wave_reduce_i32<0, 2>(hh);
+        const int top_nz = hh[0] - 1, top_big = hh[1] - 1;
         nslot = (top_nz + 64) >> 6;
         const int i0 = (top_nz < 0) ? 0 : 2 * (top_nz / 2 + 1);
         g.count1 = (i0 - (top_big + 1)) / 4;
@@ -295,10 +298,7 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
             const int c = (e & 31) | ((e >> 5) << 16);
             s01 += in ? c : 0;
         }
-        s01 = wave_sum_i32(s01);
-        const int sum0 = s01 & 0xffff, sum1 = (s01 >> 16) & 0xffff;
-        if (sum0 < sum1) { g.count1table_select = 0; bits = sum0; }
-        else { g.count1table_select = 1; bits = sum1; }
+        c1part = s01; // reduced further down, together with the region maxima
     }
     // subdivide (src/loop.c:1638-1706); address1..3 keep their old values when big_values == 0.
     // (Results go through plain locals and are assigned once: stores to the fields from several branches
@@ -335,7 +335,10 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         g.address1 = ad1; g.address2 = ad2; g.address3 = ad3;
     }
     g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
-    if (nslot == 0) return bits; // nothing but zeros: every region maximum is 0, no table, no bits
+    if (nslot == 0) { // nothing but zeros: every region maximum is 0, no table, no bits
+        g.count1table_select = 1; // count1_bitcount without quadruples: sum0 == sum1 -> table B
+        return bits;
+    }
     if (shortb) {
         // region maxima over lines [0,36) and [36,576); pair (6m+w, 6m+3+w), m<96, w<3
         int m1 = 0, m2 = 0;
@@ -390,9 +393,17 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
             const int v = x > y ? x : y;
             m = v > m ? v : m;
         }
-        return wave_max_i32(m);
+        return m; // this lane's part
     };
-    const int m0 = region_max(0, a1), m1 = region_max(a1, a2), m2 = region_max(a2, e2);
+    // the three region maxima and the count1 region's two bit sums: four reductions in lock-step
+    int red[4] = {c1part, region_max(0, a1), region_max(a1, a2), region_max(a2, e2)};
+    wave_reduce_i32<1, 3>(red);
+    {
+        const int sum0 = red[0] & 0xffff, sum1 = (red[0] >> 16) & 0xffff; // table A vs table B (src/loop.c:1531-1580)
+        if (sum0 < sum1) { g.count1table_select = 0; bits = sum0; }
+        else { g.count1table_select = 1; bits = sum1; }
+    }
+    const int m0 = red[1], m1 = red[2], m2 = red[3];
     const int mx[3] = {m0, m1, m2};
     int da[3], db[3];
 #pragma unroll
@@ -424,12 +435,18 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
     const int acc0 = region_cost(0, a1, m0, da[0], db[0]);
     const int acc1 = region_cost(a1, a2, m1, da[1], db[1]);
     const int acc2 = region_cost(a2, e2, m2, da[2], db[2]);
-    const int acc[3] = {acc0, acc1, acc2};
+    // candidate sums of the three regions: fields 0/1 of each region in one word, the third candidates'
+    // fields of regions 0 and 1 share a word; five reductions in lock-step
+    int fs[5] = {(acc0 & 0x3ff) | (((acc0 >> 10) & 0x3ff) << 16), (acc1 & 0x3ff) | (((acc1 >> 10) & 0x3ff) << 16),
+                 (acc2 & 0x3ff) | (((acc2 >> 10) & 0x3ff) << 16), ((acc0 >> 20) & 0x3ff) | (((acc1 >> 20) & 0x3ff) << 16),
+                 (acc2 >> 20) & 0x3ff};
+    wave_reduce_i32<5, 0>(fs);
+    const int s2v[3] = {fs[3] & 0xffff, (fs[3] >> 16) & 0xffff, fs[4]};
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         if (mx[r] == 0) continue;
-        const int s01 = wave_sum_i32((acc[r] & 0x3ff) | (((acc[r] >> 10) & 0x3ff) << 16)); // two fields per reduction
-        const int s2 = ((da[r] >> 10) & 31) ? wave_sum_i32((acc[r] >> 20) & 0x3ff) : 0;
+        const int s01 = fs[r];
+        const int s2 = ((da[r] >> 10) & 31) ? s2v[r] : 0;
         int best;
         g.table_select[r] = loop_pick(da[r], s01 & 0xffff, (s01 >> 16) & 0xffff, s2, &best);
         // bigv_bitcount (src/loop.c:1997-2011) counts region r over the same range (address3 == e2

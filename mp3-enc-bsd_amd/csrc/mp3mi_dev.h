@@ -200,6 +200,35 @@ MP3MI_DEVFN int wave_max_i32(int v) /* values >= 0 */
 }
 MP3MI_DEVFN int wave_readlane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 #endif
+
+/* Several reductions at once, step by step in lock-step.  A DPP instruction that reads the result of
+ * the previous VALU instruction needs two wait states (an s_nop each time in a lone reduction: 6 DPP +
+ * 6 s_nop); interleaved, the other chains' steps fill those slots.  NSUM sums first, then NMAX maxima
+ * (values >= 0); results are wave-uniform. */
+template <int NSUM, int NMAX>
+MP3MI_DEVFN void wave_reduce_i32(int (&v)[NSUM + NMAX])
+{
+#if defined(MP3MI_EMU)
+    for (int k = 0; k < NSUM; k++) v[k] = wave_sum_i32(v[k]);
+    for (int k = NSUM; k < NSUM + NMAX; k++) v[k] = wave_max_i32(v[k]);
+#else
+    const int ident = 0;
+#define MP3MI_RSTEP(ctrl, rmask)                                                                   \
+    _Pragma("unroll") for (int k = 0; k < NSUM + NMAX; k++) {                                      \
+        const int o = MP3MI_DPP(v[k], ctrl, rmask);                                                \
+        v[k] = (k < NSUM) ? v[k] + o : (o > v[k] ? o : v[k]);                                      \
+    }
+    MP3MI_RSTEP(0xB1, 0xf)
+    MP3MI_RSTEP(0x4E, 0xf)
+    MP3MI_RSTEP(0x141, 0xf)
+    MP3MI_RSTEP(0x140, 0xf)
+    MP3MI_RSTEP(0x142, 0xa)
+    MP3MI_RSTEP(0x143, 0xc)
+#undef MP3MI_RSTEP
+#pragma unroll
+    for (int k = 0; k < NSUM + NMAX; k++) v[k] = __builtin_amdgcn_readlane(v[k], 63);
+#endif
+}
 MP3MI_DEVFN int wave_min_i32(int v)
 {
     for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o < v ? o : v; }
