@@ -30,17 +30,21 @@ __device__ unsigned long long g_fft_prof[8];
 #endif
 
 // One wavefront transforms all C channels of a granule: every butterfly record is fetched once
-// and applied to the C long (then 3C short) arrays, which also gives each lane C independent
-// dependency chains.  es/ps reuse the long arrays' space once the long spectrum is consumed.
+// and applied to the C channels of the long (then of the three short) transforms, which also gives
+// each lane C independent dependency chains.
 // A workgroup is W such wavefronts (W granules) sharing ONE copy of the butterfly program in LDS:
 // a record costs an LDS read instead of an L2 round trip per round, which is what the transform
 // was waiting on when the program lived in global memory.
+// Element e of the long transform is the C floats at x[e * C] (the channels of one position side by
+// side), element e of short window sb those at x[(sb * 256 + e) * C]: a butterfly fetches and stores
+// both channels of an operand with one 8-byte LDS access instead of two 4-byte ones.  The short windows
+// reuse the space once the long spectrum is consumed.
 template <int C> struct fft_wave_lds {
-    union {
-        float xl[C][1024];
-        float xs[C][3][256]; // filled (from PCM again) once the long spectrum is consumed
-    };
+    float x[C * 1024];
 };
+template <int C> struct fft_vec;
+template <> struct fft_vec<1> { float c[1]; };
+template <> struct __attribute__((aligned(8))) fft_vec<2> { float c[2]; };
 template <int C, int W> struct fft_lds {
     uint32_t prog_g[64 * (MP3MI_FFT_GROUNDS_L + 2)]; // + two rounds that are read ahead but never used
     uint4 prog_r[64 * (MP3MI_FFT_RROUNDS_L + 1)];
@@ -69,60 +73,68 @@ MP3MI_DEVFN fft_idx fft_decode(uint32_t w0, uint32_t w1)
     return i;
 }
 
-template <int TYPE, int NARR, int STRIDE>
-MP3MI_DEVFN void fft_fetch(const float *x, const fft_idx &i, float (&v)[NARR][4])
+// NWIN transforms of N points with C channels each (layout above)
+template <int TYPE, int C, int NWIN, int N>
+MP3MI_DEVFN void fft_fetch(const float *x, const fft_idx &i, fft_vec<C> (&v)[NWIN][4])
 {
 #pragma unroll
-    for (int arr = 0; arr < NARR; arr++) {
-        const float *p = x + arr * STRIDE;
-        v[arr][0] = p[i.a];
-        if (TYPE != FOP_NEG) v[arr][1] = p[i.b];
-        if (TYPE == FOP_CROSS) { v[arr][2] = p[i.c]; v[arr][3] = p[i.d]; }
+    for (int w = 0; w < NWIN; w++) {
+        const float *p = x + w * N * C;
+        v[w][0] = *(const fft_vec<C> *) (p + i.a * C);
+        if (TYPE != FOP_NEG) v[w][1] = *(const fft_vec<C> *) (p + i.b * C);
+        if (TYPE == FOP_CROSS) { v[w][2] = *(const fft_vec<C> *) (p + i.c * C); v[w][3] = *(const fft_vec<C> *) (p + i.d * C); }
     }
 }
 
-template <int TYPE, int NARR, int STRIDE>
-MP3MI_DEVFN void fft_finish(float *x, const fft_idx &i, const float (&v)[NARR][4], uint32_t w1, uint32_t w2, uint32_t w3)
+template <int TYPE, int C, int NWIN, int N>
+MP3MI_DEVFN void fft_finish(float *x, const fft_idx &i, const fft_vec<C> (&v)[NWIN][4], uint32_t w1, uint32_t w2, uint32_t w3)
 {
     if (!i.on) return;
 #pragma unroll
-    for (int arr = 0; arr < NARR; arr++) {
-        float *p = x + arr * STRIDE;
-        const float va = v[arr][0], vb = v[arr][1];
-        if (TYPE == FOP_ADDSUB) {
-            p[i.b] = va - vb;
-            p[i.a] = va + vb;
-        } else if (TYPE == FOP_NEG) {
-            p[i.a] = -va;
-        } else if (TYPE == FOP_CROSS) {
-            const float r1 = va, r2 = vb, i1 = v[arr][2], i2 = v[arr][3];
-            p[i.c] = i1 - r2;
-            p[i.b] = r1 - i2;
-            p[i.a] = r1 + i2;
-            p[i.d] = i1 + r2;
-        } else if (TYPE == FOP_ROT) {
-            const float cn = __builtin_bit_cast(float, w1), spc = __builtin_bit_cast(float, w2), smc = __builtin_bit_cast(float, w3);
-            const float r1 = va, i1 = vb;
-            const float t2 = cn * (r1 + i1);
-            const float t1 = spc * r1 + t2;
-            p[i.a] = smc * i1 + t2;
-            p[i.b] = t1;
-        } else if (TYPE == FOP_SQ1) {
-            p[i.a] = (float) (R_SQHALF * (double) (va + vb));
-            p[i.b] = (float) (R_SQHALF * (double) (vb - va));
-        } else if (TYPE == FOP_SQ2) {
-            p[i.a] = (float) (R_SQHALF * (double) (vb - va));
-            p[i.b] = (float) (-R_SQHALF * (double) (va + vb));
-        } else if (TYPE == FOP_SWAPNN) {
-            p[i.a] = -vb;
-            p[i.b] = -va;
-        } else if (TYPE == FOP_SWAPN) {
-            p[i.a] = -vb;
-            p[i.b] = va;
-        } else { // FOP_SWAP
-            p[i.a] = vb;
-            p[i.b] = va;
+    for (int w = 0; w < NWIN; w++) {
+        float *p = x + w * N * C;
+        fft_vec<C> oa, ob, oc, od;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float va = v[w][0].c[c], vb = v[w][1].c[c];
+            if (TYPE == FOP_ADDSUB) {
+                ob.c[c] = va - vb;
+                oa.c[c] = va + vb;
+            } else if (TYPE == FOP_NEG) {
+                oa.c[c] = -va;
+            } else if (TYPE == FOP_CROSS) {
+                const float r1 = va, r2 = vb, i1 = v[w][2].c[c], i2 = v[w][3].c[c];
+                oc.c[c] = i1 - r2;
+                ob.c[c] = r1 - i2;
+                oa.c[c] = r1 + i2;
+                od.c[c] = i1 + r2;
+            } else if (TYPE == FOP_ROT) {
+                const float cn = __builtin_bit_cast(float, w1), spc = __builtin_bit_cast(float, w2), smc = __builtin_bit_cast(float, w3);
+                const float r1 = va, i1 = vb;
+                const float t2 = cn * (r1 + i1);
+                const float t1 = spc * r1 + t2;
+                oa.c[c] = smc * i1 + t2;
+                ob.c[c] = t1;
+            } else if (TYPE == FOP_SQ1) {
+                oa.c[c] = (float) (R_SQHALF * (double) (va + vb));
+                ob.c[c] = (float) (R_SQHALF * (double) (vb - va));
+            } else if (TYPE == FOP_SQ2) {
+                oa.c[c] = (float) (R_SQHALF * (double) (vb - va));
+                ob.c[c] = (float) (-R_SQHALF * (double) (va + vb));
+            } else if (TYPE == FOP_SWAPNN) {
+                oa.c[c] = -vb;
+                ob.c[c] = -va;
+            } else if (TYPE == FOP_SWAPN) {
+                oa.c[c] = -vb;
+                ob.c[c] = va;
+            } else { // FOP_SWAP
+                oa.c[c] = vb;
+                ob.c[c] = va;
+            }
         }
+        *(fft_vec<C> *) (p + i.a * C) = oa;
+        if (TYPE != FOP_NEG) *(fft_vec<C> *) (p + i.b * C) = ob;
+        if (TYPE == FOP_CROSS) { *(fft_vec<C> *) (p + i.c * C) = oc; *(fft_vec<C> *) (p + i.d * C) = od; }
     }
 }
 
@@ -130,7 +142,7 @@ MP3MI_DEVFN void fft_finish(float *x, const fft_idx &i, const float (&v)[NARR][4
 // rounds of 64, one record per lane, idle lanes marked by bit 31 (tables_host.cpp).  pg/pr point at
 // this lane's record of the segment's first round and are left at the next segment's.  The records
 // of the following pair of rounds are read while the current pair's operands are in flight.
-template <int TYPE, int NARR, int STRIDE>
+template <int TYPE, int C, int NWIN, int N>
 MP3MI_DEVFN void fft_segment(float *x, const uint32_t *&pg, const uint4 *&pr, int rounds)
 {
     const int gstep = (TYPE == FOP_CROSS) ? 128 : 64; // FOP_CROSS: the round's second words follow its first words
@@ -144,9 +156,9 @@ MP3MI_DEVFN void fft_segment(float *x, const uint32_t *&pg, const uint4 *&pr, in
     int t = 0;
     for (; t + 1 < rounds; t += 2) {
         const fft_idx i0 = fft_decode<TYPE>(c0.x, c0.y), i1 = fft_decode<TYPE>(c1.x, c1.y);
-        float v0[NARR][4], v1[NARR][4];
-        fft_fetch<TYPE, NARR, STRIDE>(x, i0, v0);
-        fft_fetch<TYPE, NARR, STRIDE>(x, i1, v1);
+        fft_vec<C> v0[NWIN][4], v1[NWIN][4];
+        fft_fetch<TYPE, C, NWIN, N>(x, i0, v0);
+        fft_fetch<TYPE, C, NWIN, N>(x, i1, v1);
         uint4 n0 = {0x80000000u, 0, 0, 0}, n1 = n0;
         if (TYPE == FOP_ROT) {
             pr += 128;
@@ -158,21 +170,21 @@ MP3MI_DEVFN void fft_segment(float *x, const uint32_t *&pg, const uint4 *&pr, in
                 if (TYPE == FOP_CROSS) { n0.y = pg[64]; n1.y = pg[gstep + 64]; }
             }
         }
-        fft_finish<TYPE, NARR, STRIDE>(x, i0, v0, c0.y, c0.z, c0.w);
-        fft_finish<TYPE, NARR, STRIDE>(x, i1, v1, c1.y, c1.z, c1.w);
+        fft_finish<TYPE, C, NWIN, N>(x, i0, v0, c0.y, c0.z, c0.w);
+        fft_finish<TYPE, C, NWIN, N>(x, i1, v1, c1.y, c1.z, c1.w);
         c0 = n0;
         c1 = n1;
     }
     if (t < rounds) { // odd round count: the last round alone
         const fft_idx i0 = fft_decode<TYPE>(c0.x, c0.y);
-        float v0[NARR][4];
-        fft_fetch<TYPE, NARR, STRIDE>(x, i0, v0);
-        fft_finish<TYPE, NARR, STRIDE>(x, i0, v0, c0.y, c0.z, c0.w);
+        fft_vec<C> v0[NWIN][4];
+        fft_fetch<TYPE, C, NWIN, N>(x, i0, v0);
+        fft_finish<TYPE, C, NWIN, N>(x, i0, v0, c0.y, c0.z, c0.w);
         if (TYPE == FOP_ROT) pr += 64; else pg += gstep;
     }
 }
 
-template <int NARR, int STRIDE>
+template <int C, int NWIN, int N>
 MP3MI_DEVFN void fft_run(float *x, const int32_t *segs, int nseg, const uint32_t *pg, const uint4 *pr)
 {
     int nxt = segs[0];
@@ -181,25 +193,26 @@ MP3MI_DEVFN void fft_run(float *x, const int32_t *segs, int nseg, const uint32_t
         nxt = segs[sidx + 1 < nseg ? sidx + 1 : sidx];
         const int type = sw & 0xff, rounds = (sw >> 8) & 0xff;
         switch (type) {
-        case FOP_ADDSUB: fft_segment<FOP_ADDSUB, NARR, STRIDE>(x, pg, pr, rounds); break;
-        case FOP_NEG: fft_segment<FOP_NEG, NARR, STRIDE>(x, pg, pr, rounds); break;
-        case FOP_CROSS: fft_segment<FOP_CROSS, NARR, STRIDE>(x, pg, pr, rounds); break;
-        case FOP_ROT: fft_segment<FOP_ROT, NARR, STRIDE>(x, pg, pr, rounds); break;
-        case FOP_SQ1: fft_segment<FOP_SQ1, NARR, STRIDE>(x, pg, pr, rounds); break;
-        case FOP_SQ2: fft_segment<FOP_SQ2, NARR, STRIDE>(x, pg, pr, rounds); break;
-        case FOP_SWAPNN: fft_segment<FOP_SWAPNN, NARR, STRIDE>(x, pg, pr, rounds); break;
-        case FOP_SWAPN: fft_segment<FOP_SWAPN, NARR, STRIDE>(x, pg, pr, rounds); break;
-        default: fft_segment<FOP_SWAP, NARR, STRIDE>(x, pg, pr, rounds); break;
+        case FOP_ADDSUB: fft_segment<FOP_ADDSUB, C, NWIN, N>(x, pg, pr, rounds); break;
+        case FOP_NEG: fft_segment<FOP_NEG, C, NWIN, N>(x, pg, pr, rounds); break;
+        case FOP_CROSS: fft_segment<FOP_CROSS, C, NWIN, N>(x, pg, pr, rounds); break;
+        case FOP_ROT: fft_segment<FOP_ROT, C, NWIN, N>(x, pg, pr, rounds); break;
+        case FOP_SQ1: fft_segment<FOP_SQ1, C, NWIN, N>(x, pg, pr, rounds); break;
+        case FOP_SQ2: fft_segment<FOP_SQ2, C, NWIN, N>(x, pg, pr, rounds); break;
+        case FOP_SWAPNN: fft_segment<FOP_SWAPNN, C, NWIN, N>(x, pg, pr, rounds); break;
+        case FOP_SWAPN: fft_segment<FOP_SWAPN, C, NWIN, N>(x, pg, pr, rounds); break;
+        default: fft_segment<FOP_SWAP, C, NWIN, N>(x, pg, pr, rounds); break;
         }
         if (sw >> 16) wave_sync();
     }
 }
 
 // energy of bin i of an N-point transform held as x (src/subs.c:53-123)
-MP3MI_DEVFN float fft_energy(const float *x, int N, int i)
+// (x points at channel c of element 0; consecutive elements are C floats apart)
+MP3MI_DEVFN float fft_energy(const float *x, int C, int N, int i)
 {
-    if (i == 0 || i == N / 2) return x[MP3MI_FFT_SWZ(i)] * x[MP3MI_FFT_SWZ(i)];
-    const float re = x[MP3MI_FFT_SWZ(i)], im = x[MP3MI_FFT_SWZ(N - i)];
+    if (i == 0 || i == N / 2) return x[MP3MI_FFT_SWZ(i) * C] * x[MP3MI_FFT_SWZ(i) * C];
+    const float re = x[MP3MI_FFT_SWZ(i) * C], im = x[MP3MI_FFT_SWZ(N - i) * C];
     const float e = re * re + im * im;
     return ((double) e < 0.0005) ? (float) 0.0005 : e;
 }
@@ -245,13 +258,13 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
-                L.xl[c][MP3MI_FFT_SWZ(lane + 64 * k)] = wl[k] * v; // src/l3psy.c:485
+                L.x[MP3MI_FFT_SWZ(lane + 64 * k) * C + c] = wl[k] * v; // src/l3psy.c:485
             }
     }
     __syncthreads();
     PROF(0);
 
-    fft_run<C, 1024>(&L.xl[0][0], T->seg_l, T->n_seg_l, LL.prog_g + lane, LL.prog_r + lane);
+    fft_run<C, 1, 1024>(&L.x[0], T->seg_l, T->n_seg_l, LL.prog_g + lane, LL.prog_r + lane);
     PROF(1);
 
     // the short windows' samples are requested now and land while the long spectrum is consumed
@@ -269,16 +282,16 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
 
     for (int c = 0; c < C; c++) {
         for (int i = lane; i < MP3MI_HBLK; i += 64) {
-            const float e = fft_energy(L.xl[c], 1024, i);
+            const float e = fft_energy(&L.x[c], C, 1024, i);
             if (valid) energy_l[(rec0 + c) * MP3MI_HBLK_P + i] = e;
         }
         // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
         if (lane < 6 && valid) {
-            bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = L.xl[c][MP3MI_FFT_SWZ(lane)];
-            bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? L.xl[c][MP3MI_FFT_SWZ(1024 - lane)] : -0.0f;
+            bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = L.x[MP3MI_FFT_SWZ(lane) * C + c];
+            bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? L.x[MP3MI_FFT_SWZ(1024 - lane) * C + c] : -0.0f;
         }
     }
-    wave_sync(); // xl is dead from here on
+    wave_sync(); // the long spectrum is dead from here on
     // short windows: samples 256 + 128 sb + jj, sb < 3 (src/l3psy.c:520-523); the second half of every
     // window is also the first half of the next.  Sample 256 + lane + 64 k: sb = k >> 1, jj = lane + 64 (k & 1).
 #pragma unroll
@@ -287,8 +300,8 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         for (int c = 0; c < C; c++) {
             const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
             const int sb = k >> 1, jj = lane + 64 * (k & 1);
-            if (sb < 3) L.xs[c][sb][MP3MI_FFT_SWZ(jj)] = wsv[k & 1] * v;
-            if (sb >= 1 && sb < 4) L.xs[c][sb - 1][MP3MI_FFT_SWZ(128 + jj)] = wsv[2 + (k & 1)] * v;
+            if (sb < 3) L.x[(sb * 256 + MP3MI_FFT_SWZ(jj)) * C + c] = wsv[k & 1] * v;
+            if (sb >= 1 && sb < 4) L.x[((sb - 1) * 256 + MP3MI_FFT_SWZ(128 + jj)) * C + c] = wsv[2 + (k & 1)] * v;
         }
     __syncthreads(); // every wavefront is done with the long program
     for (int i = tid; i < 64 * MP3MI_FFT_GROUNDS_S; i += 64 * W) LL.prog_g[i] = T->gops_s[i];
@@ -296,20 +309,20 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     __syncthreads();
     PROF(2);
 
-    fft_run<3 * C, 256>(&L.xs[0][0][0], T->seg_s, T->n_seg_s, LL.prog_g + lane, LL.prog_r + lane);
+    fft_run<C, 3, 256>(&L.x[0], T->seg_s, T->n_seg_s, LL.prog_g + lane, LL.prog_r + lane);
     PROF(3);
 
     for (int i = lane; i < C * 3 * MP3MI_HBLK_S; i += 64) {
         const int csb = i / MP3MI_HBLK_S, k = i % MP3MI_HBLK_S, c = csb / 3, sb = csb % 3;
-        const float e = fft_energy(L.xs[c][sb], 256, k);
+        const float e = fft_energy(&L.x[sb * 256 * C + c], C, 256, k);
         if (valid) energy_s[(rec0 + c) * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S + k] = e;
     }
     for (int i = lane; i < C * 150; i += 64) { // raw short lines 2..51 for k_cw (src/l3psy.c:531-549 reads these only)
         const int csb = i / 50, n = i % 50, c = csb / 3, sb = csb % 3;
         if (valid) {
             float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + n) * 2;
-            o[0] = L.xs[c][sb][MP3MI_FFT_SWZ(2 + n)];
-            o[1] = L.xs[c][sb][MP3MI_FFT_SWZ(254 - n)];
+            o[0] = L.x[(sb * 256 + MP3MI_FFT_SWZ(2 + n)) * C + c];
+            o[1] = L.x[(sb * 256 + MP3MI_FFT_SWZ(254 - n)) * C + c];
         }
     }
     PROF(4);
