@@ -177,8 +177,9 @@ def main():
             "value": round(frames_total / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %.1f kHz %s streams x %d frames per GPU, %d kbps CBR (BASELINE configs[1])"
-                       % (S, args.rate / 1000.0, "stereo" if C == 2 else "mono", nf, args.kbps),
+            "config": {"workload": "batch of %d synthetic %.1f kHz %s streams x %d frames per GPU, %d kbps CBR (%s)"
+                       % (S, args.rate / 1000.0, "stereo" if C == 2 else "mono", nf, args.kbps,
+                          "BASELINE configs[1]" if (S, nf, args.rate, args.kbps, C) == (4096, 383, 44100, 128, 2) else "non-default workload"),
                        "streams_per_gpu": S, "frames_per_stream": nf, "parallelism": "streams sharded across GPUs, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_loop", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

@@ -140,12 +140,13 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y
         return;
     }
     const float cq = __builtin_exp2f(-0.1875f * (float) q);
-    unsigned need = 0;
+    bool need[9]; // per line: too close to a table boundary for the estimate (kept as lane masks, not as data)
+    bool any = false;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
         // estimate f of x^(3/4) + 0.4054 (>= 0.4054); from 2047.5 on the answer is the table's last entry
         float f = loop_estimate(y34[j], cq);
-        f = f > 2047.5f ? 2047.5f : f;
+        f = __builtin_fminf(f, 2047.5f);
         const float fl = __builtin_floorf(f);
         p[j] = (int) fl;
         // near a table boundary: settle exactly.  The estimate's error is relative: < 7e-7 f from the two
@@ -154,13 +155,14 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y
         // 3.5e-6 f + 2e-6 scales with f; small values -- the common case -- are almost never ambiguous.
         // |frac - 1/2| > 1/2 - band <=> within band of an integer.
         const float d = __builtin_fabsf((f - fl) - 0.5f);
-        if (d > __builtin_fmaf(-3.5e-6f, f, 0.5f - 2e-6f)) need |= 1u << j;
+        need[j] = d > __builtin_fmaf(-3.5e-6f, f, 0.5f - 2e-6f);
+        any = any || need[j];
     }
-    if (wave_any(need != 0)) {
+    if (wave_any(any)) {
         const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
 #pragma unroll
         for (int j = 0; j < 9; j++) {
-            if (need & (1u << j)) {
+            if (need[j]) {
                 const double x = __builtin_fabs(L.xr[lane + 64 * j]) * ostep;
                 int pp = p[j];
                 while (pp > 0 && x < T->pow_nint_tab[pp]) pp--;
