@@ -100,3 +100,20 @@ def test_full_chip_batch_with_placement_and_overlap(product, oracle, monkeypatch
         refs = list(ex.map(lambda s: oracle.encode(pcm[s], rate, kb[s], ch)[0], range(S)))
     bad = [s for s in range(S) if got[s] != refs[s]]
     assert not bad, "streams differ: %s" % bad[:10]
+
+
+def test_more_streams_than_wave_slots(product, oracle, monkeypatch):
+    """5000 mono streams: more wavefronts than the chip holds at once, so k_loop runs in rounds, late
+    wavefronts take their streams through the placement's scan path, and the census gate times out.
+    Every stream is checked."""
+    from concurrent.futures import ThreadPoolExecutor
+    monkeypatch.setenv("MP3MI_CHUNK_FRAMES", "2")
+    S, nf, rate, ch, kbps = 5000, 4, 32000, 1, 64
+    base = np.stack([product.synth(nf * 1152, ch, rate, 900 + s) for s in range(50)])
+    gains = (np.arange(S) // 50 + 1).astype(np.float64) / 100.0
+    pcm = np.round(base[np.arange(S) % 50].astype(np.float64) * gains[:, None]).astype(np.int16)
+    got = product.encode_host(pcm, rate, ch, kbps, nf)
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        refs = list(ex.map(lambda s: oracle.encode(pcm[s], rate, kbps, ch)[0], range(S)))
+    bad = [s for s in range(S) if got[s] != refs[s]]
+    assert not bad, "streams differ: %s" % bad[:10]
