@@ -88,6 +88,41 @@ def cpu_baseline(pcm_sample, rate, kbps, channels, cores):
     return frames / dt, outs
 
 
+def reference_baseline(pcm_sample, rate, kbps, channels, cores):
+    """The UNMODIFIED reference encoder (oracle/_ref/encode, compiled from /root/reference/src by
+    oracle/Makefile where the sources exist; the binary travels with the repository) on the same
+    sample, one process per stream.  Returns (frames/s, outputs) or None when the binary is absent."""
+    import struct
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "encode")
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="mp3ref_")
+    for k, p in enumerate(pcm_sample):
+        data = np.ascontiguousarray(p, dtype="<i2").tobytes()
+        with open(os.path.join(tmp, "%d.wav" % k), "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " +
+                    struct.pack("<IHHIIHH", 16, 1, channels, rate, rate * channels * 2, channels * 2, 16) + b"data" +
+                    struct.pack("<I", len(data)) + data)
+
+    def run(k):
+        args = [exe, "-s", "%g" % (rate / 1000.0), "-b", str(kbps)] + (["-m", "m"] if channels == 1 else [])
+        subprocess.run(args + [os.path.join(tmp, "%d.wav" % k), os.path.join(tmp, "%d.mp3" % k)], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return open(os.path.join(tmp, "%d.mp3" % k), "rb").read()
+
+    run(0)  # warm the page cache
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        outs = list(ex.map(run, range(len(pcm_sample))))
+    dt = time.perf_counter() - t0
+    frames = sum(len(p) // (1152 * channels) for p in pcm_sample)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return frames / dt, outs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +205,13 @@ def main():
             parity_ok = all(out_h[k, : len_h[k]].tobytes() == refs[k] for k in range(len(idx)))
             cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
                    "sample": "%d of this batch's streams x %d frames, oracle/liboracle.so, one thread per stream" % (len(idx), nf)}
+            ref = reference_baseline(pcm_sample, args.rate, args.kbps, C, cores)
+            if ref is not None:  # the reference binary itself: the baseline proper, and a second parity witness
+                rfps, routs = ref
+                parity_ok = parity_ok and all(out_h[k, : len_h[k]].tobytes() == routs[k] for k in range(len(idx)))
+                cpu = {"value": round(rfps, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
+                       "sample": "%d of this batch's streams x %d frames, oracle/_ref/encode (unmodified reference, gcc -O2), one process per stream" % (len(idx), nf),
+                       "port_value": round(fps, 1)}
         lps = launches // max(args.steps, 1)
         traffic, traffic_src = pmc_traffic("k_loop", S, nf, lps) if (args.rate, args.kbps, C) == (44100, 128, 2) else (None, None)
         result = {
