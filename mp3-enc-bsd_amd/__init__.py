@@ -29,6 +29,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise Mp3miError("libmp3mi.so not found at %s -- run __graft_entry__.build()" % LIB_PATH)
+        # PyTorch bundles its own HIP runtime.  Load torch first (when it is installed) so that this
+        # process has ONE runtime whatever the caller's import order: libmp3mi.so then binds to the
+        # already loaded libamdhip64 instead of bringing in a second one that sees no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         L.mp3mi_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
