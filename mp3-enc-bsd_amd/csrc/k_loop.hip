@@ -251,6 +251,41 @@ MP3MI_DEVFN int loop_pick(int da, int s0, int s1, int s2, int *sum)
     return choice;
 }
 
+// Cost of the pairs of lines [lo, hi) under the candidate tables of one group (descriptor dA/dB), per lane:
+// *a01 = candidate 0 | candidate 1 << 16, *a2 = third candidate.  Walks 64 pairs per step straight out of
+// L.ix.  ESC: the group's tables have linbits (x or y > 14 then costs them); NC3: it has a third candidate.
+template <bool ESC, bool NC3>
+MP3MI_DEVFN void loop_region_walk(const loop_lds &L, const unsigned *ixw, int lane, int lo, int hi, int dA, int dB, int *a01, int *a2)
+{
+    const int ylen = (dA >> 15) & 31, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
+    int s01 = 0, s2 = 0;
+    for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) {
+        const int w = w0 + lane;
+        const bool in = 2 * w < hi;
+        const unsigned xy = ixw[in ? w : 0];
+        const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
+        const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
+        const int e = L.glut[dB + xc * ylen + yc];
+        int c = (e & 31) | (((e >> 5) & 31) << 16);
+        if (ESC) c += ((x > 14) + (y > 14)) * lb01;
+        s01 += in ? c : 0;
+        if (NC3) s2 += in ? (e >> 10) & 31 : 0;
+    }
+    *a01 = s01;
+    *a2 = s2;
+}
+
+MP3MI_DEVFN void loop_region_cost(const loop_lds &L, const unsigned *ixw, int lane, int lo, int hi, int m, int dA, int dB, int *a01, int *a2)
+{
+    *a01 = 0;
+    *a2 = 0;
+    if (m == 0) return; // no table, no bits (src/loop.c:1771-1777)
+    const bool esc = (dA >> 20) != 0, nc3 = ((dA >> 10) & 31) != 0; // tables with linbits never come in threes
+    if (esc) loop_region_walk<true, false>(L, ixw, lane, lo, hi, dA, dB, a01, a2);
+    else if (nc3) loop_region_walk<false, true>(L, ixw, lane, lo, hi, dA, dB, a01, a2);
+    else loop_region_walk<false, false>(L, ixw, lane, lo, hi, dA, dB, a01, a2);
+}
+
 // calc_runlen + count1_bitcount + subdivide + bigv_tab_select + bigv_bitcount
 // (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
 // Returns the Huffman bit count and fills g.  Written branch-free over the lanes: region
@@ -417,37 +452,25 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
     // cost of every candidate over its region: per lane three 10-bit partial sums per region.  A region can
     // reach past big_values (stale or clamped addresses) and a pair of zeros still has a code length, so the
     // pricing walks to the end of the region, not only over the non-zero slots.
-    auto region_cost = [&](int lo, int hi, int m, int dA, int dB) {
-        int a = 0;
-        if (m == 0) return a;
-        const int ylen = (dA >> 15) & 31, lb = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 10);
-        for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) {
-            const int w = w0 + lane;
-            const bool in = 2 * w < hi;
-            const unsigned xy = ixw[in ? w : 0];
-            const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
-            const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
-            const int nesc = (x > 14) + (y > 14);
-            const int e = L.glut[dB + xc * ylen + yc];
-            const int c = ((e & 31) | (((e >> 5) & 31) << 10) | (((e >> 10) & 31) << 20)) + nesc * lb;
-            a += in ? c : 0;
-        }
-        return a;
-    };
-    const int acc0 = region_cost(0, a1, m0, da[0], db[0]);
-    const int acc1 = region_cost(a1, a2, m1, da[1], db[1]);
-    const int acc2 = region_cost(a2, e2, m2, da[2], db[2]);
-    // candidate sums of the three regions: fields 0/1 of each region in one word, the third candidates'
-    // fields of regions 0 and 1 share a word; five reductions in lock-step
-    int fs[5] = {(acc0 & 0x3ff) | (((acc0 >> 10) & 0x3ff) << 16), (acc1 & 0x3ff) | (((acc1 >> 10) & 0x3ff) << 16),
-                 (acc2 & 0x3ff) | (((acc2 >> 10) & 0x3ff) << 16), ((acc0 >> 20) & 0x3ff) | (((acc1 >> 20) & 0x3ff) << 16),
-                 (acc2 >> 20) & 0x3ff};
-    wave_reduce_i32<5, 0>(fs);
-    const int s2v[3] = {fs[3] & 0xffff, (fs[3] >> 16) & 0xffff, fs[4]};
+    // Per region two partial sums per lane: candidates 0 and 1 in the halves of one word (the layout the
+    // reduction wants), the third candidate -- only the groups {7,8,9} and {10,11,12} have one -- in another.
+    int s01p[3], s2p[3];
+    loop_region_cost(L, ixw, lane, 0, a1, m0, da[0], db[0], &s01p[0], &s2p[0]);
+    loop_region_cost(L, ixw, lane, a1, a2, m1, da[1], db[1], &s01p[1], &s2p[1]);
+    loop_region_cost(L, ixw, lane, a2, e2, m2, da[2], db[2], &s01p[2], &s2p[2]);
+    const bool third = (((da[0] | da[1] | da[2]) >> 10) & 31) != 0; // (descriptors of empty regions are zero)
+    int s2v[3] = {0, 0, 0};
+    if (third) { // five reductions in lock-step
+        int fs[5] = {s01p[0], s01p[1], s01p[2], s2p[0] | (s2p[1] << 16), s2p[2]};
+        wave_reduce_i32<5, 0>(fs);
+        s01p[0] = fs[0]; s01p[1] = fs[1]; s01p[2] = fs[2];
+        s2v[0] = fs[3] & 0xffff; s2v[1] = (fs[3] >> 16) & 0xffff; s2v[2] = fs[4];
+    } else
+        wave_reduce_i32<3, 0>(s01p);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         if (mx[r] == 0) continue;
-        const int s01 = fs[r];
+        const int s01 = s01p[r];
         const int s2 = ((da[r] >> 10) & 31) ? s2v[r] : 0;
         int best;
         g.table_select[r] = loop_pick(da[r], s01 & 0xffff, (s01 >> 16) & 0xffff, s2, &best);
