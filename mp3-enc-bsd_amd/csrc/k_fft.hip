@@ -207,14 +207,26 @@ MP3MI_DEVFN void fft_run(float *x, const int32_t *segs, int nseg, const uint32_t
     }
 }
 
-// energy of bin i of an N-point transform held as x (src/subs.c:53-123)
-// (x points at channel c of element 0; consecutive elements are C floats apart)
-MP3MI_DEVFN float fft_energy(const float *x, int C, int N, int i)
+// energy of bin i of an N-point transform for all C channels (src/subs.c:53-123); x points at element 0.
+// Branch-free: bins 0 and N/2 are real (their "imaginary" operand is read from a valid place and not
+// used).  The reference's floor test `(double) e < 0.0005` is the same as the float test against
+// (float) 0.0005 = 0x3a03126f, the float next ABOVE 0.0005: below it both say yes, above it both say no,
+// and at it the replacement value is e itself.
+template <int C>
+MP3MI_DEVFN fft_vec<C> fft_energy(const float *x, int N, int i)
 {
-    if (i == 0 || i == N / 2) return x[MP3MI_FFT_SWZ(i) * C] * x[MP3MI_FFT_SWZ(i) * C];
-    const float re = x[MP3MI_FFT_SWZ(i) * C], im = x[MP3MI_FFT_SWZ(N - i) * C];
-    const float e = re * re + im * im;
-    return ((double) e < 0.0005) ? (float) 0.0005 : e;
+    const bool real = (i == 0) || (i == N / 2);
+    const fft_vec<C> re = *(const fft_vec<C> *) (x + MP3MI_FFT_SWZ(i) * C);
+    const fft_vec<C> im = *(const fft_vec<C> *) (x + MP3MI_FFT_SWZ(real ? i : N - i) * C);
+    fft_vec<C> e;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const float rr = re.c[c] * re.c[c];
+        const float ee = rr + im.c[c] * im.c[c];
+        const float fl = ee < (float) 0.0005 ? (float) 0.0005 : ee;
+        e.c[c] = real ? rr : fl;
+    }
+    return e;
 }
 
 template <int C, int W>
@@ -280,15 +292,23 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
 #pragma unroll
     for (int k = 0; k < 4; k++) wsv[k] = T->window_s[lane + 64 * k];
 
-    for (int c = 0; c < C; c++) {
+    {
+        float *el0 = energy_l + rec0 * MP3MI_HBLK_P;
+#pragma unroll 3
         for (int i = lane; i < MP3MI_HBLK; i += 64) {
-            const float e = fft_energy(&L.x[c], C, 1024, i);
-            if (valid) energy_l[(rec0 + c) * MP3MI_HBLK_P + i] = e;
+            const fft_vec<C> e = fft_energy<C>(L.x, 1024, i);
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < C; c++) el0[c * MP3MI_HBLK_P + i] = e.c[c];
+            }
         }
         // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
         if (lane < 6 && valid) {
-            bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = L.x[MP3MI_FFT_SWZ(lane) * C + c];
-            bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? L.x[MP3MI_FFT_SWZ(1024 - lane) * C + c] : -0.0f;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = L.x[MP3MI_FFT_SWZ(lane) * C + c];
+                bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? L.x[MP3MI_FFT_SWZ(1024 - lane) * C + c] : -0.0f;
+            }
         }
     }
     wave_sync(); // the long spectrum is dead from here on
@@ -312,17 +332,32 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     fft_run<C, 3, 256>(&L.x[0], T->seg_s, T->n_seg_s, LL.prog_g + lane, LL.prog_r + lane);
     PROF(3);
 
-    for (int i = lane; i < C * 3 * MP3MI_HBLK_S; i += 64) {
-        const int csb = i / MP3MI_HBLK_S, k = i % MP3MI_HBLK_S, c = csb / 3, sb = csb % 3;
-        const float e = fft_energy(&L.x[sb * 256 * C + c], C, 256, k);
-        if (valid) energy_s[(rec0 + c) * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S + k] = e;
-    }
-    for (int i = lane; i < C * 150; i += 64) { // raw short lines 2..51 for k_cw (src/l3psy.c:531-549 reads these only)
-        const int csb = i / 50, n = i % 50, c = csb / 3, sb = csb % 3;
-        if (valid) {
-            float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + n) * 2;
-            o[0] = L.x[(sb * 256 + MP3MI_FFT_SWZ(2 + n)) * C + c];
-            o[1] = L.x[(sb * 256 + MP3MI_FFT_SWZ(254 - n)) * C + c];
+    // energies of the three short spectra (bin k of window sb, both channels per LDS read) and the raw
+    // short lines 2..51 for k_cw (src/l3psy.c:531-549 reads these only); plain nested loops, no div/mod
+#pragma unroll
+    for (int sb = 0; sb < 3; sb++) {
+        float *es0 = energy_s + rec0 * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S;
+        const float *xw = L.x + sb * 256 * C;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int k = lane + 64 * t;
+            if (k < MP3MI_HBLK_S) {
+                const fft_vec<C> e = fft_energy<C>(xw, 256, k);
+                if (valid) {
+#pragma unroll
+                    for (int c = 0; c < C; c++) es0[c * (3 * MP3MI_HBLK_S) + k] = e.c[c];
+                }
+            }
+        }
+        if (lane < 50 && valid) {
+            const fft_vec<C> re = *(const fft_vec<C> *) (xw + MP3MI_FFT_SWZ(2 + lane) * C);
+            const fft_vec<C> im = *(const fft_vec<C> *) (xw + MP3MI_FFT_SWZ(254 - lane) * C);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + lane) * 2;
+                o[0] = re.c[c];
+                o[1] = im.c[c];
+            }
         }
     }
     PROF(4);
