@@ -4,20 +4,27 @@
 // Replaces iteration_loop (src/loop.c:232-362) with everything below it (src/loop.c:369-2140,
 // src/pow_nint.h, src/reservoir.c) for a whole batch.  The search is serial per stream (the
 // reservoir size threads through every granule), so ONE WAVEFRONT OWNS ONE STREAM and walks its
-// frames in order; the 64 lanes share each granule's 576 lines (line i lives in lane i%64,
-// register slot i/64), all loop decisions are wave-uniform, bit counts are wave-reduced (DPP).
+// frames in order; the 64 lanes share each granule's 576 lines (line i belongs to lane i%64,
+// slot i/64), all loop decisions are wave-uniform, bit counts are wave-reduced (DPP, several
+// reductions in lock-step).  The spectrum and the quantised values live in LDS; what stays in
+// registers between passes is |xr|^(3/4) of the lane's nine lines and the per-band state.
 //
-// Order-sensitive f64 sums (band energies, noise, the 576-term sums of calc_scfsi and
-// quantanf_init) are formed by ONE lane per band in the reference's index order after the
-// terms were computed in parallel; integer work is order-free.
+// The stateless head of the loop (calc_xmin, quantanf_init, the values calc_scfsi stores) comes
+// from k_prep.  Band noise -- only ever compared with the allowed distortion -- is summed in
+// ~10-line parts by all lanes, with the reference's sequential order as the fallback when a band
+// lands within 1e-12 of its threshold.  Integer work is order-free.
+//
+// The kernel is instruction-issue-bound: what matters is the total instruction count of
+// a pass and keeping memory operations out of its dependent chain (no scratch access inside the
+// pass loops: lane-derived addresses are recomputed where used, see wave_lane_here).
 //
 // Small tables the search consults with wave-uniform indices (scalefactor band edges, Huffman
 // table geometry, the region subdivision table) live one entry per lane in registers and are
 // read with v_readlane; per-line Huffman code lengths sit in LDS; the quantiser boundary table
 // and i^(4/3) are read through L1/L2.
 //
-// HBM per (granule, channel): 4608 B xr in, 472 B psy record in, 1152 B ix out, ~54 words of
-// side information out.
+// HBM per (granule, channel): 4608 B xr in, 472 B psy record and 472 B prep record in, 1152 B ix out,
+// ~54 words of side information out.
 #include "mp3mi_host.h"
 #include "dmath.h"
 
