@@ -430,4 +430,47 @@ DM_FN double dm_atan2(double y, double x)
     return ysign ? -res : res;
 }
 
+/* Plain double-precision atan2 for finite, non-zero x and y: the same reduction (a/b <= 1, the
+ * nearest j/64, atan of the small remainder) with everything in double.  |error| < 2^-50 |result|
+ * (tests/test_dmath_host.py).  NOT correctly rounded: for callers that round the result to float and
+ * can tell when that rounding does not depend on the last bits (dm_float_rounding_safe). */
+DM_FN double dm_atan2_fast(double y, double x)
+{
+    const double ay = dm_fabs(y), ax = dm_fabs(x);
+    const int ysign = dm_bits(y) < 0, xsign = dm_bits(x) < 0, swap = ay > ax;
+    double a = swap ? ax : ay, b = swap ? ay : ax; /* a <= b */
+    const double tq = a / b;
+    double v;
+    if (tq < 0x1p-30) v = tq; /* atan t = t (1 - t^2/3 ...): below 2^-60 relative */
+    else {
+        const double jd = __builtin_rint(tq * 64.0), cj = jd * 0.015625;
+        const int j = (int) jd;
+        const long long eb = (dm_bits(b) >> 52) & 0x7ff; /* scale b to [1, 2): no overflow or underflow below */
+        const double sc = dm_from_bits((long long) (2046 - eb) << 52);
+        double u, u2, pu;
+        a *= sc;
+        b *= sc;
+        u = dm_fma(-cj, b, a) / dm_fma(cj, a, b); /* |u| <= ~1/128 */
+        u2 = u * u;
+        pu = 0x1.c71c71c71c71cp-4;
+        pu = dm_fma(pu, u2, -0x1.2492492492492p-3);
+        pu = dm_fma(pu, u2, 0.2);
+        pu = dm_fma(pu, u2, -0x1.5555555555555p-2);
+        v = DM_ATAN_J64[j][0] + (DM_ATAN_J64[j][1] + dm_fma(pu * u2, u, u));
+    }
+    if (swap) v = DM_PIO2_HI + (DM_PIO2_LO - v);
+    if (xsign) v = DM_PI_HI + (DM_PI_LO - v);
+    return ysign ? -v : v;
+}
+
+/* Does (float) v depend on more than the leading bits of v?  false when v, known to within
+ * 2^-46 |v|, lies that close to the midpoint of two floats (or outside the floats' normal range). */
+DM_FN int dm_float_rounding_safe(double v)
+{
+    const long long b = dm_bits(v) & 0x7fffffffffffffffLL;
+    const long long d = (b & 0x1fffffffLL) - 0x10000000LL;
+    if (b < 0x3810000000000000LL || b >= 0x47f0000000000000LL) return 0; /* |v| < 2^-126 or >= 2^128 (or nan) */
+    return (d < 0 ? -d : d) > 64;
+}
+
 #endif

@@ -364,21 +364,36 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     PROF_END;
 }
 
-// energy, magnitude and phase of a raw bin (src/subs.c:53-123).  Bins below the energy floor have
-// phase 0 and never reach atan2; `exact` marks the real-valued bin 0, which has no floor.
-MP3MI_DEVFN void cw_bin(float re, float im, bool exact, float *energy, float *phi)
+// energy and phase of a raw bin (src/subs.c:53-123): phi = (float) atan2(-im, re).  Bins below the energy
+// floor have phase 0 and never reach atan2; `exact` marks the real-valued bin 0, which has no floor.
+// Two tiers: the phase is only needed as a FLOAT, so a plain-double atan2 (error < 2^-50) decides it unless
+// the value lies within 2^-46 of the midpoint of two floats (dm_float_rounding_safe); then *unsafe is
+// set and the caller repeats the wavefront with the correctly rounded dm_atan2 (EXACT).
+template <bool EXACT>
+MP3MI_DEVFN void cw_bin(float re, float im, bool exact, float *energy, float *phi, bool *unsafe)
 {
     const float e = re * re + im * im;
-    const bool low = !exact && (double) e < 0.0005;
+    const bool low = !exact && e < (float) 0.0005; // == ((double) e < 0.0005), see fft_energy
     *energy = low ? (float) 0.0005 : e;
-    *phi = low ? 0.0f : (float) dm_atan2(-(double) im, (double) re);
+    float ph = 0.0f;
+    if (!low) {
+        const double y = -(double) im, x = (double) re;
+        if (EXACT || y == 0.0 || x == 0.0) ph = (float) dm_atan2(y, x);
+        else {
+            const double v = dm_atan2_fast(y, x);
+            if (!dm_float_rounding_safe(v)) *unsafe = true;
+            ph = (float) v;
+        }
+    }
+    *phi = ph;
 }
 
 // Phases and the unpredictability measure from the raw FFT bins, one wavefront per (granule, channel):
 // lanes 0..49 the unpredictability of lines 6+4n..9+4n from the three short FFTs (src/l3psy.c:531-549),
 // lanes 50..55 magnitude and phase of long lines 0..5 (src/l3psy.c:497-503).  Kept out of k_fft so that
 // this double-precision chain runs at full occupancy instead of next to 150 KB of LDS.
-__global__ void __launch_bounds__(64) k_cw(const float *__restrict__ bins, double *__restrict__ cw_mid, float *__restrict__ hist6)
+__global__ void __launch_bounds__(64) k_cw(const float *__restrict__ bins, double *__restrict__ cw_mid, float *__restrict__ hist6,
+                                          int force_exact)
 {
     const int lane = wave_lane();
     const size_t rec = blockIdx.x;
@@ -392,8 +407,15 @@ __global__ void __launch_bounds__(64) k_cw(const float *__restrict__ bins, doubl
         im[0] = b[306 + lane - 50];
     }
     float e[3], ph[3];
+    bool unsafe = force_exact != 0;
+    if (!unsafe) {
 #pragma unroll
-    for (int sb = 0; sb < 3; sb++) cw_bin(re[sb], im[sb], lane == 50 && sb == 0, &e[sb], &ph[sb]);
+        for (int sb = 0; sb < 3; sb++) cw_bin<false>(re[sb], im[sb], lane == 50 && sb == 0, &e[sb], &ph[sb], &unsafe);
+    }
+    if (wave_any(unsafe)) { // rare: some phase too close to a float midpoint for the first tier
+#pragma unroll
+        for (int sb = 0; sb < 3; sb++) cw_bin<true>(re[sb], im[sb], lane == 50 && sb == 0, &e[sb], &ph[sb], &unsafe);
+    }
     if (lane < 50) {
         const double r_prime = 2.0 * __builtin_sqrt((double) e[0]) - __builtin_sqrt((double) e[2]);
         const double phi_prime = 2.0 * (double) ph[0] - (double) ph[2];
@@ -436,5 +458,5 @@ void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t 
         const int W = 16;
         hipLaunchKernelGGL((k_fft<1, W>), dim3((unsigned) ((n_task + W - 1) / W)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
     }
-    hipLaunchKernelGGL(k_cw, dim3((unsigned) (n_task * g.channels)), dim3(64), 0, st, bins, cw_mid, hist6);
+    hipLaunchKernelGGL(k_cw, dim3((unsigned) (n_task * g.channels)), dim3(64), 0, st, bins, cw_mid, hist6, (g.test_flags >> 1) & 1);
 }

@@ -8,5 +8,7 @@ void t_dm_log_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i 
 void t_dm_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_exp(x[i]); }
 void t_dm_sin(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_sin(x[i]); }
 void t_dm_cos(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_cos(x[i]); }
+void t_dm_atan2_fast(const double *a, const double *b, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2_fast(a[i], b[i]); }
+int t_dm_float_rounding_safe(double v) { return dm_float_rounding_safe(v); }
 void t_dm_atan2(const double *a, const double *b, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2(a[i], b[i]); }
 }

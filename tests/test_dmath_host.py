@@ -87,3 +87,29 @@ def test_log_fast_error_bound(dm):
     assert (err <= 2.0 ** -50 * np.maximum(1.0, np.abs(exact))).all()
     d = ulps(fast[np.abs(exact) > 1e-2], exact[np.abs(exact) > 1e-2])
     assert d.max() <= 2
+
+
+def test_atan2_fast_error_bound_and_rounding_guard(dm):
+    """dm_atan2_fast (k_cw's first tier) stays within 2^-50 relative of the correctly rounded dm_atan2,
+    and dm_float_rounding_safe rejects every argument whose float rounding the two tiers could disagree on."""
+    rng = np.random.default_rng(14)
+    n = 1 << 20
+    a = (rng.standard_normal(n) * rng.choice([1e-6, 1e-3, 1.0, 1e3, 1e6], n)).astype(np.float32).astype(np.float64)
+    b = (rng.standard_normal(n) * rng.choice([1e-6, 1e-3, 1.0, 1e3, 1e6], n)).astype(np.float32).astype(np.float64)
+    ok = (a != 0) & (b != 0)
+    a, b = a[ok], b[ok]
+    n = len(a)
+    exact, fast = np.empty(n), np.empty(n)
+    dm.t_dm_atan2(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(exact.ctypes.data), ctypes.c_size_t(n))
+    dm.t_dm_atan2_fast(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(fast.ctypes.data), ctypes.c_size_t(n))
+    assert (np.abs(fast - exact) <= 2.0 ** -50 * np.abs(exact)).all()
+    dm.t_dm_float_rounding_safe.argtypes = [ctypes.c_double]
+    differ = np.nonzero(fast.astype(np.float32) != exact.astype(np.float32))[0]
+    for i in differ:  # wherever the float roundings differ the guard must have said "not safe"
+        assert dm.t_dm_float_rounding_safe(float(fast[i])) == 0
+    safe = np.array([dm.t_dm_float_rounding_safe(float(v)) for v in fast[:20000]])
+    assert safe.mean() > 0.999  # and it almost never cries wolf
+    # a float midpoint itself and its neighbourhood are rejected, plain floats accepted
+    f = np.float32(0.7853982)
+    mid = (float(f) + float(np.nextafter(f, np.float32(1)))) / 2
+    assert dm.t_dm_float_rounding_safe(mid) == 0 and dm.t_dm_float_rounding_safe(float(f)) == 1

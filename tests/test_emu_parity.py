@@ -63,3 +63,14 @@ def test_noise_exact_tier_matches_partial_sums(emu, oracle, monkeypatch):
     assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
     monkeypatch.setenv("MP3MI_NOISE_EXACT", "1")
     assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
+
+
+def test_phase_exact_tier_matches_fast_tier(emu, oracle, monkeypatch):
+    """k_cw takes the phases (needed as floats) from a plain-double atan2 unless a value is within 2^-46
+    of a float midpoint; forcing the correctly rounded atan2 must give the same bytes."""
+    nf, rate, ch = 6, 44100, 2
+    pcm = np.stack([emu.synth(nf * 1152, ch, rate, 95 + s) for s in range(2)])
+    ref = [oracle.encode(pcm[s], rate, 128, ch)[0] for s in range(2)]
+    assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
+    monkeypatch.setenv("MP3MI_PHASE_EXACT", "1")
+    assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
