@@ -117,3 +117,22 @@ def test_more_streams_than_wave_slots(product, oracle, monkeypatch):
         refs = list(ex.map(lambda s: oracle.encode(pcm[s], rate, kbps, ch)[0], range(S)))
     bad = [s for s in range(S) if got[s] != refs[s]]
     assert not bad, "streams differ: %s" % bad[:10]
+
+
+def test_output_independent_of_schedule(product, monkeypatch):
+    """The whole chip's worth of streams under two different schedules (chunking, gate and placement on /
+    off): identical bytes.  A race between the front stream's and the loop stream's kernels, or a stream
+    taken twice by the placement, would show up as a difference (tools/determinism_check.py does the same
+    at 4096 x 96)."""
+    S, nf, rate, ch = 4096, 10, 44100, 2
+    base = np.stack([product.synth(nf * 1152, ch, rate, 1200 + s) for s in range(64)])
+    gains = (np.arange(S) // 64 + 1).astype(np.float64) / 64.0
+    pcm = np.round(base[np.arange(S) % 64].astype(np.float64) * gains[:, None]).astype(np.int16)
+    monkeypatch.setenv("MP3MI_CHUNK_FRAMES", "3")
+    a = product.encode_host(pcm, rate, ch, 128, nf)
+    b = product.encode_host(pcm, rate, ch, 128, nf)
+    monkeypatch.setenv("MP3MI_CHUNK_FRAMES", "4")
+    monkeypatch.setenv("MP3MI_NO_GATE", "1")
+    monkeypatch.setenv("MP3MI_NO_PLACE", "1")
+    c = product.encode_host(pcm, rate, ch, 128, nf)
+    assert a == b and a == c
