@@ -155,6 +155,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     { const char *e = getenv("MP3MI_PREP_EXACT"); b->prep_exact = (e && atoi(e)) ? 1 : 0; }
     { const char *e = getenv("MP3MI_NOISE_EXACT"); b->test_flags = (e && atoi(e)) ? 1 : 0; }
     { const char *e = getenv("MP3MI_PHASE_EXACT"); if (e && atoi(e)) b->test_flags |= 2; }
+    { const char *e = getenv("MP3MI_PSY_EXACT"); if (e && atoi(e)) b->test_flags |= 4; }
     b->hdr_flags = 0;
     b->gate_count = NULL; b->gate_total = 0;
     {

@@ -246,6 +246,25 @@ DM_FN double dm_exp(double x)
     return ((res.hi + res.lo) * 0x1p-600) * scale;
 }
 
+/* Plain double-precision exp for |x| < 700: the same reduction and table as dm_exp, everything after it
+ * in double.  |error| < 2^-50 relative (tests/test_dmath_host.py).  NOT correctly rounded: for callers
+ * that round a product with the result to float behind dm_float_rounding_safe_ulps (k_psy.hip). */
+DM_FN double dm_exp_fast(double x)
+{
+    const double kd = __builtin_rint(x * DM_INV_L64);
+    const long long k = (long long) kd;
+    const int j = (int) (k & 63), qe = (int) ((k - j) / 64);
+    /* r = x - k*ln2/64: the first product is exact (36-bit constant, |k| < 2^17) */
+    const double r = dm_fma(-kd, DM_L64_MID, dm_fma(-kd, DM_L64_HI, x));
+    double q = 0x1.6c16c16c16c17p-10;         /* 1/6! */
+    q = dm_fma(q, r, 0x1.1111111111111p-7);  /* 1/5! */
+    q = dm_fma(q, r, 0x1.5555555555555p-5);  /* 1/4! */
+    q = dm_fma(q, r, 0x1.5555555555555p-3);  /* 1/3! */
+    q = dm_fma(q, r, 0.5);
+    q = dm_fma(q * r, r, r);                  /* e^r - 1, |r| <= 0.0055: truncation < 2^-60 */
+    return dm_fma(DM_EXP2_64[j][0], q, DM_EXP2_64[j][1] + DM_EXP2_64[j][0]) * dm_from_bits((long long) (qe + 1023) << 52);
+}
+
 /* ------------------------------------------------------------- sin / cos */
 /* reduce x to r in [-pi/4, pi/4] (double-double) and quadrant n; |x| < 2^20 */
 DM_FN int dm_rem_pio2(double x, dm_dd *r)
@@ -465,12 +484,13 @@ DM_FN double dm_atan2_fast(double y, double x)
 
 /* Does (float) v depend on more than the leading bits of v?  false when v, known to within
  * 2^-46 |v|, lies that close to the midpoint of two floats (or outside the floats' normal range). */
-DM_FN int dm_float_rounding_safe(double v)
+DM_FN int dm_float_rounding_safe_ulps(double v, long long ulps) /* ulps of v (2^-52 relative) that v may be off by */
 {
     const long long b = dm_bits(v) & 0x7fffffffffffffffLL;
     const long long d = (b & 0x1fffffffLL) - 0x10000000LL;
     if (b < 0x3810000000000000LL || b >= 0x47f0000000000000LL) return 0; /* |v| < 2^-126 or >= 2^128 (or nan) */
-    return (d < 0 ? -d : d) > 64;
+    return (d < 0 ? -d : d) > ulps;
 }
+DM_FN int dm_float_rounding_safe(double v) { return dm_float_rounding_safe_ulps(v, 64); }
 
 #endif

@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
                                             mp3mi_psy_state *__restrict__ state, mp3mi_psy_out *__restrict__ out)
 {
     __shared__ psy_lds L;
+    const bool psy_exact = (geo.test_flags & 4) != 0; // MP3MI_PSY_EXACT=1: thresholds from dm_log / dm_exp only (tests)
     const int lane = wave_lane();
     const int C = geo.channels, G = geo.n_gran;
     const int ch = (int) blockIdx.x % C, s = (int) blockIdx.x / C;
@@ -197,10 +198,10 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
         __syncthreads();
 
         double thr = 0.0, ebv = 0.0;
+        // spreading (src/l3psy.c:586-605, 1062-1084)
+        float ecb = 0.0f;
+        double ctb = 0.0;
         if (b < MP3MI_CBANDS) {
-            // spreading (src/l3psy.c:586-605, 1062-1084)
-            float ecb = 0.0f;
-            double ctb = 0.0;
             for (int k = s3lo; k <= s3hi; k++) {
                 const double sv = T->s3_l[b][k];
                 if (sparse || sv != 1.0) {
@@ -208,20 +209,35 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
                     ctb = ctb + sv * (double) L.cb[k];
                 }
             }
-            // tonality, SNR, threshold (src/l3psy.c:610-636)
-            double cbb, tbb, snr;
-            if ((double) ecb != 0.0) {
-                cbb = ctb / (double) ecb;
-                if (cbb < 0.01) cbb = 0.01;
-                cbb = dm_log(cbb);
-            } else
-                cbb = 0.0;
-            tbb = -0.299 - 0.43 * cbb;
-            tbb = (0.0 > tbb) ? 0.0 : tbb;
-            tbb = (1.0 < tbb) ? 1.0 : tbb;
-            snr = 29.0 * tbb + 6.0 * (1.0 - tbb);
-            snr = (minval > snr) ? minval : snr;
-            const float nb = (float) (((double) ecb * norm_l) * dm_exp(-snr * R_LN_TO_LOG10));
+        }
+        // tonality, SNR, threshold (src/l3psy.c:610-636).  Only nb -- a FLOAT -- leaves this block, so the
+        // log and the exp are first taken in plain double: log off by < 2^-50 max(1,|log|) (|log| < 4.7)
+        // moves tbb by < 2^-48.9, snr by < 2^-44.3, the exponent by < 2^-46.4, and the product with
+        // exp (itself < 2^-50) by < 2^-45.9 relative; unless it lies within 2^-44 (256 ulps) of the midpoint
+        // of two floats, nb is decided.  Otherwise the wavefront repeats the block with dm_log / dm_exp.
+        float nb = 0.0f;
+        for (int tier = psy_exact ? 1 : 0; tier < 2; tier++) {
+            double pr = 0.0;
+            if (b < MP3MI_CBANDS) {
+                double cbb, tbb, snr;
+                if ((double) ecb != 0.0) {
+                    cbb = ctb / (double) ecb;
+                    if (cbb < 0.01) cbb = 0.01;
+                    cbb = tier ? dm_log(cbb) : dm_log_fast(cbb);
+                } else
+                    cbb = 0.0;
+                tbb = -0.299 - 0.43 * cbb;
+                tbb = (0.0 > tbb) ? 0.0 : tbb;
+                tbb = (1.0 < tbb) ? 1.0 : tbb;
+                snr = 29.0 * tbb + 6.0 * (1.0 - tbb);
+                snr = (minval > snr) ? minval : snr;
+                const double arg = -snr * R_LN_TO_LOG10;
+                pr = ((double) ecb * norm_l) * (tier ? dm_exp(arg) : dm_exp_fast(arg));
+                nb = (float) pr;
+            }
+            if (tier == 0 && !wave_any(pr != 0.0 && !dm_float_rounding_safe_ulps(pr, 256))) break;
+        }
+        if (b < MP3MI_CBANDS) {
             const double a2 = 2.0 * nb_1, a16 = 16.0 * nb_2;
             const double inner = (a2 < a16) ? a2 : a16;
             const double t1 = ((double) nb < inner) ? (double) nb : inner;

@@ -5,6 +5,7 @@
 extern "C" {
 void t_dm_log(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_log(x[i]); }
 void t_dm_log_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_log_fast(x[i]); }
+void t_dm_exp_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_exp_fast(x[i]); }
 void t_dm_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_exp(x[i]); }
 void t_dm_sin(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_sin(x[i]); }
 void t_dm_cos(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_cos(x[i]); }

@@ -113,3 +113,11 @@ def test_atan2_fast_error_bound_and_rounding_guard(dm):
     f = np.float32(0.7853982)
     mid = (float(f) + float(np.nextafter(f, np.float32(1)))) / 2
     assert dm.t_dm_float_rounding_safe(mid) == 0 and dm.t_dm_float_rounding_safe(float(f)) == 1
+
+
+def test_exp_fast_error_bound(dm):
+    """dm_exp_fast (k_psy's first tier) stays within 2^-50 relative of the correctly rounded dm_exp."""
+    rng = np.random.default_rng(15)
+    x = np.concatenate([rng.uniform(-60, 60, 1 << 20), rng.uniform(-8, 0, 1 << 18), np.arange(-64, 65) * (np.log(2) / 64)])
+    exact, fast = call1(dm, "exp", x), call1(dm, "exp_fast", x)
+    assert (np.abs(fast - exact) <= 2.0 ** -50 * exact).all()

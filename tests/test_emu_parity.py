@@ -74,3 +74,14 @@ def test_phase_exact_tier_matches_fast_tier(emu, oracle, monkeypatch):
     assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
     monkeypatch.setenv("MP3MI_PHASE_EXACT", "1")
     assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
+
+
+def test_psy_exact_tier_matches_fast_tier(emu, oracle, monkeypatch):
+    """k_psy takes the masking threshold nb (a float) from plain-double log / exp unless the product lies within
+    2^-44 of a float midpoint; forcing dm_log / dm_exp must give the same bytes."""
+    nf, rate, ch = 6, 48000, 2
+    pcm = np.stack([emu.synth(nf * 1152, ch, rate, 97 + s) for s in range(2)])
+    ref = [oracle.encode(pcm[s], rate, 128, ch)[0] for s in range(2)]
+    assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
+    monkeypatch.setenv("MP3MI_PSY_EXACT", "1")
+    assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
