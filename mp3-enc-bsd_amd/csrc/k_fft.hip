@@ -4,8 +4,10 @@
 // Replaces fft()/rsfft()/enphinew() (src/subs.c:38-123, 412-534) and src/l3psy.c:477-549 for
 // every (stream, granule, channel) of a chunk at once; one wavefront per (granule, channel).
 // The FFT arithmetic is single precision with the reference's exact butterfly DAG: the
-// recursion is flattened on the host (tables_host.cpp) into barrier-separated segments of
-// independent butterflies which the 64 lanes execute from LDS.
+// recursion is flattened on the host (tables_host.cpp) into rounds of 64 independent FUSED
+// butterflies -- steps 1-4 of one recursion level for one index, 4 or 8 operands -- which the
+// lanes execute from LDS; the data movement the reference ends with (step 5, bit reversal) is
+// folded into the read-out.
 //
 // Output per (granule, channel), consumed by k_psy:
 //   energy_l[513] f32, energy_s[3][129] f32, cw_mid[50] f64 (cw of lines 6+4n..9+4n),
@@ -30,194 +32,137 @@ __device__ unsigned long long g_fft_prof[8];
 #endif
 
 // One wavefront transforms all C channels of a granule: every butterfly record is fetched once
-// and applied to the C channels of the long (then of the three short) transforms, which also gives
-// each lane C independent dependency chains.
-// A workgroup is W such wavefronts (W granules) sharing ONE copy of the butterfly program in LDS:
-// a record costs an LDS read instead of an L2 round trip per round, which is what the transform
-// was waiting on when the program lived in global memory.
-// Element e of the long transform is the C floats at x[e * C] (the channels of one position side by
-// side), element e of short window sb those at x[(sb * 256 + e) * C]: a butterfly fetches and stores
-// both channels of an operand with one 8-byte LDS access instead of two 4-byte ones.  The short windows
-// reuse the space once the long spectrum is consumed.
+// and applied to the C channels, which also gives each lane C independent dependency chains.
+// A workgroup is W such wavefronts (W granules) sharing ONE copy of the butterfly program in LDS.
+// Element e of an array is the C floats at x[e * C] (the channels of one position side by side): a
+// butterfly fetches and stores both channels of an operand with one 8-byte LDS access.  The three short
+// transforms are one program over elements [256 sb, 256 sb + 256) and reuse the space once the long
+// spectrum is consumed; elements 1024 + lane are what idle lanes work on.
 template <int C> struct fft_wave_lds {
-    float x[C * 1024];
+    float x[C * (MP3MI_FFT_DUMMY + 64)];
 };
 template <int C> struct fft_vec;
 template <> struct fft_vec<1> { float c[1]; };
 template <> struct __attribute__((aligned(8))) fft_vec<2> { float c[2]; };
 template <int C, int W> struct fft_lds {
-    uint32_t prog_g[64 * (MP3MI_FFT_GROUNDS_L + 2)]; // + two rounds that are read ahead but never used
-    uint4 prog_r[64 * (MP3MI_FFT_RROUNDS_L + 1)];
+    uint32_t prog[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16)));
     fft_wave_lds<C> w[W];
 };
 
-// A butterfly is applied in two steps -- fetch the operands of all arrays, then compute and store --
-// so that the rounds of a segment (which are independent of each other) can be taken two at a time:
-// both rounds' LDS reads are in flight together and only one LDS latency is exposed per pair.
-struct fft_idx { int a, b, c, d; bool on; };
-
-template <int TYPE>
-MP3MI_DEVFN fft_idx fft_decode(uint32_t w0, uint32_t w1)
+// operand k of a record word: LDS element position in its low / high half
+template <int C> MP3MI_DEVFN fft_vec<C> *fft_at(float *x, uint32_t w, int hi)
 {
-    // operand indices are LDS positions (MP3MI_FFT_SWZ applied on the host); an idle lane (bit 31)
-    // decodes to position 0, reads it and stores nothing
-    fft_idx i;
-    i.on = !(w0 >> 31);
-    i.c = 0; i.d = 0;
-    if (TYPE == FOP_ROT) {
-        i.a = (int) (w0 & 0x3ffu); i.b = (int) ((w0 >> 16) & 0x3ffu);
-    } else {
-        i.a = (int) (w0 & 1023u); i.b = (int) ((w0 >> 10) & 1023u);
-        if (TYPE == FOP_CROSS) { i.c = (int) (w1 & 1023u); i.d = (int) ((w1 >> 10) & 1023u); }
-    }
-    return i;
+    return (fft_vec<C> *) (x + (hi ? (w >> 16) : (w & 0xffffu)) * C);
 }
 
-// NWIN transforms of N points with C channels each (layout above)
-template <int TYPE, int C, int NWIN, int N>
-MP3MI_DEVFN void fft_fetch(const float *x, const fft_idx &i, fft_vec<C> (&v)[NWIN][4])
+// twiddle stage of a fused butterfly on (r, i) (src/subs.c:330-339, 487-495): flags bit 0 rotates by
+// (cn, spcn, smcn), bit 1 by SQHALF -- `second` is the form the reference uses for the pair (xr2, xi2)
+template <bool ROT>
+MP3MI_DEVFN void fft_twiddle(float &r, float &i, uint32_t flags, bool has_sq, bool second, float cn, float spc, float smc)
 {
+    const float r1 = r, i1 = i;
+    if (ROT) {
+        const float t2 = cn * (r1 + i1);
+        const float t1 = spc * r1 + t2;
+        const float ra = smc * i1 + t2;
+        r = (flags & 1u) ? ra : r1;
+        i = (flags & 1u) ? t1 : i1;
+    }
+    if (has_sq) { // wave-uniform
+        const float sum = r1 + i1, dif = i1 - r1;
+        const float qa = second ? (float) (R_SQHALF * (double) dif) : (float) (R_SQHALF * (double) sum);
+        const float qb = second ? (float) (-R_SQHALF * (double) sum) : (float) (R_SQHALF * (double) dif);
+        r = (flags & 2u) ? qa : r;
+        i = (flags & 2u) ? qb : i;
+    }
+}
+
+// one round of four-operand butterflies (tables_host.cpp, FusedOp cls 0); blk = this lane's view of the round's blocks
+template <int C, bool ROT>
+MP3MI_DEVFN void fft_round_r(float *x, const uint32_t *blk, int lane, bool has_sq)
+{
+    const uint2 ad = *(const uint2 *) (blk + 2 * lane);
+    uint4 tw = {0, 0, 0, 0};
+    if (ROT) tw = *(const uint4 *) (blk + 128 + 4 * lane);
+    else tw.w = blk[128 + lane];
+    fft_vec<C> *pa = fft_at<C>(x, ad.x, 0), *pb = fft_at<C>(x, ad.x, 1), *pc = fft_at<C>(x, ad.y, 0), *pd = fft_at<C>(x, ad.y, 1);
+    const fft_vec<C> a = *pa, b = *pb, c = *pc, d = *pd;
+    fft_vec<C> oa, ob, oc, od;
+    const uint32_t flags = tw.w, neg = flags & 0x80000000u;
 #pragma unroll
-    for (int w = 0; w < NWIN; w++) {
-        const float *p = x + w * N * C;
-        v[w][0] = *(const fft_vec<C> *) (p + i.a * C);
-        if (TYPE != FOP_NEG) v[w][1] = *(const fft_vec<C> *) (p + i.b * C);
-        if (TYPE == FOP_CROSS) { v[w][2] = *(const fft_vec<C> *) (p + i.c * C); v[w][3] = *(const fft_vec<C> *) (p + i.d * C); }
+    for (int ch = 0; ch < C; ch++) {
+        oa.c[ch] = a.c[ch] + b.c[ch];
+        oc.c[ch] = c.c[ch] + d.c[ch];
+        float u1 = a.c[ch] - b.c[ch];
+        float u2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, c.c[ch] - d.c[ch]) ^ neg); // src/subs.c:475-479
+        fft_twiddle<ROT>(u1, u2, flags, has_sq, false, __builtin_bit_cast(float, tw.x), __builtin_bit_cast(float, tw.y), __builtin_bit_cast(float, tw.z));
+        ob.c[ch] = u1;
+        od.c[ch] = u2;
     }
+    *pa = oa; *pb = ob; *pc = oc; *pd = od;
 }
 
-template <int TYPE, int C, int NWIN, int N>
-MP3MI_DEVFN void fft_finish(float *x, const fft_idx &i, const fft_vec<C> (&v)[NWIN][4], uint32_t w1, uint32_t w2, uint32_t w3)
+// one round of eight-operand butterflies (FusedOp cls 1): steps 1-4 of srrec for one n
+template <int C, bool ROT>
+MP3MI_DEVFN void fft_round_c(float *x, const uint32_t *blk, int lane, bool has_sq)
 {
-    if (!i.on) return;
+    const uint4 ad = *(const uint4 *) (blk + 4 * lane);
+    uint4 tw1 = {0, 0, 0, 0}, tw3 = {0, 0, 0, 0};
+    if (ROT) { tw1 = *(const uint4 *) (blk + 256 + 4 * lane); tw3 = *(const uint4 *) (blk + 512 + 4 * lane); }
+    else tw1.w = blk[256 + lane];
+    fft_vec<C> *p0 = fft_at<C>(x, ad.x, 0), *p1 = fft_at<C>(x, ad.x, 1), *p2 = fft_at<C>(x, ad.y, 0), *p3 = fft_at<C>(x, ad.y, 1);
+    fft_vec<C> *p4 = fft_at<C>(x, ad.z, 0), *p5 = fft_at<C>(x, ad.z, 1), *p6 = fft_at<C>(x, ad.w, 0), *p7 = fft_at<C>(x, ad.w, 1);
+    const fft_vec<C> ar0 = *p0, ar1 = *p1, br0 = *p2, br1 = *p3, ai0 = *p4, ai1 = *p5, bi0 = *p6, bi1 = *p7;
+    fft_vec<C> o0, o1, o2, o3, o4, o5, o6, o7;
+    const uint32_t flags = tw1.w;
 #pragma unroll
-    for (int w = 0; w < NWIN; w++) {
-        float *p = x + w * N * C;
-        fft_vec<C> oa, ob, oc, od;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            const float va = v[w][0].c[c], vb = v[w][1].c[c];
-            if (TYPE == FOP_ADDSUB) {
-                ob.c[c] = va - vb;
-                oa.c[c] = va + vb;
-            } else if (TYPE == FOP_NEG) {
-                oa.c[c] = -va;
-            } else if (TYPE == FOP_CROSS) {
-                const float r1 = va, r2 = vb, i1 = v[w][2].c[c], i2 = v[w][3].c[c];
-                oc.c[c] = i1 - r2;
-                ob.c[c] = r1 - i2;
-                oa.c[c] = r1 + i2;
-                od.c[c] = i1 + r2;
-            } else if (TYPE == FOP_ROT) {
-                const float cn = __builtin_bit_cast(float, w1), spc = __builtin_bit_cast(float, w2), smc = __builtin_bit_cast(float, w3);
-                const float r1 = va, i1 = vb;
-                const float t2 = cn * (r1 + i1);
-                const float t1 = spc * r1 + t2;
-                oa.c[c] = smc * i1 + t2;
-                ob.c[c] = t1;
-            } else if (TYPE == FOP_SQ1) {
-                oa.c[c] = (float) (R_SQHALF * (double) (va + vb));
-                ob.c[c] = (float) (R_SQHALF * (double) (vb - va));
-            } else if (TYPE == FOP_SQ2) {
-                oa.c[c] = (float) (R_SQHALF * (double) (vb - va));
-                ob.c[c] = (float) (-R_SQHALF * (double) (va + vb));
-            } else if (TYPE == FOP_SWAPNN) {
-                oa.c[c] = -vb;
-                ob.c[c] = -va;
-            } else if (TYPE == FOP_SWAPN) {
-                oa.c[c] = -vb;
-                ob.c[c] = va;
-            } else { // FOP_SWAP
-                oa.c[c] = vb;
-                ob.c[c] = va;
-            }
-        }
-        *(fft_vec<C> *) (p + i.a * C) = oa;
-        if (TYPE != FOP_NEG) *(fft_vec<C> *) (p + i.b * C) = ob;
-        if (TYPE == FOP_CROSS) { *(fft_vec<C> *) (p + i.c * C) = oc; *(fft_vec<C> *) (p + i.d * C) = od; }
+    for (int ch = 0; ch < C; ch++) {
+        // step 1 (src/subs.c:288-298)
+        o0.c[ch] = ar0.c[ch] + ar1.c[ch];
+        o2.c[ch] = br0.c[ch] + br1.c[ch];
+        o4.c[ch] = ai0.c[ch] + ai1.c[ch];
+        o6.c[ch] = bi0.c[ch] + bi1.c[ch];
+        const float xr1 = ar0.c[ch] - ar1.c[ch], xr2 = br0.c[ch] - br1.c[ch];
+        const float xi1 = ai0.c[ch] - ai1.c[ch], xi2 = bi0.c[ch] - bi1.c[ch];
+        // step 2 (src/subs.c:301-312)
+        float r1 = xr1 + xi2, i2 = xi1 + xr2, i1 = xi1 - xr2, r2 = xr1 - xi2;
+        // steps 3 and 4 (src/subs.c:327-342)
+        fft_twiddle<ROT>(r1, i1, flags, has_sq, false, __builtin_bit_cast(float, tw1.x), __builtin_bit_cast(float, tw1.y), __builtin_bit_cast(float, tw1.z));
+        fft_twiddle<ROT>(r2, i2, flags, has_sq, true, __builtin_bit_cast(float, tw3.x), __builtin_bit_cast(float, tw3.y), __builtin_bit_cast(float, tw3.z));
+        o1.c[ch] = r1; o3.c[ch] = r2; o5.c[ch] = i1; o7.c[ch] = i2;
     }
+    *p0 = o0; *p1 = o1; *p2 = o2; *p3 = o3; *p4 = o4; *p5 = o5; *p6 = o6; *p7 = o7;
 }
 
-// The butterfly records are two streams (one-word records; 16-byte rotation records) laid out in
-// rounds of 64, one record per lane, idle lanes marked by bit 31 (tables_host.cpp).  pg/pr point at
-// this lane's record of the segment's first round and are left at the next segment's.  The records
-// of the following pair of rounds are read while the current pair's operands are in flight.
-template <int TYPE, int C, int NWIN, int N>
-MP3MI_DEVFN void fft_segment(float *x, const uint32_t *&pg, const uint4 *&pr, int rounds)
-{
-    const int gstep = (TYPE == FOP_CROSS) ? 128 : 64; // FOP_CROSS: the round's second words follow its first words
-    uint4 c0 = {0x80000000u, 0, 0, 0}, c1 = c0;
-    if (TYPE == FOP_ROT) { c0 = pr[0]; if (rounds > 1) c1 = pr[64]; }
-    else {
-        c0.x = pg[0];
-        if (TYPE == FOP_CROSS) c0.y = pg[64];
-        if (rounds > 1) { c1.x = pg[gstep]; if (TYPE == FOP_CROSS) c1.y = pg[gstep + 64]; }
-    }
-    int t = 0;
-    for (; t + 1 < rounds; t += 2) {
-        const fft_idx i0 = fft_decode<TYPE>(c0.x, c0.y), i1 = fft_decode<TYPE>(c1.x, c1.y);
-        fft_vec<C> v0[NWIN][4], v1[NWIN][4];
-        fft_fetch<TYPE, C, NWIN, N>(x, i0, v0);
-        fft_fetch<TYPE, C, NWIN, N>(x, i1, v1);
-        uint4 n0 = {0x80000000u, 0, 0, 0}, n1 = n0;
-        if (TYPE == FOP_ROT) {
-            pr += 128;
-            if (t + 2 < rounds) { n0 = pr[0]; n1 = pr[64]; } // the second may belong to what follows: never used then
-        } else {
-            pg += 2 * gstep;
-            if (t + 2 < rounds) {
-                n0.x = pg[0]; n1.x = pg[gstep];
-                if (TYPE == FOP_CROSS) { n0.y = pg[64]; n1.y = pg[gstep + 64]; }
-            }
-        }
-        fft_finish<TYPE, C, NWIN, N>(x, i0, v0, c0.y, c0.z, c0.w);
-        fft_finish<TYPE, C, NWIN, N>(x, i1, v1, c1.y, c1.z, c1.w);
-        c0 = n0;
-        c1 = n1;
-    }
-    if (t < rounds) { // odd round count: the last round alone
-        const fft_idx i0 = fft_decode<TYPE>(c0.x, c0.y);
-        fft_vec<C> v0[NWIN][4];
-        fft_fetch<TYPE, C, NWIN, N>(x, i0, v0);
-        fft_finish<TYPE, C, NWIN, N>(x, i0, v0, c0.y, c0.z, c0.w);
-        if (TYPE == FOP_ROT) pr += 64; else pg += gstep;
-    }
-}
-
-template <int C, int NWIN, int N>
-MP3MI_DEVFN void fft_run(float *x, const int32_t *segs, int nseg, const uint32_t *pg, const uint4 *pr)
-{
-    int nxt = segs[0];
-    for (int sidx = 0; sidx < nseg; sidx++) {
-        const int sw = nxt;
-        nxt = segs[sidx + 1 < nseg ? sidx + 1 : sidx];
-        const int type = sw & 0xff, rounds = (sw >> 8) & 0xff;
-        switch (type) {
-        case FOP_ADDSUB: fft_segment<FOP_ADDSUB, C, NWIN, N>(x, pg, pr, rounds); break;
-        case FOP_NEG: fft_segment<FOP_NEG, C, NWIN, N>(x, pg, pr, rounds); break;
-        case FOP_CROSS: fft_segment<FOP_CROSS, C, NWIN, N>(x, pg, pr, rounds); break;
-        case FOP_ROT: fft_segment<FOP_ROT, C, NWIN, N>(x, pg, pr, rounds); break;
-        case FOP_SQ1: fft_segment<FOP_SQ1, C, NWIN, N>(x, pg, pr, rounds); break;
-        case FOP_SQ2: fft_segment<FOP_SQ2, C, NWIN, N>(x, pg, pr, rounds); break;
-        case FOP_SWAPNN: fft_segment<FOP_SWAPNN, C, NWIN, N>(x, pg, pr, rounds); break;
-        case FOP_SWAPN: fft_segment<FOP_SWAPN, C, NWIN, N>(x, pg, pr, rounds); break;
-        default: fft_segment<FOP_SWAP, C, NWIN, N>(x, pg, pr, rounds); break;
-        }
-        if (sw >> 16) wave_sync();
-    }
-}
-
-// energy of bin i of an N-point transform for all C channels (src/subs.c:53-123); x points at element 0.
-// Branch-free: bins 0 and N/2 are real (their "imaginary" operand is read from a valid place and not
-// used).  The reference's floor test `(double) e < 0.0005` is the same as the float test against
-// (float) 0.0005 = 0x3a03126f, the float next ABOVE 0.0005: below it both say yes, above it both say no,
-// and at it the replacement value is e itself.
 template <int C>
-MP3MI_DEVFN fft_vec<C> fft_energy(const float *x, int N, int i)
+MP3MI_DEVFN void fft_run(float *x, const uint32_t *hdr, int nround, const uint32_t *prog, int lane)
 {
-    const bool real = (i == 0) || (i == N / 2);
-    const fft_vec<C> re = *(const fft_vec<C> *) (x + MP3MI_FFT_SWZ(i) * C);
-    const fft_vec<C> im = *(const fft_vec<C> *) (x + MP3MI_FFT_SWZ(real ? i : N - i) * C);
+    uint32_t nxt = hdr[0];
+    for (int r = 0; r < nround; r++) {
+        const uint32_t h = nxt;
+        nxt = hdr[r + 1 < nround ? r + 1 : r];
+        const bool has_sq = (h & 4u) != 0;
+        switch (h & 3u) {
+        case 0: fft_round_r<C, false>(x, prog, lane, has_sq); prog += 128 + 64; break;
+        case 2: fft_round_r<C, true>(x, prog, lane, has_sq); prog += 128 + 256; break;
+        case 1: fft_round_c<C, false>(x, prog, lane, has_sq); prog += 256 + 64; break;
+        default: fft_round_c<C, true>(x, prog, lane, has_sq); prog += 256 + 512; break;
+        }
+        if (h & 8u) wave_sync();
+    }
+}
+
+// energy of a bin for all C channels (src/subs.c:53-123); x points at element 0 of the transform and rd is
+// the bin's read-out word (fft_rd_*: where its real and imaginary part ended up).  Branch-free: bins 0 and
+// N/2 are real (`real`; their "imaginary" operand is the real one again and not used).  The reference's
+// floor test `(double) e < 0.0005` is the same as the float test against (float) 0.0005 = 0x3a03126f, the
+// float next ABOVE 0.0005: below it both say yes, above it both say no, and at it the replacement value is
+// e itself.  Signs do not matter here.
+template <int C>
+MP3MI_DEVFN fft_vec<C> fft_energy(const float *x, uint32_t rd, bool real)
+{
+    const fft_vec<C> re = *(const fft_vec<C> *) (x + (rd & 0x7fffu) * C);
+    const fft_vec<C> im = *(const fft_vec<C> *) (x + ((rd >> 16) & 0x7fffu) * C);
     fft_vec<C> e;
 #pragma unroll
     for (int c = 0; c < C; c++) {
@@ -227,6 +172,19 @@ MP3MI_DEVFN fft_vec<C> fft_energy(const float *x, int N, int i)
         e.c[c] = real ? rr : fl;
     }
     return e;
+}
+
+// raw value of a bin with the sign the reference's step 5 leaves it with (src/subs.c:506-523)
+template <int C>
+MP3MI_DEVFN void fft_bin(const float *x, uint32_t rd, fft_vec<C> *re, fft_vec<C> *im)
+{
+    *re = *(const fft_vec<C> *) (x + (rd & 0x7fffu) * C);
+    *im = *(const fft_vec<C> *) (x + ((rd >> 16) & 0x7fffu) * C);
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        re->c[c] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, re->c[c]) ^ ((rd & 0x8000u) << 16));
+        im->c[c] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, im->c[c]) ^ (rd & 0x80000000u));
+    }
 }
 
 template <int C, int W>
@@ -250,8 +208,10 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     const long t0 = 576 * gabs - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
     PROF_DECL;
 
-    for (int i = tid; i < 64 * MP3MI_FFT_GROUNDS_L; i += 64 * W) LL.prog_g[i] = T->gops_l[i];
-    for (int i = tid; i < 64 * MP3MI_FFT_RROUNDS_L; i += 64 * W) LL.prog_r[i] = ((const uint4 *) T->rops_l)[i];
+    {
+        const int nw4 = T->fft_nword_l / 4;
+        for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = ((const uint4 *) T->fft_prog_l)[i];
+    }
 
     // the 1024-sample window of all channels: every load is issued before the first use
     {
@@ -266,24 +226,25 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             wl[k] = T->window[lane + 64 * k];
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++)
+        for (int k = 0; k < 16; k++) {
+            fft_vec<C> v;
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
-                L.x[MP3MI_FFT_SWZ(lane + 64 * k) * C + c] = wl[k] * v; // src/l3psy.c:485
-            }
+            for (int c = 0; c < C; c++)
+                v.c[c] = wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16)); // src/l3psy.c:485
+            *(fft_vec<C> *) (L.x + MP3MI_FFT_SWZ(lane + 64 * k) * C) = v;
+        }
     }
     __syncthreads();
     PROF(0);
 
-    fft_run<C, 1, 1024>(&L.x[0], T->seg_l, T->n_seg_l, LL.prog_g + lane, LL.prog_r + lane);
+    fft_run<C>(&L.x[0], T->fft_hdr_l, T->fft_nround_l, LL.prog, lane);
     PROF(1);
 
     // the short windows' samples are requested now and land while the long spectrum is consumed
-    uint32_t smp[12];
+    uint32_t smp[8];
     float wsv[4];
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
+    for (int k = 0; k < 8; k++) {
         const long t = t0 + 256 + lane + 64 * k;
         const bool in = t >= 0 && t < n_per_ch;
         if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : 0u;
@@ -296,7 +257,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         float *el0 = energy_l + rec0 * MP3MI_HBLK_P;
 #pragma unroll 3
         for (int i = lane; i < MP3MI_HBLK; i += 64) {
-            const fft_vec<C> e = fft_energy<C>(L.x, 1024, i);
+            const fft_vec<C> e = fft_energy<C>(L.x, T->fft_rd_l[i], i == 0 || i == 512);
             if (valid) {
 #pragma unroll
                 for (int c = 0; c < C; c++) el0[c * MP3MI_HBLK_P + i] = e.c[c];
@@ -304,10 +265,12 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         }
         // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
         if (lane < 6 && valid) {
+            fft_vec<C> re, im;
+            fft_bin<C>(L.x, T->fft_rd_l[lane], &re, &im);
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = L.x[MP3MI_FFT_SWZ(lane) * C + c];
-                bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? L.x[MP3MI_FFT_SWZ(1024 - lane) * C + c] : -0.0f;
+                bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = re.c[c];
+                bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? im.c[c] : -0.0f;
             }
         }
     }
@@ -315,25 +278,35 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     // short windows: samples 256 + 128 sb + jj, sb < 3 (src/l3psy.c:520-523); the second half of every
     // window is also the first half of the next.  Sample 256 + lane + 64 k: sb = k >> 1, jj = lane + 64 (k & 1).
 #pragma unroll
-    for (int k = 0; k < 12; k++)
+    for (int k = 0; k < 8; k++) {
+        const int sb = k >> 1, jj = lane + 64 * (k & 1);
+        fft_vec<C> v0, v1;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
-            const int sb = k >> 1, jj = lane + 64 * (k & 1);
-            if (sb < 3) L.x[(sb * 256 + MP3MI_FFT_SWZ(jj)) * C + c] = wsv[k & 1] * v;
-            if (sb >= 1 && sb < 4) L.x[((sb - 1) * 256 + MP3MI_FFT_SWZ(128 + jj)) * C + c] = wsv[2 + (k & 1)] * v;
+            v0.c[c] = wsv[k & 1] * v;
+            v1.c[c] = wsv[2 + (k & 1)] * v;
         }
+        if (sb < 3) *(fft_vec<C> *) (L.x + (sb * 256 + MP3MI_FFT_SWZ(jj)) * C) = v0;
+        if (sb >= 1) *(fft_vec<C> *) (L.x + ((sb - 1) * 256 + MP3MI_FFT_SWZ(128 + jj)) * C) = v1;
+    }
     __syncthreads(); // every wavefront is done with the long program
-    for (int i = tid; i < 64 * MP3MI_FFT_GROUNDS_S; i += 64 * W) LL.prog_g[i] = T->gops_s[i];
-    for (int i = tid; i < 64 * MP3MI_FFT_RROUNDS_S; i += 64 * W) LL.prog_r[i] = ((const uint4 *) T->rops_s)[i];
+    {
+        const int nw4 = T->fft_nword_s / 4;
+        for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = ((const uint4 *) T->fft_prog_s)[i];
+    }
     __syncthreads();
     PROF(2);
 
-    fft_run<C, 3, 256>(&L.x[0], T->seg_s, T->n_seg_s, LL.prog_g + lane, LL.prog_r + lane);
+    fft_run<C>(&L.x[0], T->fft_hdr_s, T->fft_nround_s, LL.prog, lane);
     PROF(3);
 
     // energies of the three short spectra (bin k of window sb, both channels per LDS read) and the raw
     // short lines 2..51 for k_cw (src/l3psy.c:531-549 reads these only); plain nested loops, no div/mod
+    uint32_t rds[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) rds[t] = T->fft_rd_s[lane + 64 * t < MP3MI_HBLK_S ? lane + 64 * t : 0];
+    const uint32_t rdb = T->fft_rd_s[lane < 50 ? 2 + lane : 0];
 #pragma unroll
     for (int sb = 0; sb < 3; sb++) {
         float *es0 = energy_s + rec0 * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S;
@@ -342,7 +315,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         for (int t = 0; t < 3; t++) {
             const int k = lane + 64 * t;
             if (k < MP3MI_HBLK_S) {
-                const fft_vec<C> e = fft_energy<C>(xw, 256, k);
+                const fft_vec<C> e = fft_energy<C>(xw, rds[t], k == 0 || k == 128);
                 if (valid) {
 #pragma unroll
                     for (int c = 0; c < C; c++) es0[c * (3 * MP3MI_HBLK_S) + k] = e.c[c];
@@ -350,8 +323,8 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             }
         }
         if (lane < 50 && valid) {
-            const fft_vec<C> re = *(const fft_vec<C> *) (xw + MP3MI_FFT_SWZ(2 + lane) * C);
-            const fft_vec<C> im = *(const fft_vec<C> *) (xw + MP3MI_FFT_SWZ(254 - lane) * C);
+            fft_vec<C> re, im;
+            fft_bin<C>(xw, rdb, &re, &im);
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + lane) * 2;

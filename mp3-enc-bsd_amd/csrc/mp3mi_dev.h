@@ -22,34 +22,23 @@
 #define MP3MI_HBLK_S 129
 #define MP3MI_HBLK_P 544      /* row pitch of energy_l in floats: rows start on a 128-byte line (k_part reads whole lines) */
 #define MP3MI_PART_P 64       /* row pitch of the partition energies eb / cb handed from k_part to k_psy */
-/* FFT butterfly programs: rounds of 64 records (one per lane); sizes are checked at table build */
 #define MP3MI_FFT_BINS 312   /* raw bins handed from k_fft to k_cw per (granule, channel): short lines 2..51 of the three
                                 windows as (re, im), then re[6], im[6] of long lines 0..5 */
 #define MP3MI_FFT_SWZ(p) ((p) ^ (((p) >> 5) & 31)) /* LDS index of element p of an FFT array */
-#define MP3MI_FFT_GROUNDS_L 124
-#define MP3MI_FFT_RROUNDS_L 20
-#define MP3MI_FFT_GROUNDS_S 45
-#define MP3MI_FFT_RROUNDS_S 5
-#define MP3MI_MAX_FFT_SEGS 96
+/* FFT butterfly programs (tables_host.cpp): rounds of 64 fused butterflies, one per lane */
+#define MP3MI_FFT_DUMMY 1024      /* elements 1024 + lane: what the idle lanes of a round work on */
+#define MP3MI_FFT_MAX_ROUNDS 48
+#define MP3MI_FFT_PROG_WORDS 12288 /* capacity of a program in 32-bit words; checked at table build */
 #define MP3MI_POW43_N 8208
 #define MP3MI_STEP_MIN (-400)
 #define MP3MI_STEP_N 801
 
-/* FFT butterfly program (see tables_host.cpp).  Rotations carry their three twiddle factors in a
- * 16-byte record; every other butterfly is one word: a | b << 10 | c << 20 (d = c + b - a). */
+/* Data movement the reference's FFT ends with; folded into the read-out tables fft_rd_* (tables_host.cpp) */
 enum {
-    FOP_ADDSUB = 0, /* t=x[a]+x[b]; x[b]=x[a]-x[b]; x[a]=t               (src/subs.c:289-297, 467-472) */
-    FOP_NEG = 1,    /* x[a]=-x[a]                                        (src/subs.c:475-479) */
-    FOP_CROSS = 2,  /* complex step 2 on (r1,r2,i1,i2)=(a,b,c,d)          (src/subs.c:302-311) */
-    FOP_ROT = 3,    /* twiddle rotation of (a,b) by (c,-(s+c),s-c)        (src/subs.c:336-339, 492-495) */
-    FOP_SQ1 = 4,    /* SQHALF rotation, first form                       (src/subs.c:330-332, 487-489) */
-    FOP_SQ2 = 5,    /* SQHALF rotation, second form                      (src/subs.c:333-335) */
+    FOP_NEG = 1,    /* x[a]=-x[a]                                        (src/subs.c:523) */
     FOP_SWAPNN = 6, /* t=x[a]; x[a]=-x[b]; x[b]=-t                       (src/subs.c:509-513) */
-    FOP_SWAPN = 7,  /* t=x[a]; x[a]=-x[b]; x[b]=t                        (src/subs.c:516-522) */
-    FOP_SWAP = 8    /* bit-reversal exchange                             (src/subs.c:136-177) */
+    FOP_SWAPN = 7   /* t=x[a]; x[a]=-x[b]; x[b]=t                        (src/subs.c:516-522) */
 };
-
-typedef struct { uint32_t w[4]; } mp3mi_fftop;
 
 /* All read-only tables, one block in device memory.  Values are produced on the host with
  * the host's libm exactly as the reference's init code does (tables_host.cpp). */
@@ -75,11 +64,14 @@ typedef struct {
     int32_t s3_lo[MP3MI_CBANDS], s3_hi[MP3MI_CBANDS];
     int32_t bu_l[21], bo_l[21], bu_s[12], bo_s[12];
     double w1_l[21], w2_l[21], w1_s[12], w2_s[12];
-    /* FFT programs */
-    int32_t n_seg_l, n_seg_s;
-    int32_t seg_l[MP3MI_MAX_FFT_SEGS], seg_s[MP3MI_MAX_FFT_SEGS];   /* type | rounds << 8 | barrier << 16 */
-    uint32_t gops_l[64 * MP3MI_FFT_GROUNDS_L], gops_s[64 * MP3MI_FFT_GROUNDS_S];   /* one-word records of all segments but FOP_ROT */
-    mp3mi_fftop rops_l[64 * MP3MI_FFT_RROUNDS_L], rops_s[64 * MP3MI_FFT_RROUNDS_S]; /* records of the FOP_ROT segments */
+    /* FFT programs: per round a header word (bit 0: eight-operand butterflies, bit 1: some lane rotates by a
+       twiddle, bit 2: some lane rotates by SQHALF, bit 3: the next round reads what this rank wrote) and its
+       blocks in fft_prog_*; fft_rd_*: LDS position of bin i's real part | sign << 15 | imaginary part's << 16 |
+       sign << 31 once the butterflies are done (step 5 and the bit reversal of the reference folded in) */
+    int32_t fft_nround_l, fft_nround_s, fft_nword_l, fft_nword_s;
+    uint32_t fft_hdr_l[MP3MI_FFT_MAX_ROUNDS], fft_hdr_s[MP3MI_FFT_MAX_ROUNDS];
+    uint32_t fft_prog_l[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16))), fft_prog_s[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16)));
+    uint32_t fft_rd_l[MP3MI_HBLK], fft_rd_s[MP3MI_HBLK_S];
     /* filterbank + MDCT */
     double enwindow[512];
     double filt[32][32];             /* the 31 used columns per subband: 0..15, 33..47  */

@@ -36,12 +36,6 @@ static const double ALIAS_C[8] = {-0.6,-0.535,-0.33,-0.185,-0.095,-0.041,-0.0142
 
 namespace {
 
-struct RawOp {
-    int phase, type;
-    unsigned a, b, c, d;
-    float f0, f1, f2;
-};
-
 struct Twiddle { std::vector<float> t; int nel; };
 
 Twiddle make_twiddle(int logm, bool three)
@@ -70,210 +64,229 @@ Twiddle make_twiddle(int logm, bool three)
     return tw;
 }
 
-struct FftGen {
-    std::vector<RawOp> ops;
-    Twiddle tw_rs[11], tw_sr[11];
-    int post1, post2, brphase;
+/* One fused butterfly of the flattened FFT.  cls 0 ("R", four operands a b c d):
+ *     s1 = a + b; s2 = c + d; u1 = a - b; u2 = c - d (negated if neg);  a <- s1; c <- s2; (b, d) <- twiddle(u1, u2)
+ * which is steps 1-4 of rsrec for one n (src/subs.c:465-498: a = x[n], b = x[n+m/2], c = x[n+m/4], d = x[n+3m/4]),
+ * and, without neg and twiddle, the two length-2 butterflies of a complex block of size 2 (src/subs.c:243-250).
+ * cls 1 ("C", eight operands): steps 1-4 of srrec for one n (src/subs.c:288-342).
+ * kind: 0 none, 1 twiddle rotation, 2 SQHALF rotation. */
+struct FusedOp {
+    int cls, kind, neg;
+    unsigned p[8];
+    float tw[6];
+};
 
-    void op(int phase, int type, unsigned a, unsigned b = 0, unsigned c = 0, unsigned d = 0,
-            float f0 = 0, float f1 = 0, float f2 = 0)
+struct FftGen {
+    Twiddle tw_rs[11], tw_sr[11];
+    std::vector<std::vector<FusedOp> > rank_ops; /* [rank] */
+    struct Post { int type; unsigned a, b; };
+    std::vector<Post> post1, post2;
+
+    void add(int rank, const FusedOp &o)
     {
-        RawOp o = {phase, type, a, b, c, d, f0, f1, f2};
-        ops.push_back(o);
+        if ((int) rank_ops.size() <= rank) rank_ops.resize((size_t) rank + 1);
+        rank_ops[(size_t) rank].push_back(o);
     }
 
-    void cplx(int xr, int xi, int logm, int rank)
+    void cplx(unsigned xr, unsigned xi, int logm, int rank)
     {
         if (logm <= 0) return;
+        FusedOp o;
+        memset(&o, 0, sizeof(o));
         if (logm == 1) {
-            op(3 * rank, FOP_ADDSUB, xr, xr + 1);
-            op(3 * rank, FOP_ADDSUB, xi, xi + 1);
+            o.cls = 0;
+            o.p[0] = xr; o.p[1] = xr + 1; o.p[2] = xi; o.p[3] = xi + 1;
+            add(rank, o);
             return;
         }
-        int m = 1 << logm, m2 = m / 2, m4 = m2 / 2, m8 = m4 / 2;
-        for (int n = 0; n < m2; n++) {
-            op(3 * rank, FOP_ADDSUB, xr + n, xr + n + m2);
-            op(3 * rank, FOP_ADDSUB, xi + n, xi + n + m2);
-        }
-        for (int n = 0; n < m4; n++)
-            op(3 * rank + 1, FOP_CROSS, xr + m2 + n, xr + m2 + n + m4, xi + m2 + n, xi + m2 + n + m4);
+        const int m = 1 << logm, m2 = m / 2, m4 = m2 / 2, m8 = m4 / 2;
         const Twiddle &tw = tw_sr[logm];
-        for (int n = 1, e = 0; n < m4; n++) {
-            unsigned r1 = xr + m2 + n, r2 = r1 + m4, i1 = xi + m2 + n, i2 = i1 + m4;
-            if (n == m8) {
-                op(3 * rank + 2, FOP_SQ1, r1, i1);
-                op(3 * rank + 2, FOP_SQ2, r2, i2);
-            } else {
-                op(3 * rank + 2, FOP_ROT, r1, i1, 0, 0, tw.t[e], tw.t[tw.nel + e], tw.t[2 * tw.nel + e]);
-                op(3 * rank + 2, FOP_ROT, r2, i2, 0, 0, tw.t[3 * tw.nel + e], tw.t[4 * tw.nel + e], tw.t[5 * tw.nel + e]);
+        for (int n = 0, e = 0; n < m4; n++) {
+            memset(&o, 0, sizeof(o));
+            o.cls = 1;
+            o.p[0] = xr + n; o.p[1] = xr + n + m2; o.p[2] = xr + n + m4; o.p[3] = xr + n + m4 + m2;
+            o.p[4] = xi + n; o.p[5] = xi + n + m2; o.p[6] = xi + n + m4; o.p[7] = xi + n + m4 + m2;
+            if (n == 0) o.kind = 0;
+            else if (n == m8) o.kind = 2;
+            else {
+                o.kind = 1;
+                for (int k = 0; k < 6; k++) o.tw[k] = tw.t[(size_t) k * tw.nel + e];
                 e++;
             }
+            add(rank, o);
         }
         cplx(xr, xi, logm - 1, rank + 1);
         cplx(xr + m2, xi + m2, logm - 2, rank + 1);
         cplx(xr + 3 * (m / 4), xi + 3 * (m / 4), logm - 2, rank + 1);
     }
 
-    void real(int o, int logm, int rank)
+    void real(unsigned o0, int logm, int rank, unsigned dummy)
     {
         if (logm <= 0) return;
+        FusedOp o;
+        memset(&o, 0, sizeof(o));
         if (logm == 1) {
-            op(3 * rank, FOP_ADDSUB, o, o + 1);
+            o.cls = 0;
+            o.p[0] = o0; o.p[1] = o0 + 1; o.p[2] = dummy; o.p[3] = dummy;
+            add(rank, o);
             return;
         }
-        int m = 1 << logm, m2 = m / 2, m4 = m2 / 2, m8 = m4 / 2;
-        for (int n = 0; n < m2; n++) op(3 * rank, FOP_ADDSUB, o + n, o + n + m2);
-        for (int n = 0; n < m4; n++) op(3 * rank + 1, FOP_NEG, o + m2 + m4 + n);
+        const int m = 1 << logm, m2 = m / 2, m4 = m2 / 2, m8 = m4 / 2;
         const Twiddle &tw = tw_rs[logm];
-        for (int n = 1, e = 0; n < m4; n++) {
-            unsigned r1 = o + m2 + n, i1 = r1 + m4;
-            if (n == m8) op(3 * rank + 2, FOP_SQ1, r1, i1);
+        for (int n = 0, e = 0; n < m4; n++) {
+            memset(&o, 0, sizeof(o));
+            o.cls = 0;
+            o.neg = 1; /* step 2, src/subs.c:475-479 */
+            o.p[0] = o0 + n; o.p[1] = o0 + n + m2; o.p[2] = o0 + n + m4; o.p[3] = o0 + n + m4 + m2;
+            if (n == 0) o.kind = 0;
+            else if (n == m8) o.kind = 2;
             else {
-                op(3 * rank + 2, FOP_ROT, r1, i1, 0, 0, tw.t[e], tw.t[tw.nel + e], tw.t[2 * tw.nel + e]);
+                o.kind = 1;
+                for (int k = 0; k < 3; k++) o.tw[k] = tw.t[(size_t) k * tw.nel + e];
                 e++;
             }
+            add(rank, o);
         }
-        real(o, logm - 1, rank + 1);
-        cplx(o + m2, o + 3 * (m / 4), logm - 2, rank + 1);
-        for (int n = 0; n < m8; n++) op(post1, FOP_SWAPNN, o + m2 + m4 + n, o + m - 1 - n);
-        for (int n = 0; n < m8; n++) op(post2, FOP_SWAPN, o + m2 + 1 + 2 * n, o + m - 2 - 2 * n);
-        if (logm == 2) op(post1, FOP_NEG, o + 3);
+        real(o0, logm - 1, rank + 1, dummy);
+        cplx(o0 + m2, o0 + 3 * (m / 4), logm - 2, rank + 1);
+        /* step 5 (src/subs.c:506-523) only relabels and negates finished values: folded into the read-out table */
+        for (int n = 0; n < m8; n++) { Post p = {FOP_SWAPNN, o0 + m2 + m4 + n, o0 + m - 1 - n}; post1.push_back(p); }
+        for (int n = 0; n < m8; n++) { Post p = {FOP_SWAPN, o0 + m2 + 1 + 2 * n, o0 + m - 2 - 2 * n}; post2.push_back(p); }
+        if (logm == 2) { Post p = {FOP_NEG, o0 + 3, 0}; post1.push_back(p); }
     }
 
-    void build(int logN, uint32_t *gops, int max_gops, mp3mi_fftop *rops, int max_rops, int32_t *segw, int32_t *n_seg)
+    /* nwin transforms of 2^logN points at element offsets w << logN; returns the number of program words */
+    int build(int logN, int nwin, uint32_t *hdr, int max_rounds, int32_t *n_rounds, uint32_t *prog, int max_words, uint32_t *rd)
     {
-        ops.clear();
-        post1 = 3 * logN + 1;
-        post2 = post1 + 1;
-        brphase = post2 + 1;
-        real(0, logN, 0);
         const int N = 1 << logN;
-        for (int i = 0; i < N; i++) { /* bit reversal */
-            int j = 0;
-            for (int b = 0; b < logN; b++)
-                if (i & (1 << b)) j |= 1 << (logN - 1 - b);
-            if (j > i) op(brphase, FOP_SWAP, i, j);
-        }
-        std::stable_sort(ops.begin(), ops.end(), [](const RawOp &x, const RawOp &y) {
-            return x.phase != y.phase ? x.phase < y.phase : x.type < y.type;
-        });
-        /* the arrays live in LDS with the low five address bits XORed with the next five (MP3MI_FFT_SWZ):
-           the small transforms' operands, which in natural order share a few banks, then spread over all */
-        for (size_t i = 0; i < ops.size(); i++) {
-            RawOp &o = ops[i];
-            o.a = MP3MI_FFT_SWZ(o.a);
-            if (o.type != FOP_NEG) o.b = MP3MI_FFT_SWZ(o.b);
-            if (o.type == FOP_CROSS) { o.c = MP3MI_FFT_SWZ(o.c); o.d = MP3MI_FFT_SWZ(o.d); }
-        }
-        /* The butterflies of a segment are independent, so their order is free: place them so that the
-           32 lanes of a half wave (the unit the LDS serves a 4-byte access in) address 32 different
-           banks with every operand.  Greedy: first the butterflies that fit without any collision, then
-           -- a half wave left partly idle would cost a whole round, a collision costs a cycle -- the
-           ones that collide least. */
-        for (size_t s0 = 0; s0 < ops.size();) {
-            size_t s1 = s0;
-            while (s1 < ops.size() && ops[s1].phase == ops[s0].phase && ops[s1].type == ops[s0].type) s1++;
-            std::vector<RawOp> rest(ops.begin() + s0, ops.begin() + s1), placed;
-            const int type = ops[s0].type;
-            const int nopnd = (type == FOP_NEG) ? 1 : (type == FOP_CROSS ? 4 : 2);
-            while (!rest.empty()) {
-                int used[4][32];
-                memset(used, 0, sizeof(used));
-                std::vector<RawOp> group;
-                auto cost = [&](const RawOp &o) {
-                    const unsigned ad[4] = {o.a, o.b, o.c, o.d};
-                    int c = 0;
-                    for (int k = 0; k < nopnd; k++) c += used[k][ad[k] & 31];
-                    return c;
-                };
-                auto take = [&](size_t idx, bool flip) {
-                    RawOp o = rest[idx];
-                    if (flip) std::swap(o.a, o.b);
-                    const unsigned ad[4] = {o.a, o.b, o.c, o.d};
-                    for (int k = 0; k < nopnd; k++) used[k][ad[k] & 31]++;
-                    group.push_back(o);
-                    rest.erase(rest.begin() + (long) idx);
-                };
-                for (size_t i = 0; i < rest.size() && group.size() < 32;) { /* collision-free candidates, in order */
-                    RawOp f = rest[i];
-                    std::swap(f.a, f.b);
-                    if (cost(rest[i]) == 0) take(i, false);
-                    else if (type == FOP_SWAP && cost(f) == 0) take(i, true); /* an exchange is symmetric */
-                    else i++;
+        rank_ops.clear();
+        post1.clear();
+        post2.clear();
+        real(0, logN, 0, MP3MI_FFT_DUMMY);
+        /* read-out: where bin i's real and imaginary part are once the butterflies are done, and with which sign */
+        {
+            std::vector<int> src((size_t) N), sg((size_t) N, 0);
+            for (int i = 0; i < N; i++) src[(size_t) i] = i;
+            auto apply = [&](const Post &p) {
+                if (p.type == FOP_NEG) sg[p.a] ^= 1;
+                else {
+                    const int ta = src[p.a], sa = sg[p.a];
+                    src[p.a] = src[p.b]; sg[p.a] = sg[p.b] ^ 1;
+                    src[p.b] = ta; sg[p.b] = sa ^ (p.type == FOP_SWAPNN ? 1 : 0);
                 }
-                while (group.size() < 32 && !rest.empty()) { /* fill up with the least harmful */
-                    size_t best = 0;
-                    int bc = 1 << 30;
-                    for (size_t i = 0; i < rest.size(); i++) {
-                        const int c = cost(rest[i]);
-                        if (c < bc) { bc = c; best = i; }
+            };
+            for (size_t i = 0; i < post1.size(); i++) apply(post1[i]);
+            for (size_t i = 0; i < post2.size(); i++) apply(post2[i]);
+            for (int i = 0; i < N; i++) { /* bit reversal, src/subs.c:136-177 */
+                int j = 0;
+                for (int b = 0; b < logN; b++)
+                    if (i & (1 << b)) j |= 1 << (logN - 1 - b);
+                if (j > i) { std::swap(src[(size_t) i], src[(size_t) j]); std::swap(sg[(size_t) i], sg[(size_t) j]); }
+            }
+            for (int i = 0; i <= N / 2; i++) {
+                const int k = (i == 0 || i == N / 2) ? i : N - i;
+                rd[i] = (uint32_t) MP3MI_FFT_SWZ(src[(size_t) i]) | ((uint32_t) sg[(size_t) i] << 15) |
+                        ((uint32_t) MP3MI_FFT_SWZ(src[(size_t) k]) << 16) | ((uint32_t) sg[(size_t) k] << 31);
+            }
+        }
+        int nr = 0, nw = 0;
+        for (size_t rank = 0; rank < rank_ops.size(); rank++) {
+            int last_round_of_rank = -1;
+            for (int cls = 0; cls < 2; cls++) {
+                const int nopnd = cls ? 8 : 4;
+                std::vector<FusedOp> rest;
+                /* rotations first, SQHALF rotations last: rounds without either skip that arithmetic */
+                static const int kind_order[3] = {1, 0, 2};
+                for (int ko = 0; ko < 3; ko++)
+                    for (int w = 0; w < nwin; w++)
+                        for (size_t i = 0; i < rank_ops[rank].size(); i++) {
+                            FusedOp o = rank_ops[rank][i];
+                            if (o.cls != cls || o.kind != kind_order[ko]) continue;
+                            for (int k = 0; k < nopnd; k++)
+                                o.p[k] = (o.p[k] == MP3MI_FFT_DUMMY) ? o.p[k] : (unsigned) (w * N + MP3MI_FFT_SWZ((int) o.p[k]));
+                            rest.push_back(o);
+                        }
+                /* The butterflies of a rank are independent, so their order is free: place them so that the 32
+                   lanes an 8-byte LDS read is served in address 32 different bank pairs with every operand, and
+                   the 16 lanes a store is served in 16 different ones.  Greedy: first what fits without any
+                   collision, then -- an idle lane costs as much as a busy one, a collision one cycle -- what
+                   collides least. */
+                std::vector<FusedOp> placed;
+                while (!rest.empty()) {
+                    int usedr[8][32], usedw[8][2][16];
+                    memset(usedr, 0, sizeof(usedr));
+                    memset(usedw, 0, sizeof(usedw));
+                    std::vector<FusedOp> group;
+                    auto cost = [&](const FusedOp &o) {
+                        const size_t q = group.size() / 16;
+                        int c = 0;
+                        for (int k = 0; k < nopnd; k++) c += usedr[k][o.p[k] & 31] + usedw[k][q][o.p[k] & 15];
+                        return c;
+                    };
+                    auto take = [&](size_t idx) {
+                        const FusedOp o = rest[idx];
+                        const size_t q = group.size() / 16;
+                        for (int k = 0; k < nopnd; k++) { usedr[k][o.p[k] & 31]++; usedw[k][q][o.p[k] & 15]++; }
+                        group.push_back(o);
+                        rest.erase(rest.begin() + (long) idx);
+                    };
+                    for (size_t i = 0; i < rest.size() && group.size() < 32;) {
+                        if (cost(rest[i]) == 0) take(i);
+                        else i++;
                     }
-                    take(best, false);
+                    while (group.size() < 32 && !rest.empty()) {
+                        size_t best = 0;
+                        int bc = 1 << 30;
+                        for (size_t i = 0; i < rest.size(); i++) {
+                            const int c = cost(rest[i]);
+                            if (c < bc) { bc = c; best = i; }
+                        }
+                        take(best);
+                    }
+                    placed.insert(placed.end(), group.begin(), group.end());
+                    if (!rest.empty()) while (placed.size() % 32) { FusedOp idle; memset(&idle, 0, sizeof(idle)); idle.cls = -1; placed.push_back(idle); }
                 }
-                placed.insert(placed.end(), group.begin(), group.end());
+                /* rounds of 64: block 0 = operand positions (R: 2 words per lane, C: 4), then either the
+                   twiddle block(s) {cn, spc, smc, flags} (C: a second one {c3n, spc3n, smc3n, 0}) or, in a round
+                   without rotations, one word of flags per lane.  flags: bit 0 rotation, bit 1 SQHALF rotation,
+                   bit 31 negate u2. */
+                for (size_t r0 = 0; r0 < placed.size(); r0 += 64) {
+                    bool has_rot = false, has_sq = false;
+                    for (size_t l = r0; l < r0 + 64 && l < placed.size(); l++)
+                        if (placed[l].cls >= 0) { has_rot |= placed[l].kind == 1; has_sq |= placed[l].kind == 2; }
+                    const int words = (cls ? 256 : 128) + (has_rot ? (cls ? 512 : 256) : 64);
+                    if (nr >= max_rounds || nw + words > max_words) { fprintf(stderr, "mp3mi: fft program too large\n"); abort(); }
+                    uint32_t *blk = prog + nw;
+                    for (int l = 0; l < 64; l++) {
+                        FusedOp o;
+                        memset(&o, 0, sizeof(o));
+                        o.cls = -1;
+                        if (r0 + (size_t) l < placed.size()) o = placed[r0 + (size_t) l];
+                        if (o.cls < 0) { /* idle lane: works on its own dummy element */
+                            memset(&o, 0, sizeof(o));
+                            for (int k = 0; k < 8; k++) o.p[k] = (unsigned) (MP3MI_FFT_DUMMY + l);
+                        }
+                        for (int k = 0; k < nopnd; k++) if (o.p[k] == MP3MI_FFT_DUMMY) o.p[k] = (unsigned) (MP3MI_FFT_DUMMY + l);
+                        const uint32_t flags = (o.kind == 1 ? 1u : 0u) | (o.kind == 2 ? 2u : 0u) | (o.neg ? 0x80000000u : 0u);
+                        const int aw = cls ? 4 : 2;
+                        for (int k = 0; k < aw; k++) blk[l * aw + k] = o.p[2 * k] | (o.p[2 * k + 1] << 16);
+                        uint32_t *t = blk + 64 * aw;
+                        if (has_rot) {
+                            memcpy(&t[l * 4], o.tw, 12);
+                            t[l * 4 + 3] = flags;
+                            if (cls) { memcpy(&t[256 + l * 4], o.tw + 3, 12); t[256 + l * 4 + 3] = 0; }
+                        } else t[l] = flags;
+                    }
+                    hdr[nr] = (uint32_t) cls | (has_rot ? 2u : 0u) | (has_sq ? 4u : 0u);
+                    last_round_of_rank = nr;
+                    nr++;
+                    nw += words;
+                }
             }
-            std::copy(placed.begin(), placed.end(), ops.begin() + (long) s0);
-            s0 = s1;
+            if (last_round_of_rank >= 0) hdr[last_round_of_rank] |= 8u; /* the next rank reads what this one wrote */
         }
-        /* Every segment is padded to whole rounds of 64 records (bit 31 = idle lane): round t of the
-           g (r) stream is records [64 t, 64 t + 64), one per lane.  The kernel keeps both streams in
-           LDS and walks them in order, so a segment is just (type, rounds, barrier). */
-        struct Seg { int type, count, barrier; };
-        Seg segs[MP3MI_MAX_FFT_SEGS];
-        int ns = 0, ng = 0, nr = 0;
-        auto pad = [&](int type) {
-            if (type == FOP_ROT) {
-                while (nr % 64) { mp3mi_fftop w = {{0x80000000u, 0, 0, 0}}; if (nr >= max_rops) abort(); rops[nr++] = w; }
-            } else {
-                while (ng % 64) { if (ng >= max_gops) abort(); gops[ng++] = 0x80000000u; }
-            }
-        };
-        std::vector<uint32_t> second; /* FOP_CROSS: the round's second words (c | d << 10) follow its first words */
-        auto flush_cross = [&]() {
-            if (second.empty()) return;
-            pad(FOP_CROSS);
-            for (size_t k = 0; k < second.size(); k++) { if (ng >= max_gops) abort(); gops[ng++] = second[k]; }
-            pad(FOP_CROSS);
-            second.clear();
-        };
-        for (size_t i = 0; i < ops.size(); i++) {
-            const RawOp &o = ops[i];
-            const bool rot = o.type == FOP_ROT;
-            if (i == 0 || o.phase != ops[i - 1].phase || o.type != ops[i - 1].type) {
-                if (ns >= MP3MI_MAX_FFT_SEGS) { fprintf(stderr, "mp3mi: too many fft segments\n"); abort(); }
-                if (ns > 0) {
-                    segs[ns - 1].barrier = (o.phase != ops[i - 1].phase);
-                    flush_cross();
-                    pad(segs[ns - 1].type);
-                }
-                segs[ns].type = o.type;
-                segs[ns].count = 0;
-                segs[ns].barrier = 1;
-                ns++;
-            }
-            segs[ns - 1].count++;
-            if (rot) {
-                if (nr >= max_rops) { fprintf(stderr, "mp3mi: fft program too large\n"); abort(); }
-                mp3mi_fftop w;
-                w.w[0] = o.a | (o.b << 16);
-                memcpy(&w.w[1], &o.f0, 4);
-                memcpy(&w.w[2], &o.f1, 4);
-                memcpy(&w.w[3], &o.f2, 4);
-                rops[nr++] = w;
-            } else {
-                if (ng >= max_gops) { fprintf(stderr, "mp3mi: fft program too large\n"); abort(); }
-                gops[ng++] = o.a | (o.b << 10);
-                if (o.type == FOP_CROSS) {
-                    second.push_back(o.c | (o.d << 10));
-                    if (second.size() == 64) flush_cross();
-                }
-            }
-        }
-        flush_cross();
-        pad(segs[ns - 1].type);
-        if (ng != max_gops || nr != max_rops) { fprintf(stderr, "mp3mi: fft program size %d/%d, expected %d/%d\n", ng, nr, max_gops, max_rops); abort(); }
-        for (int k = 0; k < ns; k++) segw[k] = segs[k].type | (((segs[k].count + 63) / 64) << 8) | (segs[k].barrier << 16);
-        *n_seg = ns;
+        *n_rounds = nr;
+        return nw;
     }
 };
 
@@ -380,8 +393,9 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
     {
         FftGen *g = new FftGen();
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
-        g->build(10, T->gops_l, 64 * MP3MI_FFT_GROUNDS_L, T->rops_l, 64 * MP3MI_FFT_RROUNDS_L, T->seg_l, &T->n_seg_l);
-        g->build(8, T->gops_s, 64 * MP3MI_FFT_GROUNDS_S, T->rops_s, 64 * MP3MI_FFT_RROUNDS_S, T->seg_s, &T->n_seg_s);
+        T->fft_nword_l = g->build(10, 1, T->fft_hdr_l, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_l, T->fft_prog_l, MP3MI_FFT_PROG_WORDS, T->fft_rd_l);
+        T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS, T->fft_rd_s);
+        if (getenv("MP3MI_FFT_INFO")) fprintf(stderr, "mp3mi: fft program long %d rounds %d words, short %d rounds %d words\n", T->fft_nround_l, T->fft_nword_l, T->fft_nround_s, T->fft_nword_s);
         delete g;
     }
 
