@@ -41,114 +41,150 @@ __device__ unsigned long long g_fft_prof[8];
 template <int C> struct fft_wave_lds {
     float x[C * (MP3MI_FFT_DUMMY + 64)];
 };
+// fft_vec<C>: the C channels of one element.  For two channels a native 2-vector, so that the channel pair
+// of an operand is one 8-byte LDS access and one packed instruction (v_pk_add_f32 / v_pk_mul_f32: the same
+// IEEE results per component as the scalar ones) without any register shuffling.
+template <int C> struct fft_pair;  // the same C floats as a plain struct (windowing, read-out)
+template <> struct fft_pair<1> { float c[1]; };
+template <> struct __attribute__((aligned(8))) fft_pair<2> { float c[2]; };
+typedef float fft_v2f __attribute__((vector_size(8)));
+#if defined(MP3MI_EMU)
+#define FFT_MEMFN static inline
+#else
+#define FFT_MEMFN static __device__ __forceinline__
+#endif
+typedef uint32_t fft_v2u __attribute__((vector_size(8)));
 template <int C> struct fft_vec;
-template <> struct fft_vec<1> { float c[1]; };
-template <> struct __attribute__((aligned(8))) fft_vec<2> { float c[2]; };
+template <> struct fft_vec<1> {
+    typedef float V;
+    FFT_MEMFN V splat(float f) { return f; }
+    FFT_MEMFN V flip(V v, uint32_t signbit) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) ^ signbit); }
+    FFT_MEMFN float get(V v, int) { return v; }
+    FFT_MEMFN void set(V &v, int, float f) { v = f; }
+};
+template <> struct fft_vec<2> {
+    typedef fft_v2f V;
+    FFT_MEMFN V splat(float f) { return (V){f, f}; }
+    FFT_MEMFN V flip(V v, uint32_t signbit) { return (V) ((fft_v2u) v ^ (fft_v2u){signbit, signbit}); }
+    FFT_MEMFN float get(V v, int c) { return v[c]; }
+    FFT_MEMFN void set(V &v, int c, float f) { v[c] = f; }
+};
 template <int C, int W> struct fft_lds {
     uint32_t prog[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16)));
     fft_wave_lds<C> w[W];
 };
 
-// operand k of a record word: LDS element position in its low / high half
-template <int C> MP3MI_DEVFN fft_vec<C> *fft_at(float *x, uint32_t w, int hi)
+// Operand of a record word: LDS element position in its low (hi = 0) or high half.  xw = the workgroup's
+// arrays as bytes, woff = byte offset of this wavefront's array: position * element size + woff is ONE
+// instruction (v_mad_u32_u16 reads either half of a register).
+template <int C, int HI> MP3MI_DEVFN typename fft_vec<C>::V *fft_at(char *xw, uint32_t woff, uint32_t w)
 {
-    return (fft_vec<C> *) (x + (hi ? (w >> 16) : (w & 0xffffu)) * C);
+    uint32_t off;
+#if defined(MP3MI_EMU)
+    off = (HI ? (w >> 16) : (w & 0xffffu)) * (4u * C) + woff;
+#else
+    if (C == 2) {
+        if (HI) asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(off) : "v"(w), "v"(woff));
+        else asm("v_mad_u32_u16 %0, %1, 8, %2" : "=v"(off) : "v"(w), "v"(woff));
+    } else {
+        if (HI) asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(off) : "v"(w), "v"(woff));
+        else asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(off) : "v"(w), "v"(woff));
+    }
+#endif
+    return (typename fft_vec<C>::V *) (xw + off);
 }
 
 // twiddle stage of a fused butterfly on (r, i) (src/subs.c:330-339, 487-495): flags bit 0 rotates by
 // (cn, spcn, smcn), bit 1 by SQHALF -- `second` is the form the reference uses for the pair (xr2, xi2)
-template <bool ROT>
-MP3MI_DEVFN void fft_twiddle(float &r, float &i, uint32_t flags, bool has_sq, bool second, float cn, float spc, float smc)
+template <int C, bool ROT, bool SQ>
+MP3MI_DEVFN void fft_twiddle(typename fft_vec<C>::V &r, typename fft_vec<C>::V &i, uint32_t flags, bool second,
+                             uint32_t cn, uint32_t spc, uint32_t smc)
 {
-    const float r1 = r, i1 = i;
+    typedef fft_vec<C> F;
+    typedef typename F::V V;
+    const V r1 = r, i1 = i;
     if (ROT) {
-        const float t2 = cn * (r1 + i1);
-        const float t1 = spc * r1 + t2;
-        const float ra = smc * i1 + t2;
+        const V t2 = F::splat(__builtin_bit_cast(float, cn)) * (r1 + i1);
+        const V t1 = F::splat(__builtin_bit_cast(float, spc)) * r1 + t2;
+        const V ra = F::splat(__builtin_bit_cast(float, smc)) * i1 + t2;
         r = (flags & 1u) ? ra : r1;
         i = (flags & 1u) ? t1 : i1;
     }
-    if (has_sq) { // wave-uniform
-        const float sum = r1 + i1, dif = i1 - r1;
-        const float qa = second ? (float) (R_SQHALF * (double) dif) : (float) (R_SQHALF * (double) sum);
-        const float qb = second ? (float) (-R_SQHALF * (double) sum) : (float) (R_SQHALF * (double) dif);
+    if (SQ) {
+        const V sum = r1 + i1, dif = i1 - r1;
+        V qa, qb;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float sm = F::get(sum, c), df = F::get(dif, c);
+            F::set(qa, c, second ? (float) (R_SQHALF * (double) df) : (float) (R_SQHALF * (double) sm));
+            F::set(qb, c, second ? (float) (-R_SQHALF * (double) sm) : (float) (R_SQHALF * (double) df));
+        }
         r = (flags & 2u) ? qa : r;
         i = (flags & 2u) ? qb : i;
     }
 }
 
-// one round of four-operand butterflies (tables_host.cpp, FusedOp cls 0); blk = this lane's view of the round's blocks
-template <int C, bool ROT>
-MP3MI_DEVFN void fft_round_r(float *x, const uint32_t *blk, int lane, bool has_sq)
+// one round of four-operand butterflies (tables_host.cpp, FusedOp cls 0); blk = the round's blocks
+template <int C, bool ROT, bool SQ>
+MP3MI_DEVFN void fft_round_r(char *xw, uint32_t woff, const uint32_t *blk, int lane)
 {
+    typedef fft_vec<C> F;
+    typedef typename F::V V;
     const uint2 ad = *(const uint2 *) (blk + 2 * lane);
     uint4 tw = {0, 0, 0, 0};
     if (ROT) tw = *(const uint4 *) (blk + 128 + 4 * lane);
     else tw.w = blk[128 + lane];
-    fft_vec<C> *pa = fft_at<C>(x, ad.x, 0), *pb = fft_at<C>(x, ad.x, 1), *pc = fft_at<C>(x, ad.y, 0), *pd = fft_at<C>(x, ad.y, 1);
-    const fft_vec<C> a = *pa, b = *pb, c = *pc, d = *pd;
-    fft_vec<C> oa, ob, oc, od;
-    const uint32_t flags = tw.w, neg = flags & 0x80000000u;
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) {
-        oa.c[ch] = a.c[ch] + b.c[ch];
-        oc.c[ch] = c.c[ch] + d.c[ch];
-        float u1 = a.c[ch] - b.c[ch];
-        float u2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, c.c[ch] - d.c[ch]) ^ neg); // src/subs.c:475-479
-        fft_twiddle<ROT>(u1, u2, flags, has_sq, false, __builtin_bit_cast(float, tw.x), __builtin_bit_cast(float, tw.y), __builtin_bit_cast(float, tw.z));
-        ob.c[ch] = u1;
-        od.c[ch] = u2;
-    }
-    *pa = oa; *pb = ob; *pc = oc; *pd = od;
+    V *pa = fft_at<C, 0>(xw, woff, ad.x), *pb = fft_at<C, 1>(xw, woff, ad.x), *pc = fft_at<C, 0>(xw, woff, ad.y), *pd = fft_at<C, 1>(xw, woff, ad.y);
+    const V a = *pa, b = *pb, c = *pc, d = *pd;
+    const uint32_t flags = tw.w;
+    const V oa = a + b, oc = c + d;
+    V u1 = a - b;
+    V u2 = F::flip(c - d, flags & 0x80000000u); // src/subs.c:475-479
+    fft_twiddle<C, ROT, SQ>(u1, u2, flags, false, tw.x, tw.y, tw.z);
+    *pa = oa; *pb = u1; *pc = oc; *pd = u2;
 }
 
 // one round of eight-operand butterflies (FusedOp cls 1): steps 1-4 of srrec for one n
-template <int C, bool ROT>
-MP3MI_DEVFN void fft_round_c(float *x, const uint32_t *blk, int lane, bool has_sq)
+template <int C, bool ROT, bool SQ>
+MP3MI_DEVFN void fft_round_c(char *xw, uint32_t woff, const uint32_t *blk, int lane)
 {
+    typedef fft_vec<C> F;
+    typedef typename F::V V;
     const uint4 ad = *(const uint4 *) (blk + 4 * lane);
     uint4 tw1 = {0, 0, 0, 0}, tw3 = {0, 0, 0, 0};
     if (ROT) { tw1 = *(const uint4 *) (blk + 256 + 4 * lane); tw3 = *(const uint4 *) (blk + 512 + 4 * lane); }
     else tw1.w = blk[256 + lane];
-    fft_vec<C> *p0 = fft_at<C>(x, ad.x, 0), *p1 = fft_at<C>(x, ad.x, 1), *p2 = fft_at<C>(x, ad.y, 0), *p3 = fft_at<C>(x, ad.y, 1);
-    fft_vec<C> *p4 = fft_at<C>(x, ad.z, 0), *p5 = fft_at<C>(x, ad.z, 1), *p6 = fft_at<C>(x, ad.w, 0), *p7 = fft_at<C>(x, ad.w, 1);
-    const fft_vec<C> ar0 = *p0, ar1 = *p1, br0 = *p2, br1 = *p3, ai0 = *p4, ai1 = *p5, bi0 = *p6, bi1 = *p7;
-    fft_vec<C> o0, o1, o2, o3, o4, o5, o6, o7;
+    V *p0 = fft_at<C, 0>(xw, woff, ad.x), *p1 = fft_at<C, 1>(xw, woff, ad.x), *p2 = fft_at<C, 0>(xw, woff, ad.y), *p3 = fft_at<C, 1>(xw, woff, ad.y);
+    V *p4 = fft_at<C, 0>(xw, woff, ad.z), *p5 = fft_at<C, 1>(xw, woff, ad.z), *p6 = fft_at<C, 0>(xw, woff, ad.w), *p7 = fft_at<C, 1>(xw, woff, ad.w);
+    const V ar0 = *p0, ar1 = *p1, br0 = *p2, br1 = *p3, ai0 = *p4, ai1 = *p5, bi0 = *p6, bi1 = *p7;
     const uint32_t flags = tw1.w;
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) {
-        // step 1 (src/subs.c:288-298)
-        o0.c[ch] = ar0.c[ch] + ar1.c[ch];
-        o2.c[ch] = br0.c[ch] + br1.c[ch];
-        o4.c[ch] = ai0.c[ch] + ai1.c[ch];
-        o6.c[ch] = bi0.c[ch] + bi1.c[ch];
-        const float xr1 = ar0.c[ch] - ar1.c[ch], xr2 = br0.c[ch] - br1.c[ch];
-        const float xi1 = ai0.c[ch] - ai1.c[ch], xi2 = bi0.c[ch] - bi1.c[ch];
-        // step 2 (src/subs.c:301-312)
-        float r1 = xr1 + xi2, i2 = xi1 + xr2, i1 = xi1 - xr2, r2 = xr1 - xi2;
-        // steps 3 and 4 (src/subs.c:327-342)
-        fft_twiddle<ROT>(r1, i1, flags, has_sq, false, __builtin_bit_cast(float, tw1.x), __builtin_bit_cast(float, tw1.y), __builtin_bit_cast(float, tw1.z));
-        fft_twiddle<ROT>(r2, i2, flags, has_sq, true, __builtin_bit_cast(float, tw3.x), __builtin_bit_cast(float, tw3.y), __builtin_bit_cast(float, tw3.z));
-        o1.c[ch] = r1; o3.c[ch] = r2; o5.c[ch] = i1; o7.c[ch] = i2;
-    }
-    *p0 = o0; *p1 = o1; *p2 = o2; *p3 = o3; *p4 = o4; *p5 = o5; *p6 = o6; *p7 = o7;
+    // step 1 (src/subs.c:288-298)
+    const V o0 = ar0 + ar1, o2 = br0 + br1, o4 = ai0 + ai1, o6 = bi0 + bi1;
+    const V xr1 = ar0 - ar1, xr2 = br0 - br1, xi1 = ai0 - ai1, xi2 = bi0 - bi1;
+    // step 2 (src/subs.c:301-312)
+    V r1 = xr1 + xi2, i2 = xi1 + xr2, i1 = xi1 - xr2, r2 = xr1 - xi2;
+    // steps 3 and 4 (src/subs.c:327-342)
+    fft_twiddle<C, ROT, SQ>(r1, i1, flags, false, tw1.x, tw1.y, tw1.z);
+    fft_twiddle<C, ROT, SQ>(r2, i2, flags, true, tw3.x, tw3.y, tw3.z);
+    *p0 = o0; *p1 = r1; *p2 = o2; *p3 = r2; *p4 = o4; *p5 = i1; *p6 = o6; *p7 = i2;
 }
 
-template <int C>
-MP3MI_DEVFN void fft_run(float *x, const uint32_t *hdr, int nround, const uint32_t *prog, int lane)
+// The sequence of rounds is a compile-time constant (MP3MI_FFT_HDRS_*, checked against the generator at
+// table build): the program runs as straight-line code, every block a constant offset from the lane's
+// record address, with no per-round dispatch.
+static constexpr uint8_t fft_hdrs_l[] = {MP3MI_FFT_HDRS_L}, fft_hdrs_s[] = {MP3MI_FFT_HDRS_S};
+constexpr int fft_round_words(int h) { return ((h & 1) ? 256 : 128) + ((h & 2) ? ((h & 1) ? 512 : 256) : 64); }
+
+template <int C, bool LONG, int R, int OFF>
+MP3MI_DEVFN void fft_run(char *xw, uint32_t woff, const uint32_t *prog, int lane)
 {
-    uint32_t nxt = hdr[0];
-    for (int r = 0; r < nround; r++) {
-        const uint32_t h = nxt;
-        nxt = hdr[r + 1 < nround ? r + 1 : r];
-        const bool has_sq = (h & 4u) != 0;
-        switch (h & 3u) {
-        case 0: fft_round_r<C, false>(x, prog, lane, has_sq); prog += 128 + 64; break;
-        case 2: fft_round_r<C, true>(x, prog, lane, has_sq); prog += 128 + 256; break;
-        case 1: fft_round_c<C, false>(x, prog, lane, has_sq); prog += 256 + 64; break;
-        default: fft_round_c<C, true>(x, prog, lane, has_sq); prog += 256 + 512; break;
-        }
-        if (h & 8u) wave_sync();
+    constexpr int NR = LONG ? (int) sizeof(fft_hdrs_l) : (int) sizeof(fft_hdrs_s);
+    if constexpr (R < NR) {
+        constexpr int h = LONG ? fft_hdrs_l[R < (int) sizeof(fft_hdrs_l) ? R : 0] : fft_hdrs_s[R < (int) sizeof(fft_hdrs_s) ? R : 0];
+        if constexpr ((h & 1) == 0) fft_round_r<C, (h & 2) != 0, (h & 4) != 0>(xw, woff, prog + OFF, lane);
+        else fft_round_c<C, (h & 2) != 0, (h & 4) != 0>(xw, woff, prog + OFF, lane);
+        if constexpr ((h & 8) != 0) wave_sync(); // the next rank reads what this one wrote
+        fft_run<C, LONG, R + 1, OFF + fft_round_words(h)>(xw, woff, prog, lane);
     }
 }
 
@@ -159,11 +195,11 @@ MP3MI_DEVFN void fft_run(float *x, const uint32_t *hdr, int nround, const uint32
 // float next ABOVE 0.0005: below it both say yes, above it both say no, and at it the replacement value is
 // e itself.  Signs do not matter here.
 template <int C>
-MP3MI_DEVFN fft_vec<C> fft_energy(const float *x, uint32_t rd, bool real)
+MP3MI_DEVFN fft_pair<C> fft_energy(const float *x, uint32_t rd, bool real)
 {
-    const fft_vec<C> re = *(const fft_vec<C> *) (x + (rd & 0x7fffu) * C);
-    const fft_vec<C> im = *(const fft_vec<C> *) (x + ((rd >> 16) & 0x7fffu) * C);
-    fft_vec<C> e;
+    const fft_pair<C> re = *(const fft_pair<C> *) (x + (rd & 0x7fffu) * C);
+    const fft_pair<C> im = *(const fft_pair<C> *) (x + ((rd >> 16) & 0x7fffu) * C);
+    fft_pair<C> e;
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const float rr = re.c[c] * re.c[c];
@@ -176,10 +212,10 @@ MP3MI_DEVFN fft_vec<C> fft_energy(const float *x, uint32_t rd, bool real)
 
 // raw value of a bin with the sign the reference's step 5 leaves it with (src/subs.c:506-523)
 template <int C>
-MP3MI_DEVFN void fft_bin(const float *x, uint32_t rd, fft_vec<C> *re, fft_vec<C> *im)
+MP3MI_DEVFN void fft_bin(const float *x, uint32_t rd, fft_pair<C> *re, fft_pair<C> *im)
 {
-    *re = *(const fft_vec<C> *) (x + (rd & 0x7fffu) * C);
-    *im = *(const fft_vec<C> *) (x + ((rd >> 16) & 0x7fffu) * C);
+    *re = *(const fft_pair<C> *) (x + (rd & 0x7fffu) * C);
+    *im = *(const fft_pair<C> *) (x + ((rd >> 16) & 0x7fffu) * C);
 #pragma unroll
     for (int c = 0; c < C; c++) {
         re->c[c] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, re->c[c]) ^ ((rd & 0x8000u) << 16));
@@ -227,17 +263,17 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            fft_vec<C> v;
+            fft_pair<C> v;
 #pragma unroll
             for (int c = 0; c < C; c++)
                 v.c[c] = wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16)); // src/l3psy.c:485
-            *(fft_vec<C> *) (L.x + MP3MI_FFT_SWZ(lane + 64 * k) * C) = v;
+            *(fft_pair<C> *) (L.x + MP3MI_FFT_SWZ(lane + 64 * k) * C) = v;
         }
     }
     __syncthreads();
     PROF(0);
 
-    fft_run<C>(&L.x[0], T->fft_hdr_l, T->fft_nround_l, LL.prog, lane);
+    fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) ((tid >> 6) * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
     PROF(1);
 
     // the short windows' samples are requested now and land while the long spectrum is consumed
@@ -257,7 +293,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         float *el0 = energy_l + rec0 * MP3MI_HBLK_P;
 #pragma unroll 3
         for (int i = lane; i < MP3MI_HBLK; i += 64) {
-            const fft_vec<C> e = fft_energy<C>(L.x, T->fft_rd_l[i], i == 0 || i == 512);
+            const fft_pair<C> e = fft_energy<C>(L.x, T->fft_rd_l[i], i == 0 || i == 512);
             if (valid) {
 #pragma unroll
                 for (int c = 0; c < C; c++) el0[c * MP3MI_HBLK_P + i] = e.c[c];
@@ -265,7 +301,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         }
         // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
         if (lane < 6 && valid) {
-            fft_vec<C> re, im;
+            fft_pair<C> re, im;
             fft_bin<C>(L.x, T->fft_rd_l[lane], &re, &im);
 #pragma unroll
             for (int c = 0; c < C; c++) {
@@ -280,15 +316,15 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int sb = k >> 1, jj = lane + 64 * (k & 1);
-        fft_vec<C> v0, v1;
+        fft_pair<C> v0, v1;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
             v0.c[c] = wsv[k & 1] * v;
             v1.c[c] = wsv[2 + (k & 1)] * v;
         }
-        if (sb < 3) *(fft_vec<C> *) (L.x + (sb * 256 + MP3MI_FFT_SWZ(jj)) * C) = v0;
-        if (sb >= 1) *(fft_vec<C> *) (L.x + ((sb - 1) * 256 + MP3MI_FFT_SWZ(128 + jj)) * C) = v1;
+        if (sb < 3) *(fft_pair<C> *) (L.x + (sb * 256 + MP3MI_FFT_SWZ(jj)) * C) = v0;
+        if (sb >= 1) *(fft_pair<C> *) (L.x + ((sb - 1) * 256 + MP3MI_FFT_SWZ(128 + jj)) * C) = v1;
     }
     __syncthreads(); // every wavefront is done with the long program
     {
@@ -298,7 +334,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     __syncthreads();
     PROF(2);
 
-    fft_run<C>(&L.x[0], T->fft_hdr_s, T->fft_nround_s, LL.prog, lane);
+    fft_run<C, false, 0, 0>((char *) &LL.w[0], (uint32_t) ((tid >> 6) * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
     PROF(3);
 
     // energies of the three short spectra (bin k of window sb, both channels per LDS read) and the raw
@@ -315,7 +351,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         for (int t = 0; t < 3; t++) {
             const int k = lane + 64 * t;
             if (k < MP3MI_HBLK_S) {
-                const fft_vec<C> e = fft_energy<C>(xw, rds[t], k == 0 || k == 128);
+                const fft_pair<C> e = fft_energy<C>(xw, rds[t], k == 0 || k == 128);
                 if (valid) {
 #pragma unroll
                     for (int c = 0; c < C; c++) es0[c * (3 * MP3MI_HBLK_S) + k] = e.c[c];
@@ -323,7 +359,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             }
         }
         if (lane < 50 && valid) {
-            fft_vec<C> re, im;
+            fft_pair<C> re, im;
             fft_bin<C>(xw, rdb, &re, &im);
 #pragma unroll
             for (int c = 0; c < C; c++) {

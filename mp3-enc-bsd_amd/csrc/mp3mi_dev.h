@@ -29,6 +29,11 @@
 #define MP3MI_FFT_DUMMY 1024      /* elements 1024 + lane: what the idle lanes of a round work on */
 #define MP3MI_FFT_MAX_ROUNDS 48
 #define MP3MI_FFT_PROG_WORDS 12288 /* capacity of a program in 32-bit words; checked at table build */
+/* the header words of the rounds of the long and of the short program (fft_hdr_* below): k_fft is compiled
+   for exactly these sequences -- straight-line code, no per-round dispatch -- and table build checks that the
+   generator still produces them (MP3MI_FFT_INFO=1 prints the lists) */
+#define MP3MI_FFT_HDRS_L 2, 2, 2, 14, 2, 6, 15, 6, 3, 15, 6, 3, 15, 6, 3, 15, 6, 3, 13, 2, 4, 13, 4, 9, 8, 8
+#define MP3MI_FFT_HDRS_S 2, 2, 14, 2, 6, 15, 6, 7, 13, 6, 7, 13, 6, 13, 4, 4, 9, 8, 8
 #define MP3MI_POW43_N 8208
 #define MP3MI_STEP_MIN (-400)
 #define MP3MI_STEP_N 801

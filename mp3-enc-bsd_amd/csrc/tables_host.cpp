@@ -194,8 +194,9 @@ struct FftGen {
             int last_round_of_rank = -1;
             for (int cls = 0; cls < 2; cls++) {
                 const int nopnd = cls ? 8 : 4;
-                std::vector<FusedOp> rest;
-                /* rotations first, SQHALF rotations last: rounds without either skip that arithmetic */
+                std::vector<FusedOp> rest, sq;
+                /* rotations first; the few SQHALF rotations go last so that only the last round of the class
+                   pays for that arithmetic */
                 static const int kind_order[3] = {1, 0, 2};
                 for (int ko = 0; ko < 3; ko++)
                     for (int w = 0; w < nwin; w++)
@@ -204,7 +205,7 @@ struct FftGen {
                             if (o.cls != cls || o.kind != kind_order[ko]) continue;
                             for (int k = 0; k < nopnd; k++)
                                 o.p[k] = (o.p[k] == MP3MI_FFT_DUMMY) ? o.p[k] : (unsigned) (w * N + MP3MI_FFT_SWZ((int) o.p[k]));
-                            rest.push_back(o);
+                            (o.kind == 2 ? sq : rest).push_back(o);
                         }
                 /* The butterflies of a rank are independent, so their order is free: place them so that the 32
                    lanes an 8-byte LDS read is served in address 32 different bank pairs with every operand, and
@@ -244,8 +245,8 @@ struct FftGen {
                         take(best);
                     }
                     placed.insert(placed.end(), group.begin(), group.end());
-                    if (!rest.empty()) while (placed.size() % 32) { FusedOp idle; memset(&idle, 0, sizeof(idle)); idle.cls = -1; placed.push_back(idle); }
                 }
+                placed.insert(placed.end(), sq.begin(), sq.end());
                 /* rounds of 64: block 0 = operand positions (R: 2 words per lane, C: 4), then either the
                    twiddle block(s) {cn, spc, smc, flags} (C: a second one {c3n, spc3n, smc3n, 0}) or, in a round
                    without rotations, one word of flags per lane.  flags: bit 0 rotation, bit 1 SQHALF rotation,
@@ -395,6 +396,20 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
         T->fft_nword_l = g->build(10, 1, T->fft_hdr_l, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_l, T->fft_prog_l, MP3MI_FFT_PROG_WORDS, T->fft_rd_l);
         T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS, T->fft_rd_s);
+        {   /* the kernel is compiled for exactly this sequence of rounds (k_fft.hip) */
+            static const uint8_t hl[] = {MP3MI_FFT_HDRS_L}, hs[] = {MP3MI_FFT_HDRS_S};
+            bool same = T->fft_nround_l == (int) sizeof(hl) && T->fft_nround_s == (int) sizeof(hs);
+            for (int i = 0; same && i < T->fft_nround_l; i++) same = T->fft_hdr_l[i] == hl[i];
+            for (int i = 0; same && i < T->fft_nround_s; i++) same = T->fft_hdr_s[i] == hs[i];
+            if (getenv("MP3MI_FFT_INFO")) {
+                fprintf(stderr, "#define MP3MI_FFT_HDRS_L");
+                for (int i = 0; i < T->fft_nround_l; i++) fprintf(stderr, "%s %u", i ? "," : "", T->fft_hdr_l[i]);
+                fprintf(stderr, "\n#define MP3MI_FFT_HDRS_S");
+                for (int i = 0; i < T->fft_nround_s; i++) fprintf(stderr, "%s %u", i ? "," : "", T->fft_hdr_s[i]);
+                fprintf(stderr, "\n");
+            }
+            if (!same) { fprintf(stderr, "mp3mi: fft program does not match MP3MI_FFT_HDRS_* (mp3mi_dev.h)\n"); delete g; return -6; }
+        }
         if (getenv("MP3MI_FFT_INFO")) fprintf(stderr, "mp3mi: fft program long %d rounds %d words, short %d rounds %d words\n", T->fft_nround_l, T->fft_nword_l, T->fft_nround_s, T->fft_nword_s);
         delete g;
     }

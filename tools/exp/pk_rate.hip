@@ -12,16 +12,17 @@ __global__ void __launch_bounds__(64) k(float *out, int iters)
     for (int i = 0; i < 16; i++) a[i] = (float) threadIdx.x + i;
     for (int i = 0; i < 8; i++) p[i] = (v2f){a[2 * i], a[2 * i + 1]};
     const float c = 1.0001f;
+    const v2f c2 = {c, c};
     for (int it = 0; it < iters; it++) {
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 16; i++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
         } else if (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[i]) : "v"(c));
+            for (int i = 0; i < 8; i++) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
         } else if (MODE == 2) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[i]) : "v"(c));
+            for (int i = 0; i < 8; i++) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
         } else if (MODE == 3) {
 #pragma unroll
             for (int i = 0; i < 16; i++) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
@@ -29,7 +30,7 @@ __global__ void __launch_bounds__(64) k(float *out, int iters)
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
-                for (int i = 0; i < 8; i++) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[i]) : "v"(c));
+                for (int i = 0; i < 8; i++) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
         }
     }
     float s = 0;
@@ -40,7 +41,7 @@ __global__ void __launch_bounds__(64) k(float *out, int iters)
 int main()
 {
     float *out;
-    hipMalloc(&out, 4096 * 64 * sizeof(float));
+    (void) hipMalloc(&out, 4096 * 64 * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
