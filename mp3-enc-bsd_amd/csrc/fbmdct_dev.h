@@ -12,7 +12,7 @@
 #define MP3MI_FBMDCT_DEV_H
 #include "mp3mi_host.h"
 
-// 16.9 KB per wavefront
+// 17.3 KB per wavefront
 struct mdct_lds {
     union {
         double in[36][32]; // [k][band]: 18 slots of the previous granule, then 18 of the current one (sign-flipped
@@ -22,16 +22,19 @@ struct mdct_lds {
     double V[32][27];      // long-block operand groups per band (26 used; odd stride spreads the banks)
     double win[4][36];
     double cos_s[6][12];
+    double scoef[6][6];    // the six short output rows of the long-block transform (2 or 6 terms): coefficients,
+    uint8_t sidx[6][8];    // operand-group indices,
+    uint8_t srow[8], snt[8]; // output row and number of terms
     uint8_t g_ops[6][6], h_ops[2][18];
 };
 
-// per-lane constants of the long-block MDCT: lane owns output row m = lane % 18
+// per-lane constants of the long-block MDCT.  Twelve of the 18 output rows are the ordered sum of all 18
+// pair groups V[0..17] (T->mdct_full_row): lane < 60 owns one of them (row m_full, coefficients in registers)
+// for every fifth band.  The other six rows have 2 or 6 terms (T->mdct_small_row) and are taken from LDS.
 struct mdct_regs {
     double coef[18];
-    uint32_t vi[5]; // 18 operand-group indices, one byte each
-    int nt;
+    int m_full, grp;
 };
-MP3MI_DEVFN int mdct_vi(const mdct_regs &R, int t) { return (int) ((R.vi[t >> 2] >> (8 * (t & 3))) & 0xffu); }
 
 // s[sub] of filter_subband from the 64 folded window sums y (src/encode.c:398-408)
 MP3MI_DEVFN double fbm_matrix(const double *y, const double *frow)
@@ -44,35 +47,48 @@ MP3MI_DEVFN double fbm_matrix(const double *y, const double *frow)
 
 MP3MI_DEVFN void mdct_load_tables(mdct_lds &L, mdct_regs &R, const mp3mi_tables *T)
 {
-    const int lane = wave_lane(), m = lane % 18;
-    for (int i = lane; i < 4 * 36; i += 64) L.win[i / 36][i % 36] = T->mdct_win[i / 36][i % 36];
-    for (int i = lane; i < 72; i += 64) L.cos_s[i / 12][i % 12] = T->cos_s[i / 12][i % 12];
+    const int lane = wave_lane();
+    for (int i = lane; i < 4 * 36; i += 64) (&L.win[0][0])[i] = (&T->mdct_win[0][0])[i];
+    for (int i = lane; i < 72; i += 64) (&L.cos_s[0][0])[i] = (&T->cos_s[0][0])[i];
     if (lane < 36) L.g_ops[lane / 6][lane % 6] = T->mdct_g_ops[lane / 6][lane % 6];
-    if (lane < 36) L.h_ops[lane / 18][lane % 18] = T->mdct_h_ops[lane / 18][lane % 18];
+    if (lane < 36) (&L.h_ops[0][0])[lane] = (&T->mdct_h_ops[0][0])[lane];
+    if (lane < 36) { // the six short rows
+        const int sr = lane / 6, t = lane - 6 * sr, m = T->mdct_small_row[sr];
+        L.scoef[sr][t] = T->mdct_vcoef[m][t];
+        L.sidx[sr][t] = T->mdct_vidx[m][t];
+        if (t == 0) { L.srow[sr] = (uint8_t) m; L.snt[sr] = T->mdct_nterm[m]; }
+    }
+    R.grp = lane / 12;
+    R.m_full = T->mdct_full_row[lane < 60 ? lane - 12 * R.grp : 0];
 #pragma unroll
-    for (int t = 0; t < 5; t++) R.vi[t] = 0;
-#pragma unroll
-    for (int t = 0; t < 18; t++) { R.coef[t] = T->mdct_vcoef[m][t]; R.vi[t >> 2] |= (uint32_t) T->mdct_vidx[m][t] << (8 * (t & 3)); }
-    R.nt = T->mdct_nterm[m];
+    for (int t = 0; t < 18; t++) R.coef[t] = T->mdct_vcoef[R.m_full][t];
 }
 
-// L.in <- the 36 inputs of every band from two granules of subband samples ([slot][sub], contiguous);
-// a long block (bt == 0) gets its window applied here.  Ends with a barrier.
+// L.in <- the 36 inputs of every band from two granules of subband samples held in registers (vp: previous
+// granule, vc: current one; element lane + 64 j of the [slot][sub] block each); a long block (bt == 0) gets
+// its window applied here.  Ends with a barrier.
+MP3MI_DEVFN void mdct_store_inputs(mdct_lds &L, const double (&vp)[9], const double (&vc)[9], int bt)
+{
+    const int lane = wave_lane();
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int k = (lane >> 5) + 2 * j;
+        (&L.in[0][0])[lane + 64 * j] = (bt == 0) ? L.win[0][k] * vp[j] : vp[j];
+        (&L.in[0][0])[576 + lane + 64 * j] = (bt == 0) ? L.win[0][18 + k] * vc[j] : vc[j];
+    }
+    __syncthreads();
+}
+
 MP3MI_DEVFN void mdct_load_inputs(mdct_lds &L, const double *prev, const double *cur, int bt)
 {
     const int lane = wave_lane();
-    double v[18];
+    double vp[9], vc[9];
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-        v[j] = prev[lane + 64 * j];
-        v[9 + j] = cur[lane + 64 * j];
+        vp[j] = prev[lane + 64 * j];
+        vc[j] = cur[lane + 64 * j];
     }
-#pragma unroll
-    for (int j = 0; j < 18; j++) {
-        const int k = (j < 9) ? (lane >> 5) + 2 * j : 18 + (lane >> 5) + 2 * (j - 9);
-        (&L.in[0][0])[(j < 9 ? 0 : 576) + lane + 64 * (j < 9 ? j : j - 9)] = (bt == 0) ? L.win[0][k] * v[j] : v[j];
-    }
-    __syncthreads();
+    mdct_store_inputs(L, vp, vc, bt);
 }
 
 // ordered signed sum of windowed inputs: ops[i] = index | 0x80 (subtract / negate)
@@ -111,20 +127,29 @@ MP3MI_DEVFN void mdct_granule(mdct_lds &L, const mdct_regs &R, const mp3mi_table
             L.V[band][24 + h] = g[3];
         }
         __syncthreads(); // the inputs are dead from here on
-        if (lane < 54) { // phase B: lane owns output row m for every third band
-            const int m = lane % 18, grp = lane / 18;
-            for (int band = grp; band < 32; band += 3) {
+        // phase B: every output is the ordered sum of its terms V * coefficient (src/mdct.c:199-509)
+        if (lane < 60) { // the twelve rows over all 18 pair groups
+            for (int band = R.grp; band < 32; band += 5) {
                 double pr[18];
 #pragma unroll
-                for (int t = 0; t < 18; t++) pr[t] = L.V[band][mdct_vi(R, t)];
+                for (int t = 0; t < 18; t++) pr[t] = L.V[band][t];
                 double sum = pr[0] * R.coef[0];
 #pragma unroll
-                for (int t = 1; t < 18; t++) {
-                    const double q = pr[t] * R.coef[t];
-                    sum = (t < R.nt) ? sum + q : sum;
-                }
-                L.xr[band * 18 + m] = sum;
+                for (int t = 1; t < 18; t++) sum = sum + pr[t] * R.coef[t];
+                L.xr[band * 18 + R.m_full] = sum;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { // the six short rows: 192 outputs
+            const int o = lane + 64 * i, band = o & 31, sr = o >> 5;
+            const int nt = L.snt[sr];
+            double sum = L.V[band][L.sidx[sr][0]] * L.scoef[sr][0];
+#pragma unroll
+            for (int t = 1; t < 6; t++) {
+                const double q = L.V[band][L.sidx[sr][t]] * L.scoef[sr][t];
+                sum = (t < nt) ? sum + q : sum;
+            }
+            L.xr[band * 18 + L.srow[sr]] = sum;
         }
     } else {
         double out[9];

@@ -8,7 +8,7 @@
 //             The filterbank is feed-forward -- a pure function of 1056 PCM samples -- so every
 //             granule is independent, including the one BEFORE the chunk, which the reference
 //             would still hold in l3_sb_sample[ch][0] and which is recomputed here (granule slot 0).
-//   k_mdct    one wavefront per (stream, granule, channel): 36 inputs per band from two granules.
+//   k_mdct    one wavefront per (stream, channel, run of 8 granules): 36 inputs per band from two granules.
 //
 // Arithmetic and its ordering: fbmdct_dev.h.
 #include "fbmdct_dev.h"
@@ -106,26 +106,47 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
     }
 }
 
-__global__ void __launch_bounds__(64, 4) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+// One wavefront transforms a run of MDCT_RUN consecutive granules of one (stream, channel): the tables are
+// set up once, every granule's subband samples are read once (the current granule is the next one's
+// "previous"), and the next granule's samples are requested before the current one is transformed.
+#define MDCT_RUN 8
+__global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ sbs, const mp3mi_psy_out *__restrict__ psy,
                                                 double *__restrict__ xr_out)
 {
     __shared__ mdct_lds L;
     const int lane = wave_lane();
-    const int C = geo.channels, G = geo.n_gran;
+    const int C = geo.channels, G = geo.n_gran, NR = (G + MDCT_RUN - 1) / MDCT_RUN;
     int bid = (int) blockIdx.x;
     const int ch = bid % C; bid /= C;
-    const int gl = bid % G;
-    const int s = bid / G;
-    const size_t rec = ((size_t) s * G + gl) * C + ch;
-    const double *prev = sbs + (((size_t) s * (G + 1) + gl) * C + ch) * 576;
-    const int bt = psy[rec].block_type;
+    const int r = bid % NR;
+    const int s = bid / NR;
+    const int g_lo = r * MDCT_RUN, n = G - g_lo < MDCT_RUN ? G - g_lo : MDCT_RUN;
+    const size_t rec0 = ((size_t) s * G + g_lo) * C + ch;
+    const int btv = lane < n ? psy[rec0 + (size_t) lane * C].block_type : 0;
+    const size_t pitch = (size_t) C * 576;
+    const double *blk = sbs + (((size_t) s * (G + 1) + g_lo) * C + ch) * 576; // granule slot g_lo: the one before granule g_lo
+    double vp[9], vc[9], vn[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) { vp[j] = blk[lane + 64 * j]; vc[j] = blk[pitch + lane + 64 * j]; vn[j] = 0.0; }
     mdct_regs R;
     mdct_load_tables(L, R, T);
     __syncthreads();
-    mdct_load_inputs(L, prev, prev + (size_t) C * 576, bt);
-    mdct_granule(L, R, T, bt);
-    for (int i = lane; i < 576; i += 64) xr_out[rec * 576 + i] = L.xr[i];
+    for (int k = 0; k < n; k++) {
+        if (k + 1 < n) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) vn[j] = blk[(size_t) (k + 2) * pitch + lane + 64 * j];
+        }
+        const int bt = wave_readlane_i32(btv, k);
+        mdct_store_inputs(L, vp, vc, bt);
+        mdct_granule(L, R, T, bt);
+        double *out = xr_out + (rec0 + (size_t) k * C) * 576;
+#pragma unroll
+        for (int j = 0; j < 9; j++) out[lane + 64 * j] = L.xr[lane + 64 * j];
+        __syncthreads(); // the next granule's inputs take the place of this result
+#pragma unroll
+        for (int j = 0; j < 9; j++) { vp[j] = vc[j]; vc[j] = vn[j]; }
+    }
 }
 
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g) { return (size_t) g.n_streams * (size_t) (g.n_gran + 1) * (size_t) g.channels * 576 * sizeof(double); }
@@ -134,5 +155,5 @@ void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16
                          const mp3mi_psy_out *psy, double *sbs, double *xr, double *sb_dbg, hipStream_t st)
 {
     hipLaunchKernelGGL(k_filter, dim3((unsigned) (g.n_streams * (g.n_gran + 1) * g.channels)), dim3(64), 0, st, T, g, pcm, sbs, sb_dbg);
-    hipLaunchKernelGGL(k_mdct, dim3((unsigned) (g.n_streams * g.n_gran * g.channels)), dim3(64), 0, st, T, g, sbs, psy, xr);
+    hipLaunchKernelGGL(k_mdct, dim3((unsigned) (g.n_streams * g.channels * ((g.n_gran + MDCT_RUN - 1) / MDCT_RUN))), dim3(64), 0, st, T, g, sbs, psy, xr);
 }

@@ -223,6 +223,30 @@ MP3MI_DEVFN void fft_bin(const float *x, uint32_t rd, fft_pair<C> *re, fft_pair<
     }
 }
 
+// N x 64 consecutive samples (all channels of a sample in one word) from time t_first on, sample lane + 64 k
+// in smp[k]; outside [0, n_per_ch) the stream reads as zero.  t_first is wave-uniform: when the whole span lies
+// inside the stream -- all but its first and last granules -- the loads need no per-sample tests.
+template <int C, int N>
+MP3MI_DEVFN void fft_load_pcm(const int16_t *pcm, long t_first, long n_per_ch, int lane, uint32_t (&smp)[N])
+{
+    if (t_first >= 0 && t_first + 64 * N <= n_per_ch) {
+        const int16_t *p = pcm + t_first * C;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            if (C == 2) smp[k] = ((const uint32_t *) p)[lane + 64 * k];
+            else smp[k] = (uint32_t) (uint16_t) p[lane + 64 * k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const long t = t_first + lane + 64 * k;
+            const bool in = t >= 0 && t < n_per_ch;
+            if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : 0u;
+            else smp[k] = in ? (uint32_t) (uint16_t) pcm[t] : 0u;
+        }
+    }
+}
+
 template <int C, int W>
 __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const int16_t *__restrict__ pcm_all, float *__restrict__ energy_l,
@@ -232,7 +256,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     const int lane = wave_lane(), tid = (int) threadIdx.x;
     fft_wave_lds<C> &L = LL.w[tid >> 6];
     const int G = geo.n_gran, n_task = geo.n_streams * G;
-    int task = (int) blockIdx.x * W + (tid >> 6);
+    int task = (int) blockIdx.x * W + __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform, and known to be
     const bool valid = task < n_task; // the last workgroup may have idle wavefronts: they compute, but do not store
     task = valid ? task : n_task - 1;
     const int gl = task % G, s = task / G;
@@ -253,14 +277,9 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     {
         float wl[16];
         uint32_t smp[16];
+        fft_load_pcm<C, 16>(pcm, t0, n_per_ch, lane, smp);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const long t = t0 + lane + 64 * k;
-            const bool in = t >= 0 && t < n_per_ch;
-            if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : 0u;
-            else smp[k] = in ? (uint32_t) (uint16_t) pcm[t] : 0u;
-            wl[k] = T->window[lane + 64 * k];
-        }
+        for (int k = 0; k < 16; k++) wl[k] = T->window[lane + 64 * k];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             fft_pair<C> v;
@@ -279,13 +298,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     // the short windows' samples are requested now and land while the long spectrum is consumed
     uint32_t smp[8];
     float wsv[4];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const long t = t0 + 256 + lane + 64 * k;
-        const bool in = t >= 0 && t < n_per_ch;
-        if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : 0u;
-        else smp[k] = in ? (uint32_t) (uint16_t) pcm[t] : 0u;
-    }
+    fft_load_pcm<C, 8>(pcm, t0 + 256, n_per_ch, lane, smp);
 #pragma unroll
     for (int k = 0; k < 4; k++) wsv[k] = T->window_s[lane + 64 * k];
 

@@ -86,6 +86,7 @@ typedef struct {
        24-25: the two 18-operand groups, operand lists below, bit 7 = subtract/negate); output m is
        the ordered sum over t < mdct_nterm[m] of V[mdct_vidx[m][t]] * mdct_vcoef[m][t] */
     uint8_t mdct_vidx[18][18], mdct_nterm[18];
+    uint8_t mdct_full_row[12], mdct_small_row[6]; /* rows whose terms are V[0..17] in order / rows with at most 6 terms */
     uint8_t mdct_g_ops[6][18], mdct_h_ops[2][18];
     double mdct_vcoef[18][18];
     /* quantiser */

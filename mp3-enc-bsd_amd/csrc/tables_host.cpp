@@ -503,6 +503,17 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
             for (; nt < 18; nt++) { T->mdct_vidx[m][nt] = 0; T->mdct_vcoef[m][nt] = 0.0; }
         }
         if (n_g != 6 || n_h != 2) return -4;
+        {   /* the shape k_mdct's long-block code relies on: twelve rows over V[0..17] in order, six of <= 6 terms */
+            int nf = 0, nsm = 0;
+            for (int m = 0; m < 18; m++) {
+                bool full = T->mdct_nterm[m] == 18;
+                for (int t = 0; full && t < 18; t++) full = T->mdct_vidx[m][t] == t;
+                if (full) { if (nf >= 12) return -4; T->mdct_full_row[nf++] = (uint8_t) m; }
+                else if (T->mdct_nterm[m] >= 1 && T->mdct_nterm[m] <= 6) { if (nsm >= 6) return -4; T->mdct_small_row[nsm++] = (uint8_t) m; }
+                else return -4;
+            }
+            if (nf != 12 || nsm != 6) return -4;
+        }
     }
 
     T->pow_nint_tab[0] = 0.0;
