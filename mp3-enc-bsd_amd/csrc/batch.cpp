@@ -61,7 +61,7 @@ struct mp3mi_batch {
     double *cw_mid, *xr[2], *sbs, *sb_dbg, *part_eb;
     float *part_cb;
     mp3mi_psy_out *psy[2];
-    mp3mi_loop_prep *prep[2];
+    mp3mi_prep_block *prep[2];
     void *psy_state, *loop_state;
     int16_t *ix;
     mp3mi_frame_side *side;
@@ -196,7 +196,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     for (int i = 0; i < 2; i++) {
         CHK(hipMalloc((void **) &b->xr[i], ngc * 576 * sizeof(double)));
         CHK(hipMalloc((void **) &b->psy[i], ngc * sizeof(mp3mi_psy_out)));
-        CHK(hipMalloc((void **) &b->prep[i], ngc * sizeof(mp3mi_loop_prep)));
+        CHK(hipMalloc((void **) &b->prep[i], ((ngc + 63) / 64) * sizeof(mp3mi_prep_block)));
     }
     CHK(hipMalloc((void **) &b->sbs, (ngc + (size_t) n_streams * channels) * 576 * sizeof(double)));
     CHK(hipMalloc((void **) &b->ix, ngc * 576 * sizeof(int16_t)));

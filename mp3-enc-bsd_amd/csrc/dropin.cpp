@@ -66,7 +66,7 @@ struct DropIn {
     int32_t *bt_d = nullptr;
     // loop
     mp3mi_psy_out *psy4 = nullptr;
-    mp3mi_loop_prep *prep4 = nullptr;
+    mp3mi_prep_block *prep4 = nullptr;
     int16_t *ix_d = nullptr;
     mp3mi_frame_side *side_d = nullptr;
     void *loop_state = nullptr;
@@ -118,7 +118,7 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.xr_d, 4 * 576 * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.bt_d, 4 * sizeof(int32_t)));
     HIPOK(hipMalloc((void **) &D.psy4, 4 * sizeof(mp3mi_psy_out)));
-    HIPOK(hipMalloc((void **) &D.prep4, 4 * sizeof(mp3mi_loop_prep)));
+    HIPOK(hipMalloc((void **) &D.prep4, sizeof(mp3mi_prep_block)));
     HIPOK(hipMalloc((void **) &D.ix_d, 4 * 576 * sizeof(int16_t)));
     HIPOK(hipMalloc((void **) &D.side_d, sizeof(mp3mi_frame_side)));
     HIPOK(hipMalloc((void **) &D.loop_state, mp3mi_loop_state_size()));

@@ -8,7 +8,7 @@
 //             The filterbank is feed-forward -- a pure function of 1056 PCM samples -- so every
 //             granule is independent, including the one BEFORE the chunk, which the reference
 //             would still hold in l3_sb_sample[ch][0] and which is recomputed here (granule slot 0).
-//   k_mdct    one wavefront per (stream, channel, run of 8 granules): 36 inputs per band from two granules.
+//   k_mdct    one wavefront per (stream, channel, run of 11 granules): 36 inputs per band from two granules.
 //
 // Arithmetic and its ordering: fbmdct_dev.h.
 #include "fbmdct_dev.h"
@@ -51,10 +51,12 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
         for (int k = 0; k < 17; k++)
             if (lane + 64 * k < 1056) L.pcm[lane + 64 * k] = v[k];
     }
-    // per-lane constants: 8 window taps for y[lane], the 31 filter coefficients of subband lane & 31
+    // per-lane constants: 8 window taps for y[lane] -- with the 1/32768 of src/encode.c:306-312 folded in: scaling
+    // by a power of two commutes with the rounding of the product, (x / 32768) * w == x * (w / 32768) bit for
+    // bit (no product comes near the subnormals) -- and the 31 filter coefficients of subband lane & 31
     double enw[8], frow[31];
 #pragma unroll
-    for (int k = 0; k < 8; k++) enw[k] = T->enwindow[lane + 64 * k];
+    for (int k = 0; k < 8; k++) enw[k] = T->enwindow[lane + 64 * k] * (1.0 / 32768.0);
 #pragma unroll
     for (int j = 0; j < 31; j++) frow[j] = T->filt[sub][j];
     // where this lane's y goes in the matrixing step: lane j < 16 forms y[j] + y[32-j], lane 16 passes
@@ -74,9 +76,9 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
                 for (int k = 0; k < 8; k++) tp[h][k] = L.pcm[480 + 32 * (pair * 2 + h) + 31 - lane - 64 * k];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                double acc = ((double) tp[h][0] * (1.0 / 32768.0)) * enw[0];
+                double acc = (double) tp[h][0] * enw[0];
 #pragma unroll
-                for (int k = 1; k < 8; k++) acc = acc + ((double) tp[h][k] * (1.0 / 32768.0)) * enw[k];
+                for (int k = 1; k < 8; k++) acc = acc + (double) tp[h][k] * enw[k];
                 y[h] = acc;
             }
         }
@@ -109,8 +111,8 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
 // One wavefront transforms a run of MDCT_RUN consecutive granules of one (stream, channel): the tables are
 // set up once, every granule's subband samples are read once (the current granule is the next one's
 // "previous"), and the next granule's samples are requested before the current one is transformed.
-#define MDCT_RUN 8
-__global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+#define MDCT_RUN 11
+__global__ void __launch_bounds__(64, 2) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ sbs, const mp3mi_psy_out *__restrict__ psy,
                                                 double *__restrict__ xr_out)
 {

@@ -632,7 +632,7 @@ void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st)
 
 __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
-                                                const mp3mi_loop_prep *__restrict__ prep,
+                                                const mp3mi_prep_block *__restrict__ prep,
                                                 const int32_t *__restrict__ bits_per_frame,
                                                 mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
                                                 mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
@@ -722,19 +722,20 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
                 //      were computed by k_prep; only the stateful decision of calc_scfsi happens here ----
                 PROF(0);
-                const mp3mi_loop_prep *pp = &prep[rec];
+                const mp3mi_prep_block *pp = &prep[rec >> 6]; // records come in blocks of 64, field by field
+                const int ps = (int) (rec & 63);
                 // per-band state lives in the band lanes' registers: allowed distortion, noise, scalefactor
-                double xmin_r = bandlane ? pp->xmin[lane] : 0.0, xfsf_r = 0.0;
+                double xmin_r = bandlane ? pp->xmin[lane][ps] : 0.0, xfsf_r = 0.0;
                 int sf_r = 0, sfsave_r = 0;
                 if (lane == 0) {
-                    L.st.sc_xrmax[gr][ch] = pp->sc_xrmax;
-                    L.st.sc_en_tot[gr][ch] = pp->sc_en_tot;
+                    L.st.sc_xrmax[gr][ch] = pp->sc_xrmax[ps];
+                    L.st.sc_en_tot[gr][ch] = pp->sc_en_tot[ps];
                 }
                 if (!shortb && lane < 21) {
-                    L.st.sc_en[gr][ch][lane] = pp->sc_en[lane];
-                    L.st.sc_xm[gr][ch][lane] = pp->sc_xm[lane];
+                    L.st.sc_en[gr][ch][lane] = pp->sc_en[lane][ps];
+                    L.st.sc_xm[gr][ch][lane] = pp->sc_xm[lane][ps];
                 }
-                const int nonzero = pp->nonzero;
+                const int nonzero = pp->nonzero[ps];
                 __syncthreads();
                 if (gr == 1) {
                     int condition = 0;
@@ -792,7 +793,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 __syncthreads();
 
                 if (nonzero) {
-                    g.q = pp->q0; // quantanf_init (src/loop.c:369-402), from k_prep
+                    g.q = pp->q0[ps]; // quantanf_init (src/loop.c:369-402), from k_prep
 
                     // ---- outer_loop (src/loop.c:415-558) ----
                     int iteration = 0, bits = 0, over, status, save_preflag, save_compress;
@@ -1083,7 +1084,7 @@ extern "C" void mp3mi_debug_loop_waves(unsigned long long *out, int n_streams)
 size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
-                       const mp3mi_loop_prep *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
+                       const mp3mi_prep_block *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
                        mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place, hipStream_t st)
 {
     hipLaunchKernelGGL(k_loop, dim3((unsigned) g.n_streams), dim3(64), 0, st, T, g, xr, psy, prep, bits_per_frame,

@@ -45,7 +45,7 @@ struct prep_walk_state {
 // parked RAW in out->xmin[] when a band closes; prep_finish turns them into xmin and the log-energies.
 template <bool EXACT>
 MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double x, int w, int line1, bool shortb, bool live,
-                           mp3mi_loop_prep *out)
+                           mp3mi_prep_block *out, int lane)
 {
     const double sq = x * x, ax = __builtin_fabs(x);
     S.tot = S.tot + sq;
@@ -59,16 +59,16 @@ MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double x, 
     }
     S.slog = S.slog + lg;
     if (line1 == S.edgeL) { // a long scalefactor band ends here
-        if (S.bandL < 21 && !shortb && live) out->xmin[S.bandL] = S.accL;
+        if (S.bandL < 21 && !shortb && live) out->xmin[S.bandL][lane] = S.accL;
         S.accL = 0.0;
         S.bandL++;
         S.edgeL = S.bandL < 22 ? T->sfb_l[S.bandL + 1] : 577;
     }
     if (w == 2 && line1 == S.edgeS) { // a short scalefactor band ends here for all three windows
         if (S.bandS < 12 && shortb && live) {
-            out->xmin[S.bandS * 3 + 0] = S.a0;
-            out->xmin[S.bandS * 3 + 1] = S.a1;
-            out->xmin[S.bandS * 3 + 2] = S.a2;
+            out->xmin[S.bandS * 3 + 0][lane] = S.a0;
+            out->xmin[S.bandS * 3 + 1][lane] = S.a1;
+            out->xmin[S.bandS * 3 + 2][lane] = S.a2;
         }
         S.a0 = S.a1 = S.a2 = 0.0;
         S.bandS++;
@@ -78,19 +78,19 @@ MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double x, 
 
 template <int PH>
 MP3MI_DEVFN void prep_block(const mp3mi_tables *T, prep_walk_state &S, const prep_d2 (&v)[PREP_BLOCK / 2], int k, bool shortb,
-                            bool live, mp3mi_loop_prep *out)
+                            bool live, mp3mi_prep_block *out, int lane)
 {
 #pragma unroll
     for (int j = 0; j < PREP_BLOCK; j++) {
         const double x = (j & 1) ? v[j >> 1].y : v[j >> 1].x;
-        prep_line<false>(T, S, x, (PH + j) % 3, k + j + 1, shortb, live, out);
+        prep_line<false>(T, S, x, (PH + j) % 3, k + j + 1, shortb, live, out, lane);
         PREP_SCHED_FENCE(); // one line at a time: the wavefronts of the SIMD hide the latency, not ILP across lines
     }
 }
 
 __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
-                                                mp3mi_loop_prep *__restrict__ prep, int force_exact)
+                                                mp3mi_prep_block *__restrict__ prep, int force_exact)
 {
     const int lane = wave_lane();
     const size_t n_rec = (size_t) geo.n_streams * (size_t) geo.n_gran * (size_t) geo.channels;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__
     const bool live = rec0 + lane < n_rec;
     const size_t rec = live ? rec0 + lane : n_rec - 1;
     const mp3mi_psy_out *po = &psy[rec];
-    mp3mi_loop_prep *out = &prep[rec];
+    mp3mi_prep_block *out = &prep[blockIdx.x]; // this wavefront's 64 records: lane = slot (mp3mi_dev.h)
     const double *row = xr_all + rec * 576;
     const bool shortb = po->block_type == 2;
 
@@ -119,13 +119,13 @@ __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__
                 for (int q = 0; q < PREP_BLOCK / 2; q++) v[q] = *(const prep_d2 *) (row + k + 2 * q);
                 // 16 = 1 mod 3: the short-block window of the block's first line cycles 0, 1, 2 (wave-uniform)
                 const int ph = k % 3;
-                if (ph == 0) prep_block<0>(T, S, v, k, shortb, live, out);
-                else if (ph == 1) prep_block<1>(T, S, v, k, shortb, live, out);
-                else prep_block<2>(T, S, v, k, shortb, live, out);
+                if (ph == 0) prep_block<0>(T, S, v, k, shortb, live, out, lane);
+                else if (ph == 1) prep_block<1>(T, S, v, k, shortb, live, out, lane);
+                else prep_block<2>(T, S, v, k, shortb, live, out, lane);
             }
         } else { // second tier, rare: plain line-by-line walk
 #pragma unroll 1
-            for (int k = 0; k < 576; k++) prep_line<true>(T, S, row[k], k % 3, k + 1, shortb, live, out);
+            for (int k = 0; k < 576; k++) prep_line<true>(T, S, row[k], k % 3, k + 1, shortb, live, out, lane);
         }
         // quantanf_init (src/loop.c:369-402)
         tp = 0;
@@ -143,30 +143,30 @@ __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__
         if (exact || !wave_any(S.amb && live)) break;
     }
     if (!live) return;
-    out->q0 = tp - 70;
-    out->sc_en_tot = prep_ilog2(T, S.tot);
-    out->sc_xrmax = (int) S.amax;
-    out->nonzero = (S.amax != 0.0) ? 1 : 0;
+    out->q0[lane] = tp - 70;
+    out->sc_en_tot[lane] = prep_ilog2(T, S.tot);
+    out->sc_xrmax[lane] = (int) S.amax;
+    out->nonzero[lane] = (S.amax != 0.0) ? 1 : 0;
     // calc_xmin (src/loop.c:1085-1118) and calc_scfsi's stored values (src/loop.c:642-667) from the parked energies
     if (shortb) {
         for (int b = 0; b < 12; b++) {
             const double cnt = (double) (T->sfb_s[b + 1] - T->sfb_s[b]);
-            for (int w = 0; w < 3; w++) out->xmin[b * 3 + w] = po->ratio_s[b][w] * out->xmin[b * 3 + w] / cnt;
+            for (int w = 0; w < 3; w++) out->xmin[b * 3 + w][lane] = po->ratio_s[b][w] * out->xmin[b * 3 + w][lane] / cnt;
         }
     } else {
 #pragma unroll 1
         for (int b = 0; b < 21; b++) {
-            const double en = out->xmin[b];
+            const double en = out->xmin[b][lane];
             const double xmin = po->ratio_l[b] * en / (double) (T->sfb_l[b + 1] - T->sfb_l[b]);
-            out->xmin[b] = xmin;
-            out->sc_en[b] = prep_ilog2(T, en);   // truncation to int as the reference's statics do
-            out->sc_xm[b] = prep_ilog2(T, xmin);
+            out->xmin[b][lane] = xmin;
+            out->sc_en[b][lane] = prep_ilog2(T, en);   // truncation to int as the reference's statics do
+            out->sc_xm[b][lane] = prep_ilog2(T, xmin);
         }
     }
 }
 
 void mp3mi_launch_prep(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
-                       mp3mi_loop_prep *prep, int force_exact, hipStream_t st)
+                       mp3mi_prep_block *prep, int force_exact, hipStream_t st)
 {
     const size_t n_rec = (size_t) g.n_streams * (size_t) g.n_gran * (size_t) g.channels;
     hipLaunchKernelGGL(k_prep, dim3((unsigned) ((n_rec + 63) / 64)), dim3(64), 0, st, T, g, xr, psy, prep, force_exact);

@@ -126,6 +126,13 @@ typedef struct {
     int32_t sc_en[21], sc_xm[21];    /* written for non-short granules only */
     int32_t sc_en_tot, sc_xrmax, q0, nonzero;
 } mp3mi_loop_prep;
+/* In memory the records come in blocks of 64, field by field: k_prep's 64 lanes are 64 consecutive records
+ * and store one field of all of them as one contiguous line (record r = slot r % 64 of block r / 64). */
+typedef struct {
+    double xmin[36][64];
+    int32_t sc_en[21][64], sc_xm[21][64];
+    int32_t sc_en_tot[64], sc_xrmax[64], q0[64], nonzero[64];
+} mp3mi_prep_block;
 
 /* Side information of one (granule, channel) as the iteration loop leaves it
  * (subset of gr_info, src/l3side.h:60-87, that the formatter needs). */

@@ -51,7 +51,7 @@ void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16
                          const mp3mi_psy_out *psy, double *sbs, double *xr, double *sb_dbg, hipStream_t st);
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g); /* subband samples between k_filter and k_mdct */
 void mp3mi_launch_prep(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
-                       const mp3mi_psy_out *psy, mp3mi_loop_prep *prep, int force_exact, hipStream_t st);
+                       const mp3mi_psy_out *psy, mp3mi_prep_block *prep, int force_exact, hipStream_t st);
 /* stream placement of k_loop (k_loop.hip: loop_place_stream); all pointers NULL = stream == blockIdx */
 #define MP3MI_PLACE_KEYS 8192
 struct mp3mi_loop_place {
@@ -65,7 +65,7 @@ struct mp3mi_loop_place {
 };
 void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st);
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
-                       const mp3mi_psy_out *psy, const mp3mi_loop_prep *prep, const int32_t *bits_per_frame,
+                       const mp3mi_psy_out *psy, const mp3mi_prep_block *prep, const int32_t *bits_per_frame,
                        void *loop_state, int16_t *ix, mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place,
                        hipStream_t st);
 /* bounded wait (one wavefront) until k_loop's start census reaches `target` -- see k_loop.hip */
