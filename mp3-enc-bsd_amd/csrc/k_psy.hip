@@ -48,8 +48,33 @@ struct part_walk {
     int b, pend; // open partition and the line after its last (wave-uniform)
 };
 
-MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, int j, float ef, double cw, bool live,
-                           double *__restrict__ eb_row, float *__restrict__ cb_row)
+// A closed partition's 64 values (one per lane = record) wait in an LDS tile; every eight partitions the tile
+// goes out transposed, 64 contiguous bytes of eb (32 of cb) per record, instead of one 8-byte store per lane
+// and partition into 64 different lines.
+struct part_tile {
+    double eb[8][65];
+    float cb[8][65];
+};
+
+// partitions [b_last & ~7, b_last] of the wavefront's records rec0 .. rec0 + 63 (partition 0 is stored at the end)
+MP3MI_DEVFN void part_flush(part_tile &Lt, int b_last, size_t rec0, size_t n_rec, double *__restrict__ eb_all, float *__restrict__ cb_all)
+{
+    const int lane = wave_lane_here();
+    wave_sync();
+    const int base = b_last & ~7, np = (b_last & 7) + 1, p = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int r = 8 * i + (lane >> 3);
+        if (p < np && base + p >= 1 && rec0 + r < n_rec) {
+            eb_all[(rec0 + r) * MP3MI_PART_P + base + p] = Lt.eb[p][r];
+            cb_all[(rec0 + r) * MP3MI_PART_P + base + p] = Lt.cb[p][r];
+        }
+    }
+    wave_sync(); // the tile is written again
+}
+
+MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, int j, float ef, double cw, size_t rec0, size_t n_rec,
+                           double *__restrict__ eb_all, float *__restrict__ cb_all)
 {
     const double e = (double) ef;
     if (j < T->part_l_covered) {
@@ -57,7 +82,12 @@ MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, int j, float ef,
         W.cb = (float) ((double) W.cb + cw * e);
         while (W.b < MP3MI_CBANDS && j + 1 == W.pend) { // closes this partition and any empty ones after it
             if (W.b == 0) { W.eb0 = W.eb; W.cb0 = W.cb; }
-            else if (live) { eb_row[W.b] = W.eb; cb_row[W.b] = W.cb; }
+            else {
+                const int lane = wave_lane_here();
+                Lt.eb[W.b & 7][lane] = W.eb;
+                Lt.cb[W.b & 7][lane] = W.cb;
+            }
+            if ((W.b & 7) == 7) part_flush(Lt, W.b, rec0, n_rec, eb_all, cb_all);
             W.eb = 0.0; W.cb = 0.0f;
             W.b++;
             W.pend = W.b < MP3MI_CBANDS ? T->part_l_start[W.b + 1] : -1;
@@ -84,8 +114,7 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
     const mp3mi_psy_state *st = &state[s * C + ch];
     const float *er = energy_l + rec * MP3MI_HBLK_P;
     const double *cwr = cw_mid + rec * 50;
-    double *eb_row = eb_all + rec * MP3MI_PART_P;
-    float *cb_row = cb_all + rec * MP3MI_PART_P;
+    __shared__ part_tile Lt;
 
     part_walk W;
     W.eb = W.eb0 = 0.0; W.cb = W.cb0 = 0.0f;
@@ -108,7 +137,7 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
         const double t2 = (double) rn * sn - r_prime * sp;
         const double t3 = (double) rn + __builtin_fabs(r_prime);
         const double cw = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
-        part_line(T, W, j, er[j], cw, live, eb_row, cb_row);
+        part_line(T, W, Lt, j, er[j], cw, rec0, n_rec, eb_all, cb_all);
     }
     // lines 6..511 in blocks of 32 = one 128-byte line of the energy row; the unpredictability of lines
     // 6+4n..9+4n is cw_mid[n] (src/l3psy.c:531-549), from line 206 on the constant 0.4 (src/l3psy.c:555-556).
@@ -138,14 +167,19 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
             const int jj = 32 * k + l;
             if (jj < 6) continue; // done above (only in block 0; wave-uniform)
             const int q = ((l - 6) >> 2) + 2; // arithmetic shift: l < 6 never reaches here with k == 0
-            part_line(T, W, jj, ev[l], jj < 206 ? cwv[q] : 0.4, live, eb_row, cb_row);
+            part_line(T, W, Lt, jj, ev[l], jj < 206 ? cwv[q] : 0.4, rec0, n_rec, eb_all, cb_all);
         }
     }
-    part_line(T, W, 512, er[512], 0.4, live, eb_row, cb_row);
+    part_line(T, W, Lt, 512, er[512], 0.4, rec0, n_rec, eb_all, cb_all);
+    for (int b = W.b < 1 ? 1 : W.b; b < MP3MI_CBANDS; b++) { // partitions without lines
+        Lt.eb[b & 7][lane] = 0.0;
+        Lt.cb[b & 7][lane] = 0.0f;
+        if ((b & 7) == 7) part_flush(Lt, b, rec0, n_rec, eb_all, cb_all);
+    }
+    if (((MP3MI_CBANDS - 1) & 7) != 7) part_flush(Lt, MP3MI_CBANDS - 1, rec0, n_rec, eb_all, cb_all); // the last, partial group
     if (live) {
-        eb_row[0] = W.eb0;
-        cb_row[0] = W.cb0;
-        for (int b = W.b < 1 ? 1 : W.b; b < MP3MI_CBANDS; b++) { eb_row[b] = 0.0; cb_row[b] = 0.0f; } // partitions without lines
+        eb_all[rec * MP3MI_PART_P] = W.eb0;
+        cb_all[rec * MP3MI_PART_P] = W.cb0;
     }
 }
 
