@@ -50,8 +50,10 @@ template <> struct __attribute__((aligned(8))) fft_pair<2> { float c[2]; };
 typedef float fft_v2f __attribute__((vector_size(8)));
 #if defined(MP3MI_EMU)
 #define FFT_MEMFN static inline
+#define MP3MI_DEVFN_M inline
 #else
 #define FFT_MEMFN static __device__ __forceinline__
+#define MP3MI_DEVFN_M __device__ __forceinline__
 #endif
 typedef uint32_t fft_v2u __attribute__((vector_size(8)));
 template <int C> struct fft_vec;
@@ -124,50 +126,65 @@ MP3MI_DEVFN void fft_twiddle(typename fft_vec<C>::V &r, typename fft_vec<C>::V &
     }
 }
 
-// one round of four-operand butterflies (tables_host.cpp, FusedOp cls 0); blk = the round's blocks
-template <int C, bool ROT, bool SQ>
-MP3MI_DEVFN void fft_round_r(char *xw, uint32_t woff, const uint32_t *blk, int lane)
-{
+// A round in two halves -- fetch (records, operand addresses, operands) and finish (arithmetic, stores) -- so
+// that two rounds of the same rank, which touch different elements, can have their LDS reads in flight
+// together: the kernel runs 3 wavefronts per SIMD and every round is two dependent LDS round trips.
+// H = the round's header bits (bit 0: eight operands, bit 1: rotations, bit 2: SQHALF rotations).
+template <int C, int H> struct fft_round {
     typedef fft_vec<C> F;
     typedef typename F::V V;
-    const uint2 ad = *(const uint2 *) (blk + 2 * lane);
-    uint4 tw = {0, 0, 0, 0};
-    if (ROT) tw = *(const uint4 *) (blk + 128 + 4 * lane);
-    else tw.w = blk[128 + lane];
-    V *pa = fft_at<C, 0>(xw, woff, ad.x), *pb = fft_at<C, 1>(xw, woff, ad.x), *pc = fft_at<C, 0>(xw, woff, ad.y), *pd = fft_at<C, 1>(xw, woff, ad.y);
-    const V a = *pa, b = *pb, c = *pc, d = *pd;
-    const uint32_t flags = tw.w;
-    const V oa = a + b, oc = c + d;
-    V u1 = a - b;
-    V u2 = F::flip(c - d, flags & 0x80000000u); // src/subs.c:475-479
-    fft_twiddle<C, ROT, SQ>(u1, u2, flags, false, tw.x, tw.y, tw.z);
-    *pa = oa; *pb = u1; *pc = oc; *pd = u2;
-}
+    static constexpr int N = (H & 1) ? 8 : 4;
+    static constexpr bool ROT = (H & 2) != 0, SQ = (H & 4) != 0;
+    V *p[N];
+    V v[N];
+    uint4 tw1, tw3;
 
-// one round of eight-operand butterflies (FusedOp cls 1): steps 1-4 of srrec for one n
-template <int C, bool ROT, bool SQ>
-MP3MI_DEVFN void fft_round_c(char *xw, uint32_t woff, const uint32_t *blk, int lane)
-{
-    typedef fft_vec<C> F;
-    typedef typename F::V V;
-    const uint4 ad = *(const uint4 *) (blk + 4 * lane);
-    uint4 tw1 = {0, 0, 0, 0}, tw3 = {0, 0, 0, 0};
-    if (ROT) { tw1 = *(const uint4 *) (blk + 256 + 4 * lane); tw3 = *(const uint4 *) (blk + 512 + 4 * lane); }
-    else tw1.w = blk[256 + lane];
-    V *p0 = fft_at<C, 0>(xw, woff, ad.x), *p1 = fft_at<C, 1>(xw, woff, ad.x), *p2 = fft_at<C, 0>(xw, woff, ad.y), *p3 = fft_at<C, 1>(xw, woff, ad.y);
-    V *p4 = fft_at<C, 0>(xw, woff, ad.z), *p5 = fft_at<C, 1>(xw, woff, ad.z), *p6 = fft_at<C, 0>(xw, woff, ad.w), *p7 = fft_at<C, 1>(xw, woff, ad.w);
-    const V ar0 = *p0, ar1 = *p1, br0 = *p2, br1 = *p3, ai0 = *p4, ai1 = *p5, bi0 = *p6, bi1 = *p7;
-    const uint32_t flags = tw1.w;
-    // step 1 (src/subs.c:288-298)
-    const V o0 = ar0 + ar1, o2 = br0 + br1, o4 = ai0 + ai1, o6 = bi0 + bi1;
-    const V xr1 = ar0 - ar1, xr2 = br0 - br1, xi1 = ai0 - ai1, xi2 = bi0 - bi1;
-    // step 2 (src/subs.c:301-312)
-    V r1 = xr1 + xi2, i2 = xi1 + xr2, i1 = xi1 - xr2, r2 = xr1 - xi2;
-    // steps 3 and 4 (src/subs.c:327-342)
-    fft_twiddle<C, ROT, SQ>(r1, i1, flags, false, tw1.x, tw1.y, tw1.z);
-    fft_twiddle<C, ROT, SQ>(r2, i2, flags, true, tw3.x, tw3.y, tw3.z);
-    *p0 = o0; *p1 = r1; *p2 = o2; *p3 = r2; *p4 = o4; *p5 = i1; *p6 = o6; *p7 = i2;
-}
+    MP3MI_DEVFN_M void fetch(char *xw, uint32_t woff, const uint32_t *blk, int lane)
+    {
+        tw1 = tw3 = uint4{0, 0, 0, 0};
+        if (N == 4) { // tables_host.cpp, FusedOp cls 0
+            const uint2 ad = *(const uint2 *) (blk + 2 * lane);
+            if (ROT) tw1 = *(const uint4 *) (blk + 128 + 4 * lane);
+            else tw1.w = blk[128 + lane];
+            p[0] = fft_at<C, 0>(xw, woff, ad.x); p[1] = fft_at<C, 1>(xw, woff, ad.x);
+            p[2] = fft_at<C, 0>(xw, woff, ad.y); p[3] = fft_at<C, 1>(xw, woff, ad.y);
+        } else { // FusedOp cls 1
+            const uint4 ad = *(const uint4 *) (blk + 4 * lane);
+            if (ROT) { tw1 = *(const uint4 *) (blk + 256 + 4 * lane); tw3 = *(const uint4 *) (blk + 512 + 4 * lane); }
+            else tw1.w = blk[256 + lane];
+            p[0] = fft_at<C, 0>(xw, woff, ad.x); p[1] = fft_at<C, 1>(xw, woff, ad.x);
+            p[2] = fft_at<C, 0>(xw, woff, ad.y); p[3] = fft_at<C, 1>(xw, woff, ad.y);
+            p[4 % N] = fft_at<C, 0>(xw, woff, ad.z); p[5 % N] = fft_at<C, 1>(xw, woff, ad.z);
+            p[6 % N] = fft_at<C, 0>(xw, woff, ad.w); p[7 % N] = fft_at<C, 1>(xw, woff, ad.w);
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = *p[k];
+    }
+
+    MP3MI_DEVFN_M void finish()
+    {
+        const uint32_t flags = tw1.w;
+        if (N == 4) { // steps 1-4 of rsrec for one n (src/subs.c:465-498), or two length-2 butterflies
+            const V a = v[0], b = v[1], c = v[2], d = v[3];
+            const V oa = a + b, oc = c + d;
+            V u1 = a - b;
+            V u2 = F::flip(c - d, flags & 0x80000000u); // src/subs.c:475-479
+            fft_twiddle<C, ROT, SQ>(u1, u2, flags, false, tw1.x, tw1.y, tw1.z);
+            *p[0] = oa; *p[1] = u1; *p[2] = oc; *p[3] = u2;
+        } else { // steps 1-4 of srrec for one n
+            const V ar0 = v[0], ar1 = v[1], br0 = v[2], br1 = v[3], ai0 = v[4 % N], ai1 = v[5 % N], bi0 = v[6 % N], bi1 = v[7 % N];
+            // step 1 (src/subs.c:288-298)
+            const V o0 = ar0 + ar1, o2 = br0 + br1, o4 = ai0 + ai1, o6 = bi0 + bi1;
+            const V xr1 = ar0 - ar1, xr2 = br0 - br1, xi1 = ai0 - ai1, xi2 = bi0 - bi1;
+            // step 2 (src/subs.c:301-312)
+            V r1 = xr1 + xi2, i2 = xi1 + xr2, i1 = xi1 - xr2, r2 = xr1 - xi2;
+            // steps 3 and 4 (src/subs.c:327-342)
+            fft_twiddle<C, ROT, SQ>(r1, i1, flags, false, tw1.x, tw1.y, tw1.z);
+            fft_twiddle<C, ROT, SQ>(r2, i2, flags, true, tw3.x, tw3.y, tw3.z);
+            *p[0] = o0; *p[1] = r1; *p[2] = o2; *p[3] = r2; *p[4 % N] = o4; *p[5 % N] = i1; *p[6 % N] = o6; *p[7 % N] = i2;
+        }
+    }
+};
 
 // The sequence of rounds is a compile-time constant (MP3MI_FFT_HDRS_*, checked against the generator at
 // table build): the program runs as straight-line code, every block a constant offset from the lane's
@@ -178,13 +195,26 @@ constexpr int fft_round_words(int h) { return ((h & 1) ? 256 : 128) + ((h & 2) ?
 template <int C, bool LONG, int R, int OFF>
 MP3MI_DEVFN void fft_run(char *xw, uint32_t woff, const uint32_t *prog, int lane)
 {
-    constexpr int NR = LONG ? (int) sizeof(fft_hdrs_l) : (int) sizeof(fft_hdrs_s);
+    constexpr int NL = (int) sizeof(fft_hdrs_l), NS = (int) sizeof(fft_hdrs_s), NR = LONG ? NL : NS;
     if constexpr (R < NR) {
-        constexpr int h = LONG ? fft_hdrs_l[R < (int) sizeof(fft_hdrs_l) ? R : 0] : fft_hdrs_s[R < (int) sizeof(fft_hdrs_s) ? R : 0];
-        if constexpr ((h & 1) == 0) fft_round_r<C, (h & 2) != 0, (h & 4) != 0>(xw, woff, prog + OFF, lane);
-        else fft_round_c<C, (h & 2) != 0, (h & 4) != 0>(xw, woff, prog + OFF, lane);
-        if constexpr ((h & 8) != 0) wave_sync(); // the next rank reads what this one wrote
-        fft_run<C, LONG, R + 1, OFF + fft_round_words(h)>(xw, woff, prog, lane);
+        constexpr int h = LONG ? fft_hdrs_l[R < NL ? R : 0] : fft_hdrs_s[R < NS ? R : 0];
+        if constexpr ((h & 8) == 0 && R + 1 < NR) { // the next round belongs to the same rank: both in flight together
+            constexpr int h2 = LONG ? fft_hdrs_l[R + 1 < NL ? R + 1 : 0] : fft_hdrs_s[R + 1 < NS ? R + 1 : 0];
+            fft_round<C, h & 7> a;
+            fft_round<C, h2 & 7> b;
+            a.fetch(xw, woff, prog + OFF, lane);
+            b.fetch(xw, woff, prog + OFF + fft_round_words(h), lane);
+            a.finish();
+            b.finish();
+            if constexpr ((h2 & 8) != 0) wave_sync(); // the next rank reads what this one wrote
+            fft_run<C, LONG, R + 2, OFF + fft_round_words(h) + fft_round_words(h2)>(xw, woff, prog, lane);
+        } else {
+            fft_round<C, h & 7> a;
+            a.fetch(xw, woff, prog + OFF, lane);
+            a.finish();
+            if constexpr ((h & 8) != 0) wave_sync();
+            fft_run<C, LONG, R + 1, OFF + fft_round_words(h)>(xw, woff, prog, lane);
+        }
     }
 }
 
