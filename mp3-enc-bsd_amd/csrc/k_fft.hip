@@ -71,8 +71,8 @@ template <> struct fft_vec<2> {
     FFT_MEMFN float get(V v, int c) { return v[c]; }
     FFT_MEMFN void set(V &v, int c, float f) { v[c] = f; }
 };
-template <int C, int W> struct fft_lds {
-    uint32_t prog[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16)));
+template <int C, int W, int PW> struct fft_lds { // PW: capacity of the program in words
+    uint32_t prog[PW] __attribute__((aligned(16)));
     fft_wave_lds<C> w[W];
 };
 
@@ -277,142 +277,145 @@ MP3MI_DEVFN void fft_load_pcm(const int16_t *pcm, long t_first, long n_per_ch, i
     }
 }
 
-template <int C, int W>
+// Two kernels, one for the 1024-point transform and one for the three 256-point ones (LONG), each with ITS
+// program resident in LDS and W wavefronts that work through the (stream, granule) tasks on their own: a
+// workgroup takes every gridDim.x-th batch of W tasks, the program is loaded once per workgroup, and after
+// that no wavefront ever waits for another (one workgroup fills a CU's LDS, so a workgroup that started and
+// ended together would leave the CU idle while the next one loads its program and samples).
+template <int C, int W, bool LONG>
 __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const int16_t *__restrict__ pcm_all, float *__restrict__ energy_l,
                                                 float *__restrict__ energy_s, float *__restrict__ bins)
 {
-    __shared__ fft_lds<C, W> LL;
+    __shared__ fft_lds<C, W, LONG ? MP3MI_FFT_PROG_WORDS : MP3MI_FFT_PROG_WORDS_S> LL;
     const int lane = wave_lane(), tid = (int) threadIdx.x;
-    fft_wave_lds<C> &L = LL.w[tid >> 6];
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform, and known to be
+    fft_wave_lds<C> &L = LL.w[wv];
     const int G = geo.n_gran, n_task = geo.n_streams * G;
-    int task = (int) blockIdx.x * W + __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform, and known to be
-    const bool valid = task < n_task; // the last workgroup may have idle wavefronts: they compute, but do not store
-    task = valid ? task : n_task - 1;
-    const int gl = task % G, s = task / G;
-    const size_t rec0 = ((size_t) s * G + gl) * C;
-    const long gabs = (long) geo.g0 + gl;
     const long n_pitch = (long) geo.n_frames * 1152; // row pitch of the PCM buffer
-    const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch; // valid samples: the rest reads as zero (src/encode.c:162-166)
-    const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
-    const long t0 = 576 * gabs - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
     PROF_DECL;
-
     {
-        const int nw4 = T->fft_nword_l / 4;
-        for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = ((const uint4 *) T->fft_prog_l)[i];
-    }
-
-    // the 1024-sample window of all channels: every load is issued before the first use
-    {
-        float wl[16];
-        uint32_t smp[16];
-        fft_load_pcm<C, 16>(pcm, t0, n_per_ch, lane, smp);
-#pragma unroll
-        for (int k = 0; k < 16; k++) wl[k] = T->window[lane + 64 * k];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            fft_pair<C> v;
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                v.c[c] = wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16)); // src/l3psy.c:485
-            *(fft_pair<C> *) (L.x + MP3MI_FFT_SWZ(lane + 64 * k) * C) = v;
-        }
+        const int nw4 = (LONG ? T->fft_nword_l : T->fft_nword_s) / 4;
+        const uint4 *src = (const uint4 *) (LONG ? T->fft_prog_l : T->fft_prog_s);
+        for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = src[i];
     }
     __syncthreads();
     PROF(0);
 
-    fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) ((tid >> 6) * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
-    PROF(1);
+    for (int batch = (int) blockIdx.x; batch * W < n_task; batch += (int) gridDim.x) {
+        int task = batch * W + wv;
+        const bool valid = task < n_task; // the last batch may have idle wavefronts: they compute, but do not store
+        task = valid ? task : n_task - 1;
+        const int gl = task % G, s = task / G;
+        const size_t rec0 = ((size_t) s * G + gl) * C;
+        const long gabs = (long) geo.g0 + gl;
+        const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch; // valid samples: the rest reads as zero (src/encode.c:162-166)
+        const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
+        const long t0 = 576 * gabs - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
 
-    // the short windows' samples are requested now and land while the long spectrum is consumed
-    uint32_t smp[8];
-    float wsv[4];
-    fft_load_pcm<C, 8>(pcm, t0 + 256, n_per_ch, lane, smp);
+        if (LONG) {
+            // the 1024-sample window of all channels: every load is issued before the first use
+            {
+                float wl[16];
+                uint32_t smp[16];
+                fft_load_pcm<C, 16>(pcm, t0, n_per_ch, lane, smp);
 #pragma unroll
-    for (int k = 0; k < 4; k++) wsv[k] = T->window_s[lane + 64 * k];
-
-    {
-        float *el0 = energy_l + rec0 * MP3MI_HBLK_P;
-#pragma unroll 3
-        for (int i = lane; i < MP3MI_HBLK; i += 64) {
-            const fft_pair<C> e = fft_energy<C>(L.x, T->fft_rd_l[i], i == 0 || i == 512);
-            if (valid) {
+                for (int k = 0; k < 16; k++) wl[k] = T->window[lane + 64 * k];
 #pragma unroll
-                for (int c = 0; c < C; c++) el0[c * MP3MI_HBLK_P + i] = e.c[c];
-            }
-        }
-        // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
-        if (lane < 6 && valid) {
-            fft_pair<C> re, im;
-            fft_bin<C>(L.x, T->fft_rd_l[lane], &re, &im);
+                for (int k = 0; k < 16; k++) {
+                    fft_pair<C> v;
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = re.c[c];
-                bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? im.c[c] : -0.0f;
-            }
-        }
-    }
-    wave_sync(); // the long spectrum is dead from here on
-    // short windows: samples 256 + 128 sb + jj, sb < 3 (src/l3psy.c:520-523); the second half of every
-    // window is also the first half of the next.  Sample 256 + lane + 64 k: sb = k >> 1, jj = lane + 64 (k & 1).
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int sb = k >> 1, jj = lane + 64 * (k & 1);
-        fft_pair<C> v0, v1;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
-            v0.c[c] = wsv[k & 1] * v;
-            v1.c[c] = wsv[2 + (k & 1)] * v;
-        }
-        if (sb < 3) *(fft_pair<C> *) (L.x + (sb * 256 + MP3MI_FFT_SWZ(jj)) * C) = v0;
-        if (sb >= 1) *(fft_pair<C> *) (L.x + ((sb - 1) * 256 + MP3MI_FFT_SWZ(128 + jj)) * C) = v1;
-    }
-    __syncthreads(); // every wavefront is done with the long program
-    {
-        const int nw4 = T->fft_nword_s / 4;
-        for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = ((const uint4 *) T->fft_prog_s)[i];
-    }
-    __syncthreads();
-    PROF(2);
-
-    fft_run<C, false, 0, 0>((char *) &LL.w[0], (uint32_t) ((tid >> 6) * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
-    PROF(3);
-
-    // energies of the three short spectra (bin k of window sb, both channels per LDS read) and the raw
-    // short lines 2..51 for k_cw (src/l3psy.c:531-549 reads these only); plain nested loops, no div/mod
-    uint32_t rds[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) rds[t] = T->fft_rd_s[lane + 64 * t < MP3MI_HBLK_S ? lane + 64 * t : 0];
-    const uint32_t rdb = T->fft_rd_s[lane < 50 ? 2 + lane : 0];
-#pragma unroll
-    for (int sb = 0; sb < 3; sb++) {
-        float *es0 = energy_s + rec0 * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S;
-        const float *xw = L.x + sb * 256 * C;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int k = lane + 64 * t;
-            if (k < MP3MI_HBLK_S) {
-                const fft_pair<C> e = fft_energy<C>(xw, rds[t], k == 0 || k == 128);
-                if (valid) {
-#pragma unroll
-                    for (int c = 0; c < C; c++) es0[c * (3 * MP3MI_HBLK_S) + k] = e.c[c];
+                    for (int c = 0; c < C; c++)
+                        v.c[c] = wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16)); // src/l3psy.c:485
+                    *(fft_pair<C> *) (L.x + MP3MI_FFT_SWZ(lane + 64 * k) * C) = v;
                 }
             }
-        }
-        if (lane < 50 && valid) {
-            fft_pair<C> re, im;
-            fft_bin<C>(xw, rdb, &re, &im);
+            wave_sync();
+            PROF(1);
+            fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
+            PROF(2);
+            float *el0 = energy_l + rec0 * MP3MI_HBLK_P;
+#pragma unroll 3
+            for (int i = lane; i < MP3MI_HBLK; i += 64) {
+                const fft_pair<C> e = fft_energy<C>(L.x, T->fft_rd_l[i], i == 0 || i == 512);
+                if (valid) {
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + lane) * 2;
-                o[0] = re.c[c];
-                o[1] = im.c[c];
+                    for (int c = 0; c < C; c++) el0[c * MP3MI_HBLK_P + i] = e.c[c];
+                }
             }
+            // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
+            if (lane < 6 && valid) {
+                fft_pair<C> re, im;
+                fft_bin<C>(L.x, T->fft_rd_l[lane], &re, &im);
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = re.c[c];
+                    bins[(rec0 + c) * MP3MI_FFT_BINS + 306 + lane] = lane ? im.c[c] : -0.0f;
+                }
+            }
+            wave_sync(); // the spectrum is dead: the next task's samples take its place
+            PROF(3);
+        } else {
+            // short windows: samples 256 + 128 sb + jj, sb < 3 (src/l3psy.c:520-523); the second half of every
+            // window is also the first half of the next.  Sample 256 + lane + 64 k: sb = k >> 1, jj = lane + 64 (k & 1).
+            uint32_t smp[8];
+            float wsv[4];
+            fft_load_pcm<C, 8>(pcm, t0 + 256, n_per_ch, lane, smp);
+#pragma unroll
+            for (int k = 0; k < 4; k++) wsv[k] = T->window_s[lane + 64 * k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int sb = k >> 1, jj = lane + 64 * (k & 1);
+                fft_pair<C> v0, v1;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
+                    v0.c[c] = wsv[k & 1] * v;
+                    v1.c[c] = wsv[2 + (k & 1)] * v;
+                }
+                if (sb < 3) *(fft_pair<C> *) (L.x + (sb * 256 + MP3MI_FFT_SWZ(jj)) * C) = v0;
+                if (sb >= 1) *(fft_pair<C> *) (L.x + ((sb - 1) * 256 + MP3MI_FFT_SWZ(128 + jj)) * C) = v1;
+            }
+            wave_sync();
+            PROF(1);
+            fft_run<C, false, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
+            PROF(2);
+            // energies of the three short spectra (bin k of window sb, both channels per LDS read) and the raw
+            // short lines 2..51 for k_cw (src/l3psy.c:531-549 reads these only); plain nested loops, no div/mod
+            uint32_t rds[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) rds[t] = T->fft_rd_s[lane + 64 * t < MP3MI_HBLK_S ? lane + 64 * t : 0];
+            const uint32_t rdb = T->fft_rd_s[lane < 50 ? 2 + lane : 0];
+#pragma unroll
+            for (int sb = 0; sb < 3; sb++) {
+                float *es0 = energy_s + rec0 * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S;
+                const float *xw = L.x + sb * 256 * C;
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int k = lane + 64 * t;
+                    if (k < MP3MI_HBLK_S) {
+                        const fft_pair<C> e = fft_energy<C>(xw, rds[t], k == 0 || k == 128);
+                        if (valid) {
+#pragma unroll
+                            for (int c = 0; c < C; c++) es0[c * (3 * MP3MI_HBLK_S) + k] = e.c[c];
+                        }
+                    }
+                }
+                if (lane < 50 && valid) {
+                    fft_pair<C> re, im;
+                    fft_bin<C>(xw, rdb, &re, &im);
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + lane) * 2;
+                        o[0] = re.c[c];
+                        o[1] = im.c[c];
+                    }
+                }
+            }
+            wave_sync(); // the spectra are dead: the next task's samples take their place
+            PROF(3);
         }
     }
-    PROF(4);
     PROF_END;
 }
 
@@ -501,14 +504,24 @@ extern "C" void mp3mi_debug_fft_profile(unsigned long long *out)
 void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, float *energy_l,
                       float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st)
 {
-    // W: as many wavefronts as fit the 160 KB of LDS next to the shared program
+    // W: as many wavefronts as fit the 160 KB of LDS next to the shared program; one workgroup per CU (that
+    // is all the LDS allows), each working through its share of the batches
     const int n_task = g.n_streams * g.n_gran;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
     if (g.channels == 2) {
-        const int W = 13;
-        hipLaunchKernelGGL((k_fft<2, W>), dim3((unsigned) ((n_task + W - 1) / W)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
+        const int W = 13, WS = 15, nb = (n_task + W - 1) / W, nbs = (n_task + WS - 1) / WS;
+        hipLaunchKernelGGL((k_fft<2, W, true>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
+        hipLaunchKernelGGL((k_fft<2, WS, false>), dim3((unsigned) (nbs < n_cu ? nbs : n_cu)), dim3(64 * WS), 0, st, T, g, pcm, energy_l, energy_s, bins);
     } else {
-        const int W = 16;
-        hipLaunchKernelGGL((k_fft<1, W>), dim3((unsigned) ((n_task + W - 1) / W)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
+        const int W = 16, nb = (n_task + W - 1) / W, grid = nb < n_cu ? nb : n_cu;
+        hipLaunchKernelGGL((k_fft<1, W, true>), dim3((unsigned) grid), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
+        hipLaunchKernelGGL((k_fft<1, W, false>), dim3((unsigned) grid), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
     }
     hipLaunchKernelGGL(k_cw, dim3((unsigned) (n_task * g.channels)), dim3(64), 0, st, bins, cw_mid, hist6, (g.test_flags >> 1) & 1);
 }

@@ -28,7 +28,8 @@
 /* FFT butterfly programs (tables_host.cpp): rounds of 64 fused butterflies, one per lane */
 #define MP3MI_FFT_DUMMY 1024      /* elements 1024 + lane: what the idle lanes of a round work on */
 #define MP3MI_FFT_MAX_ROUNDS 48
-#define MP3MI_FFT_PROG_WORDS 12288 /* capacity of a program in 32-bit words; checked at table build */
+#define MP3MI_FFT_PROG_WORDS 12288 /* capacity of the long program in 32-bit words; checked at table build */
+#define MP3MI_FFT_PROG_WORDS_S 8192 /* capacity of the short program */
 /* the header words of the rounds of the long and of the short program (fft_hdr_* below): k_fft is compiled
    for exactly these sequences -- straight-line code, no per-round dispatch -- and table build checks that the
    generator still produces them (MP3MI_FFT_INFO=1 prints the lists) */
@@ -75,7 +76,7 @@ typedef struct {
        sign << 31 once the butterflies are done (step 5 and the bit reversal of the reference folded in) */
     int32_t fft_nround_l, fft_nround_s, fft_nword_l, fft_nword_s;
     uint32_t fft_hdr_l[MP3MI_FFT_MAX_ROUNDS], fft_hdr_s[MP3MI_FFT_MAX_ROUNDS];
-    uint32_t fft_prog_l[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16))), fft_prog_s[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16)));
+    uint32_t fft_prog_l[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16))), fft_prog_s[MP3MI_FFT_PROG_WORDS_S] __attribute__((aligned(16)));
     uint32_t fft_rd_l[MP3MI_HBLK], fft_rd_s[MP3MI_HBLK_S];
     /* filterbank + MDCT */
     double enwindow[512];

@@ -395,7 +395,7 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
         FftGen *g = new FftGen();
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
         T->fft_nword_l = g->build(10, 1, T->fft_hdr_l, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_l, T->fft_prog_l, MP3MI_FFT_PROG_WORDS, T->fft_rd_l);
-        T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS, T->fft_rd_s);
+        T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS_S, T->fft_rd_s);
         {   /* the kernel is compiled for exactly this sequence of rounds (k_fft.hip) */
             static const uint8_t hl[] = {MP3MI_FFT_HDRS_L}, hs[] = {MP3MI_FFT_HDRS_S};
             bool same = T->fft_nround_l == (int) sizeof(hl) && T->fft_nround_s == (int) sizeof(hs);
