@@ -515,7 +515,7 @@ void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t 
         if (n_cu <= 0) n_cu = 256;
     }
     if (g.channels == 2) {
-        const int W = 13, WS = 15, nb = (n_task + W - 1) / W, nbs = (n_task + WS - 1) / WS;
+        const int W = 12, WS = 15, nb = (n_task + W - 1) / W, nbs = (n_task + WS - 1) / WS;
         hipLaunchKernelGGL((k_fft<2, W, true>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
         hipLaunchKernelGGL((k_fft<2, WS, false>), dim3((unsigned) (nbs < n_cu ? nbs : n_cu)), dim3(64 * WS), 0, st, T, g, pcm, energy_l, energy_s, bins);
     } else {
