@@ -33,6 +33,7 @@ struct mdct_lds {
 // for every fifth band.  The other six rows have 2 or 6 terms (T->mdct_small_row) and are taken from LDS.
 struct mdct_regs {
     double coef[18];
+    double cs, ca; // alias butterfly coefficients of k = lane & 7 (every step of the alias loop has that k)
     int m_full, grp;
 };
 
@@ -62,6 +63,8 @@ MP3MI_DEVFN void mdct_load_tables(mdct_lds &L, mdct_regs &R, const mp3mi_tables 
     R.m_full = T->mdct_full_row[lane < 60 ? lane - 12 * R.grp : 0];
 #pragma unroll
     for (int t = 0; t < 18; t++) R.coef[t] = T->mdct_vcoef[R.m_full][t];
+    R.cs = T->cs[lane & 7];
+    R.ca = T->ca[lane & 7];
 }
 
 // L.in <- the 36 inputs of every band from two granules of subband samples held in registers (vp: previous
@@ -174,8 +177,8 @@ MP3MI_DEVFN void mdct_granule(mdct_lds &L, const mdct_regs &R, const mp3mi_table
         for (int i = lane; i < 31 * 8; i += 64) {
             const int band = i >> 3, k = i & 7;
             double up = L.xr[band * 18 + 17 - k], dn = L.xr[(band + 1) * 18 + k];
-            double bu = up * T->cs[k] + dn * T->ca[k];
-            double bd = dn * T->cs[k] - up * T->ca[k];
+            double bu = up * R.cs + dn * R.ca;
+            double bd = dn * R.cs - up * R.ca;
             L.xr[band * 18 + 17 - k] = bu;
             L.xr[(band + 1) * 18 + k] = bd;
         }
