@@ -2,8 +2,9 @@
 // real split-radix FFTs, energies, phases and the unpredictability of lines 6..205.
 //
 // Replaces fft()/rsfft()/enphinew() (src/subs.c:38-123, 412-534) and src/l3psy.c:477-549 for
-// every (stream, granule, channel) of a chunk at once; one wavefront per (granule, channel).
-// The FFT arithmetic is single precision with the reference's exact butterfly DAG: the
+// every (stream, granule, channel) of a chunk at once: k_fft<.., true> (the long transform) and
+// k_fft<.., false> (the three short ones), one wavefront per (stream, granule) task and all channels,
+// then k_cw.  The FFT arithmetic is single precision with the reference's exact butterfly DAG: the
 // recursion is flattened on the host (tables_host.cpp) into rounds of 64 independent FUSED
 // butterflies -- steps 1-4 of one recursion level for one index, 4 or 8 operands -- which the
 // lanes execute from LDS; the data movement the reference ends with (step 5, bit reversal) is
