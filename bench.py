@@ -75,6 +75,25 @@ def pmc_traffic(kernel, streams, frames, launches_per_step):
     return None, None
 
 
+def issue_rate(kernel, streams, frames, kernel_s_per_launch, launches_per_step):
+    """What actually bounds the kernel: wavefront instructions per launch (SQ_INSTS_VALU + SALU + LDS of the newest
+    committed counter pass of this workload, profiles/*_insts_*.json, tools/gpu_insts.sh) over the live launch
+    time -> cycles per instruction and SIMD at the nominal 2.4 GHz of 1024 SIMDs.  None without a matching pass."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_insts_%dx%d.json" % (streams, frames))), reverse=True):
+        try:
+            k = json.load(open(f))[kernel]
+            if k["dispatches"] != launches_per_step:
+                continue
+            insts = (k["SQ_INSTS_VALU"] + k["SQ_INSTS_SALU"] + k["SQ_INSTS_LDS"]) / k["dispatches"]
+            return {"wave_instructions_per_launch": int(insts), "cycles_per_instruction_per_simd": round(kernel_s_per_launch * 2.4e9 * 1024 / insts, 2),
+                    "source": os.path.basename(f),
+                    "note": "instruction-bound: an f32 VALU instruction costs 2.9, an f64 or scalar one 4.3-4.8 cycles per SIMD (tools/exp/issue_mix.hip, DESIGN.md section 4)"}
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(pcm_sample, rate, kbps, channels, cores):
     """Oracle (CPU restatement of the reference) on a bounded sample of the same workload."""
     from mp3common import Oracle
@@ -231,7 +250,8 @@ def main():
                          "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_frame": alg_bytes_per_frame,
                          "kernel_ms_per_launch": round(avg_launch_s * 1e3, 3), "launches_per_step": lps,
-                         "all_kernels_ms_per_step": round(all_ms / max(args.steps, 1), 3)},
+                         "all_kernels_ms_per_step": round(all_ms / max(args.steps, 1), 3),
+                         "issue": issue_rate("k_loop", S, nf, avg_launch_s, lps) if (args.rate, args.kbps, C) == (44100, 128, 2) else None},
             "cpu_baseline": cpu,
             "parity_spot_check": {"streams": len(idx), "bit_exact": parity_ok},
         }
