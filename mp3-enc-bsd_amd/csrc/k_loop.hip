@@ -297,7 +297,7 @@ MP3MI_DEVFN void loop_region_cost(const loop_lds &L, const unsigned *ixw, int la
 // (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
 // Returns the Huffman bit count and fills g.  Written branch-free over the lanes: region
 // membership is a predicate, never a divergent branch.
-MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9], bool all_zero)
+MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9], bool all_zero)
 {
     const int lane = wave_lane_here();
     const bool shortb = g.wsf && g.block_type == 2;
@@ -352,19 +352,13 @@ MP3MI_DEVFN int loop_count_bits(const loop_regs &R, loop_lds &L, loop_gr &g, con
         if (g.big_values != 0) {
             const int bvr = 2 * g.big_values;
             if (g.wsf == 0) {
-                // scfb_anz = number of band edges below bvr; K = last edge not above bvr
-                const int anz = __popcll(__ballot(lane < 23 && R.sfb_l < bvr));
-                const int K = __popcll(__ballot(lane < 23 && R.sfb_l <= bvr)) - 1;
-                const int sd = wave_readlane_i32(R.subdv, anz);
-                int c0 = sd & 0xff, c1 = (sd >> 8) & 0xff;
-                const int lim0 = K - 1 > 0 ? K - 1 : 0;
-                c0 = c0 < lim0 ? c0 : lim0;          // while (cnt && edge[cnt+1] > bvr) cnt--
-                const int lim1 = K - c0 - 2 > 0 ? K - c0 - 2 : 0;
-                c1 = c1 < lim1 ? c1 : lim1;          // while (cnt && edge[r0+cnt+2] > bvr) cnt--
-                r0c = c0;
-                r1c = c1;
-                ad1 = wave_readlane_i32(R.sfb_l, c0 + 1);
-                ad2 = wave_readlane_i32(R.sfb_l, c0 + c1 + 2);
+                // scfb_anz = number of band edges below bvr picks the counts from subdv_table, both lowered until
+                // the regions end at or below bvr: a function of big_values alone, tabulated at table build
+                const unsigned sd = T->subdiv_lut[g.big_values];
+                r0c = (int) (sd & 15u);
+                r1c = (int) ((sd >> 4) & 15u);
+                ad1 = (int) ((sd >> 8) & 1023u);
+                ad2 = (int) (sd >> 18);
                 ad3 = bvr;
             } else {
                 const bool sb = g.block_type == 2;
@@ -815,7 +809,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 work += 4;
                                 loop_quantize(T, L, y34, g.q, az, p);
                                 PROF(2);
-                                bit = loop_count_bits(R, L, g, p, az);
+                                bit = loop_count_bits(T, R, L, g, p, az);
                                 PROF(3);
                                 __syncthreads();
                                 if (bit > max_bits) top = next; else bot = next;
@@ -835,7 +829,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 work += 4;
                                 loop_quantize(T, L, y34, g.q, az, p);
                                 PROF(2);
-                                bits = loop_count_bits(R, L, g, p, az);
+                                bits = loop_count_bits(T, R, L, g, p, az);
                                 PROF(3);
                                 __syncthreads();
                             }

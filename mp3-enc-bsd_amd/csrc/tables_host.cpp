@@ -391,6 +391,24 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
         T->w1_s[i] = T_SS_W1[ri][i]; T->w2_s[i] = T_SS_W2[ri][i];
     }
 
+    {   /* subdivide of a granule without window switching, for every big_values (src/loop.c:1596-1625, 1638-1679):
+           scfb_anz = band edges below 2*big_values pick the counts from subdv_table; both are then lowered
+           until the regions end at or below 2*big_values */
+        static const int SUBDV0[23] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 6};
+        static const int SUBDV1[23] = {0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6, 7, 7, 7};
+        for (int bv = 0; bv <= 288; bv++) {
+            const int bvr = 2 * bv;
+            int anz = 0, K = -1;
+            for (int i = 0; i < 23; i++) { if (T->sfb_l[i] < bvr) anz++; if (T->sfb_l[i] <= bvr) K++; }
+            int c0 = SUBDV0[anz], c1 = SUBDV1[anz];
+            const int lim0 = K - 1 > 0 ? K - 1 : 0;
+            c0 = c0 < lim0 ? c0 : lim0;          /* while (cnt && edge[cnt+1] > bvr) cnt-- */
+            const int lim1 = K - c0 - 2 > 0 ? K - c0 - 2 : 0;
+            c1 = c1 < lim1 ? c1 : lim1;          /* while (cnt && edge[r0+cnt+2] > bvr) cnt-- */
+            T->subdiv_lut[bv] = (uint32_t) c0 | ((uint32_t) c1 << 4) | ((uint32_t) T->sfb_l[c0 + 1] << 8) | ((uint32_t) T->sfb_l[c0 + c1 + 2] << 18);
+        }
+    }
+
     {
         FftGen *g = new FftGen();
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
