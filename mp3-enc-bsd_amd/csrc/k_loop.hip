@@ -947,10 +947,15 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                     m2 = (lane >= 11 && lane < 21) ? sf_r : 0;
                                 }
                                 const int mm1 = wave_max_i32(m1), mm2 = wave_max_i32(m2);
-                                int ep = 2, k;
-                                for (k = 0; k < 16; k++)
-                                    if (mm1 < (1 << LOOP_SLEN1[k]) && mm2 < (1 << LOOP_SLEN2[k])) { ep = 0; break; }
-                                if (ep == 0) g.scalefac_compress = k;
+                                // the first k with mm1 < 2^slen1[k] and mm2 < 2^slen2[k] only depends on the bit lengths
+                                // of the two maxima: tabulated, a nibble per (length of mm1 <= 4, length of mm2 <= 3)
+                                const int bl1 = 32 - __clz(mm1), bl2 = 32 - __clz(mm2);
+                                int ep = 2;
+                                if (bl1 <= 4 && bl2 <= 3) {
+                                    const unsigned long long w = bl1 < 4 ? (0xdcb4a98476543210ull >> (16 * bl1)) : 0xfeeeull;
+                                    g.scalefac_compress = (int) ((w >> (4 * bl2)) & 15ull);
+                                    ep = 0;
+                                }
                                 status = ep;
                             }
                         }
