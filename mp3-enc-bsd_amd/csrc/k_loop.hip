@@ -323,11 +323,15 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         }
         int hh[2] = {hi_nz, hi_big};
         wave_reduce_i32<0, 2>(hh);
-        const int top_nz = hh[0] - 1, top_big = hh[1] - 1;
-        nslot = (top_nz + 64) >> 6;
-        const int i0 = (top_nz < 0) ? 0 : 2 * (top_nz / 2 + 1);
-        g.count1 = (i0 - (top_big + 1)) / 4;
-        g.big_values = (i0 - 4 * g.count1) / 2;
+        // hh[0] = n: lines up to the last non-zero one, hh[1] = b <= n: lines up to the last one above 1.  The
+        // reference's i = 2 * (top / 2 + 1) is n rounded up to even (0 for n = 0); everything is non-negative,
+        // so the divisions are shifts (src/loop.c:1488-1520)
+        const unsigned n_nz = (unsigned) hh[0], n_big = (unsigned) hh[1];
+        nslot = (int) ((n_nz + 63u) >> 6);
+        const unsigned i0 = (n_nz + 1u) & ~1u;
+        const unsigned c1 = (i0 - n_big) >> 2;
+        g.count1 = (int) c1;
+        g.big_values = (int) ((i0 - 4u * c1) >> 1);
         // count1 region: table A vs table B (values are 0/1, so v+2w+4x+8y comes from two words)
         int s01 = 0;
 #pragma unroll
