@@ -266,7 +266,8 @@ MP3MI_DEVFN void loop_region_walk(const loop_lds &L, const unsigned *ixw, int la
 {
     const int ylen = (dA >> 15) & 31, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
     int s01 = 0, s2 = 0;
-    for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) {
+#pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
+    for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // (one to three steps: unrolling only adds scalar bookkeeping)
         const int w = w0 + lane;
         const bool in = 2 * w < hi;
         const unsigned xy = ixw[in ? w : 0];
@@ -428,6 +429,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     auto region_max = [&](int lo, int hi) {
         hi = hi < nzend ? hi : nzend; // both even
         int m = 0;
+#pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
         for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // pair index of lane 0
             const int w = w0 + lane;
             const unsigned xy = 2 * w < hi ? ixw[w] : 0u;
