@@ -49,7 +49,7 @@ struct loop_lds {
                       // quantise/count passes only need |xr|^(3/4) (registers) and the 18 VGPRs decide
                       // between 4 wavefronts per SIMD with and without scratch spills
     double part[64];
-    int16_t ix[576 + 8];
+    int16_t ix[576 + 128]; // padded: the region walks read whole 64-pair steps and mask what lies past the end
     uint16_t glut[928];
     int sf_gr0[2][21];
     mp3mi_loop_state st;
@@ -432,7 +432,9 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
         for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // pair index of lane 0
             const int w = w0 + lane;
-            const unsigned xy = 2 * w < hi ? ixw[w] : 0u;
+            // read unconditionally (L.ix is padded: pairs past the end exist) and mask: a conditional load costs
+            // three scalar instructions and two branches per step
+            const unsigned xy = ixw[w] & (unsigned) ((2 * w - hi) >> 31);
             const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
             const int v = x > y ? x : y;
             m = v > m ? v : m;
