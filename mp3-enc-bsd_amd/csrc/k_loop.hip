@@ -268,16 +268,17 @@ MP3MI_DEVFN void loop_region_walk(const loop_lds &L, const unsigned *ixw, int la
     int s01 = 0, s2 = 0;
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
     for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // (one to three steps: unrolling only adds scalar bookkeeping)
+        // pairs past the end of the region are read all the same (L.ix is padded) and masked out of the sums
         const int w = w0 + lane;
-        const bool in = 2 * w < hi;
-        const unsigned xy = ixw[in ? w : 0];
+        const int in = (2 * w - hi) >> 31; // all ones inside the region
+        const unsigned xy = ixw[w];
         const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
         const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
-        const int e = L.glut[dB + xc * ylen + yc];
+        const int e = L.glut[(dB + xc * ylen + yc) & in];
         int c = (e & 31) | (((e >> 5) & 31) << 16);
         if (ESC) c += ((x > 14) + (y > 14)) * lb01;
-        s01 += in ? c : 0;
-        if (NC3) s2 += in ? (e >> 10) & 31 : 0;
+        s01 += c & in;
+        if (NC3) s2 += (e >> 10) & 31 & in;
     }
     *a01 = s01;
     *a2 = s2;
