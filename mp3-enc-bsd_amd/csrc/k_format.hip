@@ -265,18 +265,24 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
     // ---- scatter: header + side info at n*frame_bytes, main data behind the back pointer ----
     const size_t hdr = (size_t) n_abs * (size_t) frame_bytes;
     if (lane < si_bytes) dst[hdr + lane] = (uint8_t) (L.si[lane >> 2] >> (24 - 8 * (lane & 3)));
-    const long m0 = n_abs * (long) slot - sd->main_data_begin;
+    // main-data byte m = n_abs * slot - main_data_begin + k lives in frame m / slot at offset m % slot behind that
+    // frame's side info.  main_data_begin < 512, so the quotient and remainder of the first byte come from small
+    // 32-bit numbers, and every further byte needs one 32-bit division instead of two 64-bit ones.
+    const unsigned mdb = (unsigned) sd->main_data_begin, uslot = (unsigned) slot;
+    const unsigned back = (mdb + uslot - 1u) / uslot;          // frames the data reaches back
+    const long q0 = (long) n_abs - (long) back;                // frame of the first byte (>= 0: the reservoir starts empty)
+    const unsigned r0 = back * uslot - mdb;                    // its offset
     const int nbytes = gpos / 8;
     for (int k = lane; k < nbytes; k += 64) {
-        const long m = m0 + k;
-        const size_t phys = (size_t) (m / slot) * (size_t) frame_bytes + (size_t) si_bytes + (size_t) (m % slot);
+        const unsigned r = r0 + (unsigned) k, dq = r / uslot, rem = r - dq * uslot;
+        const size_t phys = (size_t) (q0 + (long) dq) * (size_t) frame_bytes + (size_t) si_bytes + (size_t) rem;
         dst[phys] = (uint8_t) (L.words[k >> 2] >> (24 - 8 * (k & 3)));
     }
     if (n_abs == n_frames_s - 1 && lane == 0) {
         // file length (src/formatBitstream.c:87-120 + src/common.c:843-868, 968): the flush stops
         // short of the last slot by what the current slot still has free, and close writes the
         // byte under construction as well
-        const long mend = m0 + nbytes;
+        const long mend = (long) n_abs * (long) slot - (long) mdb + nbytes; // once per stream
         const long rem = ((mend + slot - 1) / slot) * slot - mend;
         out_len[s] = (uint32_t) (n_frames_s * frame_bytes - rem + 1);
     }
