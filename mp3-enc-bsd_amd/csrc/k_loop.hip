@@ -147,8 +147,14 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y
         return;
     }
     const float cq = __builtin_exp2f(-0.1875f * (float) q);
-    bool need[9]; // per line: too close to a table boundary for the estimate (kept as lane masks, not as data)
-    bool any = false;
+    // Near a table boundary a line is settled exactly.  The estimate's error is relative: < 7e-7 f from the two
+    // 1-ulp roots, exp2 and two roundings, plus < 1.2e-7 f for each of the at most 17 rescalings of y34 by
+    // loop_rescale34 (16 amplifications, one pre-emphasis) = 2.8e-6 f.  The guard band 3.5e-6 f + 2e-6 scales
+    // with f; small values -- the common case -- are almost never ambiguous.  With d = |frac - 1/2|: within the
+    // band of an integer <=> d + 3.5e-6 f > 1/2 - 2e-6.  The pass only needs to know whether ANY line is (the
+    // maximum of that sum over the nine lines, one compare); which ones is found again in the rare branch.
+    const float guard = 0.5f - 2e-6f;
+    float gmax = 0.0f;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
         // estimate f of x^(3/4) + 0.4054 (>= 0.4054); from 2047.5 on the answer is the table's last entry
@@ -156,20 +162,16 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y
         f = __builtin_fminf(f, 2047.5f);
         const float fl = __builtin_floorf(f);
         p[j] = (int) fl;
-        // near a table boundary: settle exactly.  The estimate's error is relative: < 7e-7 f from the two
-        // 1-ulp roots, exp2 and two roundings, plus < 1.2e-7 f for each of the at most 17 rescalings of
-        // y34 by loop_rescale34 (16 amplifications, one pre-emphasis) = 2.8e-6 f.  The guard band
-        // 3.5e-6 f + 2e-6 scales with f; small values -- the common case -- are almost never ambiguous.
-        // |frac - 1/2| > 1/2 - band <=> within band of an integer.
         const float d = __builtin_fabsf((f - fl) - 0.5f);
-        need[j] = d > __builtin_fmaf(-3.5e-6f, f, 0.5f - 2e-6f);
-        any = any || need[j];
+        gmax = __builtin_fmaxf(gmax, __builtin_fmaf(3.5e-6f, f, d));
     }
-    if (wave_any(any)) {
+    if (wave_any(gmax > guard)) {
         const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
 #pragma unroll
         for (int j = 0; j < 9; j++) {
-            if (need[j]) {
+            const float f = __builtin_fminf(loop_estimate(y34[j], cq), 2047.5f);
+            const float d = __builtin_fabsf((f - __builtin_floorf(f)) - 0.5f);
+            if (__builtin_fmaf(3.5e-6f, f, d) > guard) {
                 const double x = __builtin_fabs(L.xr[lane + 64 * j]) * ostep;
                 int pp = p[j];
                 while (pp > 0 && x < T->pow_nint_tab[pp]) pp--;
