@@ -99,8 +99,10 @@ MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int
 // square root is enough; the correctly rounded expansion costs ~20 instructions per root.
 #if defined(MP3MI_EMU)
 #define LOOP_FAST_SQRTF(x) __builtin_sqrtf(x)
+#define LOOP_FAST_EXP2F(x) __builtin_exp2f(x)
 #else
 #define LOOP_FAST_SQRTF(x) __builtin_amdgcn_sqrtf(x)
+#define LOOP_FAST_EXP2F(x) __builtin_amdgcn_exp2f(x) /* |x| < 80 here: no denormal range to care for */
 #endif
 // Returns the largest y34 of the granule (wave-uniform): a step size that quantises it to zero
 // quantises everything to zero.
@@ -134,7 +136,7 @@ MP3MI_DEVFN float loop_estimate(float y34, float cq) { return __builtin_fmaf(y34
 // quantiser, which is monotone in y34, so the quantiser would leave every line at 0 unflagged.
 MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
 {
-    return loop_estimate(y34max, __builtin_exp2f(-0.1875f * (float) q)) < 0.999f;
+    return loop_estimate(y34max, LOOP_FAST_EXP2F(-0.1875f * (float) q)) < 0.999f;
 }
 
 MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], int q, bool all_zero, int p[9])
@@ -146,7 +148,7 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y
         __syncthreads();
         return;
     }
-    const float cq = __builtin_exp2f(-0.1875f * (float) q);
+    const float cq = LOOP_FAST_EXP2F(-0.1875f * (float) q);
     // Near a table boundary a line is settled exactly.  The estimate's error is relative: < 7e-7 f from the two
     // 1-ulp roots, exp2 and two roundings, plus < 1.2e-7 f for each of the at most 17 rescalings of y34 by
     // loop_rescale34 (16 amplifications, one pre-emphasis) = 2.8e-6 f.  The guard band 3.5e-6 f + 2e-6 scales
