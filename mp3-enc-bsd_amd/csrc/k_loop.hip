@@ -45,7 +45,8 @@ struct loop_gr { // wave-uniform working copy of gr_info (src/l3side.h:60-87)
 // 9.7 KB per wavefront: 16 single-wave workgroups fit the 160 KB of a CU, i.e. 4 waves per SIMD,
 // which is what 4096 streams on 256 CUs need to be resident all at once.
 struct loop_lds {
-    double xr[576];   // the granule's spectrum (amplified in place): kept here, not in registers, because the
+    double xr[576 + 1]; // the granule's spectrum (amplified in place; [576] = 0: the line a finished noise job
+                      // reads on, ix[576] = 0 too): kept here, not in registers, because the
                       // quantise/count passes only need |xr|^(3/4) (registers) and the 18 VGPRs decide
                       // between 4 wavefronts per SIMD with and without scratch spills
     double part[64];
@@ -532,6 +533,25 @@ MP3MI_DEVFN double loop_noise_sum(const mp3mi_tables *T, const loop_lds &L, doub
     return sum;
 }
 
+// The partial-sum jobs of the first tier: all lanes take the same number of steps (kmax, the longest job,
+// a multiple of 4) and a job that is through reads line 576 -- xr = 0, ix = 0, a term of exactly +0 -- instead
+// of dropping out: no divergent loop, no remainder loop, four loads in flight throughout.
+MP3MI_DEVFN double loop_noise_jobs(const mp3mi_tables *T, const loop_lds &L, double step, int first, int count, int stride, int kmax)
+{
+    double sum = 0.0;
+    for (int k = 0; k < kmax; k += 4) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int line = k + u < count ? first + (k + u) * stride : 576;
+            t[u] = __builtin_fabs(L.xr[line]) - T->pow43[L.ix[line]] * step;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) sum = sum + t[u] * t[u];
+    }
+    return sum;
+}
+
 // the reference's sequential band sums (src/loop.c:1030-1060)
 MP3MI_DEVFN double loop_noise_exact(const mp3mi_tables *T, const loop_lds &L, double step, bool bandlane, int sfirst, int scount, int sstride)
 {
@@ -671,6 +691,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     for (int i = lane; i < 928; i += 64) L.glut[i] = T->glut[i];
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];
     if (lane < 8) L.ix[576 + lane] = 0;
+    if (lane == 0) L.xr[576] = 0.0;
     __syncthreads();
 
     // ragged batch: frames of this stream beyond its last (zero-filled) one are not encoded
@@ -713,6 +734,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 loop_sum_range(R, shortb, nband, &sfirst, &scount, &sstride);
                 // calc_noise's partial-sum jobs (mp3mi_tables::nj_*): this lane's job, and for band lanes their parts
                 const int jfirst = T->nj_first[shortb][lane], jcount = T->nj_count[shortb][lane];
+                const int jmax4 = (T->nj_max[shortb] + 3) & ~3; // the longest job, in steps of four terms
                 const int pj0 = bandlane ? T->nj_job0[shortb][lane] : 0, pn = bandlane ? T->nj_njobs[shortb][lane] : 0;
 
                 int p[9];
@@ -861,7 +883,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         {
                             noise_step = T->step[g.q - MP3MI_STEP_MIN];
                             if (!xfsf_exact) {
-                                L.part[lane] = loop_noise_sum(T, L, noise_step, jfirst, jcount, shortb ? 3 : 1);
+                                L.part[lane] = loop_noise_jobs(T, L, noise_step, jfirst, jcount, shortb ? 3 : 1, jmax4);
                                 __syncthreads();
                                 double sum = 0.0;
                                 for (int i = 0; i < pn; i++) sum = sum + L.part[pj0 + i];

@@ -328,6 +328,7 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
                     const int cnt = (w - off + (parts - q) - 1) / (parts - q); // even split of what is left
                     T->nj_first[t][j] = (int16_t) (t ? (e0 + off) * 3 + b % 3 : e0 + off);
                     T->nj_count[t][j] = (uint8_t) cnt;
+                    if (cnt > T->nj_max[t]) T->nj_max[t] = (uint8_t) cnt;
                     off += cnt;
                     j++;
                 }
