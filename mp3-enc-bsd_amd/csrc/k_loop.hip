@@ -49,7 +49,6 @@ struct loop_lds {
                       // reads on, ix[576] = 0 too): kept here, not in registers, because the
                       // quantise/count passes only need |xr|^(3/4) (registers) and the 18 VGPRs decide
                       // between 4 wavefronts per SIMD with and without scratch spills
-    double part[64];
     int16_t ix[576 + 128]; // padded: the region walks read whole 64-pair steps and mask what lies past the end
     uint16_t glut[928];
     int sf_gr0[2][21];
@@ -735,6 +734,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 // calc_noise's partial-sum jobs (mp3mi_tables::nj_*): this lane's job, and for band lanes their parts
                 const int jfirst = T->nj_first[shortb][lane], jcount = T->nj_count[shortb][lane];
                 const int jmax4 = (T->nj_max[shortb] + 3) & ~3; // the longest job, in steps of four terms
+                const int jseg = T->nj_seg[shortb][lane];        // bit d: lane + d is a job of the same band
                 const int pj0 = bandlane ? T->nj_job0[shortb][lane] : 0, pn = bandlane ? T->nj_njobs[shortb][lane] : 0;
 
                 int p[9];
@@ -883,10 +883,17 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         {
                             noise_step = T->step[g.q - MP3MI_STEP_MIN];
                             if (!xfsf_exact) {
-                                L.part[lane] = loop_noise_jobs(T, L, noise_step, jfirst, jcount, shortb ? 3 : 1, jmax4);
-                                __syncthreads();
-                                double sum = 0.0;
-                                for (int i = 0; i < pn; i++) sum = sum + L.part[pj0 + i];
+                                // The jobs of a band sit in consecutive lanes: a segmented sum by doubling (lane l takes
+                                // over the sum of lane l + d where that is a job of the same band: bit of jseg) leaves
+                                // the band's sum in its first job's lane, where the band lane fetches it.  Any order
+                                // of these non-negative terms is as good as another here (see above).
+                                double v = loop_noise_jobs(T, L, noise_step, jfirst, jcount, shortb ? 3 : 1, jmax4);
+#pragma unroll
+                                for (int d = 1; d <= 16; d <<= 1) {
+                                    const double o = __shfl_down(v, (unsigned) d);
+                                    v = v + ((jseg & d) ? o : 0.0);
+                                }
+                                const double sum = __shfl(v, pj0);
                                 xfsf_r = bandlane ? sum / (double) scount : 0.0;
                                 if (wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) xfsf_exact = true;
                             }
@@ -955,13 +962,15 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             const unsigned long long ampmask = __ballot(amp); // bit b = band lane b amplified
                             over = __popcll(ampmask);
                             if (over) {
+                                // branch-free: a line outside the amplified bands is multiplied by 1 (exact).  ampmask only
+                                // has bits of band lanes, so lines above the last band (b >= nband) find a zero bit.
+                                const unsigned alo = (unsigned) ampmask, ahi = (unsigned) (ampmask >> 32);
 #pragma unroll
                                 for (int j = 0; j < 9; j++) {
-                                    const int b = (int) ((bandpack >> (6 * j)) & 63ull);
-                                    if (b < nband && ((ampmask >> b) & 1ull)) {
-                                        L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * ifqstep;
-                                        y34[j] = loop_rescale34(y34[j], 1);
-                                    }
+                                    const unsigned b = (unsigned) ((bandpack >> (6 * j)) & 63ull);
+                                    const bool f = (((b < 32u ? alo : ahi) >> (b & 31u)) & 1u) != 0;
+                                    L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * (f ? ifqstep : 1.0);
+                                    y34[j] = y34[j] * (f ? 1.2968395546510096f : 1.0f); // loop_rescale34(y34, 1)
                                 }
                                 y34max = y34max * LOOP_Y34MAX_GROW;
                             }

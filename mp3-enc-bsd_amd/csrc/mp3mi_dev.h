@@ -59,6 +59,7 @@ typedef struct {
     int16_t nj_first[2][64];
     uint8_t nj_count[2][64], nj_job0[2][36], nj_njobs[2][36];
     uint8_t nj_max[2];               /* the longest job */
+    uint8_t nj_seg[2][64];           /* bit d (1, 2, 4, 8, 16): job j + d belongs to the same band as job j (bands have < 32 jobs) */
     /* subdivide (src/loop.c:1596-1706) for blocks without window switching, by big_values:
        region0_count | region1_count << 4 | address1 << 8 | address2 << 18 (tables_host.cpp) */
     uint32_t subdiv_lut[289];
