@@ -184,7 +184,10 @@ MP3MI_DEVFN int wave_readlane_i32(int v, int lane) { return __shfl(v, lane); }
 #else
 /* DPP reductions (gfx9 family): xor-1 and xor-2 inside each quad, then half-row and row mirrors
  * give every lane of a 16-lane row the row total; row_bcast15 / row_bcast31 carry the totals
- * across rows into lane 63, which is read back as a wave-uniform scalar. */
+ * across rows into lane 63, which is read back as a wave-uniform scalar.  The broadcasts run with all rows
+ * enabled (rows that have no source take 0, the identity of a sum and of a maximum of non-negative values;
+ * row 2 also picks up row 1's total in the first broadcast, which never reaches lane 63's chain): a step
+ * with a partial row mask has to keep the other rows' old values and costs three instructions, not one. */
 #define MP3MI_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp(ident, (v), (ctrl), (rmask), 0xf, false)
 MP3MI_DEVFN int wave_sum_i32(int v)
 {
@@ -193,8 +196,8 @@ MP3MI_DEVFN int wave_sum_i32(int v)
     v += MP3MI_DPP(v, 0x4E, 0xf);  /* quad_perm [2,3,0,1] */
     v += MP3MI_DPP(v, 0x141, 0xf); /* row_half_mirror */
     v += MP3MI_DPP(v, 0x140, 0xf); /* row_mirror */
-    v += MP3MI_DPP(v, 0x142, 0xa); /* row_bcast15 into rows 1 and 3 */
-    v += MP3MI_DPP(v, 0x143, 0xc); /* row_bcast31 into rows 2 and 3 */
+    v += MP3MI_DPP(v, 0x142, 0xf); /* row_bcast15: row 3 takes row 2's total, row 1 row 0's */
+    v += MP3MI_DPP(v, 0x143, 0xf); /* row_bcast31: row 3 takes lane 31's = rows 0 + 1 */
     return __builtin_amdgcn_readlane(v, 63);
 }
 MP3MI_DEVFN int wave_max_i32(int v) /* values >= 0 */
@@ -205,8 +208,8 @@ MP3MI_DEVFN int wave_max_i32(int v) /* values >= 0 */
     o = MP3MI_DPP(v, 0x4E, 0xf); v = o > v ? o : v;
     o = MP3MI_DPP(v, 0x141, 0xf); v = o > v ? o : v;
     o = MP3MI_DPP(v, 0x140, 0xf); v = o > v ? o : v;
-    o = MP3MI_DPP(v, 0x142, 0xa); v = o > v ? o : v;
-    o = MP3MI_DPP(v, 0x143, 0xc); v = o > v ? o : v;
+    o = MP3MI_DPP(v, 0x142, 0xf); v = o > v ? o : v;
+    o = MP3MI_DPP(v, 0x143, 0xf); v = o > v ? o : v;
     return __builtin_amdgcn_readlane(v, 63);
 }
 MP3MI_DEVFN int wave_readlane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -233,8 +236,8 @@ MP3MI_DEVFN void wave_reduce_i32(int (&v)[NSUM + NMAX])
     MP3MI_RSTEP(0x4E, 0xf)
     MP3MI_RSTEP(0x141, 0xf)
     MP3MI_RSTEP(0x140, 0xf)
-    MP3MI_RSTEP(0x142, 0xa)
-    MP3MI_RSTEP(0x143, 0xc)
+    MP3MI_RSTEP(0x142, 0xf)
+    MP3MI_RSTEP(0x143, 0xf)
 #undef MP3MI_RSTEP
 #pragma unroll
     for (int k = 0; k < NSUM + NMAX; k++) v[k] = __builtin_amdgcn_readlane(v[k], 63);
