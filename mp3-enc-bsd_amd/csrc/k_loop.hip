@@ -396,8 +396,11 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
             m1 = (i < 36 && p[j] > m1) ? p[j] : m1;
             m2 = (i >= 36 && p[j] > m2) ? p[j] : m2;
         }
-        m1 = wave_max_i32(m1);
-        m2 = wave_max_i32(m2);
+        {
+            int mv[2] = {m1, m2};
+            wave_reduce_i32<0, 2>(mv);
+            m1 = mv[0]; m2 = mv[1];
+        }
         // choose_table (src/loop.c:1908-1947): the first table that can hold the maximum
         const int da0 = wave_readlane_i32(R.desc_a, loop_desc_index(m1)), db0 = wave_readlane_i32(R.desc_b, loop_desc_index(m1));
         const int da1 = wave_readlane_i32(R.desc_a, loop_desc_index(m2)), db1 = wave_readlane_i32(R.desc_b, loop_desc_index(m2));
@@ -990,7 +993,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                     m1 = (lane < 11) ? sf_r : 0;
                                     m2 = (lane >= 11 && lane < 21) ? sf_r : 0;
                                 }
-                                const int mm1 = wave_max_i32(m1), mm2 = wave_max_i32(m2);
+                                int mmv[2] = {m1, m2};
+                                wave_reduce_i32<0, 2>(mmv); // in lock-step: each fills the other's DPP wait states
+                                const int mm1 = mmv[0], mm2 = mmv[1];
                                 // the first k with mm1 < 2^slen1[k] and mm2 < 2^slen2[k] only depends on the bit lengths
                                 // of the two maxima: tabulated, a nibble per (length of mm1 <= 4, length of mm2 <= 3)
                                 const int bl1 = 32 - __clz(mm1), bl2 = 32 - __clz(mm2);
