@@ -2,16 +2,28 @@
 """Headline benchmark: stereo 44.1 kHz Layer III frames/s at 128 kbps (bit-exact), MI355X.
 
 One "step" = one pass of the whole hot path (psy FFTs, thresholds, filterbank+MDCT, iteration
-loop, bitstream formatting) over one batch of synthetic PCM that is already resident in HBM:
-BASELINE.json configs[1] -- 4096 independent 44.1 kHz stereo streams x 383 frames (10 s) at
-128 kbps per GPU.  With N GPUs every rank owns its own 4096 streams (no collective on the data
-path: streams are independent), so scaling is weak and `value` is the whole-job frames/s.
+loop, bitstream formatting) over one batch of synthetic PCM that is already resident in HBM.
+The workloads are BASELINE.json's configs, selected with --config:
+
+  1  4096 streams x 383 frames, 44.1 kHz stereo, 128 kbps            (configs[1]; the default, the metric's config)
+  2  8192 streams x 383 frames per GPU, 44.1 kHz stereo, 128 kbps    (configs[2]: 65 536 streams on 8 GPUs, plain
+                                                                      stereo -- the reference refuses joint stereo;
+                                                                      the default when launched on 8 GPUs)
+  3  4096 streams x 417 frames, 48 kHz stereo, stream s at {64,96,128,192,256,320}[s mod 6] kbps   (configs[3])
+  4  16384 streams x 278 frames, 32 kHz mono, 64 kbps                (configs[4])
+
+With N GPUs every rank owns its own streams (no collective on the data path: streams are independent), so
+scaling is weak and `value` is the whole-job frames/s.  The PCM is the deterministic generator of
+csrc/pcm_synth_core.h run on the device (md5-pinned by tests/test_synth.py).  A sample of the timed batch's
+streams is compared byte for byte with the CPU oracle and with the unmodified reference binary; a mismatch
+makes the run FAIL (exit 1, value null).  tools/full_parity.py compares every stream.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import glob
 import importlib
 import json
 import os
@@ -26,36 +38,59 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+SEED = 0x6D70336D
+MIX48 = [64, 96, 128, 192, 256, 320]
+
+CONFIGS = {
+    1: dict(streams=4096, frames=383, rate=44100, channels=2, kbps=128, name="BASELINE configs[1]"),
+    2: dict(streams=8192, frames=383, rate=44100, channels=2, kbps=128, name="BASELINE configs[2] (8192 streams per GPU, plain stereo)"),
+    3: dict(streams=4096, frames=417, rate=48000, channels=2, kbps="mix48", name="BASELINE configs[3] (stream s at {64..320}[s mod 6] kbps)"),
+    4: dict(streams=16384, frames=278, rate=32000, channels=1, kbps=64, name="BASELINE configs[4]"),
+}
 
 
-def synth_on_device(dev, n_streams, n_per_ch, channels, rate, stream0, seed=0x6D70336D):
-    """Per-stream log sweep + noise + bursts, generated on the GPU so that a
-    7 GB batch is ready in seconds.  Parity is checked on the exact bytes produced here."""
-    out = torch.empty((n_streams, n_per_ch * channels), dtype=torch.int16, device=dev)
-    t = torch.arange(n_per_ch, device=dev, dtype=torch.float64) / rate
-    T, f0, f1 = 10.0, 20.0, 0.45 * rate
-    lr = np.log(f1 / f0)
-    ph = 2 * np.pi * f0 * T / lr * (torch.exp(lr * t / T) - 1.0)
-    half = rate // 2
-    n = torch.arange(n_per_ch, device=dev, dtype=torch.int64)
-    noise_amp = torch.tensor([1386.0, 90.0, 350.0, 5200.0], dtype=torch.float64, device=dev)
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed * 1000003 + stream0)
-    B = 32
-    for i0 in range(0, n_streams, B):
-        s = torch.arange(stream0 + i0, stream0 + min(i0 + B, n_streams), device=dev, dtype=torch.int64)[:, None]
-        amp = 32767.0 * (0.15 + 0.25 * ((s * 37) % 16).to(torch.float64) / 15.0)
-        namp = noise_amp[(s // 3) % 4]
-        burst = ((n[None, :] + (s * 977) % half) % half) < 300
-        chans = []
-        for c in range(channels):
-            v = amp * torch.sin((1.01 if c else 1.0) * ph[None, :] + 0.3 * s.to(torch.float64))
-            v = v + namp * (2.0 * torch.rand(v.shape, device=dev, dtype=torch.float64, generator=g) - 1.0)
-            sign = torch.where(torch.rand(v.shape, device=dev, generator=g) < 0.5, -12000.0, 12000.0).to(torch.float64)
-            v = v + torch.where(burst, sign, torch.zeros_like(sign))
-            chans.append(torch.clamp(torch.floor(v + 0.5), -32768, 32767).to(torch.int16))
-        out[i0:i0 + s.shape[0]] = torch.stack(chans, dim=2).reshape(s.shape[0], -1)
-    return out
+def kbps_of(cfg, stream):
+    return MIX48[stream % 6] if cfg["kbps"] == "mix48" else cfg["kbps"]
+
+
+class Workload:
+    """A config's batch on one GPU: encoder, deterministic PCM in HBM, output buffers."""
+
+    def __init__(self, mp3, cfg, dev, stream0):
+        self.cfg, self.dev, self.stream0 = cfg, dev, stream0
+        S, nf, C, rate = cfg["streams"], cfg["frames"], cfg["channels"], cfg["rate"]
+        self.kbps = [kbps_of(cfg, stream0 + s) for s in range(S)]
+        uniform = len(set(self.kbps)) == 1
+        self.batch = mp3.Batch(S, rate, C, self.kbps[0] if uniform else self.kbps, nf)
+        self.pcm = torch.empty((S, nf * 1152 * C), dtype=torch.int16, device=dev)
+        mp3.synth_pcm_device(self.pcm, nf * 1152, C, rate, stream0=stream0, seed=SEED)
+        self.out = torch.zeros((S, self.batch.out_stride(nf)), dtype=torch.uint8, device=dev)
+        self.out_len = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.frame_bytes = [mp3.frame_bytes(rate, k) for k in self.kbps]
+        torch.cuda.synchronize()
+
+    def step(self):
+        self.batch.encode(self.pcm, self.cfg["frames"], self.out, self.out_len)
+        self.batch.sync()
+
+    def alg_bytes_per_frame(self):
+        """PCM in + bitstream out, averaged over the batch's bitrates"""
+        return 1152 * self.cfg["channels"] * 2 + float(np.mean(self.frame_bytes))
+
+    def close(self):
+        self.batch.close()
+
+
+def newest_profile(pattern, pred):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.getmtime, reverse=True):
+        try:
+            d = json.load(open(f))
+            r = pred(d)
+            if r is not None:
+                return r, os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
 
 
 def pmc_traffic(kernel, streams, frames, launches_per_step):
@@ -63,54 +98,64 @@ def pmc_traffic(kernel, streams, frames, launches_per_step):
     (profiles/*_pmc_hbm_*.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     command, gfx950 correction applied there).  Counters cannot be read from inside the timed run,
     so this is the figure of the profiling pass, or None when no summary matches the workload."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_*.json")), reverse=True):
-        try:
-            d = json.load(open(f))
-            k = d["kernels"][kernel]
-            if d.get("streams") == streams and d.get("frames") == frames and k["dispatches"] == launches_per_step:
-                return k["hbm_bytes_per_launch"], os.path.basename(f)
-        except Exception:
-            continue
-    return None, None
+    def pred(d):
+        k = d["kernels"][kernel]
+        if d.get("streams") == streams and d.get("frames") == frames and k["dispatches"] == launches_per_step:
+            return k["hbm_bytes_per_launch"]
+        return None
+    return newest_profile("*_pmc_hbm_*.json", pred)
 
 
-def issue_rate(kernel, streams, frames, kernel_s_per_launch, launches_per_step):
-    """What actually bounds the kernel: wavefront instructions per launch (SQ_INSTS_VALU + SALU + LDS of the newest
-    committed counter pass of this workload, profiles/*_insts_*.json, tools/gpu_insts.sh) over the live launch
-    time -> cycles per instruction and SIMD at the nominal 2.4 GHz of 1024 SIMDs.  None without a matching pass."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_insts_%dx%d.json" % (streams, frames))), reverse=True):
-        try:
-            k = json.load(open(f))[kernel]
-            if k["dispatches"] != launches_per_step:
-                continue
-            insts = (k["SQ_INSTS_VALU"] + k["SQ_INSTS_SALU"] + k["SQ_INSTS_LDS"]) / k["dispatches"]
-            return {"wave_instructions_per_launch": int(insts), "cycles_per_instruction_per_simd": round(kernel_s_per_launch * 2.4e9 * 1024 / insts, 2),
-                    "source": os.path.basename(f),
-                    "note": "instruction-bound: an f32 VALU instruction costs 2.9, an f64 or scalar one 4.3-4.8 cycles per SIMD (tools/exp/issue_mix.hip, DESIGN.md section 4)"}
-        except Exception:
-            continue
-    return None
+def issue_roofline(kernel, streams, frames, kernel_s_per_launch, launches_per_step):
+    """The bound the kernel actually runs against: instruction issue.  From the newest committed SQ counter pass of
+    this workload (profiles/*_insts_<S>x<F>.json, tools/gpu_insts.sh): wavefront instructions per launch by class,
+    each priced at its measured issue cost per SIMD (tools/exp/issue_mix.hip), over the SIMD
+    cycles the launch had: achieved = sum(count x cost) busy SIMD-cycles, peak = 1024 SIMDs x 2.4 GHz x launch time."""
+    COST = {"valu_f64": 4.5, "valu_other": 3.0, "salu": 4.6, "lds": 4.0, "vmem": 4.0}  # cycles per wave-instruction and SIMD
+
+    def pred(d):
+        k = d[kernel]
+        if k["dispatches"] != launches_per_step:
+            return None
+        n = float(k["dispatches"])
+        valu, salu, lds = k["SQ_INSTS_VALU"] / n, k["SQ_INSTS_SALU"] / n, k["SQ_INSTS_LDS"] / n
+        f64 = sum(k.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) / n
+        vmem = (k.get("SQ_INSTS_VMEM_RD", 0) + k.get("SQ_INSTS_VMEM_WR", 0)) / n
+        busy = f64 * COST["valu_f64"] + (valu - f64) * COST["valu_other"] + salu * COST["salu"] + lds * COST["lds"] + vmem * COST["vmem"]
+        peak = kernel_s_per_launch * 2.4e9 * 1024
+        r = {"achieved": int(busy), "peak": int(peak), "unit": "SIMD issue cycles per launch", "frac": round(busy / peak, 4),
+             "wave_instructions_per_launch": int(valu + salu + lds + vmem),
+             "mix": {"valu": int(valu), "valu_f64": int(f64), "salu": int(salu), "lds": int(lds), "vmem": int(vmem)},
+             "cycles_per_instruction_per_simd": round(peak / max(valu + salu + lds + vmem, 1.0), 2),
+             "cost_model": COST}
+        for c in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY"):
+            if c in k:
+                r.setdefault("sq", {})[c] = int(k[c] / n)
+        return r
+    r, src = newest_profile("*_insts_%dx%d.json" % (streams, frames), pred)
+    if r is not None:
+        r["source"] = src
+    return r
 
 
-def cpu_baseline(pcm_sample, rate, kbps, channels, cores):
+def cpu_baseline(pcm_sample, rate, kbps_list, channels, cores):
     """Oracle (CPU restatement of the reference) on a bounded sample of the same workload."""
     from mp3common import Oracle
     orc = Oracle()
-    orc.encode(pcm_sample[0][: 1152 * channels * 8], rate, kbps, channels)  # warm up tables/page cache
+    orc.encode(pcm_sample[0][: 1152 * channels * 8], rate, kbps_list[0], channels)  # warm up tables/page cache
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
-        outs = list(ex.map(lambda p: orc.encode(p, rate, kbps, channels)[0], pcm_sample))
+        outs = list(ex.map(lambda a: orc.encode(a[0], rate, a[1], channels)[0], zip(pcm_sample, kbps_list)))
     dt = time.perf_counter() - t0
     frames = sum(len(p) // (1152 * channels) for p in pcm_sample)
     return frames / dt, outs
 
 
-def reference_baseline(pcm_sample, rate, kbps, channels, cores):
+def reference_baseline(pcm_sample, rate, kbps_list, channels, cores):
     """The UNMODIFIED reference encoder (oracle/_ref/encode, compiled from /root/reference/src by
     oracle/Makefile where the sources exist; the binary travels with the repository) on the same
     sample, one process per stream.  Returns (frames/s, outputs) or None when the binary is absent."""
+    import shutil
     import struct
     import subprocess
     import tempfile
@@ -126,7 +171,7 @@ def reference_baseline(pcm_sample, rate, kbps, channels, cores):
                     struct.pack("<I", len(data)) + data)
 
     def run(k):
-        args = [exe, "-s", "%g" % (rate / 1000.0), "-b", str(kbps)] + (["-m", "m"] if channels == 1 else [])
+        args = [exe, "-s", "%g" % (rate / 1000.0), "-b", str(kbps_list[k])] + (["-m", "m"] if channels == 1 else [])
         subprocess.run(args + [os.path.join(tmp, "%d.wav" % k), os.path.join(tmp, "%d.mp3" % k)], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return open(os.path.join(tmp, "%d.mp3" % k), "rb").read()
@@ -137,7 +182,6 @@ def reference_baseline(pcm_sample, rate, kbps, channels, cores):
         outs = list(ex.map(run, range(len(pcm_sample))))
     dt = time.perf_counter() - t0
     frames = sum(len(p) // (1152 * channels) for p in pcm_sample)
-    import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     return frames / dt, outs
 
@@ -147,12 +191,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
-    ap.add_argument("--frames", type=int, default=383, help="frames per stream (383 = 10 s at 44.1 kHz)")
-    ap.add_argument("--rate", type=int, default=44100)
-    ap.add_argument("--kbps", type=int, default=128)
-    ap.add_argument("--channels", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE.json workload (see the module docstring); 0 = 1, or 2 when launched on 8 GPUs")
+    ap.add_argument("--streams", type=int, default=0, help="override: streams per GPU")
+    ap.add_argument("--frames", type=int, default=0, help="override: frames per stream")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the timed CPU baseline (profiling passes); a small oracle parity check remains")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,16 +212,15 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     mp3 = importlib.import_module("mp3-enc-bsd_amd")
-    S, nf, C = args.streams, args.frames, args.channels
-    batch = mp3.Batch(S, args.rate, C, args.kbps, nf)
-    pcm = synth_on_device(dev, S, nf * 1152, C, args.rate, stream0=rank * S)
-    out = torch.zeros((S, batch.out_stride(nf)), dtype=torch.uint8, device=dev)
-    out_len = torch.zeros(S, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-
-    def step():
-        batch.encode(pcm, nf, out, out_len)
-        batch.sync()
+    cfg_id = args.config or (2 if world == 8 else 1)
+    cfg = dict(CONFIGS[cfg_id])
+    default_size = not (args.streams or args.frames)
+    if args.streams:
+        cfg["streams"] = args.streams
+    if args.frames:
+        cfg["frames"] = args.frames
+    S, nf, C, rate = cfg["streams"], cfg["frames"], cfg["channels"], cfg["rate"]
+    wl = Workload(mp3, cfg, dev, stream0=rank * S)
 
     def barrier():
         if distributed:
@@ -185,13 +228,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     barrier()
     t0 = time.perf_counter()
     loop_ms, all_ms, launches = 0.0, 0.0, 0
     for _ in range(args.steps):
-        step()
-        a, b, n = batch.last_timing()
+        wl.step()
+        a, b, n = wl.batch.last_timing()
         loop_ms += a
         all_ms += b
         launches += n
@@ -202,64 +245,75 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # parity spot check on the exact device bytes of THIS rank (every rank checks its own streams; the CPU baseline
+    # is timed on rank 0 at N = 1 only)
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    timed_baseline = rank == 0 and world == 1 and not args.no_cpu_baseline
+    n_sample = max(4, cores * 2) if timed_baseline else 8
+    idx = sorted(set(np.linspace(0, S - 1, n_sample).astype(int).tolist()))
+    pcm_sample = [wl.pcm[i].cpu().numpy() for i in idx]
+    kb_sample = [wl.kbps[i] for i in idx]
+    out_h, len_h = wl.out[idx].cpu().numpy(), wl.out_len[idx].cpu().numpy()
+    got = [out_h[k, : len_h[k]].tobytes() for k in range(len(idx))]
+    fps, refs = cpu_baseline(pcm_sample, rate, kb_sample, C, cores)
+    bad = [int(idx[k]) for k in range(len(idx)) if got[k] != refs[k]]
+    cpu = None
+    if timed_baseline:
+        cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d of this batch's streams x %d frames, oracle/liboracle.so, one thread per stream" % (len(idx), nf)}
+        ref = reference_baseline(pcm_sample, rate, kb_sample, C, cores)
+        if ref is not None:  # the reference binary itself: the baseline proper, and a second parity witness
+            rfps, routs = ref
+            bad += [int(idx[k]) for k in range(len(idx)) if got[k] != routs[k] and int(idx[k]) not in bad]
+            cpu = {"value": round(rfps, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
+                   "sample": "%d of this batch's streams x %d frames, oracle/_ref/encode (unmodified reference, gcc -O2), one process per stream" % (len(idx), nf),
+                   "port_value": round(fps, 1)}
+    n_bad = torch.tensor([len(bad)], dtype=torch.int64, device=dev)
+    if distributed:
+        dist.all_reduce(n_bad, op=dist.ReduceOp.SUM)
+    parity_ok = int(n_bad.item()) == 0
+
     frames_total = S * nf * args.steps * world
-    fb = mp3.frame_bytes(args.rate, args.kbps)
-    alg_bytes_per_frame = 1152 * C * 2 + fb  # PCM in + bitstream out
-    result = None
     if rank == 0:
-        # dominant kernel: k_loop; algorithmic bytes of one launch / its average duration
+        # dominant kernel: k_loop; algorithmic bytes of one launch / its average duration (HIP events on its stream)
+        alg = wl.alg_bytes_per_frame()
         frames_per_launch = S * nf * args.steps / max(launches, 1)
         avg_launch_s = loop_ms / 1e3 / max(launches, 1)
-        achieved = alg_bytes_per_frame * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # parity spot check on the exact device bytes + CPU baseline on the same sample
-        # (the CPU baseline is timed at N = 1 only; with more ranks a small oracle spot check remains)
-        cores = max(1, min(os.cpu_count() or 1, 64))
-        n_sample = max(4, cores * 2) if world == 1 else 8
-        idx = sorted(set(np.linspace(0, S - 1, n_sample).astype(int).tolist()))
-        pcm_sample = [pcm[i].cpu().numpy() for i in idx]
-        out_h, len_h = out[idx].cpu().numpy(), out_len[idx].cpu().numpy()
-        cpu = None
-        parity_ok = None
-        if not args.no_cpu_baseline:
-            fps, refs = cpu_baseline(pcm_sample, args.rate, args.kbps, C, cores)
-            parity_ok = all(out_h[k, : len_h[k]].tobytes() == refs[k] for k in range(len(idx)))
-            cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "%d of this batch's streams x %d frames, oracle/liboracle.so, one thread per stream" % (len(idx), nf)}
-            ref = reference_baseline(pcm_sample, args.rate, args.kbps, C, cores) if world == 1 else None
-            if world > 1:
-                cpu = None
-            if ref is not None:  # the reference binary itself: the baseline proper, and a second parity witness
-                rfps, routs = ref
-                parity_ok = parity_ok and all(out_h[k, : len_h[k]].tobytes() == routs[k] for k in range(len(idx)))
-                cpu = {"value": round(rfps, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
-                       "sample": "%d of this batch's streams x %d frames, oracle/_ref/encode (unmodified reference, gcc -O2), one process per stream" % (len(idx), nf),
-                       "port_value": round(fps, 1)}
+        achieved = alg * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         lps = launches // max(args.steps, 1)
-        traffic, traffic_src = pmc_traffic("k_loop", S, nf, lps) if (args.rate, args.kbps, C) == (44100, 128, 2) else (None, None)
+        traffic, traffic_src = pmc_traffic("k_loop", S, nf, lps) if cfg_id in (1, 2) else (None, None)
+        issue = issue_roofline("k_loop", S, nf, avg_launch_s, lps) if cfg_id in (1, 2) else None
         result = {
             "metric": "stereo 44.1 kHz frames/s @128 kbps (bit-exact), 1/2/4/8 MI355X + %HBM roofline",
-            "value": round(frames_total / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(frames_total / dt, 1) if parity_ok else None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %.1f kHz %s streams x %d frames per GPU, %d kbps CBR (%s)"
-                       % (S, args.rate / 1000.0, "stereo" if C == 2 else "mono", nf, args.kbps,
-                          "BASELINE configs[1]" if (S, nf, args.rate, args.kbps, C) == (4096, 383, 44100, 128, 2) else "non-default workload"),
-                       "streams_per_gpu": S, "frames_per_stream": nf, "parallelism": "streams sharded across GPUs, no collective"},
+            "config": {"workload": "batch of %d synthetic %.1f kHz %s streams x %d frames per GPU, %s kbps CBR (%s%s)"
+                       % (S, rate / 1000.0, "stereo" if C == 2 else "mono", nf,
+                          "64-320 mixed" if cfg["kbps"] == "mix48" else str(cfg["kbps"]), cfg["name"],
+                          "" if default_size else ", size overridden"),
+                       "config_id": cfg_id, "streams_per_gpu": S, "frames_per_stream": nf,
+                       "pcm": "mp3mi_synth_pcm_device, seed 0x%08x, streams rank*S .." % SEED,
+                       "parallelism": "streams sharded across GPUs, no collective"},
             "roofline": {"bound": "hbm", "kernel": "k_loop", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_frame": alg_bytes_per_frame,
+                         "algorithmic_bytes_per_frame": round(alg, 1),
                          "kernel_ms_per_launch": round(avg_launch_s * 1e3, 3), "launches_per_step": lps,
                          "all_kernels_ms_per_step": round(all_ms / max(args.steps, 1), 3),
-                         "issue": issue_rate("k_loop", S, nf, avg_launch_s, lps) if (args.rate, args.kbps, C) == (44100, 128, 2) else None},
+                         "limited_by": "instruction issue, not HBM (see issue)",
+                         "issue": issue},
             "cpu_baseline": cpu,
-            "parity_spot_check": {"streams": len(idx), "bit_exact": parity_ok},
+            "parity_spot_check": {"streams_per_rank": len(idx), "bit_exact": parity_ok, "mismatching_streams_rank0": bad,
+                                  "witness": "oracle/liboracle.so" + (" + oracle/_ref/encode" if cpu and cpu["kind"] == "reference" else "")},
         }
         print(json.dumps(result), flush=True)
-    batch.close()
+    wl.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit("bench.py: PARITY FAILURE -- the GPU bitstream differs from the reference on %d sampled streams" % int(n_bad.item()))
 
 
 if __name__ == "__main__":

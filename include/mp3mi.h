@@ -98,6 +98,20 @@ int mp3mi_encode_host_ex(int n_streams, int rate_hz, int channels, const int *kb
 long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst, size_t cap);
 void mp3mi_batch_debug_enable(mp3mi_batch *b, int on);
 
+/* Two-tier decisions: five places decide from a cheap value with a proven error bound and
+ * repeat the computation the reference's way only when the decision could depend on the last bits.  Each bit
+ * forces the second (exact) tier everywhere; the emitted bytes must not change (tests/test_gpu_tiers.py).  The
+ * environment variables MP3MI_{NOISE,PHASE,PSY,QUANT,PREP}_EXACT=1 set the same bits at mp3mi_batch_create. */
+enum {
+    MP3MI_TEST_NOISE_EXACT = 1,  /* calc_noise: the reference's sequential band sums (k_loop) */
+    MP3MI_TEST_PHASE_EXACT = 2,  /* phases: correctly rounded atan2 (k_cw) */
+    MP3MI_TEST_PSY_EXACT = 4,    /* masking threshold: dm_log / dm_exp (k_psy) */
+    MP3MI_TEST_QUANT_EXACT = 8,  /* quantiser: every line against the (i - 0.4054)^(4/3) table (k_loop) */
+    MP3MI_TEST_PREP_EXACT = 16,  /* quantanf_init: correctly rounded logs (k_prep) */
+    MP3MI_TEST_ALL_EXACT = 31
+};
+int mp3mi_batch_set_test_flags(mp3mi_batch *b, unsigned flags);
+
 /* Deterministic synthetic PCM (benchmarks / tests): interleaved int16, n_per_ch samples per channel. */
 void mp3mi_synth_pcm(int16_t *out, long n_per_ch, int channels, int rate_hz, uint32_t stream,
                      uint32_t seed);
@@ -105,6 +119,12 @@ void mp3mi_synth_pcm(int16_t *out, long n_per_ch, int channels, int rate_hz, uin
 /* Self-test hook: evaluates function fn of the device math layer (see csrc/k_debug.hip) on the
  * GPU for n host-side arguments.  Used by tests to prove device == host bit for bit. */
 int mp3mi_debug_dmath(int fn, const double *x, const double *y, double *out, size_t n);
+
+/* Self-test hook: maximum relative error, on this device, of the three approximate expressions the quantiser's
+ * first tier is built from (csrc/k_debug.hip): out[0] raw sqrt(a * raw sqrt(a)) vs a^(3/4) over all 2^24 floats
+ * of [1, 4); out[1] raw exp2 at the 801 step sizes the search can ask for; out[2] raw exp2 over 2^24 arguments
+ * of [-80, 80].  tests/test_gpu_tiers.py asserts that their sum stays inside the guard band's 7e-7 budget. */
+int mp3mi_debug_fastmath_bounds(double out[3]);
 
 /* Library / device identification string for logs. */
 const char *mp3mi_version(void);

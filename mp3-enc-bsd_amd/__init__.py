@@ -48,6 +48,8 @@ def lib():
         L.mp3mi_batch_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
         L.mp3mi_synth_pcm.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+        L.mp3mi_synth_pcm_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+        L.mp3mi_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
         L.mp3mi_version.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -56,6 +58,15 @@ def lib():
 def frame_bytes(rate_hz, kbps):
     """slots per frame, never padded (reference: src/musicin.c:562-581)"""
     return int((1152.0 / (rate_hz / 1000.0)) * (kbps / 8.0))
+
+
+def synth_pcm_device(pcm, n_per_ch, channels, rate_hz, stream0=0, seed=0x6D70336D):
+    """Fill the int16 cuda tensor pcm [S, n_per_ch*channels] with the deterministic synthetic PCM of streams
+    stream0 .. stream0+S-1 (csrc/pcm_synth_core.h: the same bytes as the host's mp3mi_synth_pcm)."""
+    assert pcm.is_cuda and pcm.is_contiguous() and pcm.shape[1] == n_per_ch * channels
+    rc = lib().mp3mi_synth_pcm_device(pcm.data_ptr(), pcm.shape[0], n_per_ch, channels, rate_hz, stream0, seed)
+    if rc != 0:
+        raise Mp3miError("mp3mi_synth_pcm_device failed with %d" % rc)
 
 
 class Batch:
@@ -74,6 +85,12 @@ class Batch:
         if rc != 0:
             raise Mp3miError("mp3mi_batch_create failed with %d" % rc)
 
+    def set_test_flags(self, flags):
+        """force the exact tier of the two-tier decisions (include/mp3mi.h, MP3MI_TEST_*)"""
+        rc = self.L.mp3mi_batch_set_test_flags(self.h, flags)
+        if rc != 0:
+            raise Mp3miError("mp3mi_batch_set_test_flags failed with %d" % rc)
+
     def out_stride(self, n_frames):
         return self.L.mp3mi_batch_out_stride(self.h, n_frames)
 
@@ -91,7 +108,9 @@ class Batch:
 
     def last_timing(self):
         a, b, n = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
-        self.L.mp3mi_batch_last_timing(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n))
+        rc = self.L.mp3mi_batch_last_timing(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n))
+        if rc != 0:
+            raise Mp3miError("mp3mi_batch_last_timing failed with %d (no encode call yet?)" % rc)
         return a.value, b.value, n.value
 
     def close(self):

@@ -156,6 +156,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     { const char *e = getenv("MP3MI_NOISE_EXACT"); b->test_flags = (e && atoi(e)) ? 1 : 0; }
     { const char *e = getenv("MP3MI_PHASE_EXACT"); if (e && atoi(e)) b->test_flags |= 2; }
     { const char *e = getenv("MP3MI_PSY_EXACT"); if (e && atoi(e)) b->test_flags |= 4; }
+    { const char *e = getenv("MP3MI_QUANT_EXACT"); if (e && atoi(e)) b->test_flags |= 8; }
     b->hdr_flags = 0;
     b->gate_count = NULL; b->gate_total = 0;
     {
@@ -240,6 +241,14 @@ extern "C" size_t mp3mi_batch_out_stride(const mp3mi_batch *b, int n_frames)
 }
 
 extern "C" void mp3mi_batch_debug_enable(mp3mi_batch *b, int on) { b->debug = on; }
+
+extern "C" int mp3mi_batch_set_test_flags(mp3mi_batch *b, unsigned flags)
+{
+    if (!b || (flags & ~(unsigned) MP3MI_TEST_ALL_EXACT)) return MP3MI_ERR_ARG;
+    b->test_flags = (int) (flags & 15u);
+    b->prep_exact = (flags & MP3MI_TEST_PREP_EXACT) ? 1 : 0;
+    return MP3MI_OK;
+}
 
 extern "C" int mp3mi_batch_set_header(mp3mi_batch *b, int copyright, int original, int emphasis)
 {

@@ -58,3 +58,57 @@ extern "C" int mp3mi_debug_dmath(int fn, const double *x, const double *y, doubl
     if (dout) hipFree(dout);
     return rc;
 }
+
+
+// ---- error of the quantiser's first-tier arithmetic on this device ----
+// what = 0: y34 = sqrt_raw(a * sqrt_raw(a)) against a^(3/4) for EVERY float a in [1, 4) (2^24 arguments: all
+// mantissas at both exponent parities; scaling a by 4 scales every intermediate by a power of two, so other
+// exponents repeat these errors exactly); what = 1: exp2_raw(-0.1875f * q) for the 801 step sizes
+// q = MP3MI_STEP_MIN .. MP3MI_STEP_MIN + 800 the kernel can ask for; what = 2: exp2_raw on 2^24 evenly spaced
+// arguments of [-80, 80].  Reference values in double (sqrt correctly rounded; 2^x = dm_exp(x ln 2), good to 1e-14).
+// Each thread folds its relative errors into max_err[what] (non-negative doubles order like their bits).
+#if defined(MP3MI_EMU)
+extern "C" int mp3mi_debug_fastmath_bounds(double out[3]) { (void) out; return MP3MI_ERR_NO_DEVICE; } // a statement about the hardware
+#else
+__global__ void k_debug_fastmath(int what, unsigned long long *__restrict__ max_err)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    double err = 0.0;
+    if (what == 0) {
+        if (i >= (1u << 24)) return;
+        const float a = __builtin_bit_cast(float, 0x3f800000u + i); // [1, 4)
+        const float y = LOOP_FAST_SQRTF(a * LOOP_FAST_SQRTF(a));
+        const double ad = (double) a, ref = __builtin_sqrt(ad * __builtin_sqrt(ad));
+        err = __builtin_fabs((double) y - ref) / ref;
+    } else {
+        float x;
+        if (what == 1) {
+            if (i >= (unsigned) MP3MI_STEP_N) return;
+            x = -0.1875f * (float) (MP3MI_STEP_MIN + (int) i);
+        } else {
+            if (i >= (1u << 24)) return;
+            x = -80.0f + (float) i * (160.0f / 16777216.0f);
+        }
+        const float y = LOOP_FAST_EXP2F(x);
+        const double ref = dm_exp((double) x * 0.6931471805599453);
+        err = __builtin_fabs((double) y - ref) / ref;
+    }
+    atomicMax(&max_err[what], __builtin_bit_cast(unsigned long long, err));
+}
+
+extern "C" int mp3mi_debug_fastmath_bounds(double out[3])
+{
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return MP3MI_ERR_NO_DEVICE;
+    unsigned long long *d = NULL;
+    int rc = MP3MI_ERR_HIP;
+    if (hipMalloc((void **) &d, 3 * sizeof(unsigned long long)) == hipSuccess && hipMemset(d, 0, 3 * sizeof(unsigned long long)) == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_fastmath, dim3(1u << 16), dim3(256), 0, 0, 0, d);
+        hipLaunchKernelGGL(k_debug_fastmath, dim3((MP3MI_STEP_N + 255) / 256), dim3(256), 0, 0, 1, d);
+        hipLaunchKernelGGL(k_debug_fastmath, dim3(1u << 16), dim3(256), 0, 0, 2, d);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, d, 3 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) rc = MP3MI_OK;
+    }
+    if (d) hipFree(d);
+    return rc;
+}
+#endif

@@ -97,13 +97,8 @@ MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int
 // y34[j] = |xr[j]|^(3/4) in float (loop_power34), so that x^(3/4) = y34 * 2^(-3q/16) costs one multiply per pass.
 // Only an estimate (the quantiser settles borderline lines exactly), so the raw 1-ulp hardware
 // square root is enough; the correctly rounded expansion costs ~20 instructions per root.
-#if defined(MP3MI_EMU)
-#define LOOP_FAST_SQRTF(x) __builtin_sqrtf(x)
-#define LOOP_FAST_EXP2F(x) __builtin_exp2f(x)
-#else
-#define LOOP_FAST_SQRTF(x) __builtin_amdgcn_sqrtf(x)
-#define LOOP_FAST_EXP2F(x) __builtin_amdgcn_exp2f(x) /* |x| < 80 here: no denormal range to care for */
-#endif
+// (LOOP_FAST_SQRTF / LOOP_FAST_EXP2F: mp3mi_dev.h; their error on the device is measured by k_debug.hip,
+// mp3mi_debug_fastmath_bounds, and asserted by tests/test_gpu_tiers.py)
 // Returns the largest y34 of the granule (wave-uniform): a step size that quantises it to zero
 // quantises everything to zero.
 MP3MI_DEVFN float loop_power34(const double xr[9], float y34[9])
@@ -139,10 +134,11 @@ MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
     return loop_estimate(y34max, LOOP_FAST_EXP2F(-0.1875f * (float) q)) < 0.999f;
 }
 
-MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], int q, bool all_zero, int p[9])
+// force_exact (MP3MI_QUANT_EXACT=1, tests): every line is settled against the exact table, whatever the estimate says.
+MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], int q, bool all_zero, int p[9], bool force_exact)
 {
     const int lane = wave_lane_here();
-    if (all_zero) {
+    if (all_zero && !force_exact) {
 #pragma unroll
         for (int j = 0; j < 9; j++) { p[j] = 0; L.ix[lane + 64 * j] = 0; }
         __syncthreads();
@@ -167,13 +163,13 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y
         const float d = __builtin_fabsf((f - fl) - 0.5f);
         gmax = __builtin_fmaxf(gmax, __builtin_fmaf(3.5e-6f, f, d));
     }
-    if (wave_any(gmax > guard)) {
+    if (force_exact || wave_any(gmax > guard)) {
         const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
 #pragma unroll
         for (int j = 0; j < 9; j++) {
             const float f = __builtin_fminf(loop_estimate(y34[j], cq), 2047.5f);
             const float d = __builtin_fabsf((f - __builtin_floorf(f)) - 0.5f);
-            if (__builtin_fmaf(3.5e-6f, f, d) > guard) {
+            if (force_exact || __builtin_fmaf(3.5e-6f, f, d) > guard) {
                 const double x = __builtin_fabs(L.xr[lane + 64 * j]) * ostep;
                 int pp = p[j];
                 while (pp > 0 && x < T->pow_nint_tab[pp]) pp--;
@@ -670,6 +666,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     __shared__ loop_lds L;
     const int lane = wave_lane();
     const int s = loop_place_stream(place, (int) gridDim.x, (int) blockIdx.x), C = geo.channels, G = 2 * geo.nf;
+    const bool quant_exact = (geo.test_flags & 8) != 0; // MP3MI_QUANT_EXACT=1: the quantiser's exact tier only (tests)
     int work = 0; // cost of this stream in this launch: 4 per quantise+count pass, 5 per distortion-loop iteration
     const int bitsPerFrame = bits_per_frame[s];
     const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2; // src/musicin.c:729-746
@@ -843,9 +840,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 next = (top + bot) / 2;
                                 g.q = next;
                                 PROF(1);
-                                const bool az = loop_all_zero(y34max, g.q);
+                                const bool az = !quant_exact && loop_all_zero(y34max, g.q);
                                 work += 4;
-                                loop_quantize(T, L, y34, g.q, az, p);
+                                loop_quantize(T, L, y34, g.q, az, p, quant_exact);
                                 PROF(2);
                                 bit = loop_count_bits(T, R, L, g, p, az);
                                 PROF(3);
@@ -863,9 +860,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             g.q += 1;
                             if (!have_pass) {
                                 PROF(1);
-                                const bool az = loop_all_zero(y34max, g.q);
+                                const bool az = !quant_exact && loop_all_zero(y34max, g.q);
                                 work += 4;
-                                loop_quantize(T, L, y34, g.q, az, p);
+                                loop_quantize(T, L, y34, g.q, az, p, quant_exact);
                                 PROF(2);
                                 bits = loop_count_bits(T, R, L, g, p, az);
                                 PROF(3);

@@ -154,6 +154,18 @@ typedef struct {
     mp3mi_gr_side gr[2][2];
 } mp3mi_frame_side;
 
+/* The quantiser's first tier (k_loop.hip, loop_quantize) estimates x^(3/4) with the raw hardware square root and
+ * exp2 (v_sqrt_f32, v_exp_f32: 1 ulp each); its guard band budgets 7e-7 relative for the two roots, the exp2
+ * and the roundings between them.  mp3mi_debug_fastmath_bounds (k_debug.hip) measures these very expressions
+ * on the device.  The CPU test build substitutes libm. */
+#if defined(MP3MI_EMU)
+#define LOOP_FAST_SQRTF(x) __builtin_sqrtf(x)
+#define LOOP_FAST_EXP2F(x) __builtin_exp2f(x)
+#else
+#define LOOP_FAST_SQRTF(x) __builtin_amdgcn_sqrtf(x)
+#define LOOP_FAST_EXP2F(x) __builtin_amdgcn_exp2f(x) /* |x| < 80 here: no denormal range to care for */
+#endif
+
 /* ---- wave helpers (64 lanes) ---- */
 MP3MI_DEVFN int wave_lane(void) { return (int) (threadIdx.x & 63); }
 /* The lane index behind an optimisation barrier: everything derived from it (addresses, masks) is

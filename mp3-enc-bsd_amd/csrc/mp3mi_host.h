@@ -27,7 +27,8 @@ struct mp3mi_geom {
                                  Samples beyond it read as zero and frames beyond ceil(n/1152) are not encoded (src/encode.c:162-166) */
     int test_flags;     /* bit 0: k_loop takes the exact (sequential) noise sums only (MP3MI_NOISE_EXACT=1, tests);
                            bit 1: k_cw takes the correctly rounded atan2 only (MP3MI_PHASE_EXACT=1, tests);
-                           bit 2: k_psy takes dm_log / dm_exp only (MP3MI_PSY_EXACT=1, tests) */
+                           bit 2: k_psy takes dm_log / dm_exp only (MP3MI_PSY_EXACT=1, tests);
+                           bit 3: k_loop's quantiser takes the exact table search only (MP3MI_QUANT_EXACT=1, tests) */
 };
 
 static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_idx, int n_frames, int f0, int nf)

@@ -43,8 +43,9 @@ def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
     import ctypes
     synth_so = os.path.join(tempfile.mkdtemp(), "libsynth.so")
-    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-o", synth_so,
-                    os.path.join(ROOT, "mp3-enc-bsd_amd", "csrc", "pcm_synth.c"), "-lm"], check=True)
+    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(ROOT, "mp3-enc-bsd_amd", "csrc"), "-o", synth_so,
+                    os.path.join(ROOT, "mp3-enc-bsd_amd", "csrc", "pcm_synth_host.cpp")], check=True)
     synth = ctypes.CDLL(synth_so)
     os.makedirs(GOLD, exist_ok=True)
     manifest = []

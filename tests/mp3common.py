@@ -97,6 +97,9 @@ class Mp3mi:
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_synth_pcm.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_version.restype = ctypes.c_char_p
+        L.mp3mi_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.mp3mi_synth_pcm_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+        L.mp3mi_debug_fastmath_bounds.argtypes = [ctypes.c_void_p]
 
     def synth(self, n_per_ch, channels, rate, stream, seed=SEED):
         out = np.zeros(n_per_ch * channels, dtype=np.int16)
@@ -147,3 +150,98 @@ def pad_frames(pcm, channels):
     out = np.zeros(n * per, dtype=np.int16)
     out[:len(pcm)] = pcm
     return out, n
+
+
+class DevMem:
+    """Memory the library under test computes on: HBM through libamdhip64 for the product, plain host memory
+    for the emulated test build (whose 'device pointers' are host pointers)."""
+
+    def __init__(self, mp):
+        self.emu = b"emulator" in mp.lib.mp3mi_version()
+        self.bufs = []
+        if not self.emu:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+            hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            hip.hipFree.argtypes = [ctypes.c_void_p]
+            self.hip = hip
+
+    def alloc(self, nbytes):
+        if self.emu:
+            a = np.zeros(max(nbytes, 1), np.uint8)
+            self.bufs.append(a)
+            return a.ctypes.data
+        p = ctypes.c_void_p()
+        assert self.hip.hipMalloc(ctypes.byref(p), max(nbytes, 1)) == 0, "hipMalloc(%d)" % nbytes
+        self.bufs.append(p)
+        return p.value
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        if self.emu:
+            ctypes.memmove(dptr, arr.ctypes.data, arr.nbytes)
+        else:
+            assert self.hip.hipMemcpy(dptr, arr.ctypes.data, arr.nbytes, 1) == 0
+
+    def download(self, dptr, shape, dtype):
+        out = np.zeros(shape, dtype)
+        if self.emu:
+            ctypes.memmove(out.ctypes.data, dptr, out.nbytes)
+        else:
+            assert self.hip.hipMemcpy(out.ctypes.data, dptr, out.nbytes, 2) == 0
+        return out
+
+    def free(self):
+        if not self.emu:
+            for p in self.bufs:
+                self.hip.hipFree(p)
+        self.bufs = []
+
+
+class BatchRun:
+    """One batch of S streams on device memory through the C ABI: PCM synthesised on the device (or uploaded),
+    encoded as often as wanted (e.g. once per test-flag setting), outputs fetched per stream."""
+
+    def __init__(self, mp, S, rate, channels, kbps, n_frames, stream0=0, pcm=None, seed=SEED):
+        self.mp, self.S, self.rate, self.ch, self.nf = mp, S, rate, channels, n_frames
+        L = mp.lib
+        self.mem = DevMem(mp)
+        self.b = ctypes.c_void_p()
+        karr = None if np.isscalar(kbps) else np.ascontiguousarray(kbps, dtype=np.int32)
+        rc = L.mp3mi_batch_create(ctypes.byref(self.b), S, rate, channels, karr.ctypes.data if karr is not None else None,
+                                  int(kbps) if karr is None else 0, n_frames)
+        assert rc == 0, "mp3mi_batch_create -> %d" % rc
+        self.stride = L.mp3mi_batch_out_stride(self.b, n_frames)
+        self.n_per_ch = n_frames * 1152
+        self.pcm_bytes = S * self.n_per_ch * channels * 2
+        self.d_pcm = self.mem.alloc(self.pcm_bytes)
+        self.d_out = self.mem.alloc(S * self.stride)
+        self.d_len = self.mem.alloc(4 * S)
+        if pcm is None:
+            rc = L.mp3mi_synth_pcm_device(self.d_pcm, S, self.n_per_ch, channels, rate, stream0, seed)
+            assert rc == 0, "mp3mi_synth_pcm_device -> %d" % rc
+        else:
+            pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+            assert pcm.nbytes == self.pcm_bytes
+            self.mem.upload(self.d_pcm, pcm)
+
+    def pcm_of(self, s):
+        """stream s's PCM as the device holds it"""
+        n = self.n_per_ch * self.ch
+        return self.mem.download(self.d_pcm + s * n * 2, (n,), np.int16)
+
+    def encode(self, flags=0):
+        L = self.mp.lib
+        assert L.mp3mi_batch_set_test_flags(self.b, flags) == 0
+        rc = L.mp3mi_batch_encode(self.b, self.d_pcm, self.nf, self.d_out, self.stride, self.d_len)
+        assert rc == 0, "mp3mi_batch_encode -> %d" % rc
+        assert L.mp3mi_batch_sync(self.b) == 0
+        out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
+        lens = self.mem.download(self.d_len, (self.S,), np.uint32)
+        return out, lens
+
+    def close(self):
+        if self.b:
+            self.mp.lib.mp3mi_batch_destroy(self.b)
+            self.b = ctypes.c_void_p()
+        self.mem.free()

@@ -85,3 +85,19 @@ def test_psy_exact_tier_matches_fast_tier(emu, oracle, monkeypatch):
     assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
     monkeypatch.setenv("MP3MI_PSY_EXACT", "1")
     assert emu.encode_host(pcm, rate, ch, 128, nf) == ref
+
+
+def test_quant_exact_tier_matches_estimate(emu, oracle):
+    """k_loop's quantiser settles a line by a float estimate of x^(3/4) unless it lies within the guard band of a
+    table boundary; forcing the table search for every line (MP3MI_TEST_QUANT_EXACT) -- and all five exact tiers
+    together -- must give the same bytes.  (The device's raw sqrt / exp2 are covered by tests/test_gpu_tiers.py.)"""
+    from mp3common import BatchRun
+    nf, rate, ch = 6, 44100, 2
+    run = BatchRun(emu, 2, rate, ch, 128, nf, stream0=60)
+    try:
+        ref = [oracle.encode(run.pcm_of(s), rate, 128, ch)[0] for s in range(2)]
+        for flags in (0, 8, 31):
+            out, lens = run.encode(flags)
+            assert [out[s, :lens[s]].tobytes() for s in range(2)] == ref, "flags %d" % flags
+    finally:
+        run.close()

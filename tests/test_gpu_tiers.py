@@ -1,0 +1,45 @@
+"""The five two-tier decisions on the DEVICE: forcing the exact tier of each -- and of all
+of them -- must not change one emitted byte on a full-chip batch, and the raw hardware square root / exp2 that
+the quantiser's first tier is built from must stay inside the error its guard band budgets."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from mp3common import BatchRun
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = {"noise": 1, "phase": 2, "psy": 4, "quant": 8, "prep": 16, "all": 31}
+
+
+def test_raw_sqrt_and_exp2_stay_inside_the_guard_band_budget(product):
+    """k_loop.hip loop_quantize: the estimate f of x^(3/4) + 0.4054 is
+         f = fma(y34, exp2_raw(-3q/16), 0.4054f),  y34 = sqrt_raw(a * sqrt_raw(a)) [* up to 17 rescalings]
+    and its guard band budgets 7e-7 relative for everything but the rescalings.  Measured on this device over
+    all 2^24 floats of [1, 4) (the error repeats exactly every factor of 4), every step size the search can ask
+    for, and 2^24 more exp2 arguments.  2^-24 each: the roundings of the product y34 * cq and of the sum."""
+    out = (ctypes.c_double * 3)()
+    assert product.lib.mp3mi_debug_fastmath_bounds(out) == 0
+    e_y34, e_exp_used, e_exp_any = out[0], out[1], out[2]
+    print("max relative error: y34 %.3e, exp2 (801 step sizes) %.3e, exp2 (2^24 arguments) %.3e" % (e_y34, e_exp_used, e_exp_any))
+    assert 0.0 < e_y34 < 3.0e-7      # two 1-ulp roots, the inner one halved, and the rounding of a * sqrt(a)
+    assert e_exp_used < 1.5e-7 and 0.0 < e_exp_any < 2.0e-7
+    assert e_y34 + max(e_exp_used, e_exp_any) + 2 * 2.0 ** -24 < 7e-7
+
+
+@pytest.mark.parametrize("rate,ch,kbps,S,nf,stream0", [(44100, 2, 128, 4096, 24, 0), (48000, 2, 320, 1024, 20, 5000), (32000, 1, 64, 2048, 20, 9000)])
+def test_every_exact_tier_gives_identical_bytes(product, oracle, rate, ch, kbps, S, nf, stream0):
+    run = BatchRun(product, S, rate, ch, kbps, nf, stream0=stream0)
+    try:
+        base, base_len = run.encode(0)
+        for name, fl in FLAGS.items():
+            out, lens = run.encode(fl)
+            assert np.array_equal(lens, base_len), "lengths differ with the %s tier forced" % name
+            bad = np.nonzero((out != base).any(axis=1))[0]
+            assert bad.size == 0, "%d streams differ with the %s tier forced (first: %d)" % (bad.size, name, bad[0])
+        for s in sorted(set(np.linspace(0, S - 1, 24).astype(int).tolist())):  # and they are the oracle's bytes
+            ref, _ = oracle.encode(run.pcm_of(s), rate, kbps, ch)
+            assert base[s, :base_len[s]].tobytes() == ref, "stream %d differs from the oracle" % s
+    finally:
+        run.close()

@@ -18,8 +18,9 @@ CASES = manifest()
 @pytest.fixture(scope="module")
 def synth():
     so = os.path.join(tempfile.mkdtemp(), "libsynth.so")
-    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-o", so,
-                    os.path.join(ROOT, "mp3-enc-bsd_amd", "csrc", "pcm_synth.c"), "-lm"], check=True)
+    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(ROOT, "mp3-enc-bsd_amd", "csrc"), "-o", so,
+                    os.path.join(ROOT, "mp3-enc-bsd_amd", "csrc", "pcm_synth_host.cpp")], check=True)
     lib = ctypes.CDLL(so)
 
     def f(n, ch, rate, stream, seed):
