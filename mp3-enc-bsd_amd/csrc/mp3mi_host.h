@@ -11,6 +11,8 @@ extern "C" {
 /* tables_host.cpp: fill the table block for MPEG-1 sampling_frequency code rate_idx
  * (0 = 44.1 kHz, 1 = 48 kHz, 2 = 32 kHz).  Returns 0 on success. */
 int mp3mi_build_tables(mp3mi_tables *T, int rate_idx);
+/* hashes of the table members as this host builds them (test / pin generation; tables_host.cpp) */
+int mp3mi_tables_digest(int rate_idx, uint64_t *hashes, const char **names, int cap);
 
 #ifdef __cplusplus
 }

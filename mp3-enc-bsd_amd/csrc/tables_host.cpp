@@ -293,7 +293,7 @@ struct FftGen {
 
 } // namespace
 
-extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
+static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
 {
     const int ri = rate_idx;
     if (ri < 0 || ri > 2) return -1;
@@ -589,4 +589,85 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
         T->ht_linmax[i] = T_HT_LINMAX[i];
     }
     return 0;
+}
+
+/* ---- pins: the tables as the reference-equivalent environment builds them ----
+ * Every member above that comes out of libm (windows, twiddles, spreading function, MDCT cosines, the power
+ * tables) changes the bitstream if one bit of it changes.  tables_pins.h holds an FNV-1a hash of every member
+ * for each sampling rate, generated where the golden vectors were generated (tools/gen_table_pins.py: glibc
+ * 2.35, the build the reference's goldens come from); mp3mi_build_tables recomputes them and refuses to hand
+ * out a table block that differs -- a host with another libm fails loudly instead of silently emitting a
+ * different stream.  MP3MI_TABLE_PINS=off skips the check (used only to generate the pins). */
+#define MP3MI_TABLE_MEMBERS(X) \
+    X(rate_idx) X(sfb_l) X(sfb_s) X(sfb_of_line_l) X(sfb_of_line_s) X(nj_first) X(nj_count) X(nj_job0) X(nj_njobs) X(nj_max) \
+    X(nj_seg) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
+    X(part_s_covered) X(minval) X(qthr_l) X(norm_l) X(qthr_s) X(exp_snr_s) X(s3_l) X(s3_lo) X(s3_hi) X(bu_l) X(bo_l) X(bu_s) \
+    X(bo_s) X(w1_l) X(w2_l) X(w1_s) X(w2_s) X(fft_nround_l) X(fft_nround_s) X(fft_nword_l) X(fft_nword_s) X(fft_hdr_l) \
+    X(fft_hdr_s) X(fft_prog_l) X(fft_prog_s) X(fft_rd_l) X(fft_rd_s) X(enwindow) X(filt) X(mdct_win) X(cos_s) X(cos_l) X(ca) \
+    X(cs) X(mdct_vidx) X(mdct_nterm) X(mdct_full_row) X(mdct_small_row) X(mdct_g_ops) X(mdct_h_ops) X(mdct_vcoef) \
+    X(pow_nint_tab) X(pow43) X(step) X(pretab_xr) X(pretab_xmin) X(sqrt2) X(log2) X(ht_off) X(ht_xlen) X(ht_ylen) \
+    X(ht_linbits) X(ht_linmax) X(ht_len) X(ht_code) X(glut)
+
+#define X(m) +1
+enum { MP3MI_N_TABLE_MEMBERS = 0 MP3MI_TABLE_MEMBERS(X) };
+#undef X
+#define X(m) #m,
+static const char *const TABLE_MEMBER_NAMES[MP3MI_N_TABLE_MEMBERS] = {MP3MI_TABLE_MEMBERS(X)};
+#undef X
+#include "tables_pins.h" /* MP3MI_TABLE_PINS_N, MP3MI_TABLE_PINS[3][MP3MI_TABLE_PINS_N] */
+
+static uint64_t fnv1a64(const void *p, size_t n)
+{
+    const unsigned char *b = (const unsigned char *) p;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+static void table_hashes(const mp3mi_tables *T, uint64_t *out)
+{
+    int i = 0;
+#define X(m) out[i++] = fnv1a64(&T->m, sizeof(T->m));
+    MP3MI_TABLE_MEMBERS(X)
+#undef X
+}
+
+/* hashes of the table members for rate_idx as THIS host builds them (no comparison with the pins); names[i]
+ * receives the member names.  Returns the number of members, or a negative error. */
+extern "C" int mp3mi_tables_digest(int rate_idx, uint64_t *hashes, const char **names, int cap)
+{
+    if (rate_idx < 0 || rate_idx > 2 || !hashes || cap < MP3MI_N_TABLE_MEMBERS) return -1;
+    mp3mi_tables *T = (mp3mi_tables *) calloc(1, sizeof(mp3mi_tables));
+    if (!T) return -1;
+    const int rc = build_tables_unpinned(T, rate_idx);
+    if (rc == 0) {
+        table_hashes(T, hashes);
+        if (names) for (int i = 0; i < MP3MI_N_TABLE_MEMBERS; i++) names[i] = TABLE_MEMBER_NAMES[i];
+    }
+    free(T);
+    return rc == 0 ? MP3MI_N_TABLE_MEMBERS : rc;
+}
+
+extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
+{
+    const int rc = build_tables_unpinned(T, rate_idx);
+    if (rc != 0) return rc;
+    const char *env = getenv("MP3MI_TABLE_PINS");
+    if (env && !strcmp(env, "off")) return 0;
+    if (MP3MI_TABLE_PINS_N != MP3MI_N_TABLE_MEMBERS) {
+        fprintf(stderr, "mp3mi: tables_pins.h lists %d members, mp3mi_tables has %d -- regenerate it (tools/gen_table_pins.py)\n",
+                (int) MP3MI_TABLE_PINS_N, (int) MP3MI_N_TABLE_MEMBERS);
+        return -8;
+    }
+    uint64_t h[MP3MI_N_TABLE_MEMBERS];
+    table_hashes(T, h);
+    int bad = 0;
+    for (int i = 0; i < MP3MI_N_TABLE_MEMBERS; i++)
+        if (h[i] != MP3MI_TABLE_PINS[rate_idx][i]) {
+            fprintf(stderr, "mp3mi: table member '%s' (rate index %d) differs from its pinned value: this host's libm does not "
+                            "reproduce the reference environment's tables; the bitstream would not be bit-exact\n",
+                    TABLE_MEMBER_NAMES[i], rate_idx);
+            bad++;
+        }
+    return bad ? -8 : 0;
 }
