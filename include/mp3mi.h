@@ -35,7 +35,9 @@ enum {
     MP3MI_ERR_ARG = -1,       /* unsupported rate / bitrate / channel count (what the reference refuses) */
     MP3MI_ERR_NO_DEVICE = -2, /* no usable GPU */
     MP3MI_ERR_HIP = -3,       /* a HIP call failed; message on stderr */
-    MP3MI_ERR_NOMEM = -4
+    MP3MI_ERR_NOMEM = -4,
+    MP3MI_ERR_TABLES = -5     /* this host's libm does not reproduce the pinned init tables (csrc/tables_pins.h):
+                                 the bitstream would not be bit-exact, so nothing is encoded */
 };
 
 /* Creates an encoder for n_streams independent streams that share sample rate and channel
@@ -72,6 +74,20 @@ int mp3mi_batch_encode_ragged(mp3mi_batch *b, const int16_t *pcm_dev, const int3
  * written at src/l3bitstream.c:330-334): copyright 0/1, original 0/1, emphasis 0..3.  Applies to later
  * encode calls of this batch. */
 int mp3mi_batch_set_header(mp3mi_batch *b, int copyright, int original, int emphasis);
+
+/* Header mode field, -m of the reference's driver (/root/reference/src/musicin.c:226-234, src/common.h:233-236):
+ * stereo or dual channel for two-channel batches, mono for one-channel ones (the default follows the channel
+ * count).  Dual channel changes nothing but the header field -- the reference's Layer III encoder treats the two
+ * channels independently in every mode.  Joint stereo is refused (MP3MI_ERR_ARG) as the reference refuses it for
+ * Layer III (src/musicin.c:548-552). */
+enum { MP3MI_MODE_STEREO = 0, MP3MI_MODE_JOINT_STEREO = 1, MP3MI_MODE_DUAL_CHANNEL = 2, MP3MI_MODE_MONO = 3 };
+int mp3mi_batch_set_mode(mp3mi_batch *b, int mode);
+
+/* Error protection, -e of the reference's driver: the protection bit of the header is cleared and a 16-bit CRC
+ * word follows the header, which the reference never computes for Layer III and writes as zero
+ * (/root/reference/src/l3bitstream.c:312, 325, 338-342); the side information grows by 16 bits, so the mean bits
+ * per granule shrink (src/musicin.c:744-746).  Reproduced bit for bit -- including the zero CRC. */
+int mp3mi_batch_set_error_protection(mp3mi_batch *b, int on);
 
 /* Milliseconds spent inside the dominant (iteration loop) kernel and inside all kernels during
  * the last encode call, measured with HIP events on the batch's stream. */

@@ -37,6 +37,7 @@ size_t mp3mi_loop_state_size(void);
     } while (0)
 
 struct mp3mi_batch {
+    int device;              // the HIP device everything of this batch lives on (current at create time)
     int n_streams, rate_idx, rate_hz, channels, max_frames, chunk_frames;
     std::vector<int> bits_per_frame_h, bitrate_index_h;
     int max_frame_bytes;
@@ -54,6 +55,8 @@ struct mp3mi_batch {
     int prep_exact;          // MP3MI_PREP_EXACT=1: k_prep skips its fast first tier (tests)
     int test_flags;          // mp3mi_geom::test_flags
     int hdr_flags;           // copyright << 3 | original << 2 | emphasis (src/l3bitstream.c:330-334)
+    int hdr_mode;            // header mode field: 0 stereo, 2 dual channel, 3 mono (src/common.h:233-236)
+    int crc;                 // error protection (-e): zero CRC word after the header, as the reference writes it
     int last_slot;
     mp3mi_tables *T;
     int32_t *bits_per_frame, *bitrate_index;
@@ -70,6 +73,22 @@ struct mp3mi_batch {
     std::vector<hipEvent_t> loop_ev;
     int loop_launches;
 };
+
+// Every entry point runs on the batch's own device whatever the calling thread's current device is, and leaves
+// the caller's current device as it found it.
+struct device_scope {
+    int prev;
+    bool ok;
+    explicit device_scope(int dev) : prev(-1), ok(true)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; prev = -1; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~device_scope() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+#define ON_DEVICE(b)                                                                                     \
+    device_scope dev_scope_((b)->device);                                                                \
+    if (!dev_scope_.ok) { fprintf(stderr, "mp3mi: cannot select device %d\n", (b)->device); return MP3MI_ERR_HIP; }
 
 static const int BITRATES[15] = {0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320}; // src/common.c:124
 
@@ -89,23 +108,20 @@ extern "C" const char *mp3mi_version(void)
 #endif
 }
 
-extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz, int channels, const int *kbps,
-                                  int kbps_all, int max_frames)
+extern "C" void mp3mi_batch_destroy(mp3mi_batch *b);
+
+// Fills *b step by step; on any failure the caller destroys the partially built object (every pointer and handle
+// starts out null, and mp3mi_batch_destroy skips what was never created).
+static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all, int max_frames)
 {
     static const double s_freq[3] = {44.1, 48, 32}; // src/common.c:113
-    if (!out) return MP3MI_ERR_ARG;
-    *out = NULL;
     int ri;
     if (rate_hz == 44100) ri = 0;
     else if (rate_hz == 48000) ri = 1;
     else if (rate_hz == 32000) ri = 2;
     else return MP3MI_ERR_ARG; // the reference's L3psycho_anal exits on anything else (src/l3psy.c:170-176)
     if (n_streams <= 0 || max_frames <= 0 || (channels != 1 && channels != 2)) return MP3MI_ERR_ARG;
-    if (!have_device()) {
-        fprintf(stderr, "mp3mi: no HIP device available -- this library has no CPU path\n");
-        return MP3MI_ERR_NO_DEVICE;
-    }
-    mp3mi_batch *b = new mp3mi_batch();
+    CHK(hipGetDevice(&b->device));
     b->n_streams = n_streams; b->rate_idx = ri; b->rate_hz = rate_hz; b->channels = channels;
     b->max_frames = max_frames; b->debug = 0; b->last_nf = 0; b->loop_launches = 0;
     b->bits_per_frame_h.resize(n_streams);
@@ -116,7 +132,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
         int bi;
         for (bi = 1; bi < 15; bi++)
             if (BITRATES[bi] == k) break;
-        if (bi == 15) { delete b; return MP3MI_ERR_ARG; }
+        if (bi == 15) return MP3MI_ERR_ARG;
         // slots per frame, never padded (src/musicin.c:562-581)
         const int whole_SpF = (int) (((double) 1152 / s_freq[ri]) * ((double) k / 8.0));
         b->bitrate_index_h[s] = bi;
@@ -136,8 +152,13 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     if (envc && atol(envc) > 0 && atol(envc) < cf) cf = atol(envc);
     b->chunk_frames = (int) cf;
 
-    mp3mi_tables *Th = (mp3mi_tables *) malloc(sizeof(mp3mi_tables));
-    if (!Th || mp3mi_build_tables(Th, ri) != 0) { free(Th); delete b; return MP3MI_ERR_ARG; }
+    std::vector<char> Th_store(sizeof(mp3mi_tables)); // host copy of the tables, released on every path
+    mp3mi_tables *Th = (mp3mi_tables *) Th_store.data();
+    {
+        const int trc = mp3mi_build_tables(Th, ri);
+        if (trc == -8) return MP3MI_ERR_TABLES; // the host's libm does not reproduce the pinned tables (tables_host.cpp)
+        if (trc != 0) return MP3MI_ERR_ARG;
+    }
     const size_t ngc = (size_t) n_streams * 2 * (size_t) cf * (size_t) channels;
     {
         int least = 0, greatest = 0;
@@ -158,6 +179,8 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     { const char *e = getenv("MP3MI_PSY_EXACT"); if (e && atoi(e)) b->test_flags |= 4; }
     { const char *e = getenv("MP3MI_QUANT_EXACT"); if (e && atoi(e)) b->test_flags |= 8; }
     b->hdr_flags = 0;
+    b->hdr_mode = (channels == 1) ? 3 : 0;
+    b->crc = 0;
     b->gate_count = NULL; b->gate_total = 0;
     {
         const char *envg = getenv("MP3MI_NO_GATE");
@@ -182,7 +205,6 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     }
     CHK(hipMalloc((void **) &b->T, sizeof(mp3mi_tables)));
     CHK(hipMemcpy(b->T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
-    free(Th);
     CHK(hipMalloc((void **) &b->bits_per_frame, sizeof(int32_t) * n_streams));
     CHK(hipMalloc((void **) &b->bitrate_index, sizeof(int32_t) * n_streams));
     CHK(hipMemcpy(b->bits_per_frame, b->bits_per_frame_h.data(), sizeof(int32_t) * n_streams, hipMemcpyHostToDevice));
@@ -207,30 +229,56 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
     b->sb_dbg = NULL;
     CHK(hipEventCreate(&b->ev0));
     CHK(hipEventCreate(&b->ev1));
-    *out = b;
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz, int channels, const int *kbps,
+                                  int kbps_all, int max_frames)
+{
+    if (!out) return MP3MI_ERR_ARG;
+    *out = NULL;
+    // argument errors first: they are the caller's, whatever the machine
+    if (rate_hz != 44100 && rate_hz != 48000 && rate_hz != 32000) return MP3MI_ERR_ARG; // src/l3psy.c:170-176 exits on anything else
+    if (n_streams <= 0 || max_frames <= 0 || (channels != 1 && channels != 2)) return MP3MI_ERR_ARG;
+    for (int s = 0; s < n_streams; s++) {
+        const int k = kbps ? kbps[s] : kbps_all;
+        int bi;
+        for (bi = 1; bi < 15; bi++)
+            if (BITRATES[bi] == k) break;
+        if (bi == 15) return MP3MI_ERR_ARG;
+        if (!kbps) break;
+    }
+    if (!have_device()) {
+        fprintf(stderr, "mp3mi: no HIP device available -- this library has no CPU path\n");
+        return MP3MI_ERR_NO_DEVICE;
+    }
+    mp3mi_batch *b = new mp3mi_batch(); // value-initialised: every pointer, handle and counter starts at zero
+    const int rc = batch_build(b, n_streams, rate_hz, channels, kbps, kbps_all, max_frames);
+    if (rc != MP3MI_OK) {
+        mp3mi_batch_destroy(b); // frees whatever was allocated before the failure
+        return rc;
+    }
+    *out = b; // published only when complete
     return MP3MI_OK;
 }
 
 extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
 {
     if (!b) return;
-    hipStreamSynchronize(b->stream);
-    hipStreamSynchronize(b->lstream);
-    hipFree(b->T); hipFree(b->bits_per_frame); hipFree(b->bitrate_index);
-    hipFree(b->energy_l); hipFree(b->energy_s); hipFree(b->hist6); hipFree(b->fft_bins); hipFree(b->cw_mid);
-    hipFree(b->part_eb); hipFree(b->part_cb);
-    for (int i = 0; i < 2; i++) { hipFree(b->xr[i]); hipFree(b->psy[i]); hipFree(b->prep[i]); }
-    hipFree(b->sbs); hipFree(b->ix); hipFree(b->side);
-    hipFree(b->psy_state); hipFree(b->loop_state);
-    if (b->gate_count) hipFree(b->gate_count);
-    if (b->place_order) { hipFree(b->place_order); hipFree(b->place_cost); hipFree(b->place_zero); }
-    if (b->sb_dbg) hipFree(b->sb_dbg);
-    hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
+    device_scope ds(b->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->lstream) hipStreamSynchronize(b->lstream);
+    void *bufs[] = {b->T, b->bits_per_frame, b->bitrate_index, b->energy_l, b->energy_s, b->hist6, b->fft_bins, b->cw_mid,
+                    b->part_eb, b->part_cb, b->xr[0], b->xr[1], b->psy[0], b->psy[1], b->prep[0], b->prep[1], b->sbs, b->ix, b->side,
+                    b->psy_state, b->loop_state, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg};
+    for (void *p : bufs)
+        if (p) hipFree(p);
+    hipEvent_t evs[] = {b->ev0, b->ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done};
+    for (hipEvent_t e : evs)
+        if (e) hipEventDestroy(e);
     for (size_t i = 0; i < b->loop_ev.size(); i++) hipEventDestroy(b->loop_ev[i]);
-    for (int i = 0; i < 2; i++) { hipEventDestroy(b->ev_front[i]); hipEventDestroy(b->ev_loop[i]); }
-    hipEventDestroy(b->ev_done);
-    hipStreamDestroy(b->stream);
-    hipStreamDestroy(b->lstream);
+    if (b->stream) hipStreamDestroy(b->stream);
+    if (b->lstream) hipStreamDestroy(b->lstream);
     delete b;
 }
 
@@ -257,6 +305,24 @@ extern "C" int mp3mi_batch_set_header(mp3mi_batch *b, int copyright, int origina
     return MP3MI_OK;
 }
 
+extern "C" int mp3mi_batch_set_mode(mp3mi_batch *b, int mode)
+{
+    if (!b) return MP3MI_ERR_ARG;
+    // -m s / d / m of the reference's driver (src/musicin.c:226-234); joint stereo is refused for Layer III by the
+    // reference itself (src/musicin.c:548-552), and the mode has to fit the channel count
+    const bool ok = (b->channels == 2 && (mode == MP3MI_MODE_STEREO || mode == MP3MI_MODE_DUAL_CHANNEL)) || (b->channels == 1 && mode == MP3MI_MODE_MONO);
+    if (!ok) return MP3MI_ERR_ARG;
+    b->hdr_mode = mode;
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_set_error_protection(mp3mi_batch *b, int on)
+{
+    if (!b || (on & ~1)) return MP3MI_ERR_ARG;
+    b->crc = on;
+    return MP3MI_OK;
+}
+
 static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames, uint8_t *out_dev,
                        size_t out_stride, uint32_t *out_len_dev);
 
@@ -278,6 +344,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
 {
     if (!b || !pcm_dev || !out_dev || !out_len_dev || n_frames <= 0 || n_frames > b->max_frames) return MP3MI_ERR_ARG;
     if (out_stride < (size_t) n_frames * (size_t) b->max_frame_bytes + 1) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
     const int S = b->n_streams, C = b->channels;
     if (b->debug && !b->sb_dbg) {
         const size_t ngc = (size_t) S * 2 * (size_t) b->chunk_frames * (size_t) C;
@@ -312,13 +379,17 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         g.test_flags = b->test_flags;
         g.n_samples = n_samples_dev;
         g.hdr_flags |= b->hdr_flags;
+        g.hdr_mode = b->hdr_mode;
+        g.crc = b->crc;
         return g;
     };
     auto stage_x = [&](int c) -> int {
         const mp3mi_geom g = geom_of(c);
         mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
+        CHK(hipGetLastError());
         if (c >= 2) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[c & 1], 0)); // k_loop of chunk c-2 has read this slot
         mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->part_eb, b->part_cb, b->psy[c & 1], b->stream);
+        CHK(hipGetLastError());
         return MP3MI_OK;
     };
     if (stage_x(0) != MP3MI_OK) return MP3MI_ERR_HIP;
@@ -329,7 +400,9 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         if (c >= 1 && b->gate_count) // stage Y of this chunk runs behind k_loop(c-1), once that is resident (<= 300 us)
             mp3mi_launch_gate(b->gate_count, b->gate_total - 16u, 30000u, b->stream);
         mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy[slot], b->sbs, b->xr[slot], b->debug ? b->sb_dbg : NULL, b->stream);
+        CHK(hipGetLastError());
         mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->prep_exact, b->stream);
+        CHK(hipGetLastError());
         if (c + 1 < nchunks && stage_x(c + 1) != MP3MI_OK) return MP3MI_ERR_HIP;
         CHK(hipEventRecord(b->ev_front[slot], b->stream));
         // ---- loop stream: the serial search and the formatter ----
@@ -339,6 +412,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
         if (b->place_order) { // rank the streams by their cost in the previous chunk, hand the tables to k_loop
             mp3mi_launch_rank(b->place_cost, b->place_order, S, b->lstream);
+            CHK(hipGetLastError());
             CHK(hipMemsetAsync(b->place_zero, 0, sizeof(unsigned) * ((size_t) S + 2 * MP3MI_PLACE_KEYS + 2), b->lstream));
             place.order = b->place_order; place.cost = b->place_cost; place.taken = b->place_zero;
             place.simd_slots = b->place_zero + S; place.simd_idx = place.simd_slots + MP3MI_PLACE_KEYS;
@@ -347,10 +421,12 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         }
         if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
         mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, b->gate_count, place, b->lstream);
+        CHK(hipGetLastError());
         CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->lstream));
         CHK(hipEventRecord(b->ev_loop[slot], b->lstream));
         mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,
                             out_len_dev, b->lstream);
+        CHK(hipGetLastError());
         b->last_nf = g.nf;
         b->last_slot = slot;
     }
@@ -364,6 +440,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
 extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
 {
     if (!b) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
     CHK(hipStreamSynchronize(b->stream));
     CHK(hipStreamSynchronize(b->lstream));
     CHK(hipGetLastError());
@@ -372,7 +449,8 @@ extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
 
 extern "C" int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_kernels_ms, int *launches)
 {
-    if (!b) return MP3MI_ERR_ARG;
+    if (!b || !b->have_done) return MP3MI_ERR_ARG; // nothing has been encoded yet
+    ON_DEVICE(b);
     CHK(hipEventSynchronize(b->ev1));
     float tot = 0, loop = 0;
     CHK(hipEventElapsedTime(&tot, b->ev0, b->ev1));
@@ -402,6 +480,7 @@ extern "C" long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst
     default: return MP3MI_ERR_ARG;
     }
     if (!src || n > cap) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
     if (hipStreamSynchronize(b->stream) != hipSuccess || hipStreamSynchronize(b->lstream) != hipSuccess) return MP3MI_ERR_HIP;
     if (hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return MP3MI_ERR_HIP;
     return (long) n;

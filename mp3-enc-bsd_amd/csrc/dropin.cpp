@@ -245,7 +245,8 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
     if (info->version != 1) DIE("iteration_loop: MPEG-2 LSF is outside this library's scope");
     ensure(info->sampling_frequency);
     const int C = stereo;
-    if (mean_bits != (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2) DIE("iteration_loop: unexpected mean_bits %d", mean_bits);
+    const int crc = info->error_protection ? 1 : 0; // 16 more bits of side information (src/musicin.c:744-746)
+    if (mean_bits != (bitsPerFrame - (32 + 16 * crc + (C == 1 ? 136 : 256))) / 2) DIE("iteration_loop: unexpected mean_bits %d", mean_bits);
     if (D.loop_first) { // src/loop.c:250-257
         l3_side->main_data_begin = 0;
         D.loop_first = false;
@@ -267,7 +268,8 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
     HIPOK(hipMemcpyAsync(D.psy4, rec, sizeof(rec), hipMemcpyHostToDevice, D.st));
     HIPOK(hipMemcpyAsync(D.xr_d, xr, sizeof(xr), hipMemcpyHostToDevice, D.st));
     HIPOK(hipMemcpyAsync(D.bits_d, &bpf, sizeof(bpf), hipMemcpyHostToDevice, D.st));
-    const mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1, 0, 1);
+    mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1, 0, 1);
+    g.crc = crc;
     mp3mi_launch_prep(D.T, g, D.xr_d, D.psy4, D.prep4, 0, D.st);
     mp3mi_launch_loop(D.T, g, D.xr_d, D.psy4, D.prep4, D.bits_d, D.loop_state, D.ix_d, D.side_d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
     static int16_t ix[4][576];
@@ -322,7 +324,7 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
     (void) ancillary;
     layer *info = fr_ps->header;
     if (anc_bits != 0) DIE("III_format_bitstream: ancillary data is not supported");
-    if (info->error_protection) DIE("III_format_bitstream: error protection is not supported (the reference writes a zero CRC)");
+    const int crc = info->error_protection ? 1 : 0; // the reference's zero CRC word (src/l3bitstream.c:312, 338-342)
     ensure(info->sampling_frequency);
     const int C = fr_ps->stereo;
     if (!D.putbits) {
@@ -330,7 +332,7 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
         if (!D.putbits) DIE("host program does not export putbits() (link it with -rdynamic)");
     }
     D.bs = bs;
-    const int frame_bytes = bitsPerFrame / 8, si_bytes = (32 + (C == 2 ? 256 : 136)) / 8, slot = frame_bytes - si_bytes;
+    const int frame_bytes = bitsPerFrame / 8, si_bytes = (32 + 16 * crc + (C == 2 ? 256 : 136)) / 8, slot = frame_bytes - si_bytes;
     if (D.frames_done == 0) {
         D.frame_bytes = frame_bytes;
         D.si_bytes = si_bytes;
@@ -390,6 +392,7 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
     HIPOK(hipMemcpyAsync(D.bri_d, &bri, sizeof(bri), hipMemcpyHostToDevice, D.st));
     mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1 << 30, widx, 1);
     g.hdr_mode = info->mode;
+    g.crc = crc;
     g.hdr_flags = ((info->mode_ext & 3) << 4) | ((info->copyright & 1) << 3) | ((info->original & 1) << 2) | (info->emphasis & 3);
     mp3mi_launch_format(D.T, g, D.ix_d, D.side_d, D.bits_d, D.bri_d, D.win_d, D.win_bytes, D.len_d, D.st);
     HIPOK(hipStreamSynchronize(D.st));

@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
     }
     const mp3mi_frame_side *sd = &side_all[(size_t) s * geo.nf + fl];
     const int frame_bytes = bits_per_frame[s] / 8;
-    const int si_bytes = (32 + (C == 2 ? 256 : 136)) / 8;
+    const int crc_bits = geo.crc ? 16 : 0; // the reference's CRC word for Layer III is always 0 (src/l3bitstream.c:312, 338-342)
+    const int si_bytes = (32 + crc_bits + (C == 2 ? 256 : 136)) / 8;
     const int slot = frame_bytes - si_bytes;
     uint8_t *dst = out + (size_t) s * out_stride;
 
@@ -135,12 +136,13 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
         fmt_put(L.si, pos, 0xfff, 12); pos += 12;
         fmt_put(L.si, pos, 1, 1); pos += 1;                       // MPEG-1
         fmt_put(L.si, pos, 1, 2); pos += 2;                       // 4 - layer
-        fmt_put(L.si, pos, 1, 1); pos += 1;                       // no CRC
+        fmt_put(L.si, pos, geo.crc ? 0u : 1u, 1); pos += 1;       // protection bit: set = no CRC
         fmt_put(L.si, pos, (unsigned) bitrate_index[s], 4); pos += 4;
         fmt_put(L.si, pos, (unsigned) T->rate_idx, 2); pos += 2;
         pos += 2;                                                 // padding 0, extension 0
         fmt_put(L.si, pos, (unsigned) geo.hdr_mode, 2); pos += 2; // mode
         fmt_put(L.si, pos, (unsigned) geo.hdr_flags, 6); pos += 6; // mode_ext, copyright, original, emphasis
+        pos += crc_bits;                                          // CRC word: zeros
         fmt_put(L.si, pos, (unsigned) sd->main_data_begin, 9); pos += 9;
         pos += (C == 2) ? 3 : 5;                                  // private_bits 0
         for (int ch = 0; ch < C; ch++)
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
     if (lane < 2 * C) {
         const int gr = lane / C, ch = lane % C;
         const mp3mi_gr_side *g = &sd->gr[gr][ch];
-        int pos = 32 + 9 + ((C == 2) ? 3 : 5) + 4 * C + 59 * lane;
+        int pos = 32 + crc_bits + 9 + ((C == 2) ? 3 : 5) + 4 * C + 59 * lane;
         fmt_put(L.si, pos, (unsigned) g->part2_3_length, 12); pos += 12;
         fmt_put(L.si, pos, (unsigned) g->big_values, 9); pos += 9;
         fmt_put(L.si, pos, (unsigned) g->global_gain, 8); pos += 8;

@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     const bool quant_exact = (geo.test_flags & 8) != 0; // MP3MI_QUANT_EXACT=1: the quantiser's exact tier only (tests)
     int work = 0; // cost of this stream in this launch: 4 per quantise+count pass, 5 per distortion-loop iteration
     const int bitsPerFrame = bits_per_frame[s];
-    const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256))) / 2; // src/musicin.c:729-746
+    const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256) + (geo.crc ? 16 : 0))) / 2; // src/musicin.c:729-746
     PROF_DECL;
     // Residency census (batch.cpp, k_gate): every wavefront counts itself in when it starts.  The
     // counter only ever grows; nothing in this kernel waits on it.

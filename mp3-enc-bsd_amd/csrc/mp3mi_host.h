@@ -25,6 +25,9 @@ struct mp3mi_geom {
     int g0, n_gran;     /* granules [g0, g0+n_gran) of the chunk: 2*f0, 2*nf for the batch path */
     int hdr_mode;       /* header mode field (src/common.h:233-236): 0 stereo, 2 dual, 3 mono */
     int hdr_flags;      /* bit 3 copyright, bit 2 original, bits 1-0 emphasis, bits 5-4 mode_ext */
+    int crc;            /* error protection on: protection bit 0 and the 16-bit CRC word after the header -- which the
+                           reference never computes for Layer III and writes as 0 (src/l3bitstream.c:312, 338-342); side
+                           info grows by 16 bits (src/musicin.c:744-746) */
     const int32_t *n_samples; /* device, [n_streams]: valid samples per channel of each stream (ragged batch), or NULL: all n_frames*1152.
                                  Samples beyond it read as zero and frames beyond ceil(n/1152) are not encoded (src/encode.c:162-166) */
     int test_flags;     /* bit 0: k_loop takes the exact (sequential) noise sums only (MP3MI_NOISE_EXACT=1, tests);
@@ -40,6 +43,7 @@ static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_i
     g.f0 = f0; g.nf = nf; g.g0 = 2 * f0; g.n_gran = 2 * nf;
     g.hdr_mode = (channels == 1) ? 3 : 0;
     g.hdr_flags = 0;
+    g.crc = 0;
     g.test_flags = 0;
     g.n_samples = NULL;
     return g;

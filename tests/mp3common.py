@@ -100,6 +100,9 @@ class Mp3mi:
         L.mp3mi_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
         L.mp3mi_synth_pcm_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_debug_fastmath_bounds.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 
     def synth(self, n_per_ch, channels, rate, stream, seed=SEED):
         out = np.zeros(n_per_ch * channels, dtype=np.int16)
@@ -202,7 +205,7 @@ class BatchRun:
     """One batch of S streams on device memory through the C ABI: PCM synthesised on the device (or uploaded),
     encoded as often as wanted (e.g. once per test-flag setting), outputs fetched per stream."""
 
-    def __init__(self, mp, S, rate, channels, kbps, n_frames, stream0=0, pcm=None, seed=SEED):
+    def __init__(self, mp, S, rate, channels, kbps, n_frames, stream0=0, pcm=None, seed=SEED, mode=None, crc=0):
         self.mp, self.S, self.rate, self.ch, self.nf = mp, S, rate, channels, n_frames
         L = mp.lib
         self.mem = DevMem(mp)
@@ -211,6 +214,10 @@ class BatchRun:
         rc = L.mp3mi_batch_create(ctypes.byref(self.b), S, rate, channels, karr.ctypes.data if karr is not None else None,
                                   int(kbps) if karr is None else 0, n_frames)
         assert rc == 0, "mp3mi_batch_create -> %d" % rc
+        if mode is not None:
+            assert L.mp3mi_batch_set_mode(self.b, mode) == 0
+        if crc:
+            assert L.mp3mi_batch_set_error_protection(self.b, 1) == 0
         self.stride = L.mp3mi_batch_out_stride(self.b, n_frames)
         self.n_per_ch = n_frames * 1152
         self.pcm_bytes = S * self.n_per_ch * channels * 2

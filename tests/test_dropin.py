@@ -25,8 +25,8 @@ def write_wav(path, pcm, ch, rate):
                 struct.pack("<IHHIIHH", 16, 1, ch, rate, rate * ch * 2, ch * 2, 16) + b"data" + struct.pack("<I", len(data)) + data)
 
 
-def run_cli(binary, wav, mp3, rate, kbps, mono):
-    args = [os.path.join(REF, binary), "-s", "%g" % (rate / 1000.0), "-b", str(kbps)]
+def run_cli(binary, wav, mp3, rate, kbps, mono, extra=()):
+    args = [os.path.join(REF, binary), "-s", "%g" % (rate / 1000.0), "-b", str(kbps)] + list(extra)
     if mono:
         args += ["-m", "m"]
     subprocess.run(args + [str(wav), str(mp3)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -56,3 +56,41 @@ def test_reference_driver_over_hip_library(product, oracle, tmp_path, rate, ch, 
     assert got == ref
     if os.path.exists(os.path.join(REF, "encode")):
         assert got == run_cli("encode", tmp_path / "a.wav", tmp_path / "r.mp3", rate, kbps, ch == 1)
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "encode_dropin_emu")) and os.path.exists(os.path.join(REF, "encode"))), reason="oracle/_ref binaries not built")
+def test_reference_driver_options_over_emulated_library(emu, tmp_path):
+    """-m d and -e of the reference's own driver reach the library through the unchanged frame_params"""
+    rate, ch, kbps = 44100, 2, 128
+    pcm = emu.synth(1152 * 4, ch, rate, 6, SEED)
+    write_wav(tmp_path / "a.wav", pcm, ch, rate)
+    for extra in (["-m", "d"], ["-e"], ["-m", "d", "-e", "-c"]):
+        got = run_cli("encode_dropin_emu", tmp_path / "a.wav", tmp_path / "a.mp3", rate, kbps, False, extra)
+        assert got == run_cli("encode", tmp_path / "a.wav", tmp_path / "r.mp3", rate, kbps, False, extra), extra
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "encode_dropin")) and os.path.exists(os.path.join(REF, "encode"))), reason="oracle/_ref binaries not built")
+def test_baseline_config0_through_the_reference_driver(product, tmp_path):
+    """BASELINE configs[0] at full length: the 10 s 44.1 kHz stereo stream (383 frames) through the reference's own
+    main() linked against libmp3mi.so, with -m d -e on a second pass.  The frames/s of this per-call plumbing path
+    (a kernel launch and a host round trip per reference call -- not the throughput path) goes to gpurun_out/."""
+    import json
+    import time
+    rate, ch, kbps = 44100, 2, 128
+    pcm = product.synth(441000, ch, rate, 0, SEED)
+    write_wav(tmp_path / "a.wav", pcm, ch, rate)
+    ref = run_cli("encode", tmp_path / "a.wav", tmp_path / "r.mp3", rate, kbps, False)
+    t0 = time.perf_counter()
+    got = run_cli("encode_dropin", tmp_path / "a.wav", tmp_path / "a.mp3", rate, kbps, False)
+    dt = time.perf_counter() - t0
+    assert got == ref and len(got) == 159704
+    extra = ["-m", "d", "-e"]
+    assert run_cli("encode_dropin", tmp_path / "a.wav", tmp_path / "b.mp3", rate, kbps, False, extra) == \
+        run_cli("encode", tmp_path / "a.wav", tmp_path / "s.mp3", rate, kbps, False, extra)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({"what": "BASELINE configs[0]: 383 frames through oracle/_ref/encode_dropin (reference main() + libmp3mi.so drop-in symbols), process start to exit",
+               "frames": 383, "seconds": round(dt, 3), "frames_per_s": round(383 / dt, 1), "bit_exact": True,
+               "note": "plumbing figure: every reference call is a kernel launch plus host round trips; throughput comes from the batched API"},
+              open(os.path.join(out, "dropin_config0.json"), "w"), indent=1)
