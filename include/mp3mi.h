@@ -62,6 +62,28 @@ int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uin
                        size_t out_stride, uint32_t *out_len_dev);
 int mp3mi_batch_sync(mp3mi_batch *b);
 
+/* Streaming: the reference is a frame-streaming encoder (/root/reference/src/musicin.c:585-805); these calls encode
+ * a stream piece by piece with everything it carries from frame to frame kept in the batch (psychoacoustic
+ * history and thresholds, the filterbank's and the FFT window's past samples, the bit reservoir, the main data
+ * that is formatted but whose slot is still open).
+ *   mp3mi_batch_encode_next  encodes the NEXT n_frames frames of every stream: pcm_dev holds only these frames,
+ *                            [n_streams][n_frames*1152][channels].  out_dev / out_len_dev receive, per stream, the
+ *                            file bytes that became final with this call -- in file order, so concatenating the
+ *                            outputs of successive calls and of the final flush gives the stream's file.  (Up to
+ *                            511 bytes of main data, plus the headers in between, stay behind in the reservoir's
+ *                            open slots until later frames fill them: src/formatBitstream.c:52-120.)  The first call
+ *                            after create, reset, flush or a whole-file encode starts new streams.
+ *   mp3mi_batch_flush        III_FlushBitstream + close_bit_stream_w (musicin.c:802-805): delivers what is left and
+ *                            ends the streams.  out_stride >= 2049 here.
+ *   mp3mi_batch_reset        abandons the current streams: fresh encoder state.
+ * mp3mi_batch_encode (above) is the same encoder run over a whole stream in one call.  Ragged batches and
+ * streaming do not combine: a stream's last partial frame is zero-filled by the caller (src/encode.c:162-166).
+ * out_stride >= mp3mi_batch_out_stride(b, n_frames). */
+int mp3mi_batch_encode_next(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev,
+                            size_t out_stride, uint32_t *out_len_dev);
+int mp3mi_batch_flush(mp3mi_batch *b, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev);
+int mp3mi_batch_reset(mp3mi_batch *b);
+
 /* Ragged batch: stream s has n_samples_dev[s] valid samples per channel (0 <= n <= n_frames*1152) in
  * its row of pcm_dev (row pitch n_frames*1152*channels as above).  As the reference's get_audio /
  * read_samples do (/root/reference/src/encode.c:123-269, zero fill :162-166), the last partial frame

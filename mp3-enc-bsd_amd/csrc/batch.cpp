@@ -46,6 +46,7 @@ struct mp3mi_batch {
     hipEvent_t ev_front[2];  // front kernels of the chunk in slot i are done
     hipEvent_t ev_loop[2];   // k_loop of the chunk in slot i is done (slot may be overwritten)
     hipEvent_t ev_done;      // everything of the previous encode call is done
+    hipEvent_t ev_hist;      // the front stream's last work of a call (the PCM history hand-over) is enqueued
     bool have_done;
     unsigned *gate_count;    // start census of k_loop's wavefronts (device memory, only ever grows), NULL = gate off
     unsigned gate_total;     // census value once every wavefront launched so far has started
@@ -68,6 +69,13 @@ struct mp3mi_batch {
     void *psy_state, *loop_state;
     int16_t *ix;
     mp3mi_frame_side *side;
+    // streaming (encode_next / flush): what a stream carries from call to call besides psy_state / loop_state
+    long frames_done;        // frames of every stream encoded since the last reset
+    bool fresh;              // reset since the last encode (or never encoded): state buffers are zero
+    int16_t *pcm_hist;       // [S][MP3MI_PCM_HIST][C]: the samples before the next call's first
+    int64_t *out_base;       // [S]: file bytes delivered so far
+    uint8_t *carry;          // [S][MP3MI_CARRY_BYTES]: file bytes formatted but not final yet
+    int32_t *carry_len;      // [S]
     int debug, last_nf;
     hipEvent_t ev0, ev1;
     std::vector<hipEvent_t> loop_ev;
@@ -171,6 +179,7 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
         CHK(hipEventCreateWithFlags(&b->ev_loop[i], hipEventDisableTiming));
     }
     CHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&b->ev_hist, hipEventDisableTiming));
     b->have_done = false;
     b->last_slot = 0;
     { const char *e = getenv("MP3MI_PREP_EXACT"); b->prep_exact = (e && atoi(e)) ? 1 : 0; }
@@ -226,6 +235,12 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     CHK(hipMalloc((void **) &b->side, (size_t) n_streams * (size_t) cf * sizeof(mp3mi_frame_side)));
     CHK(hipMalloc((void **) &b->psy_state, mp3mi_psy_state_size() * (size_t) n_streams * channels));
     CHK(hipMalloc((void **) &b->loop_state, mp3mi_loop_state_size() * (size_t) n_streams));
+    CHK(hipMalloc((void **) &b->pcm_hist, sizeof(int16_t) * MP3MI_PCM_HIST * (size_t) channels * (size_t) n_streams));
+    CHK(hipMalloc((void **) &b->out_base, sizeof(int64_t) * (size_t) n_streams));
+    CHK(hipMalloc((void **) &b->carry, (size_t) MP3MI_CARRY_BYTES * (size_t) n_streams));
+    CHK(hipMalloc((void **) &b->carry_len, sizeof(int32_t) * (size_t) n_streams));
+    b->frames_done = 0;
+    b->fresh = false;
     b->sb_dbg = NULL;
     CHK(hipEventCreate(&b->ev0));
     CHK(hipEventCreate(&b->ev1));
@@ -270,10 +285,10 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     if (b->lstream) hipStreamSynchronize(b->lstream);
     void *bufs[] = {b->T, b->bits_per_frame, b->bitrate_index, b->energy_l, b->energy_s, b->hist6, b->fft_bins, b->cw_mid,
                     b->part_eb, b->part_cb, b->xr[0], b->xr[1], b->psy[0], b->psy[1], b->prep[0], b->prep[1], b->sbs, b->ix, b->side,
-                    b->psy_state, b->loop_state, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg};
+                    b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg};
     for (void *p : bufs)
         if (p) hipFree(p);
-    hipEvent_t evs[] = {b->ev0, b->ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done};
+    hipEvent_t evs[] = {b->ev0, b->ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done, b->ev_hist};
     for (hipEvent_t e : evs)
         if (e) hipEventDestroy(e);
     for (size_t i = 0; i < b->loop_ev.size(); i++) hipEventDestroy(b->loop_ev[i]);
@@ -284,7 +299,9 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
 
 extern "C" size_t mp3mi_batch_out_stride(const mp3mi_batch *b, int n_frames)
 {
-    size_t n = (size_t) n_frames * (size_t) b->max_frame_bytes + 1;
+    // whole frames, the byte under construction that close writes, and -- for streaming calls -- the bytes an
+    // earlier call formatted but could not deliver yet, which lead the row
+    size_t n = (size_t) n_frames * (size_t) b->max_frame_bytes + 1 + MP3MI_CARRY_BYTES;
     return (n + 255) & ~(size_t) 255;
 }
 
@@ -324,26 +341,74 @@ extern "C" int mp3mi_batch_set_error_protection(mp3mi_batch *b, int on)
 }
 
 static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames, uint8_t *out_dev,
-                       size_t out_stride, uint32_t *out_len_dev);
+                       size_t out_stride, uint32_t *out_len_dev, bool whole_file);
+
+// Fresh encoder state for every stream: what the reference's function statics and the caller's buffers hold when
+// its main() starts (all zero).  Enqueued on the front stream behind whatever is still running.
+static int reset_impl(mp3mi_batch *b)
+{
+    const int S = b->n_streams, C = b->channels;
+    if (b->have_done) CHK(hipStreamWaitEvent(b->stream, b->ev_done, 0)); // the previous call's kernels may still be running on the loop stream
+    CHK(hipMemsetAsync(b->psy_state, 0, mp3mi_psy_state_size() * (size_t) S * C, b->stream));
+    CHK(hipMemsetAsync(b->loop_state, 0, mp3mi_loop_state_size() * (size_t) S, b->stream));
+    CHK(hipMemsetAsync(b->pcm_hist, 0, sizeof(int16_t) * MP3MI_PCM_HIST * (size_t) C * (size_t) S, b->stream));
+    CHK(hipMemsetAsync(b->out_base, 0, sizeof(int64_t) * (size_t) S, b->stream));
+    CHK(hipMemsetAsync(b->carry_len, 0, sizeof(int32_t) * (size_t) S, b->stream));
+    b->frames_done = 0;
+    b->fresh = true;
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_reset(mp3mi_batch *b)
+{
+    if (!b) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    return reset_impl(b);
+}
 
 extern "C" int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev,
                                   size_t out_stride, uint32_t *out_len_dev)
 {
-    return encode_impl(b, pcm_dev, NULL, n_frames, out_dev, out_stride, out_len_dev);
+    return encode_impl(b, pcm_dev, NULL, n_frames, out_dev, out_stride, out_len_dev, true);
 }
 
 extern "C" int mp3mi_batch_encode_ragged(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames,
                                          uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev)
 {
     if (!n_samples_dev) return MP3MI_ERR_ARG;
-    return encode_impl(b, pcm_dev, n_samples_dev, n_frames, out_dev, out_stride, out_len_dev);
+    return encode_impl(b, pcm_dev, n_samples_dev, n_frames, out_dev, out_stride, out_len_dev, true);
+}
+
+extern "C" int mp3mi_batch_encode_next(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev,
+                                       size_t out_stride, uint32_t *out_len_dev)
+{
+    return encode_impl(b, pcm_dev, NULL, n_frames, out_dev, out_stride, out_len_dev, false);
+}
+
+extern "C" int mp3mi_batch_flush(mp3mi_batch *b, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev)
+{
+    if (!b || !out_dev || !out_len_dev || out_stride < (size_t) MP3MI_CARRY_BYTES + 1) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    if (b->fresh) { // nothing was encoded since the reset: no file body (the reference would write one byte; see mp3mi.h)
+        CHK(hipMemsetAsync(out_len_dev, 0, sizeof(uint32_t) * (size_t) b->n_streams, b->lstream));
+        return MP3MI_OK;
+    }
+    mp3mi_geom g = mp3mi_make_geom(b->n_streams, b->channels, b->rate_idx, 0, 0, 0);
+    g.fabs0 = b->frames_done;
+    g.crc = b->crc;
+    mp3mi_launch_stream_tail(g, 1, (const int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->bits_per_frame, out_dev, out_stride,
+                             b->out_base, b->carry, b->carry_len, out_len_dev, b->lstream); // behind the last call's k_format
+    CHK(hipGetLastError());
+    CHK(hipEventRecord(b->ev_done, b->lstream));
+    b->have_done = true;
+    return reset_impl(b); // the streams are over: the next encode_next starts new ones
 }
 
 static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames, uint8_t *out_dev,
-                       size_t out_stride, uint32_t *out_len_dev)
+                       size_t out_stride, uint32_t *out_len_dev, bool whole_file)
 {
     if (!b || !pcm_dev || !out_dev || !out_len_dev || n_frames <= 0 || n_frames > b->max_frames) return MP3MI_ERR_ARG;
-    if (out_stride < (size_t) n_frames * (size_t) b->max_frame_bytes + 1) return MP3MI_ERR_ARG;
+    if (out_stride < (size_t) n_frames * (size_t) b->max_frame_bytes + 1 + (whole_file ? 0 : MP3MI_CARRY_BYTES)) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
     const int S = b->n_streams, C = b->channels;
     if (b->debug && !b->sb_dbg) {
@@ -352,11 +417,20 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     }
     // the previous call's kernels may still be running on the loop stream
     if (b->have_done) CHK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
-    // fresh encoder state for every stream (function statics of the reference start at zero)
-    CHK(hipMemsetAsync(b->psy_state, 0, mp3mi_psy_state_size() * (size_t) S * C, b->stream));
-    CHK(hipMemsetAsync(b->loop_state, 0, mp3mi_loop_state_size() * (size_t) S, b->stream));
+    // a whole-file call starts every stream afresh; a streaming call continues (the first one after create / reset /
+    // flush / a whole-file call starts afresh too)
+    if (whole_file || (b->frames_done == 0 && !b->fresh)) {
+        const int rrc = reset_impl(b);
+        if (rrc != MP3MI_OK) return rrc;
+    }
+    const long fabs0 = b->frames_done;
+    b->fresh = false;
     if (b->place_cost) CHK(hipMemsetAsync(b->place_cost, 0, sizeof(int) * (size_t) S, b->stream)); // first chunk: order = identity
     CHK(hipMemsetAsync(out_dev, 0, out_stride * (size_t) S, b->stream));
+    if (!whole_file && fabs0 > 0) { // the bytes earlier calls formatted but could not deliver lead the rows
+        mp3mi_launch_carry_in(S, b->carry, b->carry_len, out_dev, out_stride, b->stream);
+        CHK(hipGetLastError());
+    }
     const int nchunks = (n_frames + b->chunk_frames - 1) / b->chunk_frames;
     while ((int) b->loop_ev.size() < 2 * nchunks) {
         hipEvent_t e;
@@ -381,6 +455,10 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         g.hdr_flags |= b->hdr_flags;
         g.hdr_mode = b->hdr_mode;
         g.crc = b->crc;
+        g.fabs0 = fabs0;
+        g.hist = b->pcm_hist;
+        g.out_base = whole_file ? NULL : b->out_base;
+        g.whole_file = whole_file ? 1 : 0;
         return g;
     };
     auto stage_x = [&](int c) -> int {
@@ -430,6 +508,20 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         b->last_nf = g.nf;
         b->last_slot = slot;
     }
+    {   // hand over to the next call: PCM history (front stream: behind the last kernels that read the old one) and,
+        // for a streaming call, what became final / what waits (loop stream: behind the last k_format)
+        const mp3mi_geom g = geom_of(0);
+        mp3mi_launch_hist_save(g, pcm_dev, b->pcm_hist, b->stream);
+        CHK(hipGetLastError());
+        if (!whole_file) {
+            mp3mi_launch_stream_tail(g, 0, (const int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->bits_per_frame, out_dev,
+                                     out_stride, b->out_base, b->carry, b->carry_len, out_len_dev, b->lstream);
+            CHK(hipGetLastError());
+        }
+        CHK(hipEventRecord(b->ev_hist, b->stream));
+        CHK(hipStreamWaitEvent(b->lstream, b->ev_hist, 0)); // ev_done below then covers both streams
+    }
+    b->frames_done = whole_file ? 0 : fabs0 + n_frames; // a whole-file call leaves finished streams behind
     CHK(hipEventRecord(b->ev1, b->lstream));
     CHK(hipEventRecord(b->ev_done, b->lstream));
     b->have_done = true;

@@ -29,23 +29,26 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
     const int ch = bid % C; bid /= C;
     const int gi = bid % G1;   // granule slot: 0 is the granule before the chunk
     const int s = bid / G1;
-    const long gabs = (long) geo.g0 - 1 + gi;
+    const long gabs = (long) geo.g0 - 1 + gi; // relative to the call's first granule
     double *out = sbs + (((size_t) s * G1 + gi) * C + ch) * 576;
-    if (gabs < 0) { // before the stream: the reference's zero-initialised l3_sb_sample
+    if (2 * geo.fabs0 + gabs < 0) { // before the stream: the reference's zero-initialised l3_sb_sample
         for (int i = lane; i < 576; i += 64) out[i] = 0.0;
         return;
     }
     const long n_pitch = (long) geo.n_frames * 1152; // row pitch of the PCM buffer
     const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch; // valid samples: the rest reads as zero (src/encode.c:162-166)
     const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
-    // samples [576 g - 480, 576 g + 576) of this channel; outside the stream -> 0
+    const int16_t *hist = geo.hist ? geo.hist + (size_t) s * MP3MI_PCM_HIST * (size_t) C : NULL;
+    // samples [576 g - 480, 576 g + 576) of this channel; before the call's first sample the stream's history
+    // (zeros at the start of a stream), beyond the stream's last sample 0
     {
         int16_t v[17];
 #pragma unroll
         for (int k = 0; k < 17; k++) {
             const int i = lane + 64 * k;
             const long t = 576 * gabs - 480 + i;
-            v[k] = (i < 1056 && t >= 0 && t < n_per_ch) ? pcm[t * C + ch] : (int16_t) 0;
+            const bool past = hist && t < 0 && t >= -MP3MI_PCM_HIST;
+            v[k] = (i < 1056 && t >= 0 && t < n_per_ch) ? pcm[t * C + ch] : ((i < 1056 && past) ? hist[(t + MP3MI_PCM_HIST) * C + ch] : (int16_t) 0);
         }
 #pragma unroll
         for (int k = 0; k < 17; k++)

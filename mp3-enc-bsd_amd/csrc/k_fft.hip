@@ -255,10 +255,12 @@ MP3MI_DEVFN void fft_bin(const float *x, uint32_t rd, fft_pair<C> *re, fft_pair<
 }
 
 // N x 64 consecutive samples (all channels of a sample in one word) from time t_first on, sample lane + 64 k
-// in smp[k]; outside [0, n_per_ch) the stream reads as zero.  t_first is wave-uniform: when the whole span lies
-// inside the stream -- all but its first and last granules -- the loads need no per-sample tests.
+// in smp[k]; t is relative to the call's first sample.  Before it (t < 0, at most MP3MI_PCM_HIST back) the stream's
+// history buffer is read -- zeros at the start of a stream, the previous call's last samples after that -- and from
+// n_per_ch on the stream reads as zero.  t_first is wave-uniform: when the whole span lies inside the call's
+// samples -- all but its first and last granules -- the loads need no per-sample tests.
 template <int C, int N>
-MP3MI_DEVFN void fft_load_pcm(const int16_t *pcm, long t_first, long n_per_ch, int lane, uint32_t (&smp)[N])
+MP3MI_DEVFN void fft_load_pcm(const int16_t *pcm, const int16_t *hist, long t_first, long n_per_ch, int lane, uint32_t (&smp)[N])
 {
     if (t_first >= 0 && t_first + 64 * N <= n_per_ch) {
         const int16_t *p = pcm + t_first * C;
@@ -271,9 +273,10 @@ MP3MI_DEVFN void fft_load_pcm(const int16_t *pcm, long t_first, long n_per_ch, i
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const long t = t_first + lane + 64 * k;
-            const bool in = t >= 0 && t < n_per_ch;
-            if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : 0u;
-            else smp[k] = in ? (uint32_t) (uint16_t) pcm[t] : 0u;
+            const bool in = t >= 0 && t < n_per_ch, past = hist && t < 0 && t >= -MP3MI_PCM_HIST;
+            const long th = past ? t + MP3MI_PCM_HIST : 0;
+            if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : (past ? ((const uint32_t *) hist)[th] : 0u);
+            else smp[k] = in ? (uint32_t) (uint16_t) pcm[t] : (past ? (uint32_t) (uint16_t) hist[th] : 0u);
         }
     }
 }
@@ -312,6 +315,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
         const long gabs = (long) geo.g0 + gl;
         const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch; // valid samples: the rest reads as zero (src/encode.c:162-166)
         const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
+        const int16_t *hist = geo.hist ? geo.hist + (size_t) s * MP3MI_PCM_HIST * (size_t) C : NULL;
         const long t0 = 576 * gabs - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
 
         if (LONG) {
@@ -319,7 +323,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             {
                 float wl[16];
                 uint32_t smp[16];
-                fft_load_pcm<C, 16>(pcm, t0, n_per_ch, lane, smp);
+                fft_load_pcm<C, 16>(pcm, hist, t0, n_per_ch, lane, smp);
 #pragma unroll
                 for (int k = 0; k < 16; k++) wl[k] = T->window[lane + 64 * k];
 #pragma unroll
@@ -361,7 +365,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             // window is also the first half of the next.  Sample 256 + lane + 64 k: sb = k >> 1, jj = lane + 64 (k & 1).
             uint32_t smp[8];
             float wsv[4];
-            fft_load_pcm<C, 8>(pcm, t0 + 256, n_per_ch, lane, smp);
+            fft_load_pcm<C, 8>(pcm, hist, t0 + 256, n_per_ch, lane, smp);
 #pragma unroll
             for (int k = 0; k < 4; k++) wsv[k] = T->window_s[lane + 64 * k];
 #pragma unroll

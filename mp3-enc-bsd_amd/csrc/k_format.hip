@@ -110,11 +110,12 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
     const int lane = wave_lane();
     const int C = geo.channels, G = geo.n_gran;
     const int fl = (int) blockIdx.x % geo.nf, s = (int) blockIdx.x / geo.nf;
-    const long n_abs = (long) geo.f0 + fl;
+    const long n_call = (long) geo.f0 + fl;     // frame index within this call
+    const long n_abs = geo.fabs0 + n_call;      // and within the stream: what places the frame in the file
     // ragged batch: this stream's frame count; frames beyond it were not encoded and emit nothing
     const long n_frames_s = geo.n_samples ? ((long) geo.n_samples[s] + 1151) / 1152 : (long) geo.n_frames;
-    if (n_abs >= n_frames_s) {
-        if (n_frames_s == 0 && n_abs == 0 && wave_lane() == 0) out_len[s] = 0; // no samples, no file body
+    if (n_call >= n_frames_s) {
+        if (n_frames_s == 0 && n_call == 0 && geo.whole_file && wave_lane() == 0) out_len[s] = 0; // no samples, no file body
         return;
     }
     const mp3mi_frame_side *sd = &side_all[(size_t) s * geo.nf + fl];
@@ -122,7 +123,8 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
     const int crc_bits = geo.crc ? 16 : 0; // the reference's CRC word for Layer III is always 0 (src/l3bitstream.c:312, 338-342)
     const int si_bytes = (32 + crc_bits + (C == 2 ? 256 : 136)) / 8;
     const int slot = frame_bytes - si_bytes;
-    uint8_t *dst = out + (size_t) s * out_stride;
+    // byte 0 of the stream's output row is file position out_base[s] (streaming: what earlier calls delivered)
+    uint8_t *dst = out + (size_t) s * out_stride - (geo.out_base ? (size_t) geo.out_base[s] : (size_t) 0);
 
     for (int i = lane; i < 640; i += 64) L.words[i] = 0;
     if (lane < 12) L.si[lane] = 0;
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
         const size_t phys = (size_t) (q0 + (long) dq) * (size_t) frame_bytes + (size_t) si_bytes + (size_t) rem;
         dst[phys] = (uint8_t) (L.words[k >> 2] >> (24 - 8 * (k & 3)));
     }
-    if (n_abs == n_frames_s - 1 && lane == 0) {
+    if (geo.whole_file && n_call == n_frames_s - 1 && lane == 0) {
         // file length (src/formatBitstream.c:87-120 + src/common.c:843-868, 968): the flush stops
         // short of the last slot by what the current slot still has free, and close writes the
         // byte under construction as well
@@ -288,6 +290,95 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
         const long rem = ((mend + slot - 1) / slot) * slot - mend;
         out_len[s] = (uint32_t) (n_frames_s * frame_bytes - rem + 1);
     }
+}
+
+// ---- streaming (mp3mi_batch_encode_next / mp3mi_batch_flush) ----
+// The file bytes of a stream become final in order: once m bytes of main data have been written, everything up
+// to the physical position of main-data byte m - 1 is final (the reference emits exactly these, src/formatBitstream.c
+// :218-247); the rest of that slot and the headers behind it still wait for later frames' main data.  A call
+// therefore delivers the bytes [final_before, final_after) of every stream's file and keeps [final_after, end of
+// the call's last frame) in the stream's carry buffer; the next call starts its output row with them.
+MP3MI_DEVFN long fmt_final_upto(long m, int slot, int frame_bytes, int si_bytes)
+{
+    if (m == 0) return 0;
+    return ((m - 1) / slot) * (long) frame_bytes + si_bytes + ((m - 1) % slot) + 1;
+}
+
+__global__ void __launch_bounds__(64) k_carry_in(const uint8_t *__restrict__ carry, const int32_t *__restrict__ carry_len,
+                                                 uint8_t *__restrict__ out, size_t out_stride)
+{
+    const int s = (int) blockIdx.x, n = carry_len[s];
+    for (int i = (int) threadIdx.x; i < n; i += 64) out[(size_t) s * out_stride + i] = carry[(size_t) s * MP3MI_CARRY_BYTES + i];
+}
+
+// After the call's frames are formatted (flush = 0): how much of the row is final, what stays in the carry.
+// flush = 1 (III_FlushBitstream + close_bit_stream_w, src/formatBitstream.c:87-120, src/common.c:843-868, 968):
+// the carry goes out up to where the last main data ends, plus the byte under construction.
+__global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, const int32_t *__restrict__ loop_state, int loop_state_words,
+                                                    const int32_t *__restrict__ bits_per_frame, uint8_t *__restrict__ out, size_t out_stride,
+                                                    int64_t *__restrict__ out_base, uint8_t *__restrict__ carry,
+                                                    int32_t *__restrict__ carry_len, uint32_t *__restrict__ out_len)
+{
+    const int s = (int) blockIdx.x, lane = (int) threadIdx.x;
+    const int C = geo.channels;
+    const int frame_bytes = bits_per_frame[s] / 8, si_bytes = (32 + (geo.crc ? 16 : 0) + (C == 2 ? 256 : 136)) / 8, slot = frame_bytes - si_bytes;
+    const long n_done = geo.fabs0 + (flush ? 0 : geo.n_frames); // frames of the stream encoded so far
+    const long resv_bytes = loop_state[(size_t) s * loop_state_words] / 8; // ResvSize / 8 = the next frame's main_data_begin
+    const long m_end = n_done * slot - resv_bytes;                 // main data written so far
+    const long base = out_base[s];
+    uint8_t *row = out + (size_t) s * out_stride;
+    uint8_t *cr = carry + (size_t) s * MP3MI_CARRY_BYTES;
+    if (!flush) {
+        const long fin = fmt_final_upto(m_end, slot, frame_bytes, si_bytes), end = n_done * frame_bytes;
+        const int keep = (int) (end - fin); // <= 511 bytes of open slots plus the headers in between
+        for (int i = lane; i < keep && i < MP3MI_CARRY_BYTES; i += 64) cr[i] = row[fin - base + i];
+        if (lane == 0) {
+            out_len[s] = (uint32_t) (fin - base);
+            carry_len[s] = keep < MP3MI_CARRY_BYTES ? keep : MP3MI_CARRY_BYTES;
+            out_base[s] = fin;
+        }
+    } else {
+        long total = 0;
+        if (n_done > 0) {
+            const long rem = ((m_end + slot - 1) / slot) * slot - m_end;
+            total = n_done * frame_bytes - rem + 1;
+        }
+        const int n = (int) (total - base), have = carry_len[s];
+        for (int i = lane; i < n; i += 64) row[i] = i < have ? cr[i] : (uint8_t) 0;
+        if (lane == 0) {
+            out_len[s] = (uint32_t) (n > 0 ? n : 0);
+            carry_len[s] = 0;
+            out_base[s] = total;
+        }
+    }
+}
+
+// the last MP3MI_PCM_HIST samples of the call (a frame has 1152 > MP3MI_PCM_HIST) are the next call's history
+__global__ void __launch_bounds__(256) k_hist_save(mp3mi_geom geo, const int16_t *__restrict__ pcm, int16_t *__restrict__ hist)
+{
+    const int s = (int) blockIdx.x, C = geo.channels;
+    const size_t n_call = (size_t) geo.n_frames * 1152;
+    const int16_t *src = pcm + ((size_t) s * n_call + (n_call - MP3MI_PCM_HIST)) * C;
+    int16_t *dst = hist + (size_t) s * MP3MI_PCM_HIST * C;
+    for (int i = (int) threadIdx.x; i < MP3MI_PCM_HIST * C; i += 256) dst[i] = src[i];
+}
+
+void mp3mi_launch_carry_in(int n_streams, const uint8_t *carry, const int32_t *carry_len, uint8_t *out, size_t out_stride, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_carry_in, dim3((unsigned) n_streams), dim3(64), 0, st, carry, carry_len, out, out_stride);
+}
+
+void mp3mi_launch_stream_tail(const mp3mi_geom &g, int flush, const int32_t *loop_state, int loop_state_words, const int32_t *bits_per_frame,
+                              uint8_t *out, size_t out_stride, int64_t *out_base, uint8_t *carry, int32_t *carry_len, uint32_t *out_len,
+                              hipStream_t st)
+{
+    hipLaunchKernelGGL(k_stream_tail, dim3((unsigned) g.n_streams), dim3(64), 0, st, g, flush, loop_state, loop_state_words, bits_per_frame,
+                       out, out_stride, out_base, carry, carry_len, out_len);
+}
+
+void mp3mi_launch_hist_save(const mp3mi_geom &g, const int16_t *pcm, int16_t *hist, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_hist_save, dim3((unsigned) g.n_streams), dim3(256), 0, st, g, pcm, hist);
 }
 
 void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix, const mp3mi_frame_side *side,

@@ -35,6 +35,8 @@
    generator still produces them (MP3MI_FFT_INFO=1 prints the lists) */
 #define MP3MI_FFT_HDRS_L 2, 2, 2, 14, 2, 6, 15, 6, 3, 15, 6, 3, 15, 6, 3, 15, 6, 3, 13, 2, 4, 13, 4, 9, 8, 8
 #define MP3MI_FFT_HDRS_S 2, 2, 14, 2, 6, 15, 6, 7, 13, 6, 7, 13, 6, 13, 4, 4, 9, 8, 8
+#define MP3MI_PCM_HIST 1056   /* samples per channel a call needs from before its first sample: the filterbank of the granule
+                                 before the call (k_filter recomputes it: 576 + 480 taps); the FFT window reaches back 768 */
 #define MP3MI_POW43_N 8208
 #define MP3MI_STEP_MIN (-400)
 #define MP3MI_STEP_N 801

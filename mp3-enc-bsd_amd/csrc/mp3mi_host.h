@@ -30,6 +30,12 @@ struct mp3mi_geom {
                            info grows by 16 bits (src/musicin.c:744-746) */
     const int32_t *n_samples; /* device, [n_streams]: valid samples per channel of each stream (ragged batch), or NULL: all n_frames*1152.
                                  Samples beyond it read as zero and frames beyond ceil(n/1152) are not encoded (src/encode.c:162-166) */
+    /* streaming (mp3mi_batch_encode_next): the call continues streams that earlier calls began */
+    long fabs0;         /* frames of every stream encoded by earlier calls = index of the call's first frame in its stream */
+    const int16_t *hist; /* device, [n_streams][MP3MI_PCM_HIST][channels]: the samples before the call's first one (zeros at the
+                           start of a stream), or NULL: nothing precedes the call */
+    const int64_t *out_base; /* device, [n_streams]: file position of byte 0 of the stream's output row, or NULL: 0 */
+    int whole_file;     /* the call is the whole stream: k_format also finishes the file (length incl. flush + close) */
     int test_flags;     /* bit 0: k_loop takes the exact (sequential) noise sums only (MP3MI_NOISE_EXACT=1, tests);
                            bit 1: k_cw takes the correctly rounded atan2 only (MP3MI_PHASE_EXACT=1, tests);
                            bit 2: k_psy takes dm_log / dm_exp only (MP3MI_PSY_EXACT=1, tests);
@@ -44,6 +50,7 @@ static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_i
     g.hdr_mode = (channels == 1) ? 3 : 0;
     g.hdr_flags = 0;
     g.crc = 0;
+    g.fabs0 = 0; g.hist = NULL; g.out_base = NULL; g.whole_file = 1;
     g.test_flags = 0;
     g.n_samples = NULL;
     return g;
@@ -77,6 +84,14 @@ void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double 
                        hipStream_t st);
 /* bounded wait (one wavefront) until k_loop's start census reaches `target` -- see k_loop.hip */
 void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_ticks, hipStream_t st);
+/* streaming plumbing around k_format (k_format.hip): the bytes of a stream that are not final yet -- the unfilled
+   part of the bit reservoir's slots and the headers in between, at most MP3MI_CARRY_BYTES -- wait in `carry` */
+#define MP3MI_CARRY_BYTES 2048
+void mp3mi_launch_carry_in(int n_streams, const uint8_t *carry, const int32_t *carry_len, uint8_t *out, size_t out_stride, hipStream_t st);
+void mp3mi_launch_stream_tail(const mp3mi_geom &g, int flush, const int32_t *loop_state, int loop_state_words, const int32_t *bits_per_frame,
+                              uint8_t *out, size_t out_stride, int64_t *out_base, uint8_t *carry, int32_t *carry_len, uint32_t *out_len,
+                              hipStream_t st);
+void mp3mi_launch_hist_save(const mp3mi_geom &g, const int16_t *pcm, int16_t *hist, hipStream_t st);
 void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix,
                          const mp3mi_frame_side *side, const int32_t *bits_per_frame,
                          const int32_t *bitrate_index, uint8_t *out, size_t out_stride,

@@ -100,6 +100,9 @@ class Mp3mi:
         L.mp3mi_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
         L.mp3mi_synth_pcm_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_debug_fastmath_bounds.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_encode_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_flush.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_reset.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -246,6 +249,37 @@ class BatchRun:
         out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
         lens = self.mem.download(self.d_len, (self.S,), np.uint32)
         return out, lens
+
+    def encode_streaming(self, pieces):
+        """The same PCM fed piece by piece (frames per call) through mp3mi_batch_encode_next, then flushed.
+        Returns the concatenated bytes per stream."""
+        L = self.mp.lib
+        assert sum(pieces) == self.nf
+        got = [b""] * self.S
+        row = self.n_per_ch * self.ch  # int16 per stream in the resident buffer
+        f0 = 0
+        for nfp in pieces:
+            n = nfp * 1152 * self.ch
+            # the call's frames of every stream, packed [S][nfp*1152][C]
+            whole = self.mem.download(self.d_pcm, (self.S, row), np.int16)
+            piece = np.ascontiguousarray(whole[:, f0 * 1152 * self.ch: f0 * 1152 * self.ch + n])
+            d_piece = self.mem.alloc(piece.nbytes)
+            self.mem.upload(d_piece, piece)
+            rc = L.mp3mi_batch_encode_next(self.b, d_piece, nfp, self.d_out, self.stride, self.d_len)
+            assert rc == 0, "mp3mi_batch_encode_next -> %d" % rc
+            assert L.mp3mi_batch_sync(self.b) == 0
+            out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
+            lens = self.mem.download(self.d_len, (self.S,), np.uint32)
+            for s in range(self.S):
+                got[s] += out[s, :lens[s]].tobytes()
+            f0 += nfp
+        assert L.mp3mi_batch_flush(self.b, self.d_out, self.stride, self.d_len) == 0
+        assert L.mp3mi_batch_sync(self.b) == 0
+        out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
+        lens = self.mem.download(self.d_len, (self.S,), np.uint32)
+        for s in range(self.S):
+            got[s] += out[s, :lens[s]].tobytes()
+        return got
 
     def close(self):
         if self.b:

@@ -1,0 +1,71 @@
+"""Streaming continuation: a stream encoded in several mp3mi_batch_encode_next calls and flushed
+must give, concatenated, the bytes of the same stream encoded in one call -- which are the oracle's.  What is
+carried from call to call: psychoacoustic state, PCM history of the filterbank and the FFT window, MDCT overlap
+(recomputed from that history), the bit reservoir, and the formatted bytes whose slots are still open
+(/root/reference/src/musicin.c:585-805, src/formatBitstream.c:52-120)."""
+import numpy as np
+import pytest
+
+from mp3common import BatchRun
+
+
+def streaming_case(mp, oracle, rate, ch, kbps, S, pieces, stream0=0, chunk=None, monkeypatch=None):
+    nf = sum(pieces)
+    if chunk and monkeypatch:
+        monkeypatch.setenv("MP3MI_CHUNK_FRAMES", str(chunk))
+    run = BatchRun(mp, S, rate, ch, kbps, nf, stream0=stream0)
+    try:
+        kb = [kbps] * S if np.isscalar(kbps) else list(kbps)
+        ref = [oracle.encode(run.pcm_of(s), rate, kb[s], ch)[0] for s in range(S)]
+        out, lens = run.encode()
+        whole = [out[s, :lens[s]].tobytes() for s in range(S)]
+        assert whole == ref
+        got = run.encode_streaming(pieces)
+        for s in range(S):
+            assert got[s] == ref[s], "stream %d: streamed bytes differ (len %d vs %d)" % (s, len(got[s]), len(ref[s]))
+        # and once more on the same batch: flush left fresh streams behind
+        got = run.encode_streaming(pieces[::-1])
+        for s in range(S):
+            assert got[s] == ref[s], "second pass, stream %d" % s
+    finally:
+        run.close()
+
+
+def test_streaming_equals_one_call_emulated(emu, oracle, monkeypatch):
+    streaming_case(emu, oracle, 44100, 2, 128, 2, [3, 1, 4, 2], stream0=30, chunk=3, monkeypatch=monkeypatch)
+
+
+def test_streaming_low_bitrate_long_back_pointer_emulated(emu, oracle):
+    """32 kbps at 48 kHz: 60-byte slots, the reservoir reaches back over up to nine frames, so the carried bytes
+    span many headers; mixed with a 320 kbps stream in the same batch"""
+    streaming_case(emu, oracle, 48000, 2, [32, 320], 2, [2, 5, 1, 1], stream0=44)
+
+
+def test_streaming_mono_emulated(emu, oracle):
+    streaming_case(emu, oracle, 32000, 1, 64, 1, [1, 1, 3], stream0=8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,ch,kbps,S,pieces", [
+    (44100, 2, 128, 8, [100, 1, 150, 7, 125]),      # BASELINE configs[0] length: 383 frames in five calls
+    (48000, 2, [32, 64, 128, 320], 4, [9, 30, 2, 40]),
+    (32000, 1, 64, 6, [50, 50, 1, 20]),
+])
+def test_streaming_equals_one_call_gpu(product, oracle, rate, ch, kbps, S, pieces):
+    streaming_case(product, oracle, rate, ch, kbps, S, pieces, stream0=0)
+
+
+@pytest.mark.gpu
+def test_streaming_full_chip_batch_gpu(product, oracle):
+    """4096 streams in three calls: placement, pacing and chunk overlap active in every call"""
+    rate, ch, kbps, S, pieces = 44100, 2, 128, 4096, [10, 6, 8]
+    run = BatchRun(product, S, rate, ch, kbps, sum(pieces))
+    try:
+        out, lens = run.encode()
+        got = run.encode_streaming(pieces)
+        bad = [s for s in range(S) if got[s] != out[s, :lens[s]].tobytes()]
+        assert not bad, "%d streams differ between streamed and whole-file encoding (first %d)" % (len(bad), bad[0])
+        for s in (0, 1777, 4095):
+            assert got[s] == oracle.encode(run.pcm_of(s), rate, kbps, ch)[0]
+    finally:
+        run.close()
