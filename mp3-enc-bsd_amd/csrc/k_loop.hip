@@ -832,33 +832,21 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         work += 5;
                         g.part2_length = loop_part2_length(L, g, gr, ch);
                         const int huff_bits = max_bits - g.part2_length;
-                        bool have_pass = false; // p[], L.ix and g already describe step size g.q
-                        if (iteration == 1) { // bin_search_StepSize (src/loop.c:2119-2140)
-                            int top = g.q, bot = 200, next = g.q, last, bit;
-                            do {
-                                last = next;
-                                next = (top + bot) / 2;
-                                g.q = next;
-                                PROF(1);
-                                const bool az = !quant_exact && loop_all_zero(y34max, g.q);
-                                work += 4;
-                                loop_quantize(T, L, y34, g.q, az, p, quant_exact);
-                                PROF(2);
-                                bit = loop_count_bits(T, R, L, g, p, az);
-                                PROF(3);
-                                __syncthreads();
-                                if (bit > max_bits) top = next; else bot = next;
-                            } while (bit != max_bits && abs(last - next) > 1);
-                            bits = bit;
-                            have_pass = true;
-                        }
-                        // inner_loop (src/loop.c:569-606): raise the step until the bits fit.  Its first
-                        // pass repeats the last probe of the bisection (same step, same xr), so that one
-                        // is taken over instead of recomputed.
-                        g.q -= 1;
-                        do {
-                            g.q += 1;
-                            if (!have_pass) {
+                        // bin_search_StepSize (src/loop.c:2119-2140, first iteration only) and inner_loop (src/loop.c:569-606)
+                        // as ONE loop around ONE copy of the quantise+count pass (the pass is ~3 k instructions; a second
+                        // inlined copy is instruction-cache pressure for nothing).  The bisection probes (top + bot) / 2
+                        // until the count equals max_bits or the probes are one step apart; inner_loop then raises the step
+                        // until the bits fit -- and its first pass repeats the bisection's last probe (same step, same xr),
+                        // which is taken over instead of recomputed.
+                        {
+                            bool bisect = iteration == 1;
+                            int top = g.q, bot = 200, next = g.q, last = g.q;
+                            for (;;) {
+                                if (bisect) {
+                                    last = next;
+                                    next = (top + bot) / 2;
+                                    g.q = next;
+                                }
                                 PROF(1);
                                 const bool az = !quant_exact && loop_all_zero(y34max, g.q);
                                 work += 4;
@@ -867,9 +855,15 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 bits = loop_count_bits(T, R, L, g, p, az);
                                 PROF(3);
                                 __syncthreads();
+                                if (bisect) {
+                                    if (bits > max_bits) top = next; else bot = next;
+                                    if (bits != max_bits && abs(last - next) > 1) continue;
+                                    bisect = false; // this probe is inner_loop's first pass
+                                }
+                                if (!(bits > huff_bits)) break;
+                                g.q += 1;
                             }
-                            have_pass = false;
-                        } while (bits > huff_bits);
+                        }
 
                         PROF(1);
                         // calc_noise (src/loop.c:1007-1067).  The noise of a band is only ever COMPARED with the
@@ -922,9 +916,10 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                         xfsf_exact = true;
                                         xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, sfirst, scount, sstride);
                                     }
+                                    const unsigned long long bp = wave_opaque_u64(bandpack); // (rare block: nothing of it is hoisted)
 #pragma unroll
                                     for (int j = 0; j < 9; j++) {
-                                        const int b = (int) ((bandpack >> (6 * j)) & 63ull);
+                                        const int b = (int) ((bp >> (6 * j)) & 63ull);
                                         if (b < g.sfb_lmax) {
                                             L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * T->pretab_xr[LOOP_PRETAB[b]];
                                             y34[j] = loop_rescale34(y34[j], LOOP_PRETAB[b]);
@@ -1073,8 +1068,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
         }
         __syncthreads();
         {
+            const int ln = wave_lane_here(); // (addresses derived from the lane index are rebuilt here, once per frame, not carried)
             int *dst = (int *) &side_out[(size_t) s * geo.nf + fl];
-            for (int i = lane; i < (int) (sizeof(mp3mi_frame_side) / 4); i += 64) dst[i] = ((const int *) &L.side)[i];
+            for (int i = ln; i < (int) (sizeof(mp3mi_frame_side) / 4); i += 64) dst[i] = ((const int *) &L.side)[i];
         }
         __syncthreads();
 #if !defined(MP3MI_EMU)
@@ -1084,7 +1080,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
         // wavefronts of its SIMD), a stream ahead of it lowers it.  Purely a scheduling hint.
         if (gate_count) {
             const unsigned done_all = __builtin_amdgcn_readfirstlane((int) (lane == 0 ? atomicAdd(gate_count + 1, 1u) + 1u : 0u));
-            const float lead = (float) (fl + 1) - (float) done_all / (float) gridDim.x;
+            int n_waves = (int) gridDim.x;
+            asm volatile("" : "+s"(n_waves)); // converted here, once per frame, instead of living in a register for the whole kernel
+            const float lead = (float) (fl + 1) - (float) done_all / (float) n_waves;
             if (lead < -1.0f) __builtin_amdgcn_s_setprio(3);
             else if (lead < 0.0f) __builtin_amdgcn_s_setprio(2);
             else if (lead < 1.0f) __builtin_amdgcn_s_setprio(1);
@@ -1092,7 +1090,10 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
         }
 #endif
     }
-    for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &state[s])[i] = ((const int *) &L.st)[i];
+    {
+        const int ln = wave_lane_here(); // (not the address the state was loaded through, kept alive across the whole kernel)
+        for (int i = ln; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &state[s])[i] = ((const int *) &L.st)[i];
+    }
     if (place.cost && lane == 0) place.cost[s] = work;
 #if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
     if (lane == 0 && s < 65536) g_loop_work[s] = (unsigned long long) work | ((unsigned long long) __builtin_amdgcn_s_memrealtime() << 20);

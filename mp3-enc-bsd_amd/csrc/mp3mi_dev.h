@@ -182,6 +182,20 @@ MP3MI_DEVFN int wave_lane_here(void)
     return l;
 }
 
+/* A value behind an optimisation barrier: what is computed from the result cannot be hoisted above this point.
+ * Used at the top of RARELY executed blocks inside k_loop's distortion loop, whose per-line address and constant
+ * arithmetic the compiler would otherwise hoist to the top of the granule and keep alive -- in scratch memory --
+ * across the whole search. */
+MP3MI_DEVFN unsigned long long wave_opaque_u64(unsigned long long v)
+{
+#if !defined(MP3MI_EMU)
+    unsigned lo = (unsigned) v, hi = (unsigned) (v >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    v = ((unsigned long long) hi << 32) | lo;
+#endif
+    return v;
+}
+
 #if defined(MP3MI_EMU)
 MP3MI_DEVFN int wave_sum_i32(int v)
 {

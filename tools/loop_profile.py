@@ -3,12 +3,11 @@ import ctypes, importlib, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 mp3 = importlib.import_module("mp3-enc-bsd_amd")
-sys.argv = [sys.argv[0]]
-import bench
 S, nf = 4096, 48
 dev = torch.device("cuda:0")
 b = mp3.Batch(S, 44100, 2, 128, nf)
-pcm = bench.synth_on_device(dev, S, nf * 1152, 2, 44100, 0)
+pcm = torch.empty((S, nf * 1152 * 2), dtype=torch.int16, device=dev)
+mp3.synth_pcm_device(pcm, nf * 1152, 2, 44100, stream0=0)
 out = torch.zeros((S, b.out_stride(nf)), dtype=torch.uint8, device=dev); ln = torch.zeros(S, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 L = mp3.lib()
