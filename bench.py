@@ -107,30 +107,31 @@ def pmc_traffic(kernel, streams, frames, launches_per_step):
 
 
 def issue_roofline(kernel, streams, frames, kernel_s_per_launch, launches_per_step):
-    """The bound the kernel actually runs against: instruction issue.  From the newest committed SQ counter pass of
-    this workload (profiles/*_insts_<S>x<F>.json, tools/gpu_insts.sh): wavefront instructions per launch by class,
-    each priced at its measured issue cost per SIMD (tools/exp/issue_mix.hip), over the SIMD
-    cycles the launch had: achieved = sum(count x cost) busy SIMD-cycles, peak = 1024 SIMDs x 2.4 GHz x launch time."""
-    COST = {"valu_f64": 4.5, "valu_other": 3.0, "salu": 4.6, "lds": 4.0, "vmem": 4.0}  # cycles per wave-instruction and SIMD
-
+    """The bound the kernel actually runs against: VALU issue.  From the newest committed SQ counter passes of this
+    workload (profiles/*_insts_<S>x<F>.json, tools/gpu_insts.sh; counters are per-wave quad-cycles, MI355X_MICROARCH.md):
+      achieved = SQ_ACTIVE_INST_VALU  -- quad-cycles in which a wavefront of the kernel was issuing a vector instruction
+      peak     = SQ_WAVE_CYCLES / waves resident per SIMD -- the quad-cycles the SIMDs were held by the kernel (a SIMD's
+                 vector port serves one of its resident wavefronts at a time)
+    so frac is the share of the SIMDs' vector issue capacity the launch used; what is left is waitcnt / issue stalls.
+    The instruction mix per launch goes along (what there is to remove: the kernel gets faster by executing fewer
+    vector instructions, not by moving fewer bytes)."""
     def pred(d):
         k = d[kernel]
-        if k["dispatches"] != launches_per_step:
+        if k["dispatches"] != launches_per_step or "SQ_ACTIVE_INST_VALU" not in k:
             return None
         n = float(k["dispatches"])
-        valu, salu, lds = k["SQ_INSTS_VALU"] / n, k["SQ_INSTS_SALU"] / n, k["SQ_INSTS_LDS"] / n
+        waves_per_simd = max(1.0, min(4.0, streams / 1024.0))
+        achieved, peak = k["SQ_ACTIVE_INST_VALU"] / n, k["SQ_WAVE_CYCLES"] / n / waves_per_simd
         f64 = sum(k.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) / n
+        f32 = sum(k.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")) / n
         vmem = (k.get("SQ_INSTS_VMEM_RD", 0) + k.get("SQ_INSTS_VMEM_WR", 0)) / n
-        busy = f64 * COST["valu_f64"] + (valu - f64) * COST["valu_other"] + salu * COST["salu"] + lds * COST["lds"] + vmem * COST["vmem"]
-        peak = kernel_s_per_launch * 2.4e9 * 1024
-        r = {"achieved": int(busy), "peak": int(peak), "unit": "SIMD issue cycles per launch", "frac": round(busy / peak, 4),
-             "wave_instructions_per_launch": int(valu + salu + lds + vmem),
-             "mix": {"valu": int(valu), "valu_f64": int(f64), "salu": int(salu), "lds": int(lds), "vmem": int(vmem)},
-             "cycles_per_instruction_per_simd": round(peak / max(valu + salu + lds + vmem, 1.0), 2),
-             "cost_model": COST}
-        for c in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY"):
-            if c in k:
-                r.setdefault("sq", {})[c] = int(k[c] / n)
+        r = {"bound": "valu-issue", "achieved": int(achieved), "peak": int(peak), "unit": "SIMD quad-cycles per launch", "frac": round(achieved / peak, 4),
+             "waves_per_simd": waves_per_simd,
+             "wave_time_split": {c: round(k[c] / k["SQ_WAVE_CYCLES"], 4) for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if c in k},
+             "instructions_per_launch": {"valu": int(k["SQ_INSTS_VALU"] / n), "valu_f64": int(f64), "valu_f32": int(f32),
+                                         "valu_int32": int(k.get("SQ_INSTS_VALU_INT32", 0) / n), "salu": int(k["SQ_INSTS_SALU"] / n),
+                                         "branch": int(k.get("SQ_INSTS_BRANCH", 0) / n), "lds": int(k["SQ_INSTS_LDS"] / n), "vmem": int(vmem)},
+             "effective_clock_ghz": round(4.0 * peak / 1024.0 / kernel_s_per_launch / 1e9, 3) if kernel_s_per_launch > 0 else None}
         return r
     r, src = newest_profile("*_insts_%dx%d.json" % (streams, frames), pred)
     if r is not None:
@@ -301,7 +302,7 @@ def main():
                          "algorithmic_bytes_per_frame": round(alg, 1),
                          "kernel_ms_per_launch": round(avg_launch_s * 1e3, 3), "launches_per_step": lps,
                          "all_kernels_ms_per_step": round(all_ms / max(args.steps, 1), 3),
-                         "limited_by": "instruction issue, not HBM (see issue)",
+                         "limited_by": "vector instruction issue, not HBM (see issue: share of the SIMDs' VALU issue capacity in use)",
                          "issue": issue},
             "cpu_baseline": cpu,
             "parity_spot_check": {"streams_per_rank": len(idx), "bit_exact": parity_ok, "mismatching_streams_rank0": bad,

@@ -60,16 +60,16 @@ struct loop_lds {
 struct loop_regs {
     int sfb_l;   // lane < 23: long scalefactor band edge
     int sfb_s;   // lane < 14: short scalefactor band edge
-    int subdv;   // lane < 23: region0_count | region1_count << 8 (src/loop.c:1596-1625)
     int desc_a;  // lane < 27: Huffman group descriptor of region maximum class `lane` (see loop_desc_index)
     int desc_b;  // lane < 27: offset of that group's cells in glut
 };
 
 __device__ static const int LOOP_PRETAB[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 3, 2};
-__device__ static const int LOOP_SLEN1[16] = {0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
-__device__ static const int LOOP_SLEN2[16] = {0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3};
-__device__ static const unsigned char LOOP_SUBDV0[23] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 6};
-__device__ static const unsigned char LOOP_SUBDV1[23] = {0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 5, 6, 6, 6, 7, 7, 7};
+// slen1 / slen2 of scalefac_compress k (src/loop.c:746-747: {0,0,0,0,3,1,1,1,2,2,2,3,3,3,4,4} and
+// {0,1,2,3,0,1,2,3,1,2,3,1,2,3,2,3}) as nibble k of an immediate: a table in memory would be a dependent scalar
+// load on the path between two passes
+MP3MI_DEVFN int loop_slen1(int k) { return (int) ((0x4433322211130000ull >> (4 * k)) & 15ull); }
+MP3MI_DEVFN int loop_slen2(int k) { return (int) ((0x3232132132103210ull >> (4 * k)) & 15ull); }
 
 // Diagnostic build only (-DMP3MI_LOOP_PROFILE): cycles per phase, summed over all waves.
 #if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
@@ -316,15 +316,17 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         g.count1table_select = 1;
         nslot = 0;
     } else {
-        // highest line with ix != 0 and highest line with ix > 1 (as line + 1; 0 = none)
-        int hi_nz = 0, hi_big = 0;
+        // highest line with ix != 0 and highest line with ix > 1 (as line + 1; 0 = none).  Slot j's lines are
+        // 64 j + lane, so the highest set bit of the lane mask of `p[j] != 0` in the highest non-empty slot is the
+        // answer: nine compares into scalar masks and scalar bit scans instead of 9 x (compare, select) per maximum
+        // and a wave reduction -- scalar instructions issue beside the other wavefronts' vector work.
+        int hh[2] = {0, 0};
 #pragma unroll
         for (int j = 0; j < 9; j++) {
-            hi_nz = (p[j] != 0) ? 64 * j + lane + 1 : hi_nz;
-            hi_big = (p[j] > 1) ? 64 * j + lane + 1 : hi_big;
+            const unsigned long long nz = __ballot(p[j] != 0), big = __ballot(p[j] > 1);
+            hh[0] = nz ? 64 * j + 64 - __clzll((long long) nz) : hh[0];
+            hh[1] = big ? 64 * j + 64 - __clzll((long long) big) : hh[1];
         }
-        int hh[2] = {hi_nz, hi_big};
-        wave_reduce_i32<0, 2>(hh);
         // hh[0] = n: lines up to the last non-zero one, hh[1] = b <= n: lines up to the last one above 1.  The
         // reference's i = 2 * (top / 2 + 1) is n rounded up to even (0 for n = 0); everything is non-negative,
         // so the divisions are shifts (src/loop.c:1488-1520)
@@ -494,15 +496,16 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     return bits;
 }
 
-MP3MI_DEVFN int loop_part2_length(const loop_lds &L, const loop_gr &g, int gr, int ch)
+// scfsi_m: bit b = scfsi[ch][b] of this frame when gr == 1, 0 for gr == 0 (whose scalefactors are always sent)
+MP3MI_DEVFN int loop_part2_length(const loop_gr &g, int scfsi_m)
 { // src/loop.c:731-780
-    const int slen1 = LOOP_SLEN1[g.scalefac_compress], slen2 = LOOP_SLEN2[g.scalefac_compress];
+    const int slen1 = loop_slen1(g.scalefac_compress), slen2 = loop_slen2(g.scalefac_compress);
     if (g.wsf == 1 && g.block_type == 2) return 18 * slen1 + 18 * slen2;
     int bits = 0;
-    if (gr == 0 || L.side.scfsi[ch][0] == 0) bits += 6 * slen1;
-    if (gr == 0 || L.side.scfsi[ch][1] == 0) bits += 5 * slen1;
-    if (gr == 0 || L.side.scfsi[ch][2] == 0) bits += 5 * slen2;
-    if (gr == 0 || L.side.scfsi[ch][3] == 0) bits += 5 * slen2;
+    if ((scfsi_m & 1) == 0) bits += 6 * slen1;
+    if ((scfsi_m & 2) == 0) bits += 5 * slen1;
+    if ((scfsi_m & 4) == 0) bits += 5 * slen2;
+    if ((scfsi_m & 8) == 0) bits += 5 * slen2;
     return bits;
 }
 
@@ -684,7 +687,6 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     loop_regs R;
     R.sfb_l = (lane < 23) ? T->sfb_l[lane] : 576;
     R.sfb_s = (lane < 14) ? T->sfb_s[lane] : 192;
-    R.subdv = (lane < 23) ? (LOOP_SUBDV0[lane] | (LOOP_SUBDV1[lane] << 8)) : 0;
     loop_desc_init(T, lane, &R.desc_a, &R.desc_b);
 
     for (int i = lane; i < 928; i += 64) L.glut[i] = T->glut[i];
@@ -765,6 +767,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     L.st.sc_xm[gr][ch][lane] = pp->sc_xm[lane][ps];
                 }
                 const int nonzero = pp->nonzero[ps];
+                int scfsi_m = 0; // this granule's scfsi bits (wave-uniform): what the search asks for between passes
                 __syncthreads();
                 if (gr == 1) {
                     int condition = 0;
@@ -786,6 +789,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             const bool in = lane >= lo && lane < hi;
                             const int s0 = wave_sum_i32(in ? d : 0), s1 = wave_sum_i32(in ? dx : 0);
                             const int v = (s0 < 10 && s1 < 10) ? 1 : 0;
+                            scfsi_m |= v << band;
                             if (lane == 0) L.side.scfsi[ch][band] = v;
                         }
                     } else if (lane < 4)
@@ -830,7 +834,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         const int lane = wave_lane_here(); // ... nor an iteration of the distortion loop
                         iteration++;
                         work += 5;
-                        g.part2_length = loop_part2_length(L, g, gr, ch);
+                        g.part2_length = loop_part2_length(g, scfsi_m);
                         const int huff_bits = max_bits - g.part2_length;
                         // bin_search_StepSize (src/loop.c:2119-2140, first iteration only) and inner_loop (src/loop.c:569-606)
                         // as ONE loop around ONE copy of the quantise+count pass (the pass is ~3 k instructions; a second
@@ -903,7 +907,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         // preemphasis (src/loop.c:1161-1214)
                         {
                             bool skip = false;
-                            if (gr == 1 && (L.side.scfsi[ch][0] | L.side.scfsi[ch][1] | L.side.scfsi[ch][2] | L.side.scfsi[ch][3])) {
+                            if (scfsi_m) {
                                 g.preflag = L.side.gr[0][ch].preflag;
                                 skip = true;
                             }
@@ -934,7 +938,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         // amp_scalefac_bands (src/loop.c:1225-1350)
                         {
                             int copySF = 0, preventSF = 0;
-                            if (gr == 1 && (L.side.scfsi[ch][0] | L.side.scfsi[ch][1] | L.side.scfsi[ch][2] | L.side.scfsi[ch][3])) {
+                            if (scfsi_m) {
                                 if (iteration == 1) copySF = 1; else preventSF = 1;
                             }
                             const double ifqstep = T->sqrt2, ifqstep2 = ifqstep * ifqstep;
@@ -943,7 +947,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 bool skipband = false;
                                 if (!shortb && (copySF || preventSF)) {
                                     const int sb4 = (lane < 6) ? 0 : (lane < 11 ? 1 : (lane < 16 ? 2 : 3));
-                                    if (L.side.scfsi[ch][sb4]) {
+                                    if ((scfsi_m >> sb4) & 1) {
                                         if (copySF) sf_r = L.sf_gr0[ch][lane];
                                         skipband = true;
                                     }
@@ -957,15 +961,20 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             const unsigned long long ampmask = __ballot(amp); // bit b = band lane b amplified
                             over = __popcll(ampmask);
                             if (over) {
-                                // branch-free: a line outside the amplified bands is multiplied by 1 (exact).  ampmask only
-                                // has bits of band lanes, so lines above the last band (b >= nband) find a zero bit.
-                                const unsigned alo = (unsigned) ampmask, ahi = (unsigned) (ampmask >> 32);
+                                // The amplified bands are a few runs of consecutive lines, so most of the nine slots of 64
+                                // lines hold none of them: a slot is skipped as a whole (one compare into a scalar mask),
+                                // and inside a slot only the amplified lines touch the LDS.  ampmask only has bits of
+                                // band lanes, so lines above the last band (b >= nband) find a zero bit.
 #pragma unroll
                                 for (int j = 0; j < 9; j++) {
                                     const unsigned b = (unsigned) ((bandpack >> (6 * j)) & 63ull);
-                                    const bool f = (((b < 32u ? alo : ahi) >> (b & 31u)) & 1u) != 0;
-                                    L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * (f ? ifqstep : 1.0);
-                                    y34[j] = y34[j] * (f ? 1.2968395546510096f : 1.0f); // loop_rescale34(y34, 1)
+                                    const bool f = ((ampmask >> b) & 1ull) != 0;
+                                    if (__ballot(f)) {
+                                        if (f) {
+                                            L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * ifqstep;
+                                            y34[j] = y34[j] * 1.2968395546510096f; // loop_rescale34(y34, 1)
+                                        }
+                                    }
                                 }
                                 y34max = y34max * LOOP_Y34MAX_GROW;
                             }
@@ -1004,7 +1013,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     g.preflag = save_preflag;
                     g.scalefac_compress = save_compress;
                     sf_r = sfsave_r;
-                    g.part2_length = loop_part2_length(L, g, gr, ch);
+                    g.part2_length = loop_part2_length(g, scfsi_m);
                     g.part2_3_length = g.part2_length + bits;
                 }
 
