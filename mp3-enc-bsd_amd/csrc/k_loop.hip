@@ -77,15 +77,24 @@ __device__ unsigned long long g_loop_prof[8];
 __device__ unsigned long long g_loop_wave[2 * 65536];
 __device__ unsigned long long g_loop_start[65536];
 __device__ unsigned long long g_loop_work[65536]; // per stream: cycles from first to last instruction, HW_ID
-#define PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (wave_lane() == 0 && blockIdx.x < 65536) g_loop_start[blockIdx.x] = __builtin_amdgcn_s_memrealtime()
+__device__ unsigned long long g_cb_prof[8]; // phases inside loop_count_bits
+#define CBPROF_ARG , unsigned long long *cbp
+#define CBPROF_PASS , cb_acc
+#define CBPROF_START unsigned long long cb_t = __builtin_amdgcn_s_memtime()
+#define CBPROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); cbp[i] += n_ - cb_t; cb_t = n_; } while (0)
+#define PROF_DECL unsigned long long cb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (wave_lane() == 0 && blockIdx.x < 65536) g_loop_start[blockIdx.x] = __builtin_amdgcn_s_memrealtime()
 #define PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
-#define PROF_END do { if (lane == 0) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_loop_prof[i_], prof_acc[i_]); \
+#define PROF_END do { if (lane == 0) { for (int i_ = 0; i_ < 8; i_++) { atomicAdd(&g_loop_prof[i_], prof_acc[i_]); atomicAdd(&g_cb_prof[i_], cb_acc[i_]); } \
     if (s < 65536) { unsigned long long tot_ = 0; for (int i_ = 0; i_ < 8; i_++) tot_ += prof_acc[i_]; g_loop_wave[2 * s] = tot_; \
     g_loop_wave[2 * s + 1] = (unsigned long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long) __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); } } } while (0)
 #else
 #define PROF_DECL
 #define PROF(i)
 #define PROF_END
+#define CBPROF_ARG
+#define CBPROF_PASS
+#define CBPROF_START
+#define CBPROF(i)
 #endif
 
 MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int) (in + 0.5); } // src/loop.c:2020
@@ -299,8 +308,9 @@ MP3MI_DEVFN void loop_region_cost(const loop_lds &L, const unsigned *ixw, int la
 // (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
 // Returns the Huffman bit count and fills g.  Written branch-free over the lanes: region
 // membership is a predicate, never a divergent branch.
-MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9], bool all_zero)
+MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9], bool all_zero CBPROF_ARG)
 {
+    CBPROF_START;
     const int lane = wave_lane_here();
     const bool shortb = g.wsf && g.block_type == 2;
     const unsigned *ixw = (const unsigned *) L.ix; // (x, y) of pair pr as one word: x | y << 16
@@ -352,6 +362,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         }
         c1part = s01; // reduced further down, together with the region maxima
     }
+    CBPROF(0); // run lengths + count1 region
     // subdivide (src/loop.c:1638-1706); address1..3 keep their old values when big_values == 0.
     // (Results go through plain locals and are assigned once: stores to the fields from several branches
     // made the compiler keep them in scratch memory.)
@@ -381,6 +392,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         g.address1 = ad1; g.address2 = ad2; g.address3 = ad3;
     }
     g.table_select[0] = g.table_select[1] = g.table_select[2] = 0;
+    CBPROF(1); // subdivide
     if (nslot == 0) { // nothing but zeros: every region maximum is 0, no table, no bits
         g.count1table_select = 1; // count1_bitcount without quadruples: sum0 == sum1 -> table B
         return bits;
@@ -450,6 +462,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     // the three region maxima and the count1 region's two bit sums: four reductions in lock-step
     int red[4] = {c1part, region_max(0, a1), region_max(a1, a2), region_max(a2, e2)};
     wave_reduce_i32<1, 3>(red);
+    CBPROF(2); // region maxima + reduction
     {
         const int sum0 = red[0] & 0xffff, sum1 = (red[0] >> 16) & 0xffff; // table A vs table B (src/loop.c:1531-1580)
         if (sum0 < sum1) { g.count1table_select = 0; bits = sum0; }
@@ -473,6 +486,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     loop_region_cost(L, ixw, lane, 0, a1, m0, da[0], db[0], &s01p[0], &s2p[0]);
     loop_region_cost(L, ixw, lane, a1, a2, m1, da[1], db[1], &s01p[1], &s2p[1]);
     loop_region_cost(L, ixw, lane, a2, e2, m2, da[2], db[2], &s01p[2], &s2p[2]);
+    CBPROF(3); // descriptors + region walks
     const bool third = (((da[0] | da[1] | da[2]) >> 10) & 31) != 0; // (descriptors of empty regions are zero)
     int s2v[3] = {0, 0, 0};
     if (third) { // five reductions in lock-step
@@ -493,6 +507,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         // whenever region 2 is not empty)
         bits += best;
     }
+    CBPROF(4); // cost reductions + picks
     return bits;
 }
 
@@ -856,7 +871,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 work += 4;
                                 loop_quantize(T, L, y34, g.q, az, p, quant_exact);
                                 PROF(2);
-                                bits = loop_count_bits(T, R, L, g, p, az);
+                                bits = loop_count_bits(T, R, L, g, p, az CBPROF_PASS);
                                 PROF(3);
                                 __syncthreads();
                                 if (bisect) {
@@ -1118,6 +1133,13 @@ extern "C" void mp3mi_debug_loop_profile(unsigned long long *out)
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_prof), sizeof(z));
     hipMemcpyToSymbol(HIP_SYMBOL(g_loop_prof), z, sizeof(z));
+}
+extern "C" void mp3mi_debug_cb_profile(unsigned long long *out)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cb_prof), sizeof(z));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_cb_prof), z, sizeof(z));
 }
 extern "C" void mp3mi_debug_loop_work(unsigned long long *out, int n_streams)
 {

@@ -183,20 +183,36 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
     }
 }
 
-// 8192 single-wave workgroups (4096 stereo streams) = 8 waves per SIMD: ask for that occupancy
-__global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+// The kernel is a chain of dependent steps per granule (k_part's sums in, spreading, threshold, entropy, ratios out),
+// so what it costs is latency: the next granule's partition sums are requested before the current one is worked
+// on, and the spreading function -- a row of s3_l per lane -- never comes from memory inside the loop: at 44.1 kHz
+// (SPARSE) a row has at most PSY_S3_W non-zero entries, and the PSY_W wavefronts of a workgroup share one copy of
+// these runs in LDS ([entry][lane]: conflict-free); at the other rates the rows are dense and are read column by column
+// from the transposed table (one coalesced line per step).  Every wavefront works on its own (stream, channel) with
+// its own psy_lds: apart from the table load, synchronisation is per wavefront (wave_sync).
+#define PSY_S3_W 17
+#define PSY_W 4
+template <bool SPARSE>
+__global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                             const double *__restrict__ eb_all, const float *__restrict__ cb_all,
                                             const float *__restrict__ energy_s, const float *__restrict__ hist6,
                                             mp3mi_psy_state *__restrict__ state, mp3mi_psy_out *__restrict__ out)
 {
-    __shared__ psy_lds L;
+    __shared__ psy_lds LL[PSY_W];
+    __shared__ double s3rows[SPARSE ? PSY_S3_W : 1][64];
+    const int wv = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+    psy_lds &L = LL[wv];
     const bool psy_exact = (geo.test_flags & 4) != 0; // MP3MI_PSY_EXACT=1: thresholds from dm_log / dm_exp only (tests)
     const int lane = wave_lane();
     const int C = geo.channels, G = geo.n_gran;
-    const int ch = (int) blockIdx.x % C, s = (int) blockIdx.x / C;
+    // (the last workgroup may hold wavefronts without a task: they leave after the workgroup's one barrier)
+    const int n_task = geo.n_streams * C;
+    int task = (int) blockIdx.x * PSY_W + wv;
+    const bool live = task < n_task;
+    task = live ? task : n_task - 1;
+    const int ch = task % C, s = task / C;
     mp3mi_psy_state *st = &state[(size_t) s * C + ch];
     const int b = lane; // partition owned by this lane (lane 63 idles in partition loops)
-    const bool sparse = (T->rate_idx == 0);
 
     // restore carried state
     float r1 = 0, p1 = 0, r2 = 0, p2 = 0;
@@ -213,9 +229,22 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
         minval = T->minval[b]; qthr_l = T->qthr_l[b]; norm_l = T->norm_l[b];
         numl = (double) T->numlines_pe[b];
         pl0 = T->part_l_start[b]; pl1 = T->part_l_start[b + 1];
-        if (sparse) { s3lo = T->s3_lo[b]; s3hi = T->s3_hi[b]; } else { s3lo = 0; s3hi = MP3MI_CBANDS - 1; }
+        if (SPARSE) { s3lo = T->s3_lo[b]; s3hi = T->s3_hi[b]; } else { s3lo = 0; s3hi = MP3MI_CBANDS - 1; }
+    }
+    if (SPARSE && wv == 0) { // lane b's run of the spreading function, entries s3lo .. s3lo + PSY_S3_W - 1 (0 past its end)
+#pragma unroll
+        for (int i = 0; i < PSY_S3_W; i++) s3rows[i][lane] = (b < MP3MI_CBANDS && s3lo + i <= s3hi) ? T->s3_l[b][s3lo + i] : 0.0;
+    }
+    // partition sums of the first granule (every later one is requested one granule ahead)
+    double eb_next = 0.0;
+    float cb_next = 0.0f;
+    if (b < MP3MI_CBANDS && G > 0) {
+        const size_t rec0 = ((size_t) s * G) * C + ch;
+        eb_next = eb_all[rec0 * MP3MI_PART_P + b];
+        cb_next = cb_all[rec0 * MP3MI_PART_P + b];
     }
     __syncthreads();
+    if (!live) return;
 
     for (int gl = 0; gl < G; gl++) {
         const size_t rec = ((size_t) s * G + gl) * C + ch;
@@ -226,21 +255,41 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
             r2 = r1; p2 = p1; r1 = rn; p1 = pn;
         }
         if (b < MP3MI_CBANDS) {
-            L.eb[b] = eb_all[rec * MP3MI_PART_P + b];
-            L.cb[b] = cb_all[rec * MP3MI_PART_P + b];
+            L.eb[b] = eb_next;
+            L.cb[b] = cb_next;
+            if (gl + 1 < G) { // in flight while this granule is worked on
+                eb_next = eb_all[(rec + C) * MP3MI_PART_P + b];
+                cb_next = cb_all[(rec + C) * MP3MI_PART_P + b];
+            }
         }
-        __syncthreads();
+        wave_sync();
 
         double thr = 0.0, ebv = 0.0;
         // spreading (src/l3psy.c:586-605, 1062-1084)
         float ecb = 0.0f;
         double ctb = 0.0;
-        if (b < MP3MI_CBANDS) {
-            for (int k = s3lo; k <= s3hi; k++) {
-                const double sv = T->s3_l[b][k];
-                if (sparse || sv != 1.0) {
+        if (SPARSE) { // every lane takes PSY_S3_W steps; a step past the row's end adds nothing (table build checks the width)
+#pragma unroll
+            for (int i = 0; i < PSY_S3_W; i++) {
+                const int k = s3lo + i;
+                if (b < MP3MI_CBANDS && k <= s3hi) {
+                    const double sv = s3rows[i][lane];
                     ecb = (float) ((double) ecb + sv * L.eb[k]);
                     ctb = ctb + sv * (double) L.cb[k];
+                }
+            }
+        } else if (b < MP3MI_CBANDS) {
+#pragma unroll 1
+            for (int k0 = 0; k0 < MP3MI_CBANDS; k0 += 9) { // 63 = 7 x 9: nine loads in flight, then the ordered sums
+                double svv[9];
+#pragma unroll
+                for (int u = 0; u < 9; u++) svv[u] = T->s3_lt[k0 + u][b];
+#pragma unroll
+                for (int u = 0; u < 9; u++) {
+                    if (svv[u] != 1.0) { // src/l3psy.c:596-603: entries that are exactly 1 are skipped at these rates
+                        ecb = (float) ((double) ecb + svv[u] * L.eb[k0 + u]);
+                        ctb = ctb + svv[u] * (double) L.cb[k0 + u];
+                    }
                 }
             }
         }
@@ -284,13 +333,13 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
             const double lg = dm_log((thr + 1.0) / (ebv + 1.0));
             L.pev[b] = numl * ((0.0 < lg) ? 0.0 : lg);
         }
-        __syncthreads();
+        wave_sync();
         if (lane == 0) {
             double pe = 0.0;
             for (int k = 0; k < MP3MI_CBANDS; k++) pe = pe - L.pev[k];
             L.pe = pe;
         }
-        __syncthreads();
+        wave_sync();
         const double pe = L.pe;
         const bool attack = !(pe < 1800.0);
 
@@ -310,7 +359,7 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
         if (lane < 21) out[rec].ratio_l[lane] = L.held_l[lane];
         if (lane < 36) out[rec].ratio_s[lane / 3][lane % 3] = L.held_s[lane];
         if (lane == 0) { out[rec].pe = pe; out[rec].block_type = bt_out; out[rec].pad = 0; }
-        __syncthreads();
+        wave_sync();
 
         if (!attack) { // long-block ratios (src/l3psy.c:671-684)
             if (lane < 21) {
@@ -331,7 +380,7 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
                         for (int j = T->part_s_covered; j < MP3MI_HBLK_S; j++) e = e + (double) es[j];
                     L.ebs[b] = e;
                 }
-                __syncthreads();
+                wave_sync();
                 if (b < MP3MI_CBANDS_S) {
                     float ecb = 0.0f;
                     for (int k = 0; k < MP3MI_CBANDS_S; k++) ecb = (float) ((double) ecb + T->s3_l[b][k] * L.ebs[k]);
@@ -339,7 +388,7 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
                     const double q = T->qthr_s[b];
                     L.thrs[b] = (q > (double) nb) ? q : (double) nb;
                 }
-                __syncthreads();
+                wave_sync();
                 if (lane < 12) {
                     const int bu = T->bu_s[lane], bo = T->bo_s[lane];
                     const double w1 = T->w1_s[lane], w2 = T->w2_s[lane];
@@ -348,10 +397,10 @@ __global__ void __launch_bounds__(64, 8) k_psy(const mp3mi_tables *__restrict__ 
                     for (int k = bu + 1; k < bo; k++) { en = en + L.ebs[k]; thm = thm + L.thrs[k]; }
                     L.held_s[lane * 3 + sblock] = (en != 0.0) ? thm / en : 0.0;
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 
     if (lane < 6) { st->r1[lane] = r1; st->p1[lane] = p1; st->r2[lane] = r2; st->p2[lane] = p2; }
@@ -370,7 +419,9 @@ void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *e
     const size_t n_rec = (size_t) g.n_streams * (size_t) g.n_gran * (size_t) g.channels;
     hipLaunchKernelGGL(k_part, dim3((unsigned) ((n_rec + 63) / 64)), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6,
                        (const mp3mi_psy_state *) psy_state, eb_all, cb_all);
-    const unsigned grid = (unsigned) (g.n_streams * g.channels);
-    hipLaunchKernelGGL(k_psy, dim3(grid), dim3(64), 0, st, T, g, eb_all, cb_all, energy_s, hist6,
-                       (mp3mi_psy_state *) psy_state, out);
+    const unsigned grid = (unsigned) ((g.n_streams * g.channels + PSY_W - 1) / PSY_W);
+    if (g.rate_idx == 0)
+        hipLaunchKernelGGL(k_psy<true>, dim3(grid), dim3(64 * PSY_W), 0, st, T, g, eb_all, cb_all, energy_s, hist6, (mp3mi_psy_state *) psy_state, out);
+    else
+        hipLaunchKernelGGL(k_psy<false>, dim3(grid), dim3(64 * PSY_W), 0, st, T, g, eb_all, cb_all, energy_s, hist6, (mp3mi_psy_state *) psy_state, out);
 }

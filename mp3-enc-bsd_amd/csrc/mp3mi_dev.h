@@ -74,6 +74,7 @@ typedef struct {
     double minval[MP3MI_CBANDS], qthr_l[MP3MI_CBANDS], norm_l[MP3MI_CBANDS];
     double qthr_s[MP3MI_CBANDS_S], exp_snr_s[MP3MI_CBANDS_S];
     double s3_l[MP3MI_CBANDS][MP3MI_CBANDS];
+    double s3_lt[MP3MI_CBANDS][MP3MI_PART_P]; /* transposed, [k][b]: what k_psy's lanes b read together at the rates with dense rows */
     int32_t s3_lo[MP3MI_CBANDS], s3_hi[MP3MI_CBANDS];
     int32_t bu_l[21], bo_l[21], bu_s[12], bo_s[12];
     double w1_l[21], w2_l[21], w1_s[12], w2_s[12];

@@ -375,6 +375,12 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
             tempy = 15.811389 + 7.5 * tempx - 17.5 * sqrt(1.0 + tempx * tempx);
             T->s3_l[i][j] = (tempy <= -60.0) ? 0.0 : exp((x + tempy) * R_LN_TO_LOG10);
         }
+    memset(T->s3_lt, 0, sizeof(T->s3_lt));
+    for (int i = 0; i < MP3MI_CBANDS; i++)
+        for (int j = 0; j < MP3MI_CBANDS; j++) T->s3_lt[j][i] = T->s3_l[i][j];
+    if (ri == 0) /* k_psy<SPARSE> keeps a row's non-zero run in PSY_S3_W = 17 LDS entries */
+        for (int i = 0; i < MP3MI_CBANDS; i++)
+            if (T_S3_HI[i] - T_S3_LO[i] + 1 > 17) return -9;
     k2 = 0;
     for (int i = 0; i < cb_s; i++) {
         T->numlines_pe[i] = T_PS_NUMLINES[ri][i]; /* the short table overwrites the long one: src/l3psy.c:868 */
@@ -601,7 +607,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
 #define MP3MI_TABLE_MEMBERS(X) \
     X(rate_idx) X(sfb_l) X(sfb_s) X(sfb_of_line_l) X(sfb_of_line_s) X(nj_first) X(nj_count) X(nj_job0) X(nj_njobs) X(nj_max) \
     X(nj_seg) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
-    X(part_s_covered) X(minval) X(qthr_l) X(norm_l) X(qthr_s) X(exp_snr_s) X(s3_l) X(s3_lo) X(s3_hi) X(bu_l) X(bo_l) X(bu_s) \
+    X(part_s_covered) X(minval) X(qthr_l) X(norm_l) X(qthr_s) X(exp_snr_s) X(s3_l) X(s3_lt) X(s3_lo) X(s3_hi) X(bu_l) X(bo_l) X(bu_s) \
     X(bo_s) X(w1_l) X(w2_l) X(w1_s) X(w2_s) X(fft_nround_l) X(fft_nround_s) X(fft_nword_l) X(fft_nword_s) X(fft_hdr_l) \
     X(fft_hdr_s) X(fft_prog_l) X(fft_prog_s) X(fft_rd_l) X(fft_rd_s) X(enwindow) X(filt) X(mdct_win) X(cos_s) X(cos_l) X(ca) \
     X(cs) X(mdct_vidx) X(mdct_nterm) X(mdct_full_row) X(mdct_small_row) X(mdct_g_ops) X(mdct_h_ops) X(mdct_vcoef) \

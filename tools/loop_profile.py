@@ -3,7 +3,7 @@ import ctypes, importlib, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 mp3 = importlib.import_module("mp3-enc-bsd_amd")
-S, nf = 4096, 48
+S, nf = 4096, (int(sys.argv[1]) if len(sys.argv) > 1 else 48)
 dev = torch.device("cuda:0")
 b = mp3.Batch(S, 44100, 2, 128, nf)
 pcm = torch.empty((S, nf * 1152 * 2), dtype=torch.int16, device=dev)
@@ -12,11 +12,15 @@ out = torch.zeros((S, b.out_stride(nf)), dtype=torch.uint8, device=dev); ln = to
 torch.cuda.synchronize()
 L = mp3.lib()
 prof = (ctypes.c_ulonglong * 8)()
-b.encode(pcm, nf, out, ln); b.sync(); L.mp3mi_debug_loop_profile(prof)
-b.encode(pcm, nf, out, ln); b.sync(); L.mp3mi_debug_loop_profile(prof)
+cbp = (ctypes.c_ulonglong * 8)()
+b.encode(pcm, nf, out, ln); b.sync(); L.mp3mi_debug_loop_profile(prof); L.mp3mi_debug_cb_profile(cbp)
+b.encode(pcm, nf, out, ln); b.sync(); L.mp3mi_debug_loop_profile(prof); L.mp3mi_debug_cb_profile(cbp)
 v = np.array(list(prof), dtype=np.float64)
 names = ["setup/load", "other(part2,search ctl)", "quantize", "count_bits", "calc_noise", "preemph+amp", "loop_break+scale", "tail"]
 for n, x in zip(names, v): print("%-26s %6.2f %%   %.3g cycles/(gr,ch)" % (n, 100 * x / v.sum(), x / (S * nf * 4)))
+cv = np.array(list(cbp), dtype=np.float64)
+for n, x in zip(["cb: runlen+count1", "cb: subdivide", "cb: region max+reduce", "cb: desc+walks", "cb: reduce+pick"], cv):
+    print("  %-24s %6.2f %% of count_bits   %.3g cycles/(gr,ch)" % (n, 100 * x / max(cv.sum(), 1), x / (S * nf * 4)))
 print("total cycles per (gr,ch) per wave: %.3g" % (v.sum() / (S * nf * 4)), b.last_timing())
 
 w = (ctypes.c_ulonglong * (2 * S))()
