@@ -43,10 +43,6 @@ struct mp3mi_batch {
     int max_frame_bytes;
     hipStream_t stream;      // front stream: feed-forward kernels (and the initial memsets)
     hipStream_t lstream;     // loop stream: k_loop + k_format
-    hipStream_t xstream;     // psy stream: k_fft k_cw k_part k_psy of the NEXT chunk, beside k_mdct / k_prep of the current one
-                             // (NULL: they run on the front stream, MP3MI_NO_XSTREAM=1)
-    hipEvent_t ev_x[2];      // the psy stage of the chunk in slot i is done
-    hipEvent_t ev_gate;      // the front stream has passed the gate of the current chunk: the psy stream may go on too
     hipEvent_t ev_front[2];  // front kernels of the chunk in slot i are done
     hipEvent_t ev_loop[2];   // k_loop of the chunk in slot i is done (slot may be overwritten)
     hipEvent_t ev_done;      // everything of the previous encode call is done
@@ -177,17 +173,13 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
         CHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         CHK(hipStreamCreateWithPriority(&b->stream, hipStreamDefault, least));
         CHK(hipStreamCreateWithPriority(&b->lstream, hipStreamDefault, greatest));
-        const char *envx = getenv("MP3MI_NO_XSTREAM");
-        if (!(envx && atoi(envx))) CHK(hipStreamCreateWithPriority(&b->xstream, hipStreamDefault, least));
     }
     for (int i = 0; i < 2; i++) {
         CHK(hipEventCreateWithFlags(&b->ev_front[i], hipEventDisableTiming));
         CHK(hipEventCreateWithFlags(&b->ev_loop[i], hipEventDisableTiming));
-        CHK(hipEventCreateWithFlags(&b->ev_x[i], hipEventDisableTiming));
     }
     CHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&b->ev_hist, hipEventDisableTiming));
-    CHK(hipEventCreateWithFlags(&b->ev_gate, hipEventDisableTiming));
     b->have_done = false;
     b->last_slot = 0;
     { const char *e = getenv("MP3MI_PREP_EXACT"); b->prep_exact = (e && atoi(e)) ? 1 : 0; }
@@ -291,19 +283,17 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     device_scope ds(b->device);
     if (b->stream) hipStreamSynchronize(b->stream);
     if (b->lstream) hipStreamSynchronize(b->lstream);
-    if (b->xstream) hipStreamSynchronize(b->xstream);
     void *bufs[] = {b->T, b->bits_per_frame, b->bitrate_index, b->energy_l, b->energy_s, b->hist6, b->fft_bins, b->cw_mid,
                     b->part_eb, b->part_cb, b->xr[0], b->xr[1], b->psy[0], b->psy[1], b->prep[0], b->prep[1], b->sbs, b->ix, b->side,
                     b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg};
     for (void *p : bufs)
         if (p) hipFree(p);
-    hipEvent_t evs[] = {b->ev0, b->ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done, b->ev_hist, b->ev_gate, b->ev_x[0], b->ev_x[1]};
+    hipEvent_t evs[] = {b->ev0, b->ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done, b->ev_hist};
     for (hipEvent_t e : evs)
         if (e) hipEventDestroy(e);
     for (size_t i = 0; i < b->loop_ev.size(); i++) hipEventDestroy(b->loop_ev[i]);
     if (b->stream) hipStreamDestroy(b->stream);
     if (b->lstream) hipStreamDestroy(b->lstream);
-    if (b->xstream) hipStreamDestroy(b->xstream);
     delete b;
 }
 
@@ -471,23 +461,15 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         g.whole_file = whole_file ? 1 : 0;
         return g;
     };
-    // Stage X (k_fft k_cw k_part k_psy) of chunk c.  With the psy stream it runs BESIDE k_mdct / k_prep of chunk c - 1
-    // (the FFTs wait on LDS, k_mdct / k_prep on memory: neither fills the SIMDs alone); ev_x[slot] marks its end.
-    hipStream_t xs = b->xstream ? b->xstream : b->stream;
     auto stage_x = [&](int c) -> int {
         const mp3mi_geom g = geom_of(c);
-        mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, xs);
+        mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
         CHK(hipGetLastError());
-        if (c >= 2) CHK(hipStreamWaitEvent(xs, b->ev_loop[c & 1], 0)); // k_loop of chunk c-2 has read this slot
-        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->part_eb, b->part_cb, b->psy[c & 1], xs);
+        if (c >= 2) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[c & 1], 0)); // k_loop of chunk c-2 has read this slot
+        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->part_eb, b->part_cb, b->psy[c & 1], b->stream);
         CHK(hipGetLastError());
-        if (b->xstream) CHK(hipEventRecord(b->ev_x[c & 1], xs));
         return MP3MI_OK;
     };
-    if (b->xstream) { // the psy stream starts behind the state reset / the previous call (front stream so far)
-        CHK(hipEventRecord(b->ev_hist, b->stream));
-        CHK(hipStreamWaitEvent(b->xstream, b->ev_hist, 0));
-    }
     if (stage_x(0) != MP3MI_OK) return MP3MI_ERR_HIP;
     for (int c = 0; c < nchunks; c++) {
         const int slot = c & 1;
@@ -495,11 +477,6 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         // ---- front stream: everything that does not depend on the bit reservoir ----
         if (c >= 1 && b->gate_count) // stage Y of this chunk runs behind k_loop(c-1), once that is resident (<= 300 us)
             mp3mi_launch_gate(b->gate_count, b->gate_total - 16u, 30000u, b->stream);
-        if (b->xstream && c >= 1) { // the psy stage of chunk c+1 becomes eligible together with stage Y of this chunk, not before:
-            CHK(hipEventRecord(b->ev_gate, b->stream)); // ahead of k_loop(c-1) its LDS-filling workgroups would keep k_loop's from starting
-            CHK(hipStreamWaitEvent(b->xstream, b->ev_gate, 0));
-        }
-        if (b->xstream) CHK(hipStreamWaitEvent(b->stream, b->ev_x[slot], 0)); // k_mdct needs this chunk's block types
         mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy[slot], b->sbs, b->xr[slot], b->debug ? b->sb_dbg : NULL, b->stream);
         CHK(hipGetLastError());
         mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->prep_exact, b->stream);
@@ -508,7 +485,6 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipEventRecord(b->ev_front[slot], b->stream));
         // ---- loop stream: the serial search and the formatter ----
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
-        if (b->xstream && c + 1 < nchunks) CHK(hipStreamWaitEvent(b->lstream, b->ev_x[(c + 1) & 1], 0)); // k_fft / k_psy cannot share the chip with k_loop
         CHK(hipEventRecord(b->loop_ev[2 * c], b->lstream));
         b->gate_total += (unsigned) S;
         mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
@@ -558,7 +534,6 @@ extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
     if (!b) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
     CHK(hipStreamSynchronize(b->stream));
-    if (b->xstream) CHK(hipStreamSynchronize(b->xstream));
     CHK(hipStreamSynchronize(b->lstream));
     CHK(hipGetLastError());
     return MP3MI_OK;
