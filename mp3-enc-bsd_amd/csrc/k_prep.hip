@@ -112,19 +112,11 @@ __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__
         S.edgeL = T->sfb_l[1];
         S.edgeS = 3 * T->sfb_s[1];
         if (!exact) {
-            // the next block's line of the spectrum is requested before the current one is walked: the walk is a
-            // chain of dependent adds, so without it every block would start with a full memory round trip
-            prep_d2 vn[PREP_BLOCK / 2];
-#pragma unroll
-            for (int q = 0; q < PREP_BLOCK / 2; q++) vn[q] = *(const prep_d2 *) (row + 2 * q);
 #pragma unroll 1
             for (int k = 0; k < 576; k += PREP_BLOCK) {
                 prep_d2 v[PREP_BLOCK / 2];
 #pragma unroll
-                for (int q = 0; q < PREP_BLOCK / 2; q++) v[q] = vn[q];
-                const int kn = k + PREP_BLOCK < 576 ? k + PREP_BLOCK : k; // (the last block is requested once more: no branch)
-#pragma unroll
-                for (int q = 0; q < PREP_BLOCK / 2; q++) vn[q] = *(const prep_d2 *) (row + kn + 2 * q);
+                for (int q = 0; q < PREP_BLOCK / 2; q++) v[q] = *(const prep_d2 *) (row + k + 2 * q);
                 // 16 = 1 mod 3: the short-block window of the block's first line cycles 0, 1, 2 (wave-uniform)
                 const int ph = k % 3;
                 if (ph == 0) prep_block<0>(T, S, v, k, shortb, live, out, lane);
