@@ -684,7 +684,6 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     __shared__ loop_lds L;
     const int lane = wave_lane();
     const int s = loop_place_stream(place, (int) gridDim.x, (int) blockIdx.x), C = geo.channels, G = 2 * geo.nf;
-    const bool quant_exact = (geo.test_flags & 8) != 0; // MP3MI_QUANT_EXACT=1: the quantiser's exact tier only (tests)
     int work = 0; // cost of this stream in this launch: 4 per quantise+count pass, 5 per distortion-loop iteration
     const int bitsPerFrame = bits_per_frame[s];
     const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256) + (geo.crc ? 16 : 0))) / 2; // src/musicin.c:729-746
@@ -867,6 +866,11 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                     g.q = next;
                                 }
                                 PROF(1);
+                                int tflags = geo.test_flags; // (read where it is used: as a flag held for the whole kernel it ends up in scratch)
+#if !defined(MP3MI_EMU)
+                                asm volatile("" : "+s"(tflags));
+#endif
+                                const bool quant_exact = (tflags & 8) != 0; // MP3MI_QUANT_EXACT=1: the quantiser's exact tier only (tests)
                                 const bool az = !quant_exact && loop_all_zero(y34max, g.q);
                                 work += 4;
                                 loop_quantize(T, L, y34, g.q, az, p, quant_exact);

@@ -136,3 +136,25 @@ def test_output_independent_of_schedule(product, monkeypatch):
     monkeypatch.setenv("MP3MI_NO_PLACE", "1")
     c = product.encode_host(pcm, rate, ch, 128, nf)
     assert a == b and a == c
+
+
+@pytest.mark.parametrize("rate,ch,kbps,S,nf,stream0", [(44100, 2, 128, 8192, 12, 0), (32000, 1, 64, 16384, 10, 0)])
+def test_batches_larger_than_the_chip(product, oracle, rate, ch, kbps, S, nf, stream0):
+    """BASELINE configs[2] and [4] at their stream counts: 8192 stereo streams are two residency rounds of k_loop (one
+    wavefront per stream, 4096 resident) with placement in both, 16 384 mono streams four; three chunks each.  A
+    256-stream sample spread over the batch is compared with the oracle (tools/full_parity.py compares all of them
+    at full length: profiles/r02_parity_config2.json, _config4.json)."""
+    import os
+    from mp3common import BatchRun
+    os.environ["MP3MI_CHUNK_FRAMES"] = "4"
+    try:
+        run = BatchRun(product, S, rate, ch, kbps, nf, stream0=stream0)
+    finally:
+        del os.environ["MP3MI_CHUNK_FRAMES"]
+    try:
+        out, lens = run.encode()
+        for s in sorted(set(np.linspace(0, S - 1, 256).astype(int).tolist())):
+            ref, _ = oracle.encode(run.pcm_of(s), rate, kbps, ch)
+            assert out[s, :lens[s]].tobytes() == ref, "stream %d of %d differs from the oracle" % (s, S)
+    finally:
+        run.close()
