@@ -206,11 +206,19 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the encoder has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (test hook: MP3MI_BENCH_ONE_GPU=1 runs every rank on device 0 over gloo, so that the multi-rank code path -- stream
+    # ranges per rank, barriers, max-over-ranks time, parity vote -- can be exercised on a one-GPU box)
+    one_gpu = os.environ.get("MP3MI_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+    cdev = torch.device("cpu") if (distributed and one_gpu) else dev  # where the collectives' tensors live
 
     mp3 = importlib.import_module("mp3-enc-bsd_amd")
     cfg_id = args.config or (2 if world == 8 else 1)
@@ -242,7 +250,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -269,7 +277,7 @@ def main():
             cpu = {"value": round(rfps, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
                    "sample": "%d of this batch's streams x %d frames, oracle/_ref/encode (unmodified reference, gcc -O2), one process per stream" % (len(idx), nf),
                    "port_value": round(fps, 1)}
-    n_bad = torch.tensor([len(bad)], dtype=torch.int64, device=dev)
+    n_bad = torch.tensor([len(bad)], dtype=torch.int64, device=cdev)
     if distributed:
         dist.all_reduce(n_bad, op=dist.ReduceOp.SUM)
     parity_ok = int(n_bad.item()) == 0
