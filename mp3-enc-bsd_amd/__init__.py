@@ -50,6 +50,12 @@ def lib():
         L.mp3mi_synth_pcm.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_synth_pcm_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.mp3mi_batch_encode_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_flush.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_reset.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.mp3mi_version.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -100,6 +106,35 @@ class Batch:
         rc = self.L.mp3mi_batch_encode(self.h, pcm.data_ptr(), n_frames, out.data_ptr(), out.shape[1], out_len.data_ptr())
         if rc != 0:
             raise Mp3miError("mp3mi_batch_encode failed with %d" % rc)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise Mp3miError("%s failed with %d" % (what, rc))
+
+    def encode_next(self, pcm, n_frames, out, out_len):
+        """Streaming: the NEXT n_frames frames of every stream (pcm holds only these); out / out_len receive the file
+        bytes that became final with this call.  Concatenate them call after call, then flush()."""
+        assert pcm.is_cuda and out.is_cuda and out_len.is_cuda and pcm.is_contiguous() and out.is_contiguous()
+        self._check(self.L.mp3mi_batch_encode_next(self.h, pcm.data_ptr(), n_frames, out.data_ptr(), out.shape[1], out_len.data_ptr()),
+                    "mp3mi_batch_encode_next")
+
+    def flush(self, out, out_len):
+        """III_FlushBitstream + close_bit_stream_w: the remaining bytes of every stream; ends the streams."""
+        self._check(self.L.mp3mi_batch_flush(self.h, out.data_ptr(), out.shape[1], out_len.data_ptr()), "mp3mi_batch_flush")
+
+    def reset(self):
+        self._check(self.L.mp3mi_batch_reset(self.h), "mp3mi_batch_reset")
+
+    def set_mode(self, mode):
+        """0 stereo, 2 dual channel, 3 mono (the reference's -m s|d|m); joint stereo is refused as in the reference"""
+        self._check(self.L.mp3mi_batch_set_mode(self.h, mode), "mp3mi_batch_set_mode")
+
+    def set_error_protection(self, on):
+        """the reference's -e: protection bit cleared, zero CRC word after the header"""
+        self._check(self.L.mp3mi_batch_set_error_protection(self.h, 1 if on else 0), "mp3mi_batch_set_error_protection")
+
+    def set_header(self, copyright=0, original=0, emphasis=0):
+        self._check(self.L.mp3mi_batch_set_header(self.h, copyright, original, emphasis), "mp3mi_batch_set_header")
 
     def sync(self):
         rc = self.L.mp3mi_batch_sync(self.h)
