@@ -239,6 +239,8 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     CHK(hipMalloc((void **) &b->out_base, sizeof(int64_t) * (size_t) n_streams));
     CHK(hipMalloc((void **) &b->carry, (size_t) MP3MI_CARRY_BYTES * (size_t) n_streams));
     CHK(hipMalloc((void **) &b->carry_len, sizeof(int32_t) * (size_t) n_streams));
+    CHK(hipMemset(b->out_base, 0, sizeof(int64_t) * (size_t) n_streams)); // a flush before the first encode delivers nothing
+    CHK(hipMemset(b->carry_len, 0, sizeof(int32_t) * (size_t) n_streams));
     b->frames_done = 0;
     b->fresh = false;
     b->sb_dbg = NULL;

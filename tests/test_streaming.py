@@ -69,3 +69,29 @@ def test_streaming_full_chip_batch_gpu(product, oracle):
             assert got[s] == oracle.encode(run.pcm_of(s), rate, kbps, ch)[0]
     finally:
         run.close()
+
+
+def test_flush_without_frames_and_argument_errors_emulated(emu):
+    """a flush right after create or after a whole-file encode delivers nothing; streaming calls check their arguments"""
+    import ctypes
+    from mp3common import BatchRun
+    run = BatchRun(emu, 2, 44100, 2, 128, 3, stream0=1)
+    try:
+        L = emu.lib
+        assert L.mp3mi_batch_flush(run.b, run.d_out, run.stride, run.d_len) == 0 and L.mp3mi_batch_sync(run.b) == 0
+        assert (run.mem.download(run.d_len, (2,), np.uint32) == 0).all()
+        out, lens = run.encode()
+        assert L.mp3mi_batch_flush(run.b, run.d_out, run.stride, run.d_len) == 0 and L.mp3mi_batch_sync(run.b) == 0
+        assert (run.mem.download(run.d_len, (2,), np.uint32) == 0).all()
+        assert L.mp3mi_batch_encode_next(run.b, run.d_pcm, 0, run.d_out, run.stride, run.d_len) == -1      # no frames
+        assert L.mp3mi_batch_encode_next(run.b, run.d_pcm, 4, run.d_out, run.stride, run.d_len) == -1      # more than max_frames
+        assert L.mp3mi_batch_encode_next(run.b, run.d_pcm, 3, run.d_out, 100, run.d_len) == -1             # row too short
+        assert L.mp3mi_batch_flush(run.b, run.d_out, 100, run.d_len) == -1
+        assert L.mp3mi_batch_reset(None) == -1
+        # abandon a stream half way, start again: the one-call bytes
+        assert L.mp3mi_batch_encode_next(run.b, run.d_pcm, 2, run.d_out, run.stride, run.d_len) == 0
+        assert L.mp3mi_batch_reset(run.b) == 0
+        got = run.encode_streaming([2, 1])
+        assert [got[s] for s in range(2)] == [out[s, :lens[s]].tobytes() for s in range(2)]
+    finally:
+        run.close()
