@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--ref-every", type=int, default=16, help="also compare every n-th stream with oracle/_ref/encode (0 = none)")
     ap.add_argument("--flags", type=int, default=0, help="MP3MI_TEST_* exact-tier bits for the GPU run")
+    ap.add_argument("--stream0", type=int, default=0, help="first stream index of the synthetic batch (other streams = other inputs)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     from mp3common import Oracle
@@ -64,7 +65,7 @@ def main():
     S, nf, C, rate = cfg["streams"], cfg["frames"], cfg["channels"], cfg["rate"]
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    wl = bench.Workload(mp3, cfg, dev, stream0=0)
+    wl = bench.Workload(mp3, cfg, dev, stream0=args.stream0)
     if args.flags:
         wl.batch.set_test_flags(args.flags)
     t0 = time.perf_counter()
@@ -110,7 +111,7 @@ def main():
     rec = {
         "config": args.config, "workload": cfg["name"], "streams": S, "frames_per_stream": nf, "frames_total": S * nf,
         "rate_hz": rate, "channels": C, "kbps": cfg["kbps"], "test_flags": args.flags,
-        "pcm": "mp3mi_synth_pcm_device, seed 0x%08x, streams 0..%d" % (bench.SEED, S - 1),
+        "pcm": "mp3mi_synth_pcm_device, seed 0x%08x, streams %d..%d" % (bench.SEED, args.stream0, args.stream0 + S - 1),
         "compared_with_oracle": S, "mismatching_streams": len(bad), "mismatches": bad[:32],
         "compared_with_reference_binary": ref_checked, "reference_binary_mismatches": ref_bad,
         "bit_exact": len(bad) == 0 and len(ref_bad) == 0,
