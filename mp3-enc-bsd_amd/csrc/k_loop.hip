@@ -52,6 +52,11 @@ struct loop_lds {
     int16_t ix[576 + 128]; // padded: the region walks read whole 64-pair steps and mask what lies past the end
     uint16_t glut[928];
     int sf_gr0[2][21];
+    // per-band state of the distortion loop, lane b = band b (long) / sfb * 3 + window (short): it is touched once per
+    // iteration, between two runs of quantise+count passes, and lives here -- not in registers -- across them
+    double band_xmin[36]; // allowed distortion (calc_xmin, doubled / pre-emphasised along the way)
+    int band_sf[36];      // scalefactors of the iteration in progress
+    int band_sfsave[36];  // and of the last iteration whose result stands (src/loop.c:505-519)
     mp3mi_loop_state st;
     mp3mi_frame_side side;
 };
@@ -143,16 +148,26 @@ MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
     return loop_estimate(y34max, LOOP_FAST_EXP2F(-0.1875f * (float) q)) < 0.999f;
 }
 
+// What a pass needs to know about the quantised values besides the values themselves (which go to L.ix): the run
+// lengths of calc_runlen for long blocks, the two region maxima of short blocks.  Taken while every value is still
+// in a register, so that the nine values of a lane are never alive across the counting.
+struct loop_qinfo {
+    int n_nz, n_big; // lines up to the last non-zero one / the last one above 1 (as line + 1; 0 = none)
+    int m1, m2;      // short blocks: this lane's maximum over lines [0, 36) / [36, 576)
+};
+
 // force_exact (MP3MI_QUANT_EXACT=1, tests): every line is settled against the exact table, whatever the estimate says.
-MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], int q, bool all_zero, int p[9], bool force_exact)
+MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], int q, bool all_zero, bool force_exact, bool shortb)
 {
     const int lane = wave_lane_here();
+    loop_qinfo qi = {0, 0, 0, 0};
     if (all_zero && !force_exact) {
 #pragma unroll
-        for (int j = 0; j < 9; j++) { p[j] = 0; L.ix[lane + 64 * j] = 0; }
+        for (int j = 0; j < 9; j++) L.ix[lane + 64 * j] = 0;
         __syncthreads();
-        return;
+        return qi;
     }
+    int p[9];
     const float cq = LOOP_FAST_EXP2F(-0.1875f * (float) q);
     // Near a table boundary a line is settled exactly.  The estimate's error is relative: < 7e-7 f from the two
     // 1-ulp roots, exp2 and two roundings, plus < 1.2e-7 f for each of the at most 17 rescalings of y34 by
@@ -187,9 +202,28 @@ MP3MI_DEVFN void loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y
             }
         }
     }
+    // Run lengths (calc_runlen, src/loop.c:1488-1520): slot j's lines are 64 j + lane, so the highest set bit of the
+    // lane mask of `p[j] != 0` in the highest non-empty slot is the answer: nine compares into scalar masks and scalar
+    // bit scans instead of 9 x (compare, select) per maximum and a wave reduction.  And the short-block maxima.
+    if (shortb) { // (a short block's big_values is 288 whatever the values: no run lengths)
 #pragma unroll
-    for (int j = 0; j < 9; j++) L.ix[lane + 64 * j] = (int16_t) p[j];
+        for (int j = 0; j < 9; j++) {
+            const int i = lane + 64 * j;
+            qi.m1 = (i < 36 && p[j] > qi.m1) ? p[j] : qi.m1;
+            qi.m2 = (i >= 36 && p[j] > qi.m2) ? p[j] : qi.m2;
+            L.ix[i] = (int16_t) p[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const unsigned long long nz = __ballot(p[j] != 0), big = __ballot(p[j] > 1);
+            qi.n_nz = nz ? 64 * j + 64 - __clzll((long long) nz) : qi.n_nz;
+            qi.n_big = big ? 64 * j + 64 - __clzll((long long) big) : qi.n_big;
+            L.ix[lane + 64 * j] = (int16_t) p[j];
+        }
+    }
     __syncthreads();
+    return qi;
 }
 
 // ---- Huffman table choice and code-length look-up, grouped ----
@@ -308,7 +342,7 @@ MP3MI_DEVFN void loop_region_cost(const loop_lds &L, const unsigned *ixw, int la
 // (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
 // Returns the Huffman bit count and fills g.  Written branch-free over the lanes: region
 // membership is a predicate, never a divergent branch.
-MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_lds &L, loop_gr &g, const int p[9], bool all_zero CBPROF_ARG)
+MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_lds &L, loop_gr &g, const loop_qinfo &qi, bool all_zero CBPROF_ARG)
 {
     CBPROF_START;
     const int lane = wave_lane_here();
@@ -326,17 +360,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         g.count1table_select = 1;
         nslot = 0;
     } else {
-        // highest line with ix != 0 and highest line with ix > 1 (as line + 1; 0 = none).  Slot j's lines are
-        // 64 j + lane, so the highest set bit of the lane mask of `p[j] != 0` in the highest non-empty slot is the
-        // answer: nine compares into scalar masks and scalar bit scans instead of 9 x (compare, select) per maximum
-        // and a wave reduction -- scalar instructions issue beside the other wavefronts' vector work.
-        int hh[2] = {0, 0};
-#pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const unsigned long long nz = __ballot(p[j] != 0), big = __ballot(p[j] > 1);
-            hh[0] = nz ? 64 * j + 64 - __clzll((long long) nz) : hh[0];
-            hh[1] = big ? 64 * j + 64 - __clzll((long long) big) : hh[1];
-        }
+        const int hh[2] = {qi.n_nz, qi.n_big}; // from the quantiser, taken while the values were in registers
         // hh[0] = n: lines up to the last non-zero one, hh[1] = b <= n: lines up to the last one above 1.  The
         // reference's i = 2 * (top / 2 + 1) is n rounded up to even (0 for n = 0); everything is non-negative,
         // so the divisions are shifts (src/loop.c:1488-1520)
@@ -399,13 +423,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     }
     if (shortb) {
         // region maxima over lines [0,36) and [36,576); pair (6m+w, 6m+3+w), m<96, w<3
-        int m1 = 0, m2 = 0;
-#pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const int i = lane + 64 * j;
-            m1 = (i < 36 && p[j] > m1) ? p[j] : m1;
-            m2 = (i >= 36 && p[j] > m2) ? p[j] : m2;
-        }
+        int m1 = qi.m1, m2 = qi.m2; // this lane's part, from the quantiser
         {
             int mv[2] = {m1, m2};
             wave_reduce_i32<0, 2>(mv);
@@ -736,24 +754,6 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 g.address2 = L.st.addr[gr][ch][1];
                 g.address3 = L.st.addr[gr][ch][2];
                 const int nband = shortb ? 36 : 21;   // band lanes
-                const int bbase = shortb ? 21 : 0;    // slot base in xmin/xfsf
-                const bool bandlane = lane < nband;
-                // band (lane) index of each of this lane's 9 lines, 6 bits each
-                unsigned long long bandpack = 0;
-                {
-                    const uint8_t *band_of_line = shortb ? T->sfb_of_line_s : T->sfb_of_line_l;
-#pragma unroll
-                    for (int j = 0; j < 9; j++) bandpack |= (unsigned long long) band_of_line[lane + 64 * j] << (6 * j);
-                }
-                int sfirst, scount, sstride;
-                loop_sum_range(R, shortb, nband, &sfirst, &scount, &sstride);
-                // calc_noise's partial-sum jobs (mp3mi_tables::nj_*): this lane's job, and for band lanes their parts
-                const int jfirst = T->nj_first[shortb][lane], jcount = T->nj_count[shortb][lane];
-                const int jmax4 = (T->nj_max[shortb] + 3) & ~3; // the longest job, in steps of four terms
-                const int jseg = T->nj_seg[shortb][lane];        // bit d: lane + d is a job of the same band
-                const int pj0 = bandlane ? T->nj_job0[shortb][lane] : 0, pn = bandlane ? T->nj_njobs[shortb][lane] : 0;
-
-                int p[9];
                 float y34[9], y34max;
                 {
                     double xr[9];
@@ -769,9 +769,12 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 PROF(0);
                 const mp3mi_prep_block *pp = &prep[rec >> 6]; // records come in blocks of 64, field by field
                 const int ps = (int) (rec & 63);
-                // per-band state lives in the band lanes' registers: allowed distortion, noise, scalefactor
-                double xmin_r = bandlane ? pp->xmin[lane][ps] : 0.0, xfsf_r = 0.0;
-                int sf_r = 0, sfsave_r = 0;
+                // per-band state (allowed distortion, scalefactors): L.band_*
+                if (lane < 36) {
+                    L.band_xmin[lane] = lane < nband ? pp->xmin[lane][ps] : 0.0;
+                    L.band_sf[lane] = 0;
+                    L.band_sfsave[lane] = 0;
+                }
                 if (lane == 0) {
                     L.st.sc_xrmax[gr][ch] = pp->sc_xrmax[ps];
                     L.st.sc_en_tot[gr][ch] = pp->sc_en_tot[ps];
@@ -836,7 +839,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 g.region0_count = 0; g.region1_count = 0; g.part2_length = 0; g.preflag = 0;
                 g.count1table_select = 0; g.q = 0;
 #pragma unroll
-                for (int j = 0; j < 9; j++) { p[j] = 0; L.ix[lane + 64 * j] = 0; }
+                for (int j = 0; j < 9; j++) L.ix[lane + 64 * j] = 0;
                 __syncthreads();
 
                 if (nonzero) {
@@ -873,9 +876,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 const bool quant_exact = (tflags & 8) != 0; // MP3MI_QUANT_EXACT=1: the quantiser's exact tier only (tests)
                                 const bool az = !quant_exact && loop_all_zero(y34max, g.q);
                                 work += 4;
-                                loop_quantize(T, L, y34, g.q, az, p, quant_exact);
+                                const loop_qinfo qi = loop_quantize(T, L, y34, g.q, az, quant_exact, shortb);
                                 PROF(2);
-                                bits = loop_count_bits(T, R, L, g, p, az CBPROF_PASS);
+                                bits = loop_count_bits(T, R, L, g, qi, az CBPROF_PASS);
                                 PROF(3);
                                 __syncthreads();
                                 if (bisect) {
@@ -889,6 +892,19 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         }
 
                         PROF(1);
+                        // ---- the distortion side of the iteration.  What it knows about "its" bands and noise jobs a
+                        //      lane fetches HERE (two 8-byte loads of packed constants, mp3mi_tables::lane_bands / lane_jobs),
+                        //      and the per-band state comes from / goes back to L.band_*: nothing of it is alive during
+                        //      the quantise+count passes above ----
+                        const bool bandlane = lane < nband;
+                        const unsigned long long bandpack = T->lane_bands[shortb][lane]; // band of each of this lane's 9 lines
+                        const unsigned long long jobs = T->lane_jobs[shortb][lane];
+                        const int jfirst = (int) (jobs & 1023ull), jcount = (int) ((jobs >> 10) & 255ull), jseg = (int) ((jobs >> 18) & 31ull);
+                        const int pj0 = (int) ((jobs >> 23) & 63ull), scount = (int) ((jobs >> 35) & 255ull), sfirst = (int) ((jobs >> 43) & 1023ull);
+                        const int sstride = shortb ? 3 : 1;
+                        const int jmax4 = (T->nj_max[shortb] + 3) & ~3; // the longest job, in steps of four terms
+                        double xmin_r = bandlane ? L.band_xmin[lane] : 0.0, xfsf_r = 0.0;
+                        int sf_r = bandlane ? L.band_sf[lane] : 0;
                         // calc_noise (src/loop.c:1007-1067).  The noise of a band is only ever COMPARED with the
                         // allowed distortion, and it is a sum of non-negative terms, so any summation order
                         // agrees with the reference's sequential one to within 2(n-1) ulp (n <= 102 lines:
@@ -904,7 +920,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 // over the sum of lane l + d where that is a job of the same band: bit of jseg) leaves
                                 // the band's sum in its first job's lane, where the band lane fetches it.  Any order
                                 // of these non-negative terms is as good as another here (see above).
-                                double v = loop_noise_jobs(T, L, noise_step, jfirst, jcount, shortb ? 3 : 1, jmax4);
+                                double v = loop_noise_jobs(T, L, noise_step, jfirst, jcount, sstride, jmax4);
 #pragma unroll
                                 for (int d = 1; d <= 16; d <<= 1) {
                                     const double o = __shfl_down(v, (unsigned) d);
@@ -916,7 +932,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             }
                             if (xfsf_exact) xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, sfirst, scount, sstride);
                         }
-                        sfsave_r = sf_r;
+                        if (bandlane) L.band_sfsave[lane] = sf_r; // the result of this iteration stands (src/loop.c:505-519)
                         save_preflag = g.preflag;
                         save_compress = g.scalefac_compress;
                         // bands whose noise exceeds the allowed distortion (bit b = band lane b)
@@ -939,10 +955,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                         xfsf_exact = true;
                                         xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, sfirst, scount, sstride);
                                     }
-                                    const unsigned long long bp = wave_opaque_u64(bandpack); // (rare block: nothing of it is hoisted)
 #pragma unroll
                                     for (int j = 0; j < 9; j++) {
-                                        const int b = (int) ((bp >> (6 * j)) & 63ull);
+                                        const int b = (int) ((bandpack >> (6 * j)) & 63ull);
                                         if (b < g.sfb_lmax) {
                                             L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * T->pretab_xr[LOOP_PRETAB[b]];
                                             y34[j] = loop_rescale34(y34[j], LOOP_PRETAB[b]);
@@ -976,6 +991,8 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                     xmin_r = xmin_r * ifqstep2;
                                     sf_r = sf_r + 1;
                                 }
+                                L.band_xmin[lane] = xmin_r; // (pre-emphasised and / or doubled, or as it was)
+                                L.band_sf[lane] = sf_r;
                             }
                             const unsigned long long ampmask = __ballot(amp); // bit b = band lane b amplified
                             over = __popcll(ampmask);
@@ -1031,7 +1048,6 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     } while (status == 0 && over > 0);
                     g.preflag = save_preflag;
                     g.scalefac_compress = save_compress;
-                    sf_r = sfsave_r;
                     g.part2_length = loop_part2_length(g, scfsi_m);
                     g.part2_3_length = g.part2_length + bits;
                 }
@@ -1060,8 +1076,11 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     o->part2_length = g.part2_length;
                     L.st.addr[gr][ch][0] = g.address1; L.st.addr[gr][ch][1] = g.address2; L.st.addr[gr][ch][2] = g.address3;
                 }
-                if (lane < 39) L.side.gr[gr][ch].scalefac[lane] = (lane < nband) ? sf_r : 0;
-                if (gr == 0 && lane < 21) L.sf_gr0[ch][lane] = shortb ? 0 : sf_r;
+                if (lane < 39) { // the scalefactors of the last iteration whose result stands (all 0 without a search)
+                    const int sfv = lane < nband ? L.band_sfsave[lane] : 0;
+                    L.side.gr[gr][ch].scalefac[lane] = sfv;
+                    if (gr == 0 && lane < 21) L.sf_gr0[ch][lane] = shortb ? 0 : sfv;
+                }
                 __syncthreads();
             }
 

@@ -62,6 +62,12 @@ typedef struct {
     uint8_t nj_count[2][64], nj_job0[2][36], nj_njobs[2][36];
     uint8_t nj_max[2];               /* the longest job */
     uint8_t nj_seg[2][64];           /* bit d (1, 2, 4, 8, 16): job j + d belongs to the same band as job j (bands have < 32 jobs) */
+    /* what lane l of k_loop needs to know about "its" lines and noise jobs, packed so that one 8-byte load each brings it in
+       where it is used (the distortion loop) instead of a dozen registers living through the whole search; [0] long, [1] short:
+       lane_bands: band (= band lane) of line l + 64 j in bits 6j .. 6j+5, j < 9;
+       lane_jobs: nj_first (10 bits) | nj_count << 10 (8) | nj_seg << 18 (5) | nj_job0 << 23 (6) | nj_njobs << 29 (6) |
+                  lines of band l << 35 (8) | first line of band l << 43 (10; short: l = sfb * 3 + window -> first * 3 + window) */
+    uint64_t lane_bands[2][64], lane_jobs[2][64];
     /* subdivide (src/loop.c:1596-1706) for blocks without window switching, by big_values:
        region0_count | region1_count << 4 | address1 << 8 | address2 << 18 (tables_host.cpp) */
     uint32_t subdiv_lut[289];

@@ -344,6 +344,24 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
         }
     }
 
+    for (int t = 0; t < 2; t++) { /* k_loop's per-lane constants (mp3mi_dev.h) */
+        const int nb = t ? 36 : 21;
+        for (int l = 0; l < 64; l++) {
+            uint64_t bp = 0;
+            for (int j = 0; j < 9; j++) bp |= (uint64_t) (t ? T->sfb_of_line_s[l + 64 * j] : T->sfb_of_line_l[l + 64 * j]) << (6 * j);
+            T->lane_bands[t][l] = bp;
+            uint64_t first = 0, count = 0;
+            if (l < nb) {
+                if (t) { const int sfb = l / 3, w = l % 3; first = (uint64_t) (SFB_S[ri][sfb] * 3 + w); count = (uint64_t) (SFB_S[ri][sfb + 1] - SFB_S[ri][sfb]); }
+                else { first = (uint64_t) SFB_L[ri][l]; count = (uint64_t) (SFB_L[ri][l + 1] - SFB_L[ri][l]); }
+            }
+            if (count > 255 || first > 1023 || T->nj_first[t][l] > 1023 || T->nj_first[t][l] < 0) return -10;
+            T->lane_jobs[t][l] = (uint64_t) T->nj_first[t][l] | ((uint64_t) T->nj_count[t][l] << 10) | ((uint64_t) (T->nj_seg[t][l] & 31) << 18) |
+                                 ((uint64_t) (l < nb ? T->nj_job0[t][l] : 0) << 23) | ((uint64_t) (l < nb ? T->nj_njobs[t][l] : 0) << 29) |
+                                 (count << 35) | (first << 43);
+        }
+    }
+
     for (unsigned i = 0; i < 1024; i++) T->window[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 1024)));
     for (unsigned i = 0; i < 256; i++) T->window_s[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 256)));
 
@@ -606,7 +624,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
  * different stream.  MP3MI_TABLE_PINS=off skips the check (used only to generate the pins). */
 #define MP3MI_TABLE_MEMBERS(X) \
     X(rate_idx) X(sfb_l) X(sfb_s) X(sfb_of_line_l) X(sfb_of_line_s) X(nj_first) X(nj_count) X(nj_job0) X(nj_njobs) X(nj_max) \
-    X(nj_seg) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
+    X(nj_seg) X(lane_bands) X(lane_jobs) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
     X(part_s_covered) X(minval) X(qthr_l) X(norm_l) X(qthr_s) X(exp_snr_s) X(s3_l) X(s3_lt) X(s3_lo) X(s3_hi) X(bu_l) X(bo_l) X(bu_s) \
     X(bo_s) X(w1_l) X(w2_l) X(w1_s) X(w2_s) X(fft_nround_l) X(fft_nround_s) X(fft_nword_l) X(fft_nword_s) X(fft_hdr_l) \
     X(fft_hdr_s) X(fft_prog_l) X(fft_prog_s) X(fft_rd_l) X(fft_rd_s) X(enwindow) X(filt) X(mdct_win) X(cos_s) X(cos_l) X(ca) \
