@@ -42,15 +42,15 @@ struct loop_gr { // wave-uniform working copy of gr_info (src/l3side.h:60-87)
     int sfb_lmax, sfb_smax, address1, address2, address3, q;
 };
 
-// 9.7 KB per wavefront: 16 single-wave workgroups fit the 160 KB of a CU, i.e. 4 waves per SIMD,
-// which is what 4096 streams on 256 CUs need to be resident all at once.
+// 7.6 KB per wavefront plus one 1.9 KB copy of the code-length tables per workgroup of LOOP_W = 4 wavefronts: the 16
+// wavefronts per CU that 4096 streams on 256 CUs need take 129 KB of its 160 KB of LDS, and at 80 VGPRs 320 of a SIMD's
+// 512 registers -- the feed-forward kernels of the next chunk find room beside them (batch.cpp).
 struct loop_lds {
     double xr[576 + 1]; // the granule's spectrum (amplified in place; [576] = 0: the line a finished noise job
                       // reads on, ix[576] = 0 too): kept here, not in registers, because the
                       // quantise/count passes only need |xr|^(3/4) (registers) and the 18 VGPRs decide
                       // between 4 wavefronts per SIMD with and without scratch spills
     int16_t ix[576 + 128]; // padded: the region walks read whole 64-pair steps and mask what lies past the end
-    uint16_t glut[928];
     int sf_gr0[2][21];
     // per-band state of the distortion loop, lane b = band b (long) / sfb * 3 + window (short): it is touched once per
     // iteration, between two runs of quantise+count passes, and lives here -- not in registers -- across them
@@ -58,8 +58,15 @@ struct loop_lds {
     int band_sf[36];      // scalefactors of the iteration in progress
     int band_sfsave[36];  // and of the last iteration whose result stands (src/loop.c:505-519)
     mp3mi_loop_state st;
-    mp3mi_frame_side side;
+    // of the frame's side information only what a later granule or the end of the frame reads back; the records
+    // themselves go straight to memory
+    int p23[2][2];      // part2_3_length (ResvFrameEnd adds the stuffing bits, src/reservoir.c:190-224)
+    int preflag0[2];    // granule 0's preflag (src/loop.c:1172-1176)
 };
+
+// Wavefronts (streams) per workgroup.  They share nothing but the code-length tables in LDS (1.9 KB that every stream
+// would otherwise hold a copy of) and synchronise only per wavefront.
+#define LOOP_W 4
 
 // one entry per lane, read with wave_readlane_i32(reg, uniform index)
 struct loop_regs {
@@ -87,7 +94,7 @@ __device__ unsigned long long g_cb_prof[8]; // phases inside loop_count_bits
 #define CBPROF_PASS , cb_acc
 #define CBPROF_START unsigned long long cb_t = __builtin_amdgcn_s_memtime()
 #define CBPROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); cbp[i] += n_ - cb_t; cb_t = n_; } while (0)
-#define PROF_DECL unsigned long long cb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (wave_lane() == 0 && blockIdx.x < 65536) g_loop_start[blockIdx.x] = __builtin_amdgcn_s_memrealtime()
+#define PROF_DECL unsigned long long cb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (wave_lane() == 0 && block < 65536) g_loop_start[block] = __builtin_amdgcn_s_memrealtime()
 #define PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
 #define PROF_END do { if (lane == 0) { for (int i_ = 0; i_ < 8; i_++) { atomicAdd(&g_loop_prof[i_], prof_acc[i_]); atomicAdd(&g_cb_prof[i_], cb_acc[i_]); } \
     if (s < 65536) { unsigned long long tot_ = 0; for (int i_ = 0; i_ < 8; i_++) tot_ += prof_acc[i_]; g_loop_wave[2 * s] = tot_; \
@@ -164,7 +171,7 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
     if (all_zero && !force_exact) {
 #pragma unroll
         for (int j = 0; j < 9; j++) L.ix[lane + 64 * j] = 0;
-        __syncthreads();
+        wave_sync();
         return qi;
     }
     int p[9];
@@ -222,7 +229,7 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
             L.ix[lane + 64 * j] = (int16_t) p[j];
         }
     }
-    __syncthreads();
+    wave_sync();
     return qi;
 }
 
@@ -275,12 +282,12 @@ MP3MI_DEVFN void loop_desc_init(const mp3mi_tables *T, int cls, int *desc_a, int
 // code lengths of pair (x, y), sign bits included (glut) and the linbits of src/loop.c:172-225 added,
 // for the (up to) three tables of a group, spread to 10-bit fields.
 // da/db: the group's descriptor words (may differ per lane).
-MP3MI_DEVFN int loop_pair_cost3(const loop_lds &L, int da, int db, int x, int y)
+MP3MI_DEVFN int loop_pair_cost3(const uint16_t *GL, int da, int db, int x, int y)
 {
     const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
     const int nesc = (x > 14) + (y > 14);
     const int ylen = (da >> 15) & 31, lb = ((da >> 20) & 15) | (((da >> 24) & 15) << 10);
-    const int e = L.glut[db + xc * ylen + yc];
+    const int e = GL[db + xc * ylen + yc];
     const int spread = (e & 31) | (((e >> 5) & 31) << 10) | (((e >> 10) & 31) << 20);
     return spread + nesc * lb;
 }
@@ -305,7 +312,7 @@ MP3MI_DEVFN int loop_pick(int da, int s0, int s1, int s2, int *sum)
 // *a01 = candidate 0 | candidate 1 << 16, *a2 = third candidate.  Walks 64 pairs per step straight out of
 // L.ix.  ESC: the group's tables have linbits (x or y > 14 then costs them); NC3: it has a third candidate.
 template <bool ESC, bool NC3>
-MP3MI_DEVFN void loop_region_walk(const loop_lds &L, const unsigned *ixw, int lane, int lo, int hi, int dA, int dB, int *a01, int *a2)
+MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int lane, int lo, int hi, int dA, int dB, int *a01, int *a2)
 {
     const int ylen = (dA >> 15) & 31, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
     int s01 = 0, s2 = 0;
@@ -317,7 +324,7 @@ MP3MI_DEVFN void loop_region_walk(const loop_lds &L, const unsigned *ixw, int la
         const unsigned xy = ixw[w];
         const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
         const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
-        const int e = L.glut[(dB + xc * ylen + yc) & in];
+        const int e = GL[(dB + xc * ylen + yc) & in];
         int c = (e & 31) | (((e >> 5) & 31) << 16);
         if (ESC) c += ((x > 14) + (y > 14)) * lb01;
         s01 += c & in;
@@ -327,22 +334,22 @@ MP3MI_DEVFN void loop_region_walk(const loop_lds &L, const unsigned *ixw, int la
     *a2 = s2;
 }
 
-MP3MI_DEVFN void loop_region_cost(const loop_lds &L, const unsigned *ixw, int lane, int lo, int hi, int m, int dA, int dB, int *a01, int *a2)
+MP3MI_DEVFN void loop_region_cost(const uint16_t *GL, const unsigned *ixw, int lane, int lo, int hi, int m, int dA, int dB, int *a01, int *a2)
 {
     *a01 = 0;
     *a2 = 0;
     if (m == 0) return; // no table, no bits (src/loop.c:1771-1777)
     const bool esc = (dA >> 20) != 0, nc3 = ((dA >> 10) & 31) != 0; // tables with linbits never come in threes
-    if (esc) loop_region_walk<true, false>(L, ixw, lane, lo, hi, dA, dB, a01, a2);
-    else if (nc3) loop_region_walk<false, true>(L, ixw, lane, lo, hi, dA, dB, a01, a2);
-    else loop_region_walk<false, false>(L, ixw, lane, lo, hi, dA, dB, a01, a2);
+    if (esc) loop_region_walk<true, false>(GL, ixw, lane, lo, hi, dA, dB, a01, a2);
+    else if (nc3) loop_region_walk<false, true>(GL, ixw, lane, lo, hi, dA, dB, a01, a2);
+    else loop_region_walk<false, false>(GL, ixw, lane, lo, hi, dA, dB, a01, a2);
 }
 
 // calc_runlen + count1_bitcount + subdivide + bigv_tab_select + bigv_bitcount
 // (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
 // Returns the Huffman bit count and fills g.  Written branch-free over the lanes: region
 // membership is a predicate, never a divergent branch.
-MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_lds &L, loop_gr &g, const loop_qinfo &qi, bool all_zero CBPROF_ARG)
+MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_lds &L, const uint16_t *GL, loop_gr &g, const loop_qinfo &qi, bool all_zero CBPROF_ARG)
 {
     CBPROF_START;
     const int lane = wave_lane_here();
@@ -380,7 +387,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
             const int w0 = in ? g.big_values + 2 * qd : 0;
             const unsigned a = ixw[w0], b = ixw[w0 + 1];
             const int pp = (int) ((a & 1u) | ((a >> 15) & 2u) | ((b & 1u) << 2) | ((b >> 13) & 8u));
-            const int e = L.glut[GL_C1 + pp]; // code length + sign bits: table A | table B << 5
+            const int e = GL[GL_C1 + pp]; // code length + sign bits: table A | table B << 5
             const int c = (e & 31) | ((e >> 5) << 16);
             s01 += in ? c : 0;
         }
@@ -443,7 +450,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
             const int m = in ? pr / 3 : 0, w = in ? pr - 3 * m : 0;
             const int x = L.ix[6 * m + w], y = L.ix[6 * m + 3 + w];
             const bool first = m < 6;
-            const int c = loop_pair_cost3(L, first ? da0 : da1, first ? db0 : db1, x, y) & 0x3ff;
+            const int c = loop_pair_cost3(GL, first ? da0 : da1, first ? db0 : db1, x, y) & 0x3ff;
             sum += (in && (first ? t0 : t1)) ? c : 0;
         }
         return wave_sum_i32(sum);
@@ -501,9 +508,9 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     // Per region two partial sums per lane: candidates 0 and 1 in the halves of one word (the layout the
     // reduction wants), the third candidate -- only the groups {7,8,9} and {10,11,12} have one -- in another.
     int s01p[3], s2p[3];
-    loop_region_cost(L, ixw, lane, 0, a1, m0, da[0], db[0], &s01p[0], &s2p[0]);
-    loop_region_cost(L, ixw, lane, a1, a2, m1, da[1], db[1], &s01p[1], &s2p[1]);
-    loop_region_cost(L, ixw, lane, a2, e2, m2, da[2], db[2], &s01p[2], &s2p[2]);
+    loop_region_cost(GL, ixw, lane, 0, a1, m0, da[0], db[0], &s01p[0], &s2p[0]);
+    loop_region_cost(GL, ixw, lane, a1, a2, m1, da[1], db[1], &s01p[1], &s2p[1]);
+    loop_region_cost(GL, ixw, lane, a2, e2, m2, da[2], db[2], &s01p[2], &s2p[2]);
     CBPROF(3); // descriptors + region walks
     const bool third = (((da[0] | da[1] | da[2]) >> 10) & 31) != 0; // (descriptors of empty regions are zero)
     int s2v[3] = {0, 0, 0};
@@ -691,17 +698,24 @@ void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st)
     hipLaunchKernelGGL(k_rank, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, cost, order, n);
 }
 
-__global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
-                                                const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
-                                                const mp3mi_prep_block *__restrict__ prep,
-                                                const int32_t *__restrict__ bits_per_frame,
-                                                mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
-                                                mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
-                                                mp3mi_loop_place place)
+__global__ void __launch_bounds__(64 * LOOP_W) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+                                                      const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
+                                                      const mp3mi_prep_block *__restrict__ prep,
+                                                      const int32_t *__restrict__ bits_per_frame,
+                                                      mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
+                                                      mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
+                                                      mp3mi_loop_place place)
 {
-    __shared__ loop_lds L;
+    __shared__ loop_lds LL[LOOP_W];
+    __shared__ uint16_t GL[928]; // code lengths grouped as new_choose_table compares them (mp3mi_tables::glut)
     const int lane = wave_lane();
-    const int s = loop_place_stream(place, (int) gridDim.x, (int) blockIdx.x), C = geo.channels, G = 2 * geo.nf;
+    const int wv = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
+    loop_lds &L = LL[wv];
+    for (int i = (int) threadIdx.x; i < 928; i += 64 * LOOP_W) GL[i] = T->glut[i];
+    __syncthreads(); // the workgroup's only barrier; from here on every wavefront is on its own
+    const int block = (int) blockIdx.x * LOOP_W + wv; // one wavefront per stream
+    if (block >= geo.n_streams) return;
+    const int s = loop_place_stream(place, geo.n_streams, block), C = geo.channels, G = 2 * geo.nf;
     int work = 0; // cost of this stream in this launch: 4 per quantise+count pass, 5 per distortion-loop iteration
     const int bitsPerFrame = bits_per_frame[s];
     const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256) + (geo.crc ? 16 : 0))) / 2; // src/musicin.c:729-746
@@ -711,7 +725,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     if (gate_count && lane == 0) atomicAdd(gate_count, 1u);
 #if !defined(MP3MI_EMU)
     // this wavefront is on the critical path of the whole batch: let it issue ahead of the
-    // feed-forward kernels of the next chunk that fill the chip behind it (batch.cpp); adjusted
+    // feed-forward kernels of the next chunk that run beside it (batch.cpp); adjusted
     // per frame by the pacing below
     __builtin_amdgcn_s_setprio(2);
 #endif
@@ -721,11 +735,10 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
     R.sfb_s = (lane < 14) ? T->sfb_s[lane] : 192;
     loop_desc_init(T, lane, &R.desc_a, &R.desc_b);
 
-    for (int i = lane; i < 928; i += 64) L.glut[i] = T->glut[i];
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];
     if (lane < 8) L.ix[576 + lane] = 0;
     if (lane == 0) L.xr[576] = 0.0;
-    __syncthreads();
+    wave_sync();
 
     // ragged batch: frames of this stream beyond its last (zero-filled) one are not encoded
     const int nf_s = geo.n_samples ? loop_frames_here(geo, geo.n_samples[s]) : geo.nf;
@@ -736,7 +749,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
         if (ResvMax > 4088) ResvMax = 4088;
         const int main_data_begin = ResvSize / 8;
         int resvDrain = 0;
-        __syncthreads();
+        wave_sync();
 
         for (int gr = 0; gr < 2; gr++)
             for (int ch = 0; ch < C; ch++) {
@@ -785,7 +798,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 }
                 const int nonzero = pp->nonzero[ps];
                 int scfsi_m = 0; // this granule's scfsi bits (wave-uniform): what the search asks for between passes
-                __syncthreads();
+                wave_sync();
                 if (gr == 1) {
                     int condition = 0;
                     for (int gr2 = 0; gr2 < 2; gr2++) {
@@ -807,12 +820,11 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                             const int s0 = wave_sum_i32(in ? d : 0), s1 = wave_sum_i32(in ? dx : 0);
                             const int v = (s0 < 10 && s1 < 10) ? 1 : 0;
                             scfsi_m |= v << band;
-                            if (lane == 0) L.side.scfsi[ch][band] = v;
                         }
-                    } else if (lane < 4)
-                        L.side.scfsi[ch][lane] = 0;
+                    }
+                    if (lane < 4) side_out[(size_t) s * geo.nf + fl].scfsi[ch][lane] = (scfsi_m >> lane) & 1; // (always decided in granule 1)
                 }
-                __syncthreads();
+                wave_sync();
 
                 // ---- ResvMaxBits (src/reservoir.c:101-134) ----
                 int max_bits;
@@ -840,7 +852,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                 g.count1table_select = 0; g.q = 0;
 #pragma unroll
                 for (int j = 0; j < 9; j++) L.ix[lane + 64 * j] = 0;
-                __syncthreads();
+                wave_sync();
 
                 if (nonzero) {
                     g.q = pp->q0[ps]; // quantanf_init (src/loop.c:369-402), from k_prep
@@ -878,9 +890,9 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 work += 4;
                                 const loop_qinfo qi = loop_quantize(T, L, y34, g.q, az, quant_exact, shortb);
                                 PROF(2);
-                                bits = loop_count_bits(T, R, L, g, qi, az CBPROF_PASS);
+                                bits = loop_count_bits(T, R, L, GL, g, qi, az CBPROF_PASS);
                                 PROF(3);
-                                __syncthreads();
+                                wave_sync();
                                 if (bisect) {
                                     if (bits > max_bits) top = next; else bot = next;
                                     if (bits != max_bits && abs(last - next) > 1) continue;
@@ -943,7 +955,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                         {
                             bool skip = false;
                             if (scfsi_m) {
-                                g.preflag = L.side.gr[0][ch].preflag;
+                                g.preflag = L.preflag0[ch];
                                 skip = true;
                             }
                             if (!skip && g.block_type != 2 && g.preflag == 0) {
@@ -967,7 +979,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 }
                             }
                         }
-                        __syncthreads();
+                        wave_sync();
 
                         // amp_scalefac_bands (src/loop.c:1225-1350)
                         {
@@ -1015,7 +1027,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                                 y34max = y34max * LOOP_Y34MAX_GROW;
                             }
                         }
-                        __syncthreads(); // amplified lines in L.xr are read by other lanes' noise sums
+                        wave_sync(); // amplified lines in L.xr are read by other lanes' noise sums
 
                         PROF(5);
                         // loop_break (src/loop.c:1131-1152) then scale_bitcount (src/loop.c:792-860)
@@ -1064,24 +1076,28 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
                     if (L.xr[lane + 64 * j] < 0 && v > 0) v = -v;
                     ix_out[rec * 576 + lane + 64 * j] = (int16_t) v;
                 }
-                if (lane == 0) {
-                    mp3mi_gr_side *o = &L.side.gr[gr][ch];
-                    o->part2_3_length = g.part2_3_length; o->big_values = g.big_values; o->count1 = g.count1;
-                    o->global_gain = global_gain; o->scalefac_compress = g.scalefac_compress;
-                    o->window_switching_flag = g.wsf; o->block_type = g.block_type;
-                    o->table_select[0] = g.table_select[0]; o->table_select[1] = g.table_select[1];
-                    o->table_select[2] = g.table_select[2];
-                    o->region0_count = g.region0_count; o->region1_count = g.region1_count;
-                    o->preflag = g.preflag; o->count1table_select = g.count1table_select;
-                    o->part2_length = g.part2_length;
-                    L.st.addr[gr][ch][0] = g.address1; L.st.addr[gr][ch][1] = g.address2; L.st.addr[gr][ch][2] = g.address3;
+                {
+                    mp3mi_gr_side *o = &side_out[(size_t) s * geo.nf + fl].gr[gr][ch]; // straight to memory
+                    if (lane == 0) {
+                        o->part2_3_length = g.part2_3_length; o->big_values = g.big_values; o->count1 = g.count1;
+                        o->global_gain = global_gain; o->scalefac_compress = g.scalefac_compress;
+                        o->window_switching_flag = g.wsf; o->block_type = g.block_type;
+                        o->table_select[0] = g.table_select[0]; o->table_select[1] = g.table_select[1];
+                        o->table_select[2] = g.table_select[2];
+                        o->region0_count = g.region0_count; o->region1_count = g.region1_count;
+                        o->preflag = g.preflag; o->count1table_select = g.count1table_select;
+                        o->part2_length = g.part2_length;
+                        L.p23[gr][ch] = g.part2_3_length;
+                        if (gr == 0) L.preflag0[ch] = g.preflag;
+                        L.st.addr[gr][ch][0] = g.address1; L.st.addr[gr][ch][1] = g.address2; L.st.addr[gr][ch][2] = g.address3;
+                    }
+                    if (lane < 39) { // the scalefactors of the last iteration whose result stands (all 0 without a search)
+                        const int sfv = lane < nband ? L.band_sfsave[lane] : 0;
+                        o->scalefac[lane] = sfv;
+                        if (gr == 0 && lane < 21) L.sf_gr0[ch][lane] = shortb ? 0 : sfv;
+                    }
                 }
-                if (lane < 39) { // the scalefactors of the last iteration whose result stands (all 0 without a search)
-                    const int sfv = lane < nband ? L.band_sfsave[lane] : 0;
-                    L.side.gr[gr][ch].scalefac[lane] = sfv;
-                    if (gr == 0 && lane < 21) L.sf_gr0[ch][lane] = shortb ? 0 : sfv;
-                }
-                __syncthreads();
+                wave_sync();
             }
 
         // ---- ResvFrameEnd (src/reservoir.c:155-226) ----
@@ -1093,33 +1109,33 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
             int stuffingBits = over_bits;
             if ((over_bits = ResvSize % 8)) { stuffingBits += over_bits; ResvSize -= over_bits; }
             if (lane == 0) {
+                bool moved = false; // some part2_3_length took stuffing bits: the records in memory follow
                 if (stuffingBits) {
-                    if (L.side.gr[0][0].part2_3_length + stuffingBits < 4095)
-                        L.side.gr[0][0].part2_3_length += stuffingBits;
+                    moved = true;
+                    if (L.p23[0][0] + stuffingBits < 4095)
+                        L.p23[0][0] += stuffingBits;
                     else {
                         for (int gr = 0; gr < 2; gr++)
                             for (int ch = 0; ch < C; ch++) {
                                 if (stuffingBits == 0) break;
-                                const int extra = 4095 - L.side.gr[gr][ch].part2_3_length;
+                                const int extra = 4095 - L.p23[gr][ch];
                                 const int now = extra < stuffingBits ? extra : stuffingBits;
-                                L.side.gr[gr][ch].part2_3_length += now;
+                                L.p23[gr][ch] += now;
                                 stuffingBits -= now;
                             }
                         resvDrain = stuffingBits;
                     }
                 }
-                L.side.main_data_begin = main_data_begin;
-                L.side.resvDrain = resvDrain;
+                mp3mi_frame_side *o = &side_out[(size_t) s * geo.nf + fl];
+                if (moved)
+                    for (int gr = 0; gr < 2; gr++)
+                        for (int ch = 0; ch < C; ch++) o->gr[gr][ch].part2_3_length = L.p23[gr][ch];
+                o->main_data_begin = main_data_begin;
+                o->resvDrain = resvDrain;
                 L.st.ResvSize = ResvSize;
             }
         }
-        __syncthreads();
-        {
-            const int ln = wave_lane_here(); // (addresses derived from the lane index are rebuilt here, once per frame, not carried)
-            int *dst = (int *) &side_out[(size_t) s * geo.nf + fl];
-            for (int i = ln; i < (int) (sizeof(mp3mi_frame_side) / 4); i += 64) dst[i] = ((const int *) &L.side)[i];
-        }
-        __syncthreads();
+        wave_sync();
 #if !defined(MP3MI_EMU)
         // Pacing: the kernel ends when its slowest stream ends, and streams differ by up to 1.5x in
         // work.  gate_count[1] counts the frames finished by all streams of this launch; a stream
@@ -1127,7 +1143,7 @@ __global__ void __launch_bounds__(64, 4) k_loop(const mp3mi_tables *__restrict__
         // wavefronts of its SIMD), a stream ahead of it lowers it.  Purely a scheduling hint.
         if (gate_count) {
             const unsigned done_all = __builtin_amdgcn_readfirstlane((int) (lane == 0 ? atomicAdd(gate_count + 1, 1u) + 1u : 0u));
-            int n_waves = (int) gridDim.x;
+            int n_waves = geo.n_streams;
             asm volatile("" : "+s"(n_waves)); // converted here, once per frame, instead of living in a register for the whole kernel
             const float lead = (float) (fl + 1) - (float) done_all / (float) n_waves;
             if (lead < -1.0f) __builtin_amdgcn_s_setprio(3);
@@ -1187,7 +1203,7 @@ void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double 
                        const mp3mi_prep_block *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
                        mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_loop, dim3((unsigned) g.n_streams), dim3(64), 0, st, T, g, xr, psy, prep, bits_per_frame,
+    hipLaunchKernelGGL(k_loop, dim3((unsigned) ((g.n_streams + LOOP_W - 1) / LOOP_W)), dim3(64 * LOOP_W), 0, st, T, g, xr, psy, prep, bits_per_frame,
                        (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
 }
 
