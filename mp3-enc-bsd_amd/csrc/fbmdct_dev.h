@@ -12,14 +12,17 @@
 #define MP3MI_FBMDCT_DEV_H
 #include "mp3mi_host.h"
 
-// 17.3 KB per wavefront
+// 13.1 KB per wavefront: twelve fit a CU (three per SIMD), or two beside k_loop's sixteen
 struct mdct_lds {
     union {
         double in[36][32]; // [k][band]: 18 slots of the previous granule, then 18 of the current one (sign-flipped
                            // like mdct_sub does); for a long block already multiplied by win[0][k]
-        double xr[576];    // the result takes their place
+        struct {
+            double xr[576];    // the result takes the place of the first half of the inputs,
+            double V[32][26];  // the long-block operand groups per band that of the second half and beyond: a lane
+                               // holds its groups in registers until every lane has read its inputs (mdct_granule)
+        };
     };
-    double V[32][27];      // long-block operand groups per band (26 used; odd stride spreads the banks)
     double win[4][36];
     double cos_s[6][12];
     double scoef[6][6];    // the six short output rows of the long-block transform (2 or 6 terms): coefficients,
@@ -94,15 +97,22 @@ MP3MI_DEVFN void mdct_load_inputs(mdct_lds &L, const double *prev, const double 
     mdct_store_inputs(L, vp, vc, bt);
 }
 
-// ordered signed sum of windowed inputs: ops[i] = index | 0x80 (subtract / negate)
+// ordered signed sum of windowed inputs: ops[i] = index | 0x80 (subtract / negate).  Six operands are fetched at a
+// time (the sum itself is one chain in the reference's order): eighteen at once would hold 36 registers.
 template <int N> MP3MI_DEVFN double mdct_group(const mdct_lds &L, int band, const uint8_t *ops)
 {
-    double f[N];
+    double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < N; i++) f[i] = L.in[ops[i] & 0x3f][band];
-    double acc = (ops[0] & 0x80) ? -f[0] : f[0];
+    for (int i0 = 0; i0 < N; i0 += 6) {
+        double f[6];
 #pragma unroll
-    for (int i = 1; i < N; i++) acc = (ops[i] & 0x80) ? acc - f[i] : acc + f[i];
+        for (int i = 0; i < 6; i++) f[i] = L.in[ops[i0 + i] & 0x3f][band];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            if (i0 + i == 0) acc = (ops[0] & 0x80) ? -f[0] : f[0];
+            else acc = (ops[i0 + i] & 0x80) ? acc - f[i] : acc + f[i];
+        }
+    }
     return acc;
 }
 
@@ -113,18 +123,24 @@ MP3MI_DEVFN void mdct_granule(mdct_lds &L, const mdct_regs &R, const mp3mi_table
     if (bt == 0) { // long window (src/mdct.c:199-509)
         { // phase A: the 26 operand groups of every band; lane = band*2 + h, h picks the half of the list
             const int band = lane >> 1, h = lane & 1;
-            double a[9], b[9];
+            double pq[9], g[4];
 #pragma unroll
-            for (int j = 0; j < 9; j++) {
-                a[j] = L.in[h ? 18 + j : j][band];
-                b[j] = L.in[h ? 35 - j : 17 - j][band];
+            for (int j0 = 0; j0 < 9; j0 += 3) { // (three pairs at a time: registers)
+                double a[3], b[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    a[j] = L.in[h ? 18 + j0 + j : j0 + j][band];
+                    b[j] = L.in[h ? 35 - j0 - j : 17 - j0 - j][band];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; j++) pq[j0 + j] = h ? a[j] + b[j] : a[j] - b[j];
             }
-            double g[4];
 #pragma unroll
             for (int c = 0; c < 3; c++) g[c] = mdct_group<6>(L, band, L.g_ops[3 * h + c]);
             g[3] = mdct_group<18>(L, band, L.h_ops[h]);
+            __syncthreads(); // every lane has read its inputs: the groups may take their place
 #pragma unroll
-            for (int j = 0; j < 9; j++) L.V[band][9 * h + j] = h ? a[j] + b[j] : a[j] - b[j];
+            for (int j = 0; j < 9; j++) L.V[band][9 * h + j] = pq[j];
 #pragma unroll
             for (int c = 0; c < 3; c++) L.V[band][18 + 3 * h + c] = g[c];
             L.V[band][24 + h] = g[3];
@@ -133,12 +149,15 @@ MP3MI_DEVFN void mdct_granule(mdct_lds &L, const mdct_regs &R, const mp3mi_table
         // phase B: every output is the ordered sum of its terms V * coefficient (src/mdct.c:199-509)
         if (lane < 60) { // the twelve rows over all 18 pair groups
             for (int band = R.grp; band < 32; band += 5) {
-                double pr[18];
+                double sum = 0.0; // (six operands in flight at a time, one chain in the reference's order)
 #pragma unroll
-                for (int t = 0; t < 18; t++) pr[t] = L.V[band][t];
-                double sum = pr[0] * R.coef[0];
+                for (int t0 = 0; t0 < 18; t0 += 6) {
+                    double pr[6];
 #pragma unroll
-                for (int t = 1; t < 18; t++) sum = sum + pr[t] * R.coef[t];
+                    for (int t = 0; t < 6; t++) pr[t] = L.V[band][t0 + t];
+#pragma unroll
+                    for (int t = 0; t < 6; t++) sum = (t0 + t == 0) ? pr[0] * R.coef[0] : sum + pr[t] * R.coef[t0 + t];
+                }
                 L.xr[band * 18 + R.m_full] = sum;
             }
         }

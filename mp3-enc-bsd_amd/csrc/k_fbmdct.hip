@@ -113,9 +113,11 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
 
 // One wavefront transforms a run of MDCT_RUN consecutive granules of one (stream, channel): the tables are
 // set up once, every granule's subband samples are read once (the current granule is the next one's
-// "previous"), and the next granule's samples are requested before the current one is transformed.
+// "previous"), and the next granule's samples are requested before the current one is transformed -- into the
+// registers the previous granule's just left.  168 VGPRs and 13 KB of LDS: the kernel fits beside k_loop's
+// resident wavefronts (batch.cpp).
 #define MDCT_RUN 11
-__global__ void __launch_bounds__(64, 2) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+__global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ sbs, const mp3mi_psy_out *__restrict__ psy,
                                                 double *__restrict__ xr_out)
 {
@@ -131,26 +133,26 @@ __global__ void __launch_bounds__(64, 2) k_mdct(const mp3mi_tables *__restrict__
     const int btv = lane < n ? psy[rec0 + (size_t) lane * C].block_type : 0;
     const size_t pitch = (size_t) C * 576;
     const double *blk = sbs + (((size_t) s * (G + 1) + g_lo) * C + ch) * 576; // granule slot g_lo: the one before granule g_lo
-    double vp[9], vc[9], vn[9];
+    double vp[9], vc[9];
 #pragma unroll
-    for (int j = 0; j < 9; j++) { vp[j] = blk[lane + 64 * j]; vc[j] = blk[pitch + lane + 64 * j]; vn[j] = 0.0; }
+    for (int j = 0; j < 9; j++) { vp[j] = blk[lane + 64 * j]; vc[j] = blk[pitch + lane + 64 * j]; }
     mdct_regs R;
     mdct_load_tables(L, R, T);
     __syncthreads();
     for (int k = 0; k < n; k++) {
-        if (k + 1 < n) {
-#pragma unroll
-            for (int j = 0; j < 9; j++) vn[j] = blk[(size_t) (k + 2) * pitch + lane + 64 * j];
-        }
         const int bt = wave_readlane_i32(btv, k);
         mdct_store_inputs(L, vp, vc, bt);
+#pragma unroll
+        for (int j = 0; j < 9; j++) vp[j] = vc[j]; // the current granule is the next one's previous,
+        if (k + 1 < n) {                            // and the next one's samples are on their way during the transform
+#pragma unroll
+            for (int j = 0; j < 9; j++) vc[j] = blk[(size_t) (k + 2) * pitch + lane + 64 * j];
+        }
         mdct_granule(L, R, T, bt);
         double *out = xr_out + (rec0 + (size_t) k * C) * 576;
 #pragma unroll
         for (int j = 0; j < 9; j++) out[lane + 64 * j] = L.xr[lane + 64 * j];
         __syncthreads(); // the next granule's inputs take the place of this result
-#pragma unroll
-        for (int j = 0; j < 9; j++) { vp[j] = vc[j]; vc[j] = vn[j]; }
     }
 }
 

@@ -70,8 +70,6 @@ struct loop_lds {
 
 // one entry per lane, read with wave_readlane_i32(reg, uniform index)
 struct loop_regs {
-    int sfb_l;   // lane < 23: long scalefactor band edge
-    int sfb_s;   // lane < 14: short scalefactor band edge
     int desc_a;  // lane < 27: Huffman group descriptor of region maximum class `lane` (see loop_desc_index)
     int desc_b;  // lane < 27: offset of that group's cells in glut
 };
@@ -414,7 +412,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
                 const bool sb = g.block_type == 2;
                 r0c = sb ? 8 : 7;
                 r1c = sb ? 36 : 13;
-                ad1 = sb ? 36 : wave_readlane_i32(R.sfb_l, 8);
+                ad1 = sb ? 36 : T->sfb_l[8]; // (36 at every MPEG-1 rate; start / stop blocks are rare)
                 ad2 = bvr;
                 ad3 = 0;
             }
@@ -606,25 +604,6 @@ MP3MI_DEVFN bool loop_noise_close(bool bandlane, double xfsf, double xmin)
     return bandlane && xmin > 0.0 && __builtin_fabs(xfsf - xmin) <= 1e-12 * xmin;
 }
 
-// range of lines a band lane sums (lane 63: all 576 lines, other lanes nothing)
-MP3MI_DEVFN void loop_sum_range(const loop_regs &R, bool shortb, int nband, int *first, int *count, int *stride)
-{
-    const int lane = wave_lane();
-    const int sfb = shortb ? lane / 3 : lane;
-    const int w = shortb ? lane - 3 * sfb : 0;
-    const int src = shortb ? R.sfb_s : R.sfb_l;
-    const int e0 = __shfl(src, sfb < 22 ? sfb : 22), e1 = __shfl(src, sfb + 1 < 23 ? sfb + 1 : 22);
-    if (lane < nband) {
-        *first = shortb ? e0 * 3 + w : e0;
-        *count = e1 - e0;
-        *stride = shortb ? 3 : 1;
-    } else if (lane == 63) {
-        *first = 0; *count = 576; *stride = 1;
-    } else {
-        *first = 0; *count = 0; *stride = 1;
-    }
-}
-
 // frames of the chunk [f0, f0 + nf) that a stream with n valid samples per channel still has
 MP3MI_DEVFN int loop_frames_here(const mp3mi_geom &geo, int n)
 {
@@ -698,7 +677,8 @@ void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st)
     hipLaunchKernelGGL(k_rank, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, cost, order, n);
 }
 
-__global__ void __launch_bounds__(64 * LOOP_W) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+// 80 VGPRs: four resident wavefronts per SIMD leave 192 of its 512 registers to the kernels of the next chunk.
+__global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP_W) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                       const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
                                                       const mp3mi_prep_block *__restrict__ prep,
                                                       const int32_t *__restrict__ bits_per_frame,
@@ -731,8 +711,6 @@ __global__ void __launch_bounds__(64 * LOOP_W) k_loop(const mp3mi_tables *__rest
 #endif
 
     loop_regs R;
-    R.sfb_l = (lane < 23) ? T->sfb_l[lane] : 576;
-    R.sfb_s = (lane < 14) ? T->sfb_s[lane] : 192;
     loop_desc_init(T, lane, &R.desc_a, &R.desc_b);
 
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];
