@@ -1,0 +1,37 @@
+#!/bin/bash
+# Runs on the GPU box: A/B of two prebuilt product libraries ON THE SAME DEVICE (boxes differ by several per cent, so
+# numbers from two gpurun calls do not compare).  The libraries are mp3-enc-bsd_amd/ab/lib<name>.so (built here with
+# tools/ab_build.sh <name>; *.so files travel with the snapshot).  Alternates A B A B; for every run prints the bench
+# line's ms per step and, from a kernel trace of one more step, the time of the step's last k_loop launch (the one
+# that runs alone) and the per-kernel averages.
+# Usage: tools/gpu_ab.sh <nameA> <nameB> [rounds, default 2] [bench args...]
+A=$1; B=$2; R=${3:-2}; shift 3 2>/dev/null
+cd $GRAFT_REPO_ROOT
+out=gpurun_out/ab_${A}_${B}
+mkdir -p $out
+cp mp3-enc-bsd_amd/libmp3mi.so /tmp/libmp3mi_keep.so
+export TMPDIR=/tmp
+for r in $(seq 1 $R); do
+  for n in $A $B; do
+    cp mp3-enc-bsd_amd/ab/lib$n.so mp3-enc-bsd_amd/libmp3mi.so
+    python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $out/bench_${n}_$r.json 2> $out/bench_${n}_$r.err || { echo "bench failed for $n"; tail -5 $out/bench_${n}_$r.err; }
+    ms=$(python3 -c "import json;d=json.loads(open('$out/bench_${n}_$r.json').read().strip().splitlines()[-1]);print('%.2f ms/step  value %s  exact %s' % (d['ms_per_step'], d['value'], d['parity_spot_check']['bit_exact']))" 2>/dev/null)
+    rm -rf /tmp/ab_tl
+    timeout 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/ab_tl -o tl -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 "$@" > /dev/null 2> $out/tl.err
+    python3 - "$n" "$r" "$ms" <<'PY'
+import csv, glob, sys
+f = glob.glob("/tmp/ab_tl/**/*kernel_trace.csv", recursive=True)[0]
+rows = [(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f))]
+rows = [r for r in rows if r[0].startswith("k_") and not r[0].startswith("k_synth")]
+rows.sort(key=lambda r: r[1])
+loops = [r for r in rows if r[0] == "k_loop"]
+last = loops[-1]
+avg = {}
+for n, s, e in rows[len(rows) // 2:]:
+    avg.setdefault(n, []).append((e - s) / 1e6)
+print("%-10s round %s  %s  | last k_loop alone %.3f ms | " % (sys.argv[1], sys.argv[2], sys.argv[3], (last[2] - last[1]) / 1e6) +
+      "  ".join("%s %.2f" % (k.replace("k_", ""), sum(v) / len(v)) for k, v in sorted(avg.items()) if k not in ("k_gate", "k_rank", "k_hist_save")))
+PY
+  done
+done
+cp /tmp/libmp3mi_keep.so mp3-enc-bsd_amd/libmp3mi.so
