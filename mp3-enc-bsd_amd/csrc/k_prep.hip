@@ -12,11 +12,18 @@
 // lines fetched 16 bytes at a time were evicted from the 4 MB L2 between uses (3x over-fetch
 // measured).  No LDS and no transposition pass are needed; three wavefronts per SIMD hide the latency.
 //
-// quantanf_init needs sum(log(xr^2)) only to round 8*ln(sfm) to an integer.  The first tier
-// uses dm_log_fast (plain double, |error| < 2^-50 max(1,|log|)), which moves 8*ln(sfm) by less
-// than 1e-12; unless the value lies within 1e-9 of a rounding boundary of nint() the integer
-// is already decided.  Otherwise (probability ~1e-9 per granule) the wavefront repeats the walk
-// with the correctly rounded dm_log, which is what the reference's libm call amounts to.
+// quantanf_init needs sum(log(xr^2)) only to round v = 8*ln(sfm) to an integer.  The first tier takes no logarithm
+// per line at all: sum log(t_i) = ln2 * sum e_i + log(prod m_i) with t_i = m_i 2^e_i, m_i in [1, 2) -- an integer
+// add and one multiplication per line (576 mantissas cannot overflow: the product stays below 2^576), one logarithm
+// per granule.  How far that is from the reference's value S_ref -- the sequential f64 sum of 576 rounded logs:
+//   * S_ref against exact arithmetic: each log within 1 ulp (|log t| < 1420: 2.3e-13), each of the 575 additions
+//     within half an ulp of a partial sum below 576 * 1420 < 2^20 (1.2e-10): < 6.8e-8 in all (5e-10 on audio,
+//     whose logs stay within +-25);
+//   * ours against exact arithmetic: 575 multiplications (6.4e-14 relative on the product = absolute on its
+//     log), dm_log_fast (2^-50), the product with ln2 (< 2^20 * 2^-53) and one addition: < 3e-10;
+// so S moves by < 6.9e-8 and v = 8 (S / 576 - ln(tot / 576)) by < 9.6e-10: unless v lies within 2e-9 max(1, |v|)
+// of a rounding boundary of nint() the integer is decided.  Otherwise (probability ~1e-7 per granule) the
+// wavefront repeats the walk the reference's way, with the correctly rounded dm_log per line.
 // MP3MI_PREP_EXACT=1 forces the second tier (tests run both).
 #include "mp3mi_host.h"
 #include "dmath.h"
@@ -44,7 +51,7 @@ struct prep_walk_state {
 // One spectral line.  w = line % 3 (the short-block window), line1 = line + 1.  Band energies are
 // parked RAW in out->xmin[] when a band closes; prep_finish turns them into xmin and the log-energies.
 template <bool EXACT>
-MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double x, int w, int line1, bool shortb, bool live,
+MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double &prod, int &esum, double x, int w, int line1, bool shortb, bool live,
                            mp3mi_prep_block *out, int lane)
 {
     const double sq = x * x, ax = __builtin_fabs(x);
@@ -52,12 +59,20 @@ MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double x, 
     S.accL = S.accL + sq;
     if (w == 0) S.a0 = S.a0 + sq; else if (w == 1) S.a1 = S.a1 + sq; else S.a2 = S.a2 + sq;
     S.amax = ax > S.amax ? ax : S.amax;
-    double lg = 0.0;
-    if (x != 0.0) {
-        if (sq < 0x1p-1022) { if (EXACT) lg = dm_log(sq); else S.amb = true; } // below the normal range: only dm_log handles it
-        else lg = EXACT ? dm_log(sq) : dm_log_fast(sq);
+    if (EXACT) {
+        double lg = 0.0;
+        if (x != 0.0) lg = dm_log(sq); // (also below the normal range, and log(0) = -inf when xr^2 underflows)
+        S.slog = S.slog + lg;
+    } else {
+        // sq = m 2^e: the product takes m, the exponent sum e; a zero line takes neither (src/loop.c:380-385), and
+        // xr != 0 with xr^2 below the normal range is left to the second tier
+        const long long sb = dm_bits(sq);
+        const int ef = (int) (sb >> 52); // (sq >= 0: no sign bit)
+        if (x != 0.0 && ef == 0) S.amb = true;
+        const double m = dm_from_bits((sb & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+        prod = prod * (ef != 0 ? m : 1.0);
+        esum += ef != 0 ? ef - 1023 : 0;
     }
-    S.slog = S.slog + lg;
     if (line1 == S.edgeL) { // a long scalefactor band ends here
         if (S.bandL < 21 && !shortb && live) out->xmin[S.bandL][lane] = S.accL;
         S.accL = 0.0;
@@ -77,13 +92,13 @@ MP3MI_DEVFN void prep_line(const mp3mi_tables *T, prep_walk_state &S, double x, 
 }
 
 template <int PH>
-MP3MI_DEVFN void prep_block(const mp3mi_tables *T, prep_walk_state &S, const prep_d2 (&v)[PREP_BLOCK / 2], int k, bool shortb,
+MP3MI_DEVFN void prep_block(const mp3mi_tables *T, prep_walk_state &S, double &prod, int &esum, const prep_d2 (&v)[PREP_BLOCK / 2], int k, bool shortb,
                             bool live, mp3mi_prep_block *out, int lane)
 {
 #pragma unroll
     for (int j = 0; j < PREP_BLOCK; j++) {
         const double x = (j & 1) ? v[j >> 1].y : v[j >> 1].x;
-        prep_line<false>(T, S, x, (PH + j) % 3, k + j + 1, shortb, live, out, lane);
+        prep_line<false>(T, S, prod, esum, x, (PH + j) % 3, k + j + 1, shortb, live, out, lane);
         PREP_SCHED_FENCE(); // one line at a time: the wavefronts of the SIMD hide the latency, not ILP across lines
     }
 }
@@ -112,6 +127,8 @@ __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__
         S.edgeL = T->sfb_l[1];
         S.edgeS = 3 * T->sfb_s[1];
         if (!exact) {
+            double prod = 1.0; // first tier: product of the mantissas of the non-zero xr^2,
+            int esum = 0;      // sum of their exponents
 #pragma unroll 1
             for (int k = 0; k < 576; k += PREP_BLOCK) {
                 prep_d2 v[PREP_BLOCK / 2];
@@ -119,13 +136,16 @@ __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__
                 for (int q = 0; q < PREP_BLOCK / 2; q++) v[q] = *(const prep_d2 *) (row + k + 2 * q);
                 // 16 = 1 mod 3: the short-block window of the block's first line cycles 0, 1, 2 (wave-uniform)
                 const int ph = k % 3;
-                if (ph == 0) prep_block<0>(T, S, v, k, shortb, live, out, lane);
-                else if (ph == 1) prep_block<1>(T, S, v, k, shortb, live, out, lane);
-                else prep_block<2>(T, S, v, k, shortb, live, out, lane);
+                if (ph == 0) prep_block<0>(T, S, prod, esum, v, k, shortb, live, out, lane);
+                else if (ph == 1) prep_block<1>(T, S, prod, esum, v, k, shortb, live, out, lane);
+                else prep_block<2>(T, S, prod, esum, v, k, shortb, live, out, lane);
             }
+            S.slog = (double) esum * 0x1.62e42fefa39efp-1 + dm_log_fast(prod);
         } else { // second tier, rare: plain line-by-line walk
+            double unused_p = 1.0;
+            int unused_e = 0;
 #pragma unroll 1
-            for (int k = 0; k < 576; k++) prep_line<true>(T, S, row[k], k % 3, k + 1, shortb, live, out, lane);
+            for (int k = 0; k < 576; k++) prep_line<true>(T, S, unused_p, unused_e, row[k], k % 3, k + 1, shortb, live, out, lane);
         }
         // quantanf_init (src/loop.c:369-402)
         tp = 0;
@@ -136,7 +156,7 @@ __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__
             if (tp < -100) tp = -100;
             if (!exact) { // is nint(v) independent of the last bits of the logs?
                 const double av = __builtin_fabs(v), fr = av - __builtin_floor(av);
-                if (!(__builtin_fabs(fr - 0.5) > 1e-9 * (av > 1.0 ? av : 1.0))) S.amb = true; // also catches NaN
+                if (!(__builtin_fabs(fr - 0.5) > 2e-9 * (av > 1.0 ? av : 1.0))) S.amb = true; // also catches NaN
             }
         } else
             S.amb = false;
