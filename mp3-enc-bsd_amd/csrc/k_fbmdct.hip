@@ -41,12 +41,25 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
     const int16_t *hist = geo.hist ? geo.hist + (size_t) s * MP3MI_PCM_HIST * (size_t) C : NULL;
     // samples [576 g - 480, 576 g + 576) of this channel; before the call's first sample the stream's history
     // (zeros at the start of a stream), beyond the stream's last sample 0
-    {
+    const long t0 = 576 * gabs - 480;
+    if (t0 >= 0 && t0 + 1056 <= n_per_ch) {
+        // all 1056 samples lie inside the call's PCM (every granule but the first and the last few of a stream): one
+        // scalar base, 32-bit lane offsets, no per-sample range tests (they cost ~30 instructions per sample)
+        const int16_t *p0 = pcm + t0 * C + ch;
+        const unsigned lo = (unsigned) lane * (unsigned) C, step = 64u * (unsigned) C;
+        int16_t v[17];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = p0[lo + step * (unsigned) k];
+        v[16] = lane < 32 ? p0[lo + step * 16u] : (int16_t) 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) L.pcm[lane + 64 * k] = v[k];
+        if (lane < 32) L.pcm[lane + 1024] = v[16];
+    } else {
         int16_t v[17];
 #pragma unroll
         for (int k = 0; k < 17; k++) {
             const int i = lane + 64 * k;
-            const long t = 576 * gabs - 480 + i;
+            const long t = t0 + i;
             const bool past = hist && t < 0 && t >= -MP3MI_PCM_HIST;
             v[k] = (i < 1056 && t >= 0 && t < n_per_ch) ? pcm[t * C + ch] : ((i < 1056 && past) ? hist[(t + MP3MI_PCM_HIST) * C + ch] : (int16_t) 0);
         }
