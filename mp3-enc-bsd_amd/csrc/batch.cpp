@@ -488,7 +488,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         // ---- loop stream: the serial search and the formatter ----
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
         CHK(hipEventRecord(b->loop_ev[2 * c], b->lstream));
-        b->gate_total += (unsigned) S;
+        b->gate_total += (unsigned) mp3mi_loop_waves(S);
         mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
         if (b->place_order) { // rank the streams by their cost in the previous chunk, hand the tables to k_loop
             mp3mi_launch_rank(b->place_cost, b->place_order, S, b->lstream);

@@ -27,6 +27,7 @@
 // ~54 words of side information out.
 #include "mp3mi_host.h"
 #include "dmath.h"
+#include <stdlib.h>
 
 typedef struct {
     int32_t ResvSize;
@@ -678,23 +679,17 @@ void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st)
 }
 
 // 80 VGPRs: four resident wavefronts per SIMD leave 192 of its 512 registers to the kernels of the next chunk.
-__global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP_W) k_loop(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
-                                                      const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
-                                                      const mp3mi_prep_block *__restrict__ prep,
-                                                      const int32_t *__restrict__ bits_per_frame,
-                                                      mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
-                                                      mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
-                                                      mp3mi_loop_place place)
+// One stream, start to end, by one wavefront (k_loop below).  round: streams this wavefront has finished before.
+template <bool QUEUE>
+MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geom &geo,
+                             const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
+                             const mp3mi_prep_block *__restrict__ prep,
+                             const int32_t *__restrict__ bits_per_frame,
+                             mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
+                             mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
+                             const mp3mi_loop_place &place, loop_lds &L, const uint16_t *GL, int block, int round)
 {
-    __shared__ loop_lds LL[LOOP_W];
-    __shared__ uint16_t GL[928]; // code lengths grouped as new_choose_table compares them (mp3mi_tables::glut)
-    const int lane = wave_lane();
-    const int wv = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-    loop_lds &L = LL[wv];
-    for (int i = (int) threadIdx.x; i < 928; i += 64 * LOOP_W) GL[i] = T->glut[i];
-    __syncthreads(); // the workgroup's only barrier; from here on every wavefront is on its own
-    const int block = (int) blockIdx.x * LOOP_W + wv; // one wavefront per stream
-    if (block >= geo.n_streams) return;
+    const int lane = QUEUE ? wave_lane_here() : wave_lane(); // (nothing derived from the lane index is carried from one stream to the next)
     const int s = loop_place_stream(place, geo.n_streams, block), C = geo.channels, G = 2 * geo.nf;
     int work = 0; // cost of this stream in this launch: 4 per quantise+count pass, 5 per distortion-loop iteration
     const int bitsPerFrame = bits_per_frame[s];
@@ -702,7 +697,7 @@ __global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP
     PROF_DECL;
     // Residency census (batch.cpp, k_gate): every wavefront counts itself in when it starts.  The
     // counter only ever grows; nothing in this kernel waits on it.
-    if (gate_count && lane == 0) atomicAdd(gate_count, 1u);
+    if (gate_count && lane == 0 && round == 0) atomicAdd(gate_count, 1u);
 #if !defined(MP3MI_EMU)
     // this wavefront is on the critical path of the whole batch: let it issue ahead of the
     // feed-forward kernels of the next chunk that run beside it (batch.cpp); adjusted
@@ -1121,9 +1116,11 @@ __global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP
         // wavefronts of its SIMD), a stream ahead of it lowers it.  Purely a scheduling hint.
         if (gate_count) {
             const unsigned done_all = __builtin_amdgcn_readfirstlane((int) (lane == 0 ? atomicAdd(gate_count + 1, 1u) + 1u : 0u));
-            int n_waves = geo.n_streams;
-            asm volatile("" : "+s"(n_waves)); // converted here, once per frame, instead of living in a register for the whole kernel
-            const float lead = (float) (fl + 1) - (float) done_all / (float) n_waves;
+            // (frames per wavefront so far against the average over the wavefronts of the launch: a wavefront on its
+            // second stream has that stream's frames on top of the first one's)
+            int n_act = (QUEUE && geo.n_streams > (int) gridDim.x * LOOP_W) ? (int) gridDim.x * LOOP_W : geo.n_streams;
+            asm volatile("" : "+s"(n_act)); // converted here, once per frame, instead of living in a register for the whole kernel
+            const float lead = (float) ((QUEUE ? round * geo.nf : 0) + fl + 1) - (float) done_all / (float) n_act;
             if (lead < -1.0f) __builtin_amdgcn_s_setprio(3);
             else if (lead < 0.0f) __builtin_amdgcn_s_setprio(2);
             else if (lead < 1.0f) __builtin_amdgcn_s_setprio(1);
@@ -1141,6 +1138,43 @@ __global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP
 #endif
     PROF(7);
     PROF_END;
+}
+
+#define LOOP_KERNEL_ARGS const mp3mi_tables *__restrict__ T, mp3mi_geom geo, const double *__restrict__ xr_all,                     \
+                         const mp3mi_psy_out *__restrict__ psy, const mp3mi_prep_block *__restrict__ prep,                      \
+                         const int32_t *__restrict__ bits_per_frame, mp3mi_loop_state *__restrict__ state,                     \
+                         int16_t *__restrict__ ix_out, mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count, \
+                         mp3mi_loop_place place
+// what every wavefront of a workgroup does first: its share of the code-length tables (the workgroup's only barrier;
+// from there on every wavefront is on its own)
+#define LOOP_KERNEL_PROLOGUE                                                                                         \
+    __shared__ loop_lds LL[LOOP_W];                                                                                  \
+    __shared__ uint16_t GL[928]; /* code lengths grouped as new_choose_table compares them (mp3mi_tables::glut) */    \
+    const int wv = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);                                           \
+    loop_lds &L = LL[wv];                                                                                            \
+    for (int i = (int) threadIdx.x; i < 928; i += 64 * LOOP_W) GL[i] = T->glut[i];                                   \
+    __syncthreads()
+
+// As many wavefronts as streams, each takes one.
+__global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP_W) k_loop(LOOP_KERNEL_ARGS)
+{
+    LOOP_KERNEL_PROLOGUE;
+    const int block = (int) blockIdx.x * LOOP_W + wv;
+    if (block < geo.n_streams) loop_stream<false>(T, geo, xr_all, psy, prep, bits_per_frame, state, ix_out, side_out, gate_count, place, L, GL, block, 0);
+}
+
+// More streams than wavefronts that are resident together (mp3mi_launch_loop): the grid is the resident wavefronts
+// and one that has finished its stream takes another until none is left, so that every SIMD stays four deep to the
+// end -- the hardware would otherwise start a fifth workgroup per CU first (5120 streams) and run the rest at three per
+// SIMD.  A kernel of its own because the stream loop costs registers, and with more than 80 the feed-forward kernels
+// of the next chunk no longer fit beside four resident wavefronts: the one-stream case keeps its 80.
+__global__ void __attribute__((amdgpu_num_vgpr(72))) __launch_bounds__(64 * LOOP_W) k_loop_queue(LOOP_KERNEL_ARGS)
+{
+    LOOP_KERNEL_PROLOGUE;
+    for (int block = (int) blockIdx.x * LOOP_W + wv, round = 0; block < geo.n_streams; block += (int) gridDim.x * LOOP_W, round++) {
+        loop_stream<true>(T, geo, xr_all, psy, prep, bits_per_frame, state, ix_out, side_out, gate_count, place, L, GL, block, round);
+        wave_sync();
+    }
 }
 
 #if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
@@ -1177,12 +1211,40 @@ extern "C" void mp3mi_debug_loop_waves(unsigned long long *out, int n_streams)
 
 size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 
+// workgroups that are resident together: four of LOOP_W = 4 wavefronts per CU (four wavefronts per SIMD: what stays
+// resident beside the feed-forward kernels, batch.cpp); MP3MI_LOOP_WGS_PER_CU overrides (experiments)
+static int loop_wg_cap(void)
+{
+    static int wg_cap = 0;
+    if (!wg_cap) {
+        int dev = 0, per_cu = 4;
+        hipDeviceProp_t prop;
+        const char *e = getenv("MP3MI_LOOP_WGS_PER_CU");
+        if (e && atoi(e) > 0) per_cu = atoi(e);
+        wg_cap = 256 * per_cu;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) wg_cap = prop.multiProcessorCount * per_cu;
+    }
+    return wg_cap;
+}
+
+// wavefronts of a launch over n_streams streams = what the start census (gate_count[0]) grows by
+int mp3mi_loop_waves(int n_streams)
+{
+    const int cap = loop_wg_cap() * LOOP_W;
+    return n_streams < cap ? n_streams : cap;
+}
+
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
                        const mp3mi_prep_block *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
                        mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_loop, dim3((unsigned) ((g.n_streams + LOOP_W - 1) / LOOP_W)), dim3(64 * LOOP_W), 0, st, T, g, xr, psy, prep, bits_per_frame,
-                       (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
+    const int want = (g.n_streams + LOOP_W - 1) / LOOP_W, wg_cap = loop_wg_cap();
+    if (want <= wg_cap)
+        hipLaunchKernelGGL(k_loop, dim3((unsigned) want), dim3(64 * LOOP_W), 0, st, T, g, xr, psy, prep, bits_per_frame,
+                           (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
+    else
+        hipLaunchKernelGGL(k_loop_queue, dim3((unsigned) wg_cap), dim3(64 * LOOP_W), 0, st, T, g, xr, psy, prep, bits_per_frame,
+                           (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
 }
 
 // Holds the front stream back until the k_loop launch whose census target is `target` has (all but

@@ -24,7 +24,7 @@ f = glob.glob("/tmp/ab_tl/**/*kernel_trace.csv", recursive=True)[0]
 rows = [(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f))]
 rows = [r for r in rows if r[0].startswith("k_") and not r[0].startswith("k_synth")]
 rows.sort(key=lambda r: r[1])
-loops = [r for r in rows if r[0] == "k_loop"]
+loops = [r for r in rows if r[0].startswith("k_loop")]
 last = loops[-1]
 avg = {}
 for n, s, e in rows[len(rows) // 2:]:

@@ -16,7 +16,7 @@ rows = [(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Start_Times
 rows = [r for r in rows if r[0].startswith("k_") and not r[0].startswith("k_synth")]
 rows.sort(key=lambda r: r[1])
 # the last step = the last 5 k_loop launches
-loops = [i for i, r in enumerate(rows) if r[0] == "k_loop"]
+loops = [i for i, r in enumerate(rows) if r[0].startswith("k_loop")]
 first = loops[-5]
 # start a little before: find the first k_fft of that step
 i0 = max(i for i, r in enumerate(rows[:first]) if r[0].startswith("k_fft") and (i == 0 or rows[i - 1][0] not in ("k_fft<2, 12, true>",))) if first else 0
