@@ -146,7 +146,8 @@ enum {
     MP3MI_TEST_PSY_EXACT = 4,    /* masking threshold: dm_log / dm_exp (k_psy) */
     MP3MI_TEST_QUANT_EXACT = 8,  /* quantiser: every line against the (i - 0.4054)^(4/3) table (k_loop) */
     MP3MI_TEST_PREP_EXACT = 16,  /* quantanf_init: correctly rounded logs (k_prep) */
-    MP3MI_TEST_ALL_EXACT = 31
+    MP3MI_TEST_CW_EXACT = 32,    /* unpredictability: correctly rounded sines and cosines for every record (k_cw) */
+    MP3MI_TEST_ALL_EXACT = 63
 };
 int mp3mi_batch_set_test_flags(mp3mi_batch *b, unsigned flags);
 
@@ -163,6 +164,10 @@ int mp3mi_debug_dmath(int fn, const double *x, const double *y, double *out, siz
  * of [1, 4); out[1] raw exp2 at the 801 step sizes the search can ask for; out[2] raw exp2 over 2^24 arguments
  * of [-80, 80].  tests/test_gpu_tiers.py asserts that their sum stays inside the guard band's 7e-7 budget. */
 int mp3mi_debug_fastmath_bounds(double out[3]);
+/* diagnostics: of the (granule, channel) records of the last call's LAST chunk, how many needed the second tier of
+ * the unpredictability (k_part's check); *n_records receives their number.  Call after
+ * mp3mi_batch_sync. */
+int mp3mi_batch_debug_cw_fixups(mp3mi_batch *b, int *n_listed, int *n_records);
 
 /* Library / device identification string for logs. */
 const char *mp3mi_version(void);

@@ -63,6 +63,7 @@ struct mp3mi_batch {
     int32_t *bits_per_frame, *bitrate_index;
     float *energy_l, *energy_s, *hist6, *fft_bins;
     double *cw_mid, *xr[2], *sbs, *sb_dbg, *part_eb;
+    mp3mi_cw_fixlist *cw_fix; // the (granule, channel) records whose unpredictability needs its second tier (k_part)
     float *part_cb;
     mp3mi_psy_out *psy[2];
     mp3mi_prep_block *prep[2];
@@ -187,6 +188,7 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     { const char *e = getenv("MP3MI_PHASE_EXACT"); if (e && atoi(e)) b->test_flags |= 2; }
     { const char *e = getenv("MP3MI_PSY_EXACT"); if (e && atoi(e)) b->test_flags |= 4; }
     { const char *e = getenv("MP3MI_QUANT_EXACT"); if (e && atoi(e)) b->test_flags |= 8; }
+    { const char *e = getenv("MP3MI_CW_EXACT"); if (e && atoi(e)) b->test_flags |= 16; }
     b->hdr_flags = 0;
     b->hdr_mode = (channels == 1) ? 3 : 0;
     b->crc = 0;
@@ -225,6 +227,8 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     CHK(hipMalloc((void **) &b->hist6, ngc * 12 * sizeof(float)));
     CHK(hipMalloc((void **) &b->fft_bins, ngc * MP3MI_FFT_BINS * sizeof(float)));
     CHK(hipMalloc((void **) &b->cw_mid, ngc * 50 * sizeof(double)));
+    CHK(hipMalloc((void **) &b->cw_fix, mp3mi_cw_fixlist_bytes(ngc)));
+    CHK(hipMemset(b->cw_fix, 0, sizeof(mp3mi_cw_fixlist)));
     for (int i = 0; i < 2; i++) {
         CHK(hipMalloc((void **) &b->xr[i], ngc * 576 * sizeof(double)));
         CHK(hipMalloc((void **) &b->psy[i], ngc * sizeof(mp3mi_psy_out)));
@@ -285,7 +289,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     device_scope ds(b->device);
     if (b->stream) hipStreamSynchronize(b->stream);
     if (b->lstream) hipStreamSynchronize(b->lstream);
-    void *bufs[] = {b->T, b->bits_per_frame, b->bitrate_index, b->energy_l, b->energy_s, b->hist6, b->fft_bins, b->cw_mid,
+    void *bufs[] = {b->T, b->bits_per_frame, b->bitrate_index, b->energy_l, b->energy_s, b->hist6, b->fft_bins, b->cw_mid, b->cw_fix,
                     b->part_eb, b->part_cb, b->xr[0], b->xr[1], b->psy[0], b->psy[1], b->prep[0], b->prep[1], b->sbs, b->ix, b->side,
                     b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg};
     for (void *p : bufs)
@@ -312,7 +316,7 @@ extern "C" void mp3mi_batch_debug_enable(mp3mi_batch *b, int on) { b->debug = on
 extern "C" int mp3mi_batch_set_test_flags(mp3mi_batch *b, unsigned flags)
 {
     if (!b || (flags & ~(unsigned) MP3MI_TEST_ALL_EXACT)) return MP3MI_ERR_ARG;
-    b->test_flags = (int) (flags & 15u);
+    b->test_flags = (int) (flags & 15u) | ((flags & MP3MI_TEST_CW_EXACT) ? 16 : 0);
     b->prep_exact = (flags & MP3MI_TEST_PREP_EXACT) ? 1 : 0;
     return MP3MI_OK;
 }
@@ -468,7 +472,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
         CHK(hipGetLastError());
         if (c >= 2) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[c & 1], 0)); // k_loop of chunk c-2 has read this slot
-        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->psy_state, b->part_eb, b->part_cb, b->psy[c & 1], b->stream);
+        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->fft_bins, b->cw_fix, b->psy_state, b->part_eb, b->part_cb, b->psy[c & 1], b->stream);
         CHK(hipGetLastError());
         return MP3MI_OK;
     };
@@ -538,6 +542,17 @@ extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
     CHK(hipStreamSynchronize(b->stream));
     CHK(hipStreamSynchronize(b->lstream));
     CHK(hipGetLastError());
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_debug_cw_fixups(mp3mi_batch *b, int *n_listed, int *n_records)
+{
+    if (!b || !n_listed || !n_records) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    mp3mi_cw_fixlist h;
+    CHK(hipMemcpy(&h, b->cw_fix, sizeof(h), hipMemcpyDeviceToHost));
+    *n_listed = (int) h.count;
+    *n_records = (int) h.cap;
     return MP3MI_OK;
 }
 

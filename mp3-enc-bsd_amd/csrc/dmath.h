@@ -360,6 +360,42 @@ DM_FN void dm_sincos(double x, double *sn, double *cs)
     if (dm_fabs(x) < 0x1p-27) *sn = x;
 }
 
+/* Plain double-precision sin and cos of the same argument, |x| < 2^10: Cody-Waite reduction by the same three
+ * parts of pi/2 (the first product and difference exact, one rounding after it) and the classic degree-13 / degree-14
+ * polynomials on [-pi/4, pi/4].  |error| < 2^-51 absolute on each (tests/test_dmath_host.py).  NOT correctly
+ * rounded: for callers that can tell when the last bits of the result do not matter (k_cw's first tier, whose
+ * unpredictability only reaches a bit through the float-rounded partition sums of k_part). */
+DM_FN void dm_sincos_fast(double x, double *sn, double *cs)
+{
+    const double kd = __builtin_rint(x * DM_2_OVER_PI);
+    const int n = (int) ((long long) kd & 3);
+    double r = dm_fma(-kd, DM_PIO2_1, x);      /* exact: 30-bit part, |k| < 2^10, and the difference cancels */
+    double z, ps, pc, sv, cv;
+    r = dm_fma(-kd, DM_PIO2_2, r);
+    r = dm_fma(-kd, DM_PIO2_3, r);
+    z = r * r;
+    ps = 0x1.5d93a5acfd57cp-33;                  /*  1.58969099521155010221e-10 */
+    ps = dm_fma(ps, z, -0x1.ae5e68a2b9cebp-26);  /* -2.50507602534068634195e-08 */
+    ps = dm_fma(ps, z, 0x1.71de357b1fe7dp-19);   /*  2.75573137070700676789e-06 */
+    ps = dm_fma(ps, z, -0x1.a01a019c161d5p-13);  /* -1.98412698298579493134e-04 */
+    ps = dm_fma(ps, z, 0x1.111111110f8a6p-7);    /*  8.33333333332248946124e-03 */
+    ps = dm_fma(ps, z, -0x1.5555555555549p-3);   /* -1.66666666666666324348e-01 */
+    sv = dm_fma(ps * z, r, r);
+    pc = -0x1.8fae9be8838d4p-37;                 /* -1.13596475577881948265e-11 */
+    pc = dm_fma(pc, z, 0x1.1ee9ebdb4b1c4p-29);   /*  2.08757232129817482790e-09 */
+    pc = dm_fma(pc, z, -0x1.27e4f809c52adp-22);  /* -2.75573143513906633035e-07 */
+    pc = dm_fma(pc, z, 0x1.a01a019cb1590p-16);   /*  2.48015872894767294178e-05 */
+    pc = dm_fma(pc, z, -0x1.6c16c16c15177p-10);  /* -1.38888888888741095749e-03 */
+    pc = dm_fma(pc, z, 0x1.555555555554cp-5);    /*  4.16666666666666019037e-02 */
+    cv = dm_fma(pc * z, z, dm_fma(-0.5, z, 1.0));
+    switch (n) {
+    case 0: *sn = sv; *cs = cv; break;
+    case 1: *sn = cv; *cs = -sv; break;
+    case 2: *sn = -sv; *cs = -cv; break;
+    default: *sn = -cv; *cs = sv; break;
+    }
+}
+
 DM_FN double dm_cos(double x)
 {
     dm_dd r, s, c;

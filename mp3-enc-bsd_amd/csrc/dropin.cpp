@@ -55,6 +55,7 @@ struct DropIn {
     float *el = nullptr, *es = nullptr, *h6 = nullptr, *bins = nullptr, *part_cb = nullptr;
     double *part_eb = nullptr;
     double *cw = nullptr;
+    mp3mi_cw_fixlist *cw_fix = nullptr;
     void *psy_state = nullptr;
     mp3mi_psy_out *psy1 = nullptr;
     // filterbank
@@ -106,6 +107,7 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.h6, 12 * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.bins, MP3MI_FFT_BINS * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.cw, 50 * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.cw_fix, mp3mi_cw_fixlist_bytes(4)));
     HIPOK(hipMalloc((void **) &D.psy_state, 2 * mp3mi_psy_state_size()));
     HIPOK(hipMemset(D.psy_state, 0, 2 * mp3mi_psy_state_size()));
     HIPOK(hipMalloc((void **) &D.psy1, sizeof(mp3mi_psy_out)));
@@ -184,7 +186,7 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
     g.g0 = 2;
     g.n_gran = 1;
     mp3mi_launch_fft(D.T, g, D.pcm_d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
-    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.part_eb, D.part_cb, D.psy1, D.st);
+    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.part_eb, D.part_cb, D.psy1, D.st);
     mp3mi_psy_out o;
     HIPOK(hipMemcpyAsync(&o, D.psy1, sizeof(o), hipMemcpyDeviceToHost, D.st));
     HIPOK(hipStreamSynchronize(D.st));

@@ -448,15 +448,20 @@ MP3MI_DEVFN void cw_bin(float re, float im, bool exact, float *energy, float *ph
     *phi = ph;
 }
 
-// Phases and the unpredictability measure from the raw FFT bins, one wavefront per (granule, channel):
+// Phases and the unpredictability measure from the raw FFT bins of one (granule, channel) record by one wavefront:
 // lanes 0..49 the unpredictability of lines 6+4n..9+4n from the three short FFTs (src/l3psy.c:531-549),
 // lanes 50..55 magnitude and phase of long lines 0..5 (src/l3psy.c:497-503).  Kept out of k_fft so that
 // this double-precision chain runs at full occupancy instead of next to 150 KB of LDS.
-__global__ void __launch_bounds__(64) k_cw(const float *__restrict__ bins, double *__restrict__ cw_mid, float *__restrict__ hist6,
-                                          int force_exact)
+//
+// The sines and cosines: c_w only ever reaches a bit through cb[b] += c_w * energy, a sum that is rounded to FLOAT at
+// every step (src/l3psy.c:576, k_part).  FASTSC = true takes them from dm_sincos_fast (plain double, |error| < 2^-51);
+// the c_w that comes out is within 6e-15 of the reference's (error chain: k_part, part_cw_safe), and k_part checks at
+// every step that the float it rounds to cannot depend on that; the blocks of records where it could are repeated
+// with FASTSC = false, the correctly rounded dm_sincos (k_cw_fix, then k_part again).
+template <bool FASTSC>
+MP3MI_DEVFN void cw_record(const float *__restrict__ bins, double *__restrict__ cw_mid, float *__restrict__ hist6, size_t rec, int force_exact)
 {
     const int lane = wave_lane();
-    const size_t rec = blockIdx.x;
     const float *b = bins + rec * MP3MI_FFT_BINS;
     float re[3] = {1.0f, 1.0f, 1.0f}, im[3] = {0.0f, 0.0f, 0.0f};
     if (lane < 50) {
@@ -482,18 +487,44 @@ __global__ void __launch_bounds__(64) k_cw(const float *__restrict__ bins, doubl
         const double r2 = __builtin_sqrt((double) e[1]);
         const double phi2 = (double) ph[1];
         double s2, c2, sp, cp;
-        dm_sincos(phi2, &s2, &c2);
-        dm_sincos(phi_prime, &sp, &cp);
+        if (FASTSC) {
+            dm_sincos_fast(phi2, &s2, &c2);
+            dm_sincos_fast(phi_prime, &sp, &cp);
+        } else {
+            dm_sincos(phi2, &s2, &c2);
+            dm_sincos(phi_prime, &sp, &cp);
+        }
         const double t1 = r2 * c2 - r_prime * cp;
         const double t2 = r2 * s2 - r_prime * sp;
         const double t3 = r2 + __builtin_fabs(r_prime);
         double cw = 0.0;
         if (t3 != 0.0) cw = __builtin_sqrt(t1 * t1 + t2 * t2) / t3;
         cw_mid[rec * 50 + lane] = cw;
-    } else if (lane < 56) {
+    } else if (lane < 56 && FASTSC) { // (the same in both tiers: written once)
         hist6[rec * 12 + lane - 50] = (float) __builtin_sqrt((double) e[0]); // r, src/l3psy.c:500
         hist6[rec * 12 + 6 + lane - 50] = ph[0];
     }
+}
+
+// first tier: one wavefront per record.  exact_sc (MP3MI_CW_EXACT=1, tests): the second tier for every record.
+__global__ void __launch_bounds__(64) k_cw(const float *__restrict__ bins, double *__restrict__ cw_mid, float *__restrict__ hist6,
+                                          int force_exact, int exact_sc)
+{
+    cw_record<true>(bins, cw_mid, hist6, blockIdx.x, force_exact);
+    if (exact_sc) cw_record<false>(bins, cw_mid, hist6, blockIdx.x, force_exact);
+}
+
+// second tier: the records k_part listed, a wavefront each (a fixed grid walks the list)
+__global__ void __launch_bounds__(64) k_cw_fix(const float *__restrict__ bins, double *__restrict__ cw_mid, float *__restrict__ hist6,
+                                              int force_exact, const mp3mi_cw_fixlist *__restrict__ fix)
+{
+    const unsigned n_fix = fix->count < fix->cap ? fix->count : fix->cap;
+    for (unsigned i = blockIdx.x; i < n_fix; i += gridDim.x) cw_record<false>(bins, cw_mid, hist6, fix->list[i], force_exact);
+}
+
+__global__ void __launch_bounds__(64) k_cw_fix_reset(mp3mi_cw_fixlist *fix, unsigned cap)
+{
+    if (threadIdx.x == 0) { fix->count = 0; fix->cap = cap; }
 }
 
 #if defined(MP3MI_FFT_PROFILE) && !defined(MP3MI_EMU)
@@ -528,5 +559,15 @@ void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t 
         hipLaunchKernelGGL((k_fft<1, W, true>), dim3((unsigned) grid), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
         hipLaunchKernelGGL((k_fft<1, W, false>), dim3((unsigned) grid), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
     }
-    hipLaunchKernelGGL(k_cw, dim3((unsigned) (n_task * g.channels)), dim3(64), 0, st, bins, cw_mid, hist6, (g.test_flags >> 1) & 1);
+    hipLaunchKernelGGL(k_cw, dim3((unsigned) (n_task * g.channels)), dim3(64), 0, st, bins, cw_mid, hist6, (g.test_flags >> 1) & 1, (g.test_flags >> 4) & 1);
+}
+
+// the second tier of the unpredictability for the records k_part listed (mp3mi_launch_psy)
+void mp3mi_launch_cw_fix_reset(mp3mi_cw_fixlist *fix, unsigned cap, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cw_fix_reset, dim3(1), dim3(64), 0, st, fix, cap);
+}
+void mp3mi_launch_cw_fix(const mp3mi_geom &g, const float *bins, double *cw_mid, float *hist6, const mp3mi_cw_fixlist *fix, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cw_fix, dim3(2048), dim3(64), 0, st, bins, cw_mid, hist6, (g.test_flags >> 1) & 1, fix);
 }

@@ -54,10 +54,12 @@ struct part_walk {
 struct part_tile {
     double eb[8][65];
     float cb[8][65];
+    unsigned rec[64]; // the lanes' records (PART_NO_REC: none)
 };
+#define PART_NO_REC 0xffffffffu
 
-// partitions [b_last & ~7, b_last] of the wavefront's records rec0 .. rec0 + 63 (partition 0 is stored at the end)
-MP3MI_DEVFN void part_flush(part_tile &Lt, int b_last, size_t rec0, size_t n_rec, double *__restrict__ eb_all, float *__restrict__ cb_all)
+// partitions [b_last & ~7, b_last] of the wavefront's records Lt.rec[0 .. 63] (partition 0 is stored at the end)
+MP3MI_DEVFN void part_flush(part_tile &Lt, int b_last, double *__restrict__ eb_all, float *__restrict__ cb_all)
 {
     const int lane = wave_lane_here();
     wave_sync();
@@ -65,21 +67,44 @@ MP3MI_DEVFN void part_flush(part_tile &Lt, int b_last, size_t rec0, size_t n_rec
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int r = 8 * i + (lane >> 3);
-        if (p < np && base + p >= 1 && rec0 + r < n_rec) {
-            eb_all[(rec0 + r) * MP3MI_PART_P + base + p] = Lt.eb[p][r];
-            cb_all[(rec0 + r) * MP3MI_PART_P + base + p] = Lt.cb[p][r];
+        const unsigned rr = Lt.rec[r];
+        if (p < np && base + p >= 1 && rr != PART_NO_REC) {
+            eb_all[(size_t) rr * MP3MI_PART_P + base + p] = Lt.eb[p][r];
+            cb_all[(size_t) rr * MP3MI_PART_P + base + p] = Lt.cb[p][r];
         }
     }
     wave_sync(); // the tile is written again
 }
 
-MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, int j, float ef, double cw, size_t rec0, size_t n_rec,
-                           double *__restrict__ eb_all, float *__restrict__ cb_all)
+// Can the float that d = cb + cw * e rounds to depend on cw's last bits?  cw is k_cw's first tier:
+//   * ours against exact arithmetic: the sines and cosines within 2^-51 = 4.4e-16 (dm_sincos_fast), so
+//     t1 = r2 c2 - r' cp and t2 within 6.6e-16 t3 (t3 = r2 + |r'| bounds every operand; the products and the
+//     difference round too), sqrt(t1^2 + t2^2) within 1.4e-15 t3, the quotient by t3 within 1.6e-15;
+//   * the reference's against exact arithmetic, with a libm that is good to one ulp: 1.3e-15 by the same chain;
+// so the two differ by less than 2.9e-15; 6e-15 is assumed.  d itself is formed in double twice (product, sum):
+// |d - d_ref| < 6e-15 e + 2^-52 cw e + 2^-52 d <= (54 e / d + 4) ulps of d, an ulp of d being >= 2^-53 d.  (float) d
+// is safe when d's distance from the nearest midpoint of two floats -- the low 29 bits of its mantissa against
+// 0x10000000 -- is larger than that (dm_float_rounding_safe_ulps, with the division multiplied out).
+MP3MI_DEVFN bool part_cw_safe(double d, double e)
+{
+    const long long b = dm_bits(d);
+    long long dist = (b & 0x1fffffffLL) - 0x10000000LL;
+    dist = dist < 0 ? -dist : dist;
+    const bool range = b >= 0x3810000000000000LL && b < 0x47f0000000000000LL; // a normal float (and positive, not nan)
+    return range && (double) dist * d > 54.0 * e + 4.0 * d;
+}
+
+// CHECK: cw is a first-tier value; *amb is set when a float rounding could depend on its last bits.
+template <bool CHECK>
+MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, int j, float ef, double cw,
+                           double *__restrict__ eb_all, float *__restrict__ cb_all, bool *amb)
 {
     const double e = (double) ef;
     if (j < T->part_l_covered) {
         W.eb = W.eb + e;
-        W.cb = (float) ((double) W.cb + cw * e);
+        const double d = (double) W.cb + cw * e;
+        if (CHECK && !part_cw_safe(d, e)) *amb = true;
+        W.cb = (float) d;
         while (W.b < MP3MI_CBANDS && j + 1 == W.pend) { // closes this partition and any empty ones after it
             if (W.b == 0) { W.eb0 = W.eb; W.cb0 = W.cb; }
             else {
@@ -87,7 +112,7 @@ MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, i
                 Lt.eb[W.b & 7][lane] = W.eb;
                 Lt.cb[W.b & 7][lane] = W.cb;
             }
-            if ((W.b & 7) == 7) part_flush(Lt, W.b, rec0, n_rec, eb_all, cb_all);
+            if ((W.b & 7) == 7) part_flush(Lt, W.b, eb_all, cb_all);
             W.eb = 0.0; W.cb = 0.0f;
             W.b++;
             W.pend = W.b < MP3MI_CBANDS ? T->part_l_start[W.b + 1] : -1;
@@ -101,20 +126,36 @@ MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, i
 __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                              const float *__restrict__ energy_l, const double *__restrict__ cw_mid,
                                              const float *__restrict__ hist6, const mp3mi_psy_state *__restrict__ state,
-                                             double *__restrict__ eb_all, float *__restrict__ cb_all)
+                                             double *__restrict__ eb_all, float *__restrict__ cb_all,
+                                             mp3mi_cw_fixlist *__restrict__ fix, int second)
 {
+    // second == 0: the lanes are the 64 consecutive records of block blockIdx.x.  With fix given, cw_mid holds k_cw's
+    // FIRST tier: every rounding it feeds is checked (part_cw_safe) and a record with one that could go either way is
+    // put on the list.  second == 1: the lanes are the records of the list, on the second-tier values k_cw_fix has
+    // written for them meanwhile.  fix == NULL (MP3MI_CW_EXACT=1): second-tier values throughout, nothing to check.
+    const bool check = !second && fix != NULL;
+    bool amb = false;
     const int lane = wave_lane();
     const int C = geo.channels, G = geo.n_gran;
     const size_t n_rec = (size_t) geo.n_streams * (size_t) G * (size_t) C;
-    const size_t rec0 = (size_t) blockIdx.x * 64;
-    const bool live = rec0 + lane < n_rec;
-    const size_t rec = live ? rec0 + lane : n_rec - 1;
+    bool live;
+    size_t rec;
+    if (second) {
+        const unsigned n_fix = fix->count < fix->cap ? fix->count : fix->cap;
+        if ((size_t) blockIdx.x * 64 >= n_fix) return;
+        live = (size_t) blockIdx.x * 64 + lane < n_fix;
+        rec = live ? fix->list[(size_t) blockIdx.x * 64 + lane] : n_rec - 1;
+    } else {
+        live = (size_t) blockIdx.x * 64 + lane < n_rec;
+        rec = live ? (size_t) blockIdx.x * 64 + lane : n_rec - 1;
+    }
+    __shared__ part_tile Lt;
+    Lt.rec[lane] = live ? (unsigned) rec : PART_NO_REC;
     const int ch = (int) (rec % C), gl = (int) ((rec / C) % G);
     const size_t s = rec / ((size_t) C * G);
     const mp3mi_psy_state *st = &state[s * C + ch];
     const float *er = energy_l + rec * MP3MI_HBLK_P;
     const double *cwr = cw_mid + rec * 50;
-    __shared__ part_tile Lt;
 
     part_walk W;
     W.eb = W.eb0 = 0.0; W.cb = W.cb0 = 0.0f;
@@ -137,7 +178,7 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
         const double t2 = (double) rn * sn - r_prime * sp;
         const double t3 = (double) rn + __builtin_fabs(r_prime);
         const double cw = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
-        part_line(T, W, Lt, j, er[j], cw, rec0, n_rec, eb_all, cb_all);
+        part_line<false>(T, W, Lt, j, er[j], cw, eb_all, cb_all, &amb); // (correctly rounded sines: nothing to check)
     }
     // lines 6..511 in blocks of 32 = one 128-byte line of the energy row; the unpredictability of lines
     // 6+4n..9+4n is cw_mid[n] (src/l3psy.c:531-549), from line 206 on the constant 0.4 (src/l3psy.c:555-556).
@@ -167,19 +208,24 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
             const int jj = 32 * k + l;
             if (jj < 6) continue; // done above (only in block 0; wave-uniform)
             const int q = ((l - 6) >> 2) + 2; // arithmetic shift: l < 6 never reaches here with k == 0
-            part_line(T, W, Lt, jj, ev[l], jj < 206 ? cwv[q] : 0.4, rec0, n_rec, eb_all, cb_all);
+            if (jj < 206 && check) part_line<true>(T, W, Lt, jj, ev[l], cwv[q], eb_all, cb_all, &amb);
+            else part_line<false>(T, W, Lt, jj, ev[l], jj < 206 ? cwv[q] : 0.4, eb_all, cb_all, &amb);
         }
     }
-    part_line(T, W, Lt, 512, er[512], 0.4, rec0, n_rec, eb_all, cb_all);
+    part_line<false>(T, W, Lt, 512, er[512], 0.4, eb_all, cb_all, &amb);
     for (int b = W.b < 1 ? 1 : W.b; b < MP3MI_CBANDS; b++) { // partitions without lines
         Lt.eb[b & 7][lane] = 0.0;
         Lt.cb[b & 7][lane] = 0.0f;
-        if ((b & 7) == 7) part_flush(Lt, b, rec0, n_rec, eb_all, cb_all);
+        if ((b & 7) == 7) part_flush(Lt, b, eb_all, cb_all);
     }
-    if (((MP3MI_CBANDS - 1) & 7) != 7) part_flush(Lt, MP3MI_CBANDS - 1, rec0, n_rec, eb_all, cb_all); // the last, partial group
+    if (((MP3MI_CBANDS - 1) & 7) != 7) part_flush(Lt, MP3MI_CBANDS - 1, eb_all, cb_all); // the last, partial group
     if (live) {
         eb_all[rec * MP3MI_PART_P] = W.eb0;
         cb_all[rec * MP3MI_PART_P] = W.cb0;
+    }
+    if (check && amb && live) { // (rare: a list entry per record, in no particular order)
+        const unsigned i = atomicAdd(&fix->count, 1u);
+        if (i < fix->cap) fix->list[i] = (unsigned) rec;
     }
 }
 
@@ -412,13 +458,25 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
 
 size_t mp3mi_psy_state_size(void) { return sizeof(mp3mi_psy_state); }
 
+// bins, fix: for the second tier of the unpredictability -- k_cw_fix and k_part again on the records the first k_part
+// lists (fix holds at least as many entries as there are records); with MP3MI_CW_EXACT=1 (test_flags bit 4) k_cw has
+// already written second-tier values everywhere and nothing is checked.
 void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l, const float *energy_s,
-                      const double *cw_mid, const float *hist6, void *psy_state, double *eb_all, float *cb_all,
+                      double *cw_mid, float *hist6, const float *bins, mp3mi_cw_fixlist *fix, void *psy_state, double *eb_all, float *cb_all,
                       mp3mi_psy_out *out, hipStream_t st)
 {
     const size_t n_rec = (size_t) g.n_streams * (size_t) g.n_gran * (size_t) g.channels;
-    hipLaunchKernelGGL(k_part, dim3((unsigned) ((n_rec + 63) / 64)), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6,
-                       (const mp3mi_psy_state *) psy_state, eb_all, cb_all);
+    const unsigned nblk = (unsigned) ((n_rec + 63) / 64);
+    if ((g.test_flags >> 4) & 1)
+        hipLaunchKernelGGL(k_part, dim3(nblk), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all,
+                           (mp3mi_cw_fixlist *) NULL, 0);
+    else {
+        mp3mi_launch_cw_fix_reset(fix, (unsigned) n_rec, st);
+        hipLaunchKernelGGL(k_part, dim3(nblk), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all, fix, 0);
+        mp3mi_launch_cw_fix(g, bins, cw_mid, hist6, fix, st);
+        // (as many blocks as the list could need: those beyond its end leave at once)
+        hipLaunchKernelGGL(k_part, dim3(nblk), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all, fix, 1);
+    }
     const unsigned grid = (unsigned) ((g.n_streams * g.channels + PSY_W - 1) / PSY_W);
     if (g.rate_idx == 0)
         hipLaunchKernelGGL(k_psy<true>, dim3(grid), dim3(64 * PSY_W), 0, st, T, g, eb_all, cb_all, energy_s, hist6, (mp3mi_psy_state *) psy_state, out);

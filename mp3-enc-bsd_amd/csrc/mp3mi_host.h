@@ -39,7 +39,8 @@ struct mp3mi_geom {
     int test_flags;     /* bit 0: k_loop takes the exact (sequential) noise sums only (MP3MI_NOISE_EXACT=1, tests);
                            bit 1: k_cw takes the correctly rounded atan2 only (MP3MI_PHASE_EXACT=1, tests);
                            bit 2: k_psy takes dm_log / dm_exp only (MP3MI_PSY_EXACT=1, tests);
-                           bit 3: k_loop's quantiser takes the exact table search only (MP3MI_QUANT_EXACT=1, tests) */
+                           bit 3: k_loop's quantiser takes the exact table search only (MP3MI_QUANT_EXACT=1, tests);
+                           bit 4: k_cw takes the correctly rounded sines and cosines for every record (MP3MI_CW_EXACT=1, tests) */
 };
 
 static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_idx, int n_frames, int f0, int nf)
@@ -58,8 +59,17 @@ static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_i
 
 void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
                       float *energy_l, float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st);
+/* records whose unpredictability needs its second tier (k_part lists them, k_cw_fix and k_part's second run work
+ * through the list); device memory, mp3mi_cw_fixlist_bytes(records) */
+struct mp3mi_cw_fixlist {
+    unsigned count, cap, pad[2];
+    unsigned list[1]; /* cap entries */
+};
+static inline size_t mp3mi_cw_fixlist_bytes(size_t n_rec) { return sizeof(mp3mi_cw_fixlist) + n_rec * sizeof(unsigned); }
+void mp3mi_launch_cw_fix_reset(mp3mi_cw_fixlist *fix, unsigned cap, hipStream_t st);
+void mp3mi_launch_cw_fix(const mp3mi_geom &g, const float *bins, double *cw_mid, float *hist6, const mp3mi_cw_fixlist *fix, hipStream_t st);
 void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l,
-                      const float *energy_s, const double *cw_mid, const float *hist6,
+                      const float *energy_s, double *cw_mid, float *hist6, const float *bins, mp3mi_cw_fixlist *fix,
                       void *psy_state, double *eb_all, float *cb_all, mp3mi_psy_out *out, hipStream_t st);
 void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
                          const mp3mi_psy_out *psy, double *sbs, double *xr, double *sb_dbg, hipStream_t st);

@@ -121,3 +121,17 @@ def test_exp_fast_error_bound(dm):
     x = np.concatenate([rng.uniform(-60, 60, 1 << 20), rng.uniform(-8, 0, 1 << 18), np.arange(-64, 65) * (np.log(2) / 64)])
     exact, fast = call1(dm, "exp", x), call1(dm, "exp_fast", x)
     assert (np.abs(fast - exact) <= 2.0 ** -50 * exact).all()
+
+
+def test_sincos_fast_error_bound(dm):
+    """dm_sincos_fast (k_cw's first tier) stays within 2^-51 absolute of the correctly rounded dm_sin / dm_cos
+    over the phases it is given: floats in [-pi, pi] and 2 phi0 - phi2 in [-3 pi, 3 pi]."""
+    rng = np.random.default_rng(16)
+    ph = rng.uniform(-np.pi, np.pi, 1 << 20).astype(np.float32).astype(np.float64)
+    pp = 2.0 * rng.uniform(-np.pi, np.pi, 1 << 20).astype(np.float32).astype(np.float64) - rng.uniform(-np.pi, np.pi, 1 << 20).astype(np.float32).astype(np.float64)
+    k = np.arange(-6, 7) * (np.pi / 2)
+    edge = np.concatenate([k, np.nextafter(k, 10), np.nextafter(k, -10), k + np.pi / 4, np.array([0.0, 1e-30, -1e-30, 1e-9])])
+    x = np.concatenate([ph, pp, edge])
+    for name in ("sin", "cos"):
+        exact, fast = call1(dm, name, x), call1(dm, name + "_fast", x)
+        assert np.abs(fast - exact).max() <= 2.0 ** -51

@@ -96,7 +96,7 @@ def test_quant_exact_tier_matches_estimate(emu, oracle):
     run = BatchRun(emu, 2, rate, ch, 128, nf, stream0=60)
     try:
         ref = [oracle.encode(run.pcm_of(s), rate, 128, ch)[0] for s in range(2)]
-        for flags in (0, 8, 31):
+        for flags in (0, 8, 32, 63):
             out, lens = run.encode(flags)
             assert [out[s, :lens[s]].tobytes() for s in range(2)] == ref, "flags %d" % flags
     finally:

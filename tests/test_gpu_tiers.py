@@ -10,7 +10,7 @@ from mp3common import BatchRun
 
 pytestmark = pytest.mark.gpu
 
-FLAGS = {"noise": 1, "phase": 2, "psy": 4, "quant": 8, "prep": 16, "all": 31}
+FLAGS = {"noise": 1, "phase": 2, "psy": 4, "quant": 8, "prep": 16, "cw": 32, "all": 63}
 
 
 def test_raw_sqrt_and_exp2_stay_inside_the_guard_band_budget(product):
