@@ -103,6 +103,7 @@ class Mp3mi:
         L.mp3mi_batch_encode_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_batch_flush.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_batch_reset.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_debug_cw_fixups.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.mp3mi_batch_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -249,6 +250,12 @@ class BatchRun:
         out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
         lens = self.mem.download(self.d_len, (self.S,), np.uint32)
         return out, lens
+
+    def cw_fixups(self):
+        """(records listed for the second tier of the unpredictability, records) of the last call's last chunk"""
+        a, n = ctypes.c_int(), ctypes.c_int()
+        assert self.mp.lib.mp3mi_batch_debug_cw_fixups(self.b, ctypes.byref(a), ctypes.byref(n)) == 0
+        return a.value, n.value
 
     def encode_streaming(self, pieces):
         """The same PCM fed piece by piece (frames per call) through mp3mi_batch_encode_next, then flushed.

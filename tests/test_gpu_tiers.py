@@ -1,4 +1,4 @@
-"""The five two-tier decisions on the DEVICE: forcing the exact tier of each -- and of all
+"""The six two-tier decisions on the DEVICE: forcing the exact tier of each -- and of all
 of them -- must not change one emitted byte on a full-chip batch, and the raw hardware square root / exp2 that
 the quantiser's first tier is built from must stay inside the error its guard band budgets."""
 import ctypes
@@ -33,6 +33,9 @@ def test_every_exact_tier_gives_identical_bytes(product, oracle, rate, ch, kbps,
     run = BatchRun(product, S, rate, ch, kbps, nf, stream0=stream0)
     try:
         base, base_len = run.encode(0)
+        # the second tier of the unpredictability was exercised, and only for a few records (k_part's rounding check)
+        listed, records = run.cw_fixups()
+        assert 0 < listed < records // 10, "%d of %d records listed" % (listed, records)
         for name, fl in FLAGS.items():
             out, lens = run.encode(fl)
             assert np.array_equal(lens, base_len), "lengths differ with the %s tier forced" % name
