@@ -58,6 +58,40 @@ def test_silence_and_full_scale(product, oracle):
         assert got[s] == ref, "edge stream %d" % s
 
 
+def test_tonal_inputs(product, oracle):
+    """Stationary tones: the unpredictability of a well-predicted line is tiny, so a much larger share of its
+    float-rounded partition sums than on noisy input falls inside the band where k_cw's first tier (plain-double
+    sines) cannot decide them -- the records go through k_cw_fix and the second k_part run, and the bytes still are
+    the reference's."""
+    from mp3common import BatchRun
+    nf, rate, ch, S = 40, 44100, 2, 48
+    t = np.arange(nf * 1152, dtype=np.float64) / rate
+    rng = np.random.default_rng(5)
+    pcm = np.zeros((S, nf * 1152, ch), np.int16)
+    for s in range(S):
+        f1, f2 = 110.0 * 2 ** (s / 8.0), 997.0 + 371.0 * s
+        a = [3000.0, 12000.0, 30000.0][s % 3]
+        left = a * np.sin(2 * np.pi * f1 * t)
+        right = a * np.sin(2 * np.pi * f1 * t + 0.5) if s % 2 else 0.5 * a * (np.sin(2 * np.pi * f1 * t) + np.sin(2 * np.pi * f2 * t))
+        if s % 4 == 3:
+            left = left + rng.normal(0.0, 2.0, left.shape)  # a little noise under the tone
+        pcm[s, :, 0] = np.clip(np.rint(left), -32768, 32767)
+        pcm[s, :, 1] = np.clip(np.rint(right), -32768, 32767)
+    run = BatchRun(product, S, rate, ch, 128, nf, pcm=pcm.reshape(S, -1))
+    try:
+        out, lens = run.encode(0)
+        listed, records = run.cw_fixups()
+        print("tonal input: %d of %d records took the second tier of the unpredictability" % (listed, records))
+        assert listed > 0
+        for s in range(S):
+            ref, _ = oracle.encode(pcm[s].reshape(-1), rate, 128, ch)
+            assert out[s, :lens[s]].tobytes() == ref, "tonal stream %d" % s
+        out2, lens2 = run.encode(32)  # and with the second tier for every record
+        assert np.array_equal(lens, lens2) and np.array_equal(out, out2)
+    finally:
+        run.close()
+
+
 def test_chunked_equals_unchunked(product, oracle, monkeypatch):
     """the internal frame chunking must not change a byte (state carried across chunks)"""
     nf, rate, ch, S = 23, 44100, 2, 3
