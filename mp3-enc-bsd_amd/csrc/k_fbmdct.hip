@@ -8,7 +8,7 @@
 //             The filterbank is feed-forward -- a pure function of 1056 PCM samples -- so every
 //             granule is independent, including the one BEFORE the chunk, which the reference
 //             would still hold in l3_sb_sample[ch][0] and which is recomputed here (granule slot 0).
-//   k_mdct    one wavefront per (stream, channel, run of 11 granules): 36 inputs per band from two granules.
+//   k_mdct    one wavefront per (stream, channel, run of 22 granules): 36 inputs per band from two granules.
 //
 // Arithmetic and its ordering: fbmdct_dev.h.
 #include "fbmdct_dev.h"
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
 // "previous"), and the next granule's samples are requested before the current one is transformed -- into the
 // registers the previous granule's just left.  168 VGPRs and 13 KB of LDS: the kernel fits beside k_loop's
 // resident wavefronts (batch.cpp).
-#define MDCT_RUN 11
+#define MDCT_RUN 22
 __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ sbs, const mp3mi_psy_out *__restrict__ psy,
                                                 double *__restrict__ xr_out)

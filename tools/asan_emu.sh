@@ -24,7 +24,7 @@ for rate, ch, kbps, nf, s0 in [(44100, 2, 128, 5, 5), (48000, 2, 32, 4, 3), (320
     out, lens = run.encode()
     got = run.encode_streaming([1, nf - 1])
     assert all(got[s] == out[s, :lens[s]].tobytes() for s in range(2))
-    out2, _ = run.encode(31)
+    out2, _ = run.encode(63)
     assert (out2 == out).all()
     run.close()
     print("sanitizer run ok:", rate, ch, kbps)
