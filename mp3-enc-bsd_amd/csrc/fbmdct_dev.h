@@ -12,7 +12,7 @@
 #define MP3MI_FBMDCT_DEV_H
 #include "mp3mi_host.h"
 
-// 13.1 KB per wavefront: twelve fit a CU (three per SIMD), or two beside k_loop's sixteen
+// 14.8 KB per wavefront: ten fit a CU, or two beside k_loop's sixteen
 struct mdct_lds {
     union {
         double in[36][32]; // [k][band]: 18 slots of the previous granule, then 18 of the current one (sign-flipped
@@ -25,6 +25,8 @@ struct mdct_lds {
     };
     double win[4][36];
     double cos_s[6][12];
+    double fcoef[12][18];  // the twelve full output rows of the long-block transform: coefficient of pair group t
+    uint8_t frow[16];      // and their output row
     double scoef[6][6];    // the six short output rows of the long-block transform (2 or 6 terms): coefficients,
     uint8_t sidx[6][8];    // operand-group indices,
     uint8_t srow[8], snt[8]; // output row and number of terms
@@ -32,12 +34,12 @@ struct mdct_lds {
 };
 
 // per-lane constants of the long-block MDCT.  Twelve of the 18 output rows are the ordered sum of all 18
-// pair groups V[0..17] (T->mdct_full_row): lane < 60 owns one of them (row m_full, coefficients in registers)
-// for every fifth band.  The other six rows have 2 or 6 terms (T->mdct_small_row) and are taken from LDS.
+// pair groups V[0..17] (T->mdct_full_row): a lane owns ONE BAND (lane & 31) and six of those rows (lane >> 5),
+// reads the band's 18 groups once and takes the rows' coefficients from LDS, the same address for all lanes of a
+// half (L.fcoef; 36 registers of per-lane coefficients were what made the kernel spill at 168 VGPRs).  The other
+// six rows have 2 or 6 terms (T->mdct_small_row) and are taken from LDS.
 struct mdct_regs {
-    double coef[18];
     double cs, ca; // alias butterfly coefficients of k = lane & 7 (every step of the alias loop has that k)
-    int m_full, grp;
 };
 
 // s[sub] of filter_subband from the 64 folded window sums y (src/encode.c:398-408)
@@ -62,10 +64,8 @@ MP3MI_DEVFN void mdct_load_tables(mdct_lds &L, mdct_regs &R, const mp3mi_tables 
         L.sidx[sr][t] = T->mdct_vidx[m][t];
         if (t == 0) { L.srow[sr] = (uint8_t) m; L.snt[sr] = T->mdct_nterm[m]; }
     }
-    R.grp = lane / 12;
-    R.m_full = T->mdct_full_row[lane < 60 ? lane - 12 * R.grp : 0];
-#pragma unroll
-    for (int t = 0; t < 18; t++) R.coef[t] = T->mdct_vcoef[R.m_full][t];
+    for (int i = lane; i < 12 * 18; i += 64) L.fcoef[i / 18][i % 18] = T->mdct_vcoef[T->mdct_full_row[i / 18]][i % 18];
+    if (lane < 12) L.frow[lane] = T->mdct_full_row[lane];
     R.cs = T->cs[lane & 7];
     R.ca = T->ca[lane & 7];
 }
@@ -147,18 +147,18 @@ MP3MI_DEVFN void mdct_granule(mdct_lds &L, const mdct_regs &R, const mp3mi_table
         }
         __syncthreads(); // the inputs are dead from here on
         // phase B: every output is the ordered sum of its terms V * coefficient (src/mdct.c:199-509)
-        if (lane < 60) { // the twelve rows over all 18 pair groups
-            for (int band = R.grp; band < 32; band += 5) {
-                double sum = 0.0; // (six operands in flight at a time, one chain in the reference's order)
+        { // the twelve rows over all 18 pair groups: this lane's band, rows 6 h .. 6 h + 5
+            const int band = lane & 31, h = lane >> 5;
+            double pr[18];
 #pragma unroll
-                for (int t0 = 0; t0 < 18; t0 += 6) {
-                    double pr[6];
+            for (int t = 0; t < 18; t++) pr[t] = L.V[band][t];
+#pragma unroll 2
+            for (int r = 0; r < 6; r++) {
+                const double *cf = L.fcoef[6 * h + r];
+                double sum = pr[0] * cf[0]; // (one chain in the reference's order)
 #pragma unroll
-                    for (int t = 0; t < 6; t++) pr[t] = L.V[band][t0 + t];
-#pragma unroll
-                    for (int t = 0; t < 6; t++) sum = (t0 + t == 0) ? pr[0] * R.coef[0] : sum + pr[t] * R.coef[t0 + t];
-                }
-                L.xr[band * 18 + R.m_full] = sum;
+                for (int t = 1; t < 18; t++) sum = sum + pr[t] * cf[t];
+                L.xr[band * 18 + L.frow[6 * h + r]] = sum;
             }
         }
 #pragma unroll

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
 // One wavefront transforms a run of MDCT_RUN consecutive granules of one (stream, channel): the tables are
 // set up once, every granule's subband samples are read once (the current granule is the next one's
 // "previous"), and the next granule's samples are requested before the current one is transformed -- into the
-// registers the previous granule's just left.  168 VGPRs and 13 KB of LDS: the kernel fits beside k_loop's
+// registers the previous granule's just left.  168 VGPRs (no spills) and 15 KB of LDS: the kernel fits beside k_loop's
 // resident wavefronts (batch.cpp).
 #define MDCT_RUN 22
 __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
