@@ -136,7 +136,7 @@ int mp3mi_encode_host_ex(int n_streams, int rate_hz, int channels, const int *kb
 long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst, size_t cap);
 void mp3mi_batch_debug_enable(mp3mi_batch *b, int on);
 
-/* Two-tier decisions: five places decide from a cheap value with a proven error bound and
+/* Two-tier decisions: six places decide from a cheap value with a proven error bound and
  * repeat the computation the reference's way only when the decision could depend on the last bits.  Each bit
  * forces the second (exact) tier everywhere; the emitted bytes must not change (tests/test_gpu_tiers.py).  The
  * environment variables MP3MI_{NOISE,PHASE,PSY,QUANT,PREP}_EXACT=1 set the same bits at mp3mi_batch_create. */
