@@ -69,8 +69,11 @@ class Workload:
         self.frame_bytes = [mp3.frame_bytes(rate, k) for k in self.kbps]
         torch.cuda.synchronize()
 
-    def step(self):
+    def encode(self):
         self.batch.encode(self.pcm, self.cfg["frames"], self.out, self.out_len)
+
+    def step(self):
+        self.encode()
         self.batch.sync()
 
     def alg_bytes_per_frame(self):
@@ -236,19 +239,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A step = one mp3mi_batch_encode call over the whole batch.  The K timed calls are issued back to back, as a
+    # service encoding batch after batch would issue them: a call's feed-forward kernels may start beside the last
+    # loop kernel of the call before (batch.cpp, encode_impl); the timed region is closed by a sync of the batch,
+    # the barrier and a device-wide synchronize, and the HIP-event timing of the K calls is read after it.
+    # (MP3MI_BENCH_SYNC_EACH=1: a sync after every call, as rounds 1-2 measured.)
+    sync_each = os.environ.get("MP3MI_BENCH_SYNC_EACH", "0") == "1"
     for _ in range(args.warmup):
         wl.step()
     barrier()
+    t_before = wl.batch.total_timing()
     t0 = time.perf_counter()
-    loop_ms, all_ms, launches = 0.0, 0.0, 0
     for _ in range(args.steps):
-        wl.step()
-        a, b, n = wl.batch.last_timing()
-        loop_ms += a
-        all_ms += b
-        launches += n
+        if sync_each:
+            wl.step()
+        else:
+            wl.encode()
+    wl.batch.sync()
     barrier()
     dt = time.perf_counter() - t0
+    t_after = wl.batch.total_timing()
+    loop_ms, all_ms, launches = t_after[0] - t_before[0], t_after[1] - t_before[1], t_after[2] - t_before[2]
+    assert t_after[3] - t_before[3] == args.steps
     if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

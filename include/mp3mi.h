@@ -116,6 +116,12 @@ int mp3mi_batch_set_error_protection(mp3mi_batch *b, int on);
 int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_kernels_ms,
                             int *loop_kernel_launches);
 
+/* The same summed over all encode calls since the batch was created (waits for the calls issued so far): calls
+ * may be issued back to back without a sync in between -- a call's feed-forward kernels then run beside the loop
+ * kernels of the call before -- and their timing read once at the end. */
+int mp3mi_batch_total_timing(mp3mi_batch *b, double *loop_kernel_ms, double *all_kernels_ms,
+                             long *loop_kernel_launches, long *calls);
+
 /* Host-buffer convenience wrapper (tests, smoke): copies PCM up, encodes, copies results back.
  * pcm: [n_streams][n_frames*1152*channels]; out: [n_streams][out_stride]; out_len: [n_streams]. */
 int mp3mi_encode_host(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,

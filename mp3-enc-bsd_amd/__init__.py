@@ -47,6 +47,8 @@ def lib():
         L.mp3mi_batch_sync.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+        L.mp3mi_batch_total_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                               ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
         L.mp3mi_synth_pcm.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_synth_pcm_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
@@ -147,6 +149,15 @@ class Batch:
         if rc != 0:
             raise Mp3miError("mp3mi_batch_last_timing failed with %d (no encode call yet?)" % rc)
         return a.value, b.value, n.value
+
+    def total_timing(self):
+        """(ms inside the loop kernel, ms inside all kernels, loop kernel launches, calls) summed over every encode
+        call of this batch so far; waits for them"""
+        a, b, n, k = ctypes.c_double(), ctypes.c_double(), ctypes.c_long(), ctypes.c_long()
+        rc = self.L.mp3mi_batch_total_timing(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n), ctypes.byref(k))
+        if rc != 0:
+            raise Mp3miError("mp3mi_batch_total_timing failed with %d" % rc)
+        return a.value, b.value, n.value, k.value
 
     def close(self):
         if self.h:

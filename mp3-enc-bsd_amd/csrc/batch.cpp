@@ -48,6 +48,9 @@ struct mp3mi_batch {
     hipEvent_t ev_done;      // everything of the previous encode call is done
     hipEvent_t ev_hist;      // the front stream's last work of a call (the PCM history hand-over) is enqueued
     bool have_done;
+    bool overlap_calls;      // a call's front stream does not wait for the call before it (MP3MI_CALL_OVERLAP=0: it does)
+    int slot_base;           // parity of the double-buffer slot the next call's chunk 0 takes
+    bool slot_used[2];       // ev_loop[i] has been recorded: the slot's last reader is a k_loop that may still run
     unsigned *gate_count;    // start census of k_loop's wavefronts (device memory, only ever grows), NULL = gate off
     unsigned gate_total;     // census value once every wavefront launched so far has started
     int *place_order, *place_cost; // k_loop stream placement (mp3mi_loop_place), NULL = off
@@ -78,9 +81,20 @@ struct mp3mi_batch {
     uint8_t *carry;          // [S][MP3MI_CARRY_BYTES]: file bytes formatted but not final yet
     int32_t *carry_len;      // [S]
     int debug, last_nf;
-    hipEvent_t ev0, ev1;
-    std::vector<hipEvent_t> loop_ev;
-    int loop_launches;
+    // HIP-event timing of the calls: two sets taken in turn, so that a call can be issued while the one before still
+    // runs; a set is read out (harvested) when its turn comes again -- which also keeps the host at most two calls
+    // ahead of the device -- or when the timing is asked for
+    struct timing_set {
+        hipEvent_t ev0, ev1;
+        std::vector<hipEvent_t> loop_ev;
+        int launches;
+        bool pending;
+    } ts[2];
+    unsigned call_no;
+    float last_loop_ms, last_all_ms;
+    int last_launches;
+    double tot_loop_ms, tot_all_ms;
+    long tot_launches, tot_calls;
 };
 
 // Every entry point runs on the batch's own device whatever the calling thread's current device is, and leaves
@@ -132,7 +146,7 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     if (n_streams <= 0 || max_frames <= 0 || (channels != 1 && channels != 2)) return MP3MI_ERR_ARG;
     CHK(hipGetDevice(&b->device));
     b->n_streams = n_streams; b->rate_idx = ri; b->rate_hz = rate_hz; b->channels = channels;
-    b->max_frames = max_frames; b->debug = 0; b->last_nf = 0; b->loop_launches = 0;
+    b->max_frames = max_frames; b->debug = 0; b->last_nf = 0;
     b->bits_per_frame_h.resize(n_streams);
     b->bitrate_index_h.resize(n_streams);
     b->max_frame_bytes = 0;
@@ -183,6 +197,9 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     CHK(hipEventCreateWithFlags(&b->ev_hist, hipEventDisableTiming));
     b->have_done = false;
     b->last_slot = 0;
+    { const char *e = getenv("MP3MI_CALL_OVERLAP"); b->overlap_calls = !(e && !atoi(e)); }
+    b->slot_base = 0;
+    b->slot_used[0] = b->slot_used[1] = false;
     { const char *e = getenv("MP3MI_PREP_EXACT"); b->prep_exact = (e && atoi(e)) ? 1 : 0; }
     { const char *e = getenv("MP3MI_NOISE_EXACT"); b->test_flags = (e && atoi(e)) ? 1 : 0; }
     { const char *e = getenv("MP3MI_PHASE_EXACT"); if (e && atoi(e)) b->test_flags |= 2; }
@@ -248,8 +265,17 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     b->frames_done = 0;
     b->fresh = false;
     b->sb_dbg = NULL;
-    CHK(hipEventCreate(&b->ev0));
-    CHK(hipEventCreate(&b->ev1));
+    for (int i = 0; i < 2; i++) {
+        CHK(hipEventCreate(&b->ts[i].ev0));
+        CHK(hipEventCreate(&b->ts[i].ev1));
+        b->ts[i].launches = 0;
+        b->ts[i].pending = false;
+    }
+    b->call_no = 0;
+    b->last_loop_ms = b->last_all_ms = 0;
+    b->last_launches = 0;
+    b->tot_loop_ms = b->tot_all_ms = 0;
+    b->tot_launches = b->tot_calls = 0;
     return MP3MI_OK;
 }
 
@@ -294,10 +320,11 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
                     b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg};
     for (void *p : bufs)
         if (p) hipFree(p);
-    hipEvent_t evs[] = {b->ev0, b->ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done, b->ev_hist};
+    hipEvent_t evs[] = {b->ts[0].ev0, b->ts[0].ev1, b->ts[1].ev0, b->ts[1].ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done, b->ev_hist};
     for (hipEvent_t e : evs)
         if (e) hipEventDestroy(e);
-    for (size_t i = 0; i < b->loop_ev.size(); i++) hipEventDestroy(b->loop_ev[i]);
+    for (int k = 0; k < 2; k++)
+        for (size_t i = 0; i < b->ts[k].loop_ev.size(); i++) hipEventDestroy(b->ts[k].loop_ev[i]);
     if (b->stream) hipStreamDestroy(b->stream);
     if (b->lstream) hipStreamDestroy(b->lstream);
     delete b;
@@ -348,6 +375,25 @@ extern "C" int mp3mi_batch_set_error_protection(mp3mi_batch *b, int on)
 
 static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames, uint8_t *out_dev,
                        size_t out_stride, uint32_t *out_len_dev, bool whole_file);
+
+// reads a timing set out (waits for its call to finish)
+static int harvest_timing(mp3mi_batch *b, int k)
+{
+    mp3mi_batch::timing_set &ts = b->ts[k];
+    if (!ts.pending) return MP3MI_OK;
+    CHK(hipEventSynchronize(ts.ev1));
+    float tot = 0, loop = 0;
+    CHK(hipEventElapsedTime(&tot, ts.ev0, ts.ev1));
+    for (int c = 0; c < ts.launches; c++) {
+        float ms = 0;
+        CHK(hipEventElapsedTime(&ms, ts.loop_ev[2 * c], ts.loop_ev[2 * c + 1]));
+        loop += ms;
+    }
+    b->last_loop_ms = loop; b->last_all_ms = tot; b->last_launches = ts.launches;
+    b->tot_loop_ms += loop; b->tot_all_ms += tot; b->tot_launches += ts.launches; b->tot_calls++;
+    ts.pending = false;
+    return MP3MI_OK;
+}
 
 // Fresh encoder state for every stream: what the reference's function statics and the caller's buffers hold when
 // its main() starts (all zero).  Enqueued on the front stream behind whatever is still running.
@@ -421,30 +467,43 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         const size_t ngc = (size_t) S * 2 * (size_t) b->chunk_frames * (size_t) C;
         CHK(hipMalloc((void **) &b->sb_dbg, ngc * 576 * sizeof(double)));
     }
-    // the previous call's kernels may still be running on the loop stream
-    if (b->have_done) CHK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
+    // The call before this one may still be running.  Its kernels and this call's share nothing but the batch's own
+    // buffers, and every one of those is either touched on ONE stream only (in-order: the FFT outputs, the subband
+    // samples, the psy state and the PCM history on the front stream; ix, the side information, the loop state, the
+    // carry and the caller's output on the loop stream) or double-buffered across the two (psy / xr / prep: the slots
+    // go on alternating from call to call, and a slot's writer waits for the k_loop that read it last, ev_loop).  So
+    // this call's feed-forward kernels start at once and fill the chip while the last k_loop of the call before -- 4096
+    // wavefronts, serial, nothing beside them -- runs out: back-to-back calls lose no pipeline fill.
+    // (MP3MI_CALL_OVERLAP=0: the front stream waits for the whole call before, as reset / flush still do.)
+    if (b->have_done && !b->overlap_calls) CHK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
     // a whole-file call starts every stream afresh; a streaming call continues (the first one after create / reset /
     // flush / a whole-file call starts afresh too)
     if (whole_file || (b->frames_done == 0 && !b->fresh)) {
-        const int rrc = reset_impl(b);
-        if (rrc != MP3MI_OK) return rrc;
+        CHK(hipMemsetAsync(b->psy_state, 0, mp3mi_psy_state_size() * (size_t) S * C, b->stream));
+        CHK(hipMemsetAsync(b->pcm_hist, 0, sizeof(int16_t) * MP3MI_PCM_HIST * (size_t) C * (size_t) S, b->stream));
+        CHK(hipMemsetAsync(b->loop_state, 0, mp3mi_loop_state_size() * (size_t) S, b->lstream));
+        CHK(hipMemsetAsync(b->out_base, 0, sizeof(int64_t) * (size_t) S, b->lstream));
+        CHK(hipMemsetAsync(b->carry_len, 0, sizeof(int32_t) * (size_t) S, b->lstream));
+        b->frames_done = 0;
     }
     const long fabs0 = b->frames_done;
     b->fresh = false;
-    if (b->place_cost) CHK(hipMemsetAsync(b->place_cost, 0, sizeof(int) * (size_t) S, b->stream)); // first chunk: order = identity
-    CHK(hipMemsetAsync(out_dev, 0, out_stride * (size_t) S, b->stream));
+    if (b->place_cost) CHK(hipMemsetAsync(b->place_cost, 0, sizeof(int) * (size_t) S, b->lstream)); // first chunk: order = identity
+    CHK(hipMemsetAsync(out_dev, 0, out_stride * (size_t) S, b->lstream)); // (behind the formatter of the call before: it may be the same buffer)
     if (!whole_file && fabs0 > 0) { // the bytes earlier calls formatted but could not deliver lead the rows
-        mp3mi_launch_carry_in(S, b->carry, b->carry_len, out_dev, out_stride, b->stream);
+        mp3mi_launch_carry_in(S, b->carry, b->carry_len, out_dev, out_stride, b->lstream);
         CHK(hipGetLastError());
     }
     const int nchunks = (n_frames + b->chunk_frames - 1) / b->chunk_frames;
-    while ((int) b->loop_ev.size() < 2 * nchunks) {
+    if (harvest_timing(b, (int) (b->call_no & 1)) != MP3MI_OK) return MP3MI_ERR_HIP; // (the call before the last one)
+    mp3mi_batch::timing_set &ts = b->ts[b->call_no & 1];
+    while ((int) ts.loop_ev.size() < 2 * nchunks) {
         hipEvent_t e;
         CHK(hipEventCreate(&e));
-        b->loop_ev.push_back(e);
+        ts.loop_ev.push_back(e);
     }
-    b->loop_launches = nchunks;
-    CHK(hipEventRecord(b->ev0, b->stream));
+    ts.launches = nchunks;
+    CHK(hipEventRecord(ts.ev0, b->stream));
     // Two kinds of front-end kernels cannot share the chip with k_loop: k_fft takes a whole CU's LDS
     // per workgroup, and k_psy's wavefronts live for the whole chunk (serial over granules), so
     // whichever is in flight when k_loop is launched keeps k_loop's wavefronts from starting.  Both
@@ -471,14 +530,15 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         const mp3mi_geom g = geom_of(c);
         mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
         CHK(hipGetLastError());
-        if (c >= 2) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[c & 1], 0)); // k_loop of chunk c-2 has read this slot
-        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->fft_bins, b->cw_fix, b->psy_state, b->part_eb, b->part_cb, b->psy[c & 1], b->stream);
+        const int xs = (c + b->slot_base) & 1;
+        if (b->slot_used[xs]) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[xs], 0)); // the k_loop that read this slot last (two chunks ago, maybe in the call before)
+        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->fft_bins, b->cw_fix, b->psy_state, b->part_eb, b->part_cb, b->psy[xs], b->stream);
         CHK(hipGetLastError());
         return MP3MI_OK;
     };
     if (stage_x(0) != MP3MI_OK) return MP3MI_ERR_HIP;
     for (int c = 0; c < nchunks; c++) {
-        const int slot = c & 1;
+        const int slot = (c + b->slot_base) & 1;
         const mp3mi_geom g = geom_of(c);
         // ---- front stream: everything that does not depend on the bit reservoir ----
         if (c >= 1 && b->gate_count) // stage Y of this chunk runs behind k_loop(c-1), once that is resident (<= 300 us)
@@ -491,7 +551,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipEventRecord(b->ev_front[slot], b->stream));
         // ---- loop stream: the serial search and the formatter ----
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
-        CHK(hipEventRecord(b->loop_ev[2 * c], b->lstream));
+        CHK(hipEventRecord(ts.loop_ev[2 * c], b->lstream));
         b->gate_total += (unsigned) mp3mi_loop_waves(S);
         mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
         if (b->place_order) { // rank the streams by their cost in the previous chunk, hand the tables to k_loop
@@ -506,8 +566,9 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
         mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, b->gate_count, place, b->lstream);
         CHK(hipGetLastError());
-        CHK(hipEventRecord(b->loop_ev[2 * c + 1], b->lstream));
+        CHK(hipEventRecord(ts.loop_ev[2 * c + 1], b->lstream));
         CHK(hipEventRecord(b->ev_loop[slot], b->lstream));
+        b->slot_used[slot] = true;
         mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,
                             out_len_dev, b->lstream);
         CHK(hipGetLastError());
@@ -527,8 +588,11 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipEventRecord(b->ev_hist, b->stream));
         CHK(hipStreamWaitEvent(b->lstream, b->ev_hist, 0)); // ev_done below then covers both streams
     }
+    b->slot_base = (b->slot_base + nchunks) & 1;
     b->frames_done = whole_file ? 0 : fabs0 + n_frames; // a whole-file call leaves finished streams behind
-    CHK(hipEventRecord(b->ev1, b->lstream));
+    CHK(hipEventRecord(ts.ev1, b->lstream));
+    ts.pending = true;
+    b->call_no++;
     CHK(hipEventRecord(b->ev_done, b->lstream));
     b->have_done = true;
     CHK(hipGetLastError());
@@ -558,19 +622,24 @@ extern "C" int mp3mi_batch_debug_cw_fixups(mp3mi_batch *b, int *n_listed, int *n
 
 extern "C" int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_kernels_ms, int *launches)
 {
-    if (!b || !b->have_done) return MP3MI_ERR_ARG; // nothing has been encoded yet
+    if (!b || !b->have_done || b->call_no == 0) return MP3MI_ERR_ARG; // nothing has been encoded yet
     ON_DEVICE(b);
-    CHK(hipEventSynchronize(b->ev1));
-    float tot = 0, loop = 0;
-    CHK(hipEventElapsedTime(&tot, b->ev0, b->ev1));
-    for (int c = 0; c < b->loop_launches; c++) {
-        float ms = 0;
-        CHK(hipEventElapsedTime(&ms, b->loop_ev[2 * c], b->loop_ev[2 * c + 1]));
-        loop += ms;
-    }
-    if (loop_kernel_ms) *loop_kernel_ms = loop;
-    if (all_kernels_ms) *all_kernels_ms = tot;
-    if (launches) *launches = b->loop_launches;
+    if (harvest_timing(b, (int) (b->call_no & 1)) != MP3MI_OK || harvest_timing(b, (int) ((b->call_no - 1) & 1)) != MP3MI_OK) return MP3MI_ERR_HIP;
+    if (loop_kernel_ms) *loop_kernel_ms = b->last_loop_ms;
+    if (all_kernels_ms) *all_kernels_ms = b->last_all_ms;
+    if (launches) *launches = b->last_launches;
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_total_timing(mp3mi_batch *b, double *loop_kernel_ms, double *all_kernels_ms, long *launches, long *calls)
+{
+    if (!b) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    if (harvest_timing(b, (int) (b->call_no & 1)) != MP3MI_OK || harvest_timing(b, (int) ((b->call_no - 1) & 1)) != MP3MI_OK) return MP3MI_ERR_HIP;
+    if (loop_kernel_ms) *loop_kernel_ms = b->tot_loop_ms;
+    if (all_kernels_ms) *all_kernels_ms = b->tot_all_ms;
+    if (launches) *launches = b->tot_launches;
+    if (calls) *calls = b->tot_calls;
     return MP3MI_OK;
 }
 

@@ -288,6 +288,44 @@ class BatchRun:
             got[s] += out[s, :lens[s]].tobytes()
         return got
 
+    def encode_streaming_unsynced(self, pieces, whole_first=False):
+        """encode_streaming with every call (and the flush) issued back to back, each into an output buffer of its
+        own, and ONE mp3mi_batch_sync at the end: a call's feed-forward kernels start while the loop kernels of the
+        call before still run (batch.cpp, encode_impl).  whole_first: a whole-file call of the same PCM is issued
+        first, unsynchronised too; its bytes per stream are returned as a second list."""
+        L = self.mp.lib
+        assert sum(pieces) == self.nf
+        row = self.n_per_ch * self.ch
+        whole = self.mem.download(self.d_pcm, (self.S, row), np.int16)
+        calls, f0 = [], 0
+        for nfp in pieces:
+            n = nfp * 1152 * self.ch
+            piece = np.ascontiguousarray(whole[:, f0 * 1152 * self.ch: f0 * 1152 * self.ch + n])
+            d_piece = self.mem.alloc(piece.nbytes)
+            self.mem.upload(d_piece, piece)
+            calls.append((d_piece, nfp, self.mem.alloc(self.S * self.stride), self.mem.alloc(4 * self.S)))
+            f0 += nfp
+        d_fout, d_flen = self.mem.alloc(self.S * self.stride), self.mem.alloc(4 * self.S)
+        d_wout, d_wlen = self.mem.alloc(self.S * self.stride), self.mem.alloc(4 * self.S)
+        if whole_first:
+            assert L.mp3mi_batch_encode(self.b, self.d_pcm, self.nf, d_wout, self.stride, d_wlen) == 0
+        for d_piece, nfp, d_o, d_l in calls:
+            rc = L.mp3mi_batch_encode_next(self.b, d_piece, nfp, d_o, self.stride, d_l)
+            assert rc == 0, "mp3mi_batch_encode_next -> %d" % rc
+        assert L.mp3mi_batch_flush(self.b, d_fout, self.stride, d_flen) == 0
+        assert L.mp3mi_batch_sync(self.b) == 0
+        got = [b""] * self.S
+        for d_o, d_l in [(c[2], c[3]) for c in calls] + [(d_fout, d_flen)]:
+            out = self.mem.download(d_o, (self.S, self.stride), np.uint8)
+            lens = self.mem.download(d_l, (self.S,), np.uint32)
+            for s in range(self.S):
+                got[s] += out[s, :lens[s]].tobytes()
+        if not whole_first:
+            return got
+        out = self.mem.download(d_wout, (self.S, self.stride), np.uint8)
+        lens = self.mem.download(d_wlen, (self.S,), np.uint32)
+        return got, [out[s, :lens[s]].tobytes() for s in range(self.S)]
+
     def close(self):
         if self.b:
             self.mp.lib.mp3mi_batch_destroy(self.b)

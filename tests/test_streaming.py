@@ -71,6 +71,36 @@ def test_streaming_full_chip_batch_gpu(product, oracle):
         run.close()
 
 
+def unsynced_case(mp, oracle, rate, ch, kbps, S, pieces, n_oracle, chunk, monkeypatch):
+    monkeypatch.setenv("MP3MI_CHUNK_FRAMES", str(chunk))
+    run = BatchRun(mp, S, rate, ch, kbps, sum(pieces))
+    try:
+        kb = [kbps] * S if np.isscalar(kbps) else list(kbps)
+        got, whole = run.encode_streaming_unsynced(pieces, whole_first=True)
+        bad = [s for s in range(S) if got[s] != whole[s]]
+        assert not bad, "%d streams differ between the streamed and the whole-file call (first %d)" % (len(bad), bad[0])
+        for s in sorted(set(int(x) for x in np.linspace(0, S - 1, n_oracle))):
+            assert whole[s] == oracle.encode(run.pcm_of(s), rate, kb[s], ch)[0], "stream %d" % s
+    finally:
+        run.close()
+
+
+def test_back_to_back_calls_without_sync_emulated(emu, oracle, monkeypatch):
+    unsynced_case(emu, oracle, 44100, 2, 128, 2, [3, 2, 4], 2, 2, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,pieces,chunk", [
+    (4096, [5, 3, 6, 1, 4], 2),   # odd and even numbers of chunks per call: the double-buffer slots change sides between calls
+    (600, [40, 7, 33], 9),
+])
+def test_back_to_back_calls_without_sync_gpu(product, oracle, monkeypatch, S, pieces, chunk):
+    """A whole-file call, streaming calls and the flush issued without a sync between them: every call's feed-forward
+    kernels overlap with the loop kernels of the call before (encode_impl).  The bytes must be those of
+    synchronised calls -- the oracle's."""
+    unsynced_case(product, oracle, 44100, 2, [(96, 128, 160, 128)[s % 4] for s in range(S)], S, pieces, 12, chunk, monkeypatch)
+
+
 def test_flush_without_frames_and_argument_errors_emulated(emu):
     """a flush right after create or after a whole-file encode delivers nothing; streaming calls check their arguments"""
     import ctypes
