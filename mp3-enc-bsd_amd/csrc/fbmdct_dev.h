@@ -11,6 +11,7 @@
 #ifndef MP3MI_FBMDCT_DEV_H
 #define MP3MI_FBMDCT_DEV_H
 #include "mp3mi_host.h"
+#include "mdct_shape.h"
 
 // 14.8 KB per wavefront: ten fit a CU, or two beside k_loop's sixteen
 struct mdct_lds {

@@ -8,7 +8,7 @@
 //             The filterbank is feed-forward -- a slot is a pure function of 512 PCM samples -- so every
 //             slot is independent, including those of the granule BEFORE the chunk, which the reference
 //             would still hold in l3_sb_sample[ch][0] and which is recomputed here (granule slot 0).
-//   k_mdct    one wavefront per (stream, channel, run of 22 granules): 36 inputs per band from two granules.
+//   k_mdct    one wavefront per (two tracks, run of 22 granules); a lane transforms one band: 36 inputs from two granules.
 //
 // Arithmetic and its ordering: fbmdct_dev.h.
 #include "fbmdct_dev.h"
@@ -143,48 +143,170 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
     }
 }
 
-// One wavefront transforms a run of MDCT_RUN consecutive granules of one (stream, channel): the tables are
-// set up once, every granule's subband samples are read once (the current granule is the next one's
-// "previous"), and the next granule's samples are requested before the current one is transformed -- into the
-// registers the previous granule's just left.  168 VGPRs (no spills) and 15 KB of LDS: the kernel fits beside k_loop's
-// resident wavefronts (batch.cpp).
-#define MDCT_RUN 22
+// k_mdct: one LANE per band.  Lanes 0-31 are the 32 bands of one (stream, channel) -- a track --, lanes 32-63 those of
+// the next track; the wavefront walks a run of MDCT_RUN consecutive granules.  A band's 36 inputs, its 26 operand
+// groups and its 18 outputs live in the lane's registers; every window value and every transform coefficient is the
+// same for all lanes -- scalar loads, SGPR operands of the f64 multiplies --; LDS holds the finished [band][18]
+// blocks only: for the alias butterflies' neighbour values and for coalesced stores.  (A wavefront per granule with the inputs in LDS, as before, spent two thirds of its
+// instructions on LDS traffic and its addresses, and waited on the LDS pipe.)
+#define MDCT_RUN 22 // <= 32: lane k of a half holds the block type of the run's granule k
+struct mdct_out_lds { double x[2][576]; };
+
+// ordered signed sum of windowed inputs: ops[i] = index | 0x80 (subtract / negate)   (src/mdct.c:205-508)
+template <int N> MP3MI_DEVFN double mdct_group_reg(const double (&fin)[36], const uint8_t *ops)
+{
+    double acc = (ops[0] & 0x80) ? -fin[ops[0] & 0x3f] : fin[ops[0] & 0x3f];
+#pragma unroll
+    for (int i = 1; i < N; i++) acc = (ops[i] & 0x80) ? acc - fin[ops[i] & 0x3f] : acc + fin[ops[i] & 0x3f];
+    return acc;
+}
+
+// long window (src/mdct.c:199-509): prev / cur = the band's 18 samples of the previous granule and of this one (stride 32)
+MP3MI_DEVFN void mdct_long_reg(const double *prev, const double *cur, const mp3mi_tables *T, double (&o)[18])
+{
+    double V[26];
+    {
+        double fin[36];
+#pragma unroll
+        for (int k = 0; k < 18; k++) { fin[k] = T->mdct_win[0][k] * prev[32 * k]; fin[18 + k] = T->mdct_win[0][18 + k] * cur[32 * k]; }
+#pragma unroll
+        for (int j = 0; j < 9; j++) { V[j] = fin[j] - fin[17 - j]; V[9 + j] = fin[18 + j] + fin[35 - j]; }
+#pragma unroll
+        for (int c = 0; c < 6; c++) V[18 + c] = mdct_group_reg<6>(fin, MDCT_G_OPS[c]);
+#pragma unroll
+        for (int c = 0; c < 2; c++) V[24 + c] = mdct_group_reg<18>(fin, MDCT_H_OPS[c]);
+    }
+    // every output is the ordered sum of its terms V * coefficient
+#pragma unroll
+    for (int r = 0; r < 12; r++) { // the twelve rows over all 18 pair groups
+        const double *cf = T->mdct_vcoef[MDCT_FULL_ROW[r]];
+        double sum = V[0] * cf[0];
+#pragma unroll
+        for (int t = 1; t < 18; t++) sum = sum + V[t] * cf[t];
+        o[MDCT_FULL_ROW[r]] = sum;
+        if (r & 1) __asm__ volatile("" ::: "memory"); // (two rows of coefficients in flight, not all 216)
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) { // the six short rows
+        const double *cf = T->mdct_vcoef[MDCT_SMALL_ROW[r]];
+        double sum = V[MDCT_SMALL_IDX[r][0]] * cf[0];
+#pragma unroll
+        for (int t = 1; t < 6; t++)
+            if (t < MDCT_SMALL_NT[r]) sum = sum + V[MDCT_SMALL_IDX[r][t]] * cf[t];
+        o[MDCT_SMALL_ROW[r]] = sum;
+    }
+}
+
+// the other block types; bt (1, 2, 3) is the same for all lanes that keep the result
+MP3MI_DEVFN void mdct_other_reg(const double *prev, const double *cur, const mp3mi_tables *T, int bt, double (&o)[18])
+{
+    double in[36];
+#pragma unroll
+    for (int k = 0; k < 18; k++) { in[k] = prev[32 * k]; in[18 + k] = cur[32 * k]; }
+    if (bt == 2) { // three short transforms, out[3*mm + l]   (src/mdct.c:173-185)
+        double w[3][12];
+#pragma unroll
+        for (int l = 0; l < 3; l++)
+#pragma unroll
+            for (int k = 0; k < 12; k++) w[l][k] = T->mdct_win[2][k] * in[k + 6 * l + 6];
+#pragma unroll
+        for (int mm = 0; mm < 6; mm++) {
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                double sum = 0.0;
+#pragma unroll
+                for (int k = 0; k < 12; k++) sum = sum + w[l][k] * T->cos_s[mm][k];
+                o[3 * mm + l] = sum;
+            }
+            __asm__ volatile("" ::: "memory");
+        }
+    } else { // start / stop windows, plain 36-term sums (src/mdct.c:188-198)
+        double w[36];
+#pragma unroll
+        for (int k = 0; k < 36; k++) w[k] = T->mdct_win[bt][k] * in[k];
+#pragma unroll
+        for (int m = 0; m < 18; m++) {
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 36; k++) sum = sum + w[k] * T->cos_l[m][k];
+            o[m] = sum;
+            __asm__ volatile("" ::: "memory");
+        }
+    }
+}
+
 __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ sbs, const mp3mi_psy_out *__restrict__ psy,
                                                 double *__restrict__ xr_out)
 {
-    __shared__ mdct_lds L;
-    const int lane = wave_lane();
-    const int C = geo.channels, G = geo.n_gran, NR = (G + MDCT_RUN - 1) / MDCT_RUN;
+    __shared__ mdct_out_lds L;
+    const int lane = wave_lane(), band = lane & 31, h = lane >> 5;
+    const int C = geo.channels, G = geo.n_gran, NR = (G + MDCT_RUN - 1) / MDCT_RUN, NT = geo.n_streams * C;
     int bid = (int) blockIdx.x;
-    const int ch = bid % C; bid /= C;
     const int r = bid % NR;
-    const int s = bid / NR;
+    const int pair = bid / NR;
+    const bool two = 2 * pair + 1 < NT; // (an odd number of tracks: the last wavefront's upper half idles on a copy of the lower one)
+    const int tr_lo = 2 * pair, tr_hi = two ? tr_lo + 1 : tr_lo;
     const int g_lo = r * MDCT_RUN, n = G - g_lo < MDCT_RUN ? G - g_lo : MDCT_RUN;
-    const size_t rec0 = ((size_t) s * G + g_lo) * C + ch;
-    const int btv = lane < n ? psy[rec0 + (size_t) lane * C].block_type : 0;
+    const size_t rec_lo = ((size_t) (tr_lo / C) * G + g_lo) * C + tr_lo % C, rec_hi = ((size_t) (tr_hi / C) * G + g_lo) * C + tr_hi % C;
+    const int tr = h ? tr_hi : tr_lo;
+    const int s = tr / C, ch = tr - s * C;
+    const size_t rec0 = h ? rec_hi : rec_lo;
+    const int btv = band < n ? psy[rec0 + (size_t) band * C].block_type : 0;
     const size_t pitch = (size_t) C * 576;
-    const double *blk = sbs + (((size_t) s * (G + 1) + g_lo) * C + ch) * 576; // granule slot g_lo: the one before granule g_lo
-    double vp[9], vc[9];
+    const double *blk = sbs + (((size_t) s * (G + 1) + g_lo) * C + ch) * 576 + band; // granule slot g_lo: the one before granule g_lo
+    for (int kk = 0; kk < n; kk++) {
+        // (the inputs are read where they are used, every granule twice -- as this granule and as the next one's
+        // previous; the second time from the cache: 36 values held across the transform do not fit the registers)
+        const double *prev = blk + (size_t) kk * pitch, *cur = prev + pitch;
+        const int bt0 = wave_readlane_i32(btv, kk), bt1 = wave_readlane_i32(btv, 32 + kk);
+        const int bt = h ? bt1 : bt0;
+        double o[18];
+        const bool mixed = bt0 != bt1; // (rare: the two tracks' block types differ, each half keeps its own transform's result)
+        double *own = &L.x[h][band * 18];
+#pragma unroll 1
+        for (int pass = 0; pass < (mixed ? 2 : 1); pass++) {
+            const int v = pass ? bt1 : bt0;
+            const mp3mi_tables *Tk = wave_uniform_here(T);
+            if (v == 0) mdct_long_reg(prev, cur, Tk, o);
+            else mdct_other_reg(prev, cur, Tk, v, o);
+            if (bt == v) {
 #pragma unroll
-    for (int j = 0; j < 9; j++) { vp[j] = blk[lane + 64 * j]; vc[j] = blk[pitch + lane + 64 * j]; }
-    mdct_regs R;
-    mdct_load_tables(L, R, T);
-    __syncthreads();
-    for (int k = 0; k < n; k++) {
-        const int bt = wave_readlane_i32(btv, k);
-        mdct_store_inputs(L, vp, vc, bt);
-#pragma unroll
-        for (int j = 0; j < 9; j++) vp[j] = vc[j]; // the current granule is the next one's previous,
-        if (k + 1 < n) {                            // and the next one's samples are on their way during the transform
-#pragma unroll
-            for (int j = 0; j < 9; j++) vc[j] = blk[(size_t) (k + 2) * pitch + lane + 64 * j];
+                for (int m = 0; m < 18; m++) own[m] = o[m];
+            }
         }
-        mdct_granule(L, R, T, bt);
-        double *out = xr_out + (rec0 + (size_t) k * C) * 576;
+        __syncthreads();
+        if (mixed) {
 #pragma unroll
-        for (int j = 0; j < 9; j++) out[lane + 64 * j] = L.xr[lane + 64 * j];
-        __syncthreads(); // the next granule's inputs take the place of this result
+            for (int m = 0; m < 18; m++) o[m] = own[m];
+        }
+        { // alias reduction butterflies between neighbouring bands (src/mdct.c:83-91); not for short blocks
+            double dn[8], up[8];
+            const mp3mi_tables *Tk = wave_uniform_here(T);
+            const double *above = &L.x[h][(band < 31 ? band + 1 : band) * 18], *below = &L.x[h][(band > 0 ? band - 1 : band) * 18];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { dn[k] = above[k]; up[k] = below[17 - k]; } // xr[band + 1][k], xr[band - 1][17 - k]
+            __syncthreads(); // every lane has its neighbours' values: the results may take their place
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double cs = Tk->cs[k], ca = Tk->ca[k];
+                const double bu = o[17 - k] * cs + dn[k] * ca;
+                const double bd = o[k] * cs - up[k] * ca;
+                if (bt != 2 && band < 31) own[17 - k] = bu;
+                if (bt != 2 && band > 0) own[k] = bd;
+            }
+        }
+        __syncthreads();
+        // element lane + 64 j of the two [band][18] blocks: j < 9 the lower track's, then the upper one's
+        double *out_lo = xr_out + (rec_lo + (size_t) kk * C) * 576, *out_hi = xr_out + (rec_hi + (size_t) kk * C) * 576;
+        const double *flat = &L.x[0][0];
+#pragma unroll
+        for (int j = 0; j < 9; j++) out_lo[lane + 64 * j] = flat[lane + 64 * j];
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) out_hi[lane + 64 * j] = flat[576 + lane + 64 * j];
+        }
+        __syncthreads(); // the next granule's results take the same place
     }
 }
 
@@ -194,5 +316,5 @@ void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16
                          const mp3mi_psy_out *psy, double *sbs, double *xr, double *sb_dbg, hipStream_t st)
 {
     hipLaunchKernelGGL(k_filter, dim3((unsigned) (g.n_streams * g.channels * (((g.n_gran + 1) * 18 + FILT_SLOTS - 1) / FILT_SLOTS))), dim3(64), 0, st, T, g, pcm, sbs, sb_dbg);
-    hipLaunchKernelGGL(k_mdct, dim3((unsigned) (g.n_streams * g.channels * ((g.n_gran + MDCT_RUN - 1) / MDCT_RUN))), dim3(64), 0, st, T, g, sbs, psy, xr);
+    hipLaunchKernelGGL(k_mdct, dim3((unsigned) (((g.n_streams * g.channels + 1) / 2) * ((g.n_gran + MDCT_RUN - 1) / MDCT_RUN))), dim3(64), 0, st, T, g, sbs, psy, xr);
 }

@@ -19,6 +19,7 @@
 #include <vector>
 #include "mp3mi_host.h"
 #include "mp3mi_tables_gen.h"
+#include "mdct_shape.h"
 
 #define R_PI 3.14159265358979
 #define R_LN_TO_LOG10 0.2302585093
@@ -563,6 +564,18 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
                 else return -4;
             }
             if (nf != 12 || nsm != 6) return -4;
+        }
+        {   /* ... and the compile-time copy of that shape k_mdct is built on (fbmdct_dev.h) */
+            bool ok = true;
+            for (int c = 0; c < 6; c++) for (int i = 0; i < 6; i++) ok = ok && T->mdct_g_ops[c][i] == MDCT_G_OPS[c][i];
+            for (int c = 0; c < 2; c++) for (int i = 0; i < 18; i++) ok = ok && T->mdct_h_ops[c][i] == MDCT_H_OPS[c][i];
+            for (int r = 0; r < 12; r++) ok = ok && T->mdct_full_row[r] == MDCT_FULL_ROW[r];
+            for (int r = 0; r < 6; r++) {
+                const int m = T->mdct_small_row[r];
+                ok = ok && m == MDCT_SMALL_ROW[r] && T->mdct_nterm[m] == MDCT_SMALL_NT[r];
+                for (int t = 0; ok && t < MDCT_SMALL_NT[r]; t++) ok = ok && T->mdct_vidx[m][t] == MDCT_SMALL_IDX[r][t];
+            }
+            if (!ok) { fprintf(stderr, "mp3mi: the long-block MDCT's shape does not match MDCT_* (fbmdct_dev.h)\n"); return -4; }
         }
     }
 
