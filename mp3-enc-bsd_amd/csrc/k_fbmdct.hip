@@ -123,21 +123,33 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
             __asm__ volatile("" ::: "memory"); // (likewise: one row of coefficients at a time)
         }
         __syncthreads();
+        // element lane + 64 m of [slot][16] is slot 4 m + (lane >> 4): the walk adds four slots a step; a slot's parity
+        // does not change on the way (4 and 18 are even), so the scale -- 1/32768, negated for the odd slots of odd
+        // subbands, which mdct_sub flips before use (src/mdct.c:57-60) -- is one constant per lane
         const int sub = 16 * half + (lane & 15);
-        int sgm = sg, gim = gi, qm = q;
+        const double scale = ((sub & 1) && (q & 1)) ? -0x1p-15 : 0x1p-15;
+        double *const out = sbs + ((size_t) s * G1 * C + ch) * 576 + sub;
+        // granule slots below gi_first lie before the stream: the reference's zero-initialised l3_sb_sample
+        const int gi_first = (2 * geo.fabs0 + (long) geo.g0 - 1 < 0) ? (int) (1 - (long) geo.g0 - 2 * geo.fabs0) : 0;
+        {
+            int sgm = sg, gim = gi, qm = q;
+            unsigned off = (unsigned) (gi * C * 576 + q * 32);
 #pragma unroll 4
-        for (int m = 0; m < 16; m++) { // element lane + 64 m of [slot][16]: slot 4 m + (lane >> 4)
-            const double raw = L.tr[4 * m + (lane >> 4)][lane & 15] * 0x1p-15;
-            if (sgm < NS) {
-                // before the stream: the reference's zero-initialised l3_sb_sample
-                const bool before = 2 * geo.fabs0 + (long) geo.g0 - 1 + gim < 0;
-                if (sb_dbg && gim > 0) // raw subband samples as filter_subband returns them (parity tests)
-                    sb_dbg[(((size_t) s * geo.n_gran + gim - 1) * C + ch) * 576 + qm * 32 + sub] = raw;
-                // mdct_sub negates odd slots of odd subbands before use (src/mdct.c:57-60)
-                sbs[(((size_t) s * G1 + gim) * C + ch) * 576 + qm * 32 + sub] = before ? 0.0 : (((sub & 1) && (qm & 1)) ? raw * -1.0 : raw);
+            for (int m = 0; m < 16; m++) {
+                const double v = L.tr[4 * m + (lane >> 4)][lane & 15] * scale;
+                if (sgm < NS) out[off] = gim < gi_first ? 0.0 : v;
+                sgm += 4; qm += 4; off += 128;
+                if (qm >= 18) { qm -= 18; gim++; off += (unsigned) (C - 1) * 576; }
             }
-            sgm += 4; qm += 4;
-            if (qm >= 18) { qm -= 18; gim++; }
+        }
+        if (sb_dbg) { // raw subband samples as filter_subband returns them (parity tests)
+            int sgm = sg, gim = gi, qm = q;
+            for (int m = 0; m < 16; m++) {
+                if (sgm < NS && gim > 0)
+                    sb_dbg[(((size_t) s * geo.n_gran + gim - 1) * C + ch) * 576 + qm * 32 + sub] = L.tr[4 * m + (lane >> 4)][lane & 15] * 0x1p-15;
+                sgm += 4; qm += 4;
+                if (qm >= 18) { qm -= 18; gim++; }
+            }
         }
         __syncthreads(); // the other half's results take the same place
     }
