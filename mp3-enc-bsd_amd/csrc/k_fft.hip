@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
     fft_wave_lds<C> &L = LL.w[wv];
     const int G = geo.n_gran, n_task = geo.n_streams * G;
     const long n_pitch = (long) geo.n_frames * 1152; // row pitch of the PCM buffer
+    const int lane_swz = MP3MI_FFT_SWZ(lane);
     PROF_DECL;
     {
         const int nw4 = (LONG ? T->fft_nword_l : T->fft_nword_s) / 4;
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
 #pragma unroll
                     for (int c = 0; c < C; c++)
                         v.c[c] = wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16)); // src/l3psy.c:485
-                    *(fft_pair<C> *) (L.x + MP3MI_FFT_SWZ(lane + 64 * k) * C) = v;
+                    *(fft_pair<C> *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(64 * k)) * C) = v; // == SWZ(lane + 64 k): the map is linear
                 }
             }
             wave_sync();
@@ -378,8 +379,9 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
                     v0.c[c] = wsv[k & 1] * v;
                     v1.c[c] = wsv[2 + (k & 1)] * v;
                 }
-                if (sb < 3) *(fft_pair<C> *) (L.x + (sb * 256 + MP3MI_FFT_SWZ(jj)) * C) = v0;
-                if (sb >= 1) *(fft_pair<C> *) (L.x + ((sb - 1) * 256 + MP3MI_FFT_SWZ(128 + jj)) * C) = v1;
+                // (element sb * 256 + jj of the 768-element array of the three windows; the map is linear)
+                if (sb < 3) *(fft_pair<C> *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(sb * 256 + 64 * (k & 1))) * C) = v0;
+                if (sb >= 1) *(fft_pair<C> *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ((sb - 1) * 256 + 128 + 64 * (k & 1))) * C) = v1;
             }
             wave_sync();
             PROF(1);
@@ -395,11 +397,13 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             for (int sb = 0; sb < 3; sb++) {
                 float *es0 = energy_s + rec0 * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S;
                 const float *xw = L.x + sb * 256 * C;
+                // the read-out table holds window 0's positions; window sb's differ by the swizzle of its offset
+                const uint32_t wsw = (uint32_t) (MP3MI_FFT_SWZ(sb * 256) ^ (sb * 256)) * 0x10001u;
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
                     const int k = lane + 64 * t;
                     if (k < MP3MI_HBLK_S) {
-                        const fft_pair<C> e = fft_energy<C>(xw, rds[t], k == 0 || k == 128);
+                        const fft_pair<C> e = fft_energy<C>(xw, rds[t] ^ wsw, k == 0 || k == 128);
                         if (valid) {
 #pragma unroll
                             for (int c = 0; c < C; c++) es0[c * (3 * MP3MI_HBLK_S) + k] = e.c[c];
@@ -408,7 +412,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
                 }
                 if (lane < 50 && valid) {
                     fft_pair<C> re, im;
-                    fft_bin<C>(xw, rdb, &re, &im);
+                    fft_bin<C>(xw, rdb ^ wsw, &re, &im);
 #pragma unroll
                     for (int c = 0; c < C; c++) {
                         float *o = bins + (rec0 + c) * MP3MI_FFT_BINS + (sb * 50 + lane) * 2;

@@ -24,7 +24,30 @@
 #define MP3MI_PART_P 64       /* row pitch of the partition energies eb / cb handed from k_part to k_psy */
 #define MP3MI_FFT_BINS 312   /* raw bins handed from k_fft to k_cw per (granule, channel): short lines 2..51 of the three
                                 windows as (re, im), then re[6], im[6] of long lines 0..5 */
-#define MP3MI_FFT_SWZ(p) ((p) ^ (((p) >> 5) & 31)) /* LDS index of element p of an FFT array */
+#if defined(MP3MI_FFT_SWZ_RUNTIME) /* tools/exp/fft_swz_search.cpp: the swizzle as data */
+extern unsigned mp3mi_fft_swz_col[10];
+static inline int mp3mi_fft_swz_rt(int p)
+{
+    int r = p;
+    for (int b = 4; b < 10; b++)
+        if (p & (1 << b)) r ^= (int) mp3mi_fft_swz_col[b];
+    return r;
+}
+#define MP3MI_FFT_SWZ(p) mp3mi_fft_swz_rt(p)
+#else
+/* LDS index of element p of an FFT array: index bits 4..9 are XORed into the low five bits, bit b with the constant
+ * MP3MI_FFT_SWZ_COLS names for it (bit 4's constant stays below 16: the map is a bijection).  GF(2)-linear, so
+ * SWZ(a ^ b) == SWZ(a) ^ SWZ(b): the kernels split an index into its lane part and a compile-time part.  The
+ * constants -- and with them the placement of the butterflies, fft_placement.h -- come out of a search for the
+ * fewest LDS bank conflicts of the butterfly programs (tools/exp/fft_swz_search.cpp); the three short transforms
+ * are swizzled as ONE 768-element array, so that the same butterfly of two windows does not fall on the same banks. */
+#define MP3MI_FFT_SWZ_COLS 8, 11, 9, 1, 17, 22
+#define MP3MI_FFT_SWZ_PICK(c4, c5, c6, c7, c8, c9, p) \
+    ((p) ^ ((((p) >> 4) & 1) * (c4)) ^ ((((p) >> 5) & 1) * (c5)) ^ ((((p) >> 6) & 1) * (c6)) ^ ((((p) >> 7) & 1) * (c7)) ^ \
+     ((((p) >> 8) & 1) * (c8)) ^ ((((p) >> 9) & 1) * (c9)))
+#define MP3MI_FFT_SWZ_APPLY(cols, p) MP3MI_FFT_SWZ_PICK(cols, p)
+#define MP3MI_FFT_SWZ(p) MP3MI_FFT_SWZ_APPLY(MP3MI_FFT_SWZ_COLS, p)
+#endif
 /* FFT butterfly programs (tables_host.cpp): rounds of 64 fused butterflies, one per lane */
 #define MP3MI_FFT_DUMMY 1024      /* elements 1024 + lane: what the idle lanes of a round work on */
 #define MP3MI_FFT_MAX_ROUNDS 48
@@ -33,8 +56,8 @@
 /* the header words of the rounds of the long and of the short program (fft_hdr_* below): k_fft is compiled
    for exactly these sequences -- straight-line code, no per-round dispatch -- and table build checks that the
    generator still produces them (MP3MI_FFT_INFO=1 prints the lists) */
-#define MP3MI_FFT_HDRS_L 2, 2, 2, 14, 2, 6, 15, 6, 3, 15, 6, 3, 15, 6, 3, 15, 6, 3, 13, 2, 4, 13, 4, 9, 8, 8
-#define MP3MI_FFT_HDRS_S 2, 2, 14, 2, 6, 15, 6, 7, 13, 6, 7, 13, 6, 13, 4, 4, 9, 8, 8
+#define MP3MI_FFT_HDRS_L 2, 2, 2, 14, 2, 6, 15, 6, 15, 6, 15, 6, 15, 6, 15, 6, 15, 4, 1, 13, 0, 9, 0, 8
+#define MP3MI_FFT_HDRS_S 2, 2, 14, 2, 14, 6, 15, 6, 15, 6, 15, 4, 13, 0, 9, 8
 #define MP3MI_PCM_HIST 1056   /* samples per channel a call needs from before its first sample: the filterbank of the granule
                                  before the call (k_filter recomputes it: 576 + 480 taps); the FFT window reaches back 768 */
 #define MP3MI_POW43_N 8208

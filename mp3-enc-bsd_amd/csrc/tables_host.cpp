@@ -73,6 +73,7 @@ Twiddle make_twiddle(int logm, bool three)
  * kind: 0 none, 1 twiddle rotation, 2 SQHALF rotation. */
 struct FusedOp {
     int cls, kind, neg;
+    int id; /* window * (butterflies of the rank) + index within the rank: names the butterfly in a stored placement */
     unsigned p[8];
     float tw[6];
 };
@@ -82,6 +83,8 @@ struct FftGen {
     std::vector<std::vector<FusedOp> > rank_ops; /* [rank] */
     struct Post { int type; unsigned a, b; };
     std::vector<Post> post1, post2;
+    const std::vector<uint16_t> *(*stored_order)(int logN, int rank, int cls) = NULL;
+    void (*placement_hook)(int logN, int rank, int cls, std::vector<FusedOp> &placed, int nopnd) = NULL; /* the offline search */
 
     void add(int rank, const FusedOp &o)
     {
@@ -156,6 +159,25 @@ struct FftGen {
         if (logm == 2) { Post p = {FOP_NEG, o0 + 3, 0}; post1.push_back(p); }
     }
 
+    /* LDS cycles of one round's operand k under the model the placement works to: an 8-byte store is served 16 lanes a
+       cycle (32 banks), an 8-byte load 32 lanes a cycle (64 banks); lanes of a group that fall on the same bank pair
+       take a cycle each.  pos[l]: the operand's element position in lane l. */
+    static int round_cycles(const unsigned *pos)
+    {
+        int total = 0;
+        for (int g = 0; g < 64; g += 16) {
+            int cnt[16] = {0}, mx = 0;
+            for (int l = g; l < g + 16; l++) { const int c = ++cnt[pos[l] & 15]; mx = c > mx ? c : mx; }
+            total += mx;
+        }
+        for (int g = 0; g < 64; g += 32) {
+            int cnt[32] = {0}, mx = 0;
+            for (int l = g; l < g + 32; l++) { const int c = ++cnt[pos[l] & 31]; mx = c > mx ? c : mx; }
+            total += mx;
+        }
+        return total;
+    }
+
     /* nwin transforms of 2^logN points at element offsets w << logN; returns the number of program words */
     int build(int logN, int nwin, uint32_t *hdr, int max_rounds, int32_t *n_rounds, uint32_t *prog, int max_words, uint32_t *rd)
     {
@@ -191,8 +213,68 @@ struct FftGen {
             }
         }
         int nr = 0, nw = 0;
-        for (size_t rank = 0; rank < rank_ops.size(); rank++) {
+        /* The butterflies form a DAG: one depends on those that last wrote its operands -- the level above IN ITS OWN
+           sub-transform.  The recursion's ranks are one valid order, but a wasteful one: the sub-transforms of
+           different sizes that a split-radix level spawns run out at different depths, so the deep ranks hold a few
+           butterflies each, and every (rank, class) pays whole rounds of 64 lanes (1222 butterflies in 26 rounds for
+           1024 points, 789 in 19 for the three 256-point transforms).  List scheduling instead: steps separated by a
+           wave barrier; a step takes, per class, the ready butterflies in whole rounds, the longest remaining chains
+           first, and a partial round only when it holds a butterfly of the longest chain (everything else can wait
+           for a later step and fill its round). */
+        struct Node { FusedOp o; int lp[8]; std::vector<int> succ; int npred, height; bool done; };
+        std::vector<Node> nodes;
+        for (size_t rank = 0; rank < rank_ops.size(); rank++)
+            for (int w = 0; w < nwin; w++)
+                for (size_t i = 0; i < rank_ops[rank].size(); i++) {
+                    Node nd;
+                    nd.o = rank_ops[rank][i];
+                    nd.o.id = (int) nodes.size();
+                    const int nop = nd.o.cls ? 8 : 4;
+                    for (int k = 0; k < 8; k++) nd.lp[k] = (k < nop && nd.o.p[k] != MP3MI_FFT_DUMMY) ? w * N + (int) nd.o.p[k] : -1;
+                    for (int k = 0; k < nop; k++)
+                        nd.o.p[k] = (nd.o.p[k] == MP3MI_FFT_DUMMY) ? nd.o.p[k] : (unsigned) MP3MI_FFT_SWZ(w * N + (int) nd.o.p[k]);
+                    nd.npred = 0; nd.height = 1; nd.done = false;
+                    nodes.push_back(nd);
+                }
+        {
+            std::vector<int> last_writer((size_t) nwin * (size_t) N, -1);
+            for (size_t i = 0; i < nodes.size(); i++) { /* (rank order: a butterfly's producers come before it) */
+                for (int k = 0; k < 8; k++) {
+                    const int e = nodes[i].lp[k];
+                    if (e < 0) continue;
+                    const int pr = last_writer[(size_t) e];
+                    if (pr >= 0 && pr != (int) i && std::find(nodes[(size_t) pr].succ.begin(), nodes[(size_t) pr].succ.end(), (int) i) == nodes[(size_t) pr].succ.end()) {
+                        nodes[(size_t) pr].succ.push_back((int) i);
+                        nodes[i].npred++;
+                    }
+                }
+                for (int k = 0; k < 8; k++) if (nodes[i].lp[k] >= 0) last_writer[(size_t) nodes[i].lp[k]] = (int) i;
+            }
+            for (size_t i = nodes.size(); i-- > 0;)
+                for (size_t j = 0; j < nodes[i].succ.size(); j++)
+                    nodes[i].height = std::max(nodes[i].height, 1 + nodes[(size_t) nodes[i].succ[j]].height);
+        }
+        size_t n_left = nodes.size();
+        for (int step = 0; n_left > 0; step++) {
             int last_round_of_rank = -1;
+            const size_t rank = (size_t) step;
+            std::vector<int> ready[2];
+            int maxh = 0;
+            for (size_t i = 0; i < nodes.size(); i++)
+                if (!nodes[i].done && nodes[i].npred == 0) { ready[nodes[i].o.cls].push_back((int) i); maxh = std::max(maxh, nodes[i].height); }
+            std::vector<int> chosen[2];
+            for (int cls = 0; cls < 2; cls++) {
+                std::stable_sort(ready[cls].begin(), ready[cls].end(), [&](int a, int b) { return nodes[(size_t) a].height > nodes[(size_t) b].height; });
+                size_t take = ready[cls].size() / 64 * 64;
+                bool critical = false;
+                for (size_t i = take; i < ready[cls].size(); i++) critical |= nodes[(size_t) ready[cls][i]].height == maxh;
+                if (critical) take = ready[cls].size();
+                chosen[cls].assign(ready[cls].begin(), ready[cls].begin() + (long) take);
+            }
+            if (chosen[0].empty() && chosen[1].empty()) { /* (cannot happen: the longest chain's head is ready) */
+                const int c = ready[1].size() > ready[0].size() ? 1 : 0;
+                chosen[c] = ready[c];
+            }
             for (int cls = 0; cls < 2; cls++) {
                 const int nopnd = cls ? 8 : 4;
                 std::vector<FusedOp> rest, sq;
@@ -200,14 +282,11 @@ struct FftGen {
                    pays for that arithmetic */
                 static const int kind_order[3] = {1, 0, 2};
                 for (int ko = 0; ko < 3; ko++)
-                    for (int w = 0; w < nwin; w++)
-                        for (size_t i = 0; i < rank_ops[rank].size(); i++) {
-                            FusedOp o = rank_ops[rank][i];
-                            if (o.cls != cls || o.kind != kind_order[ko]) continue;
-                            for (int k = 0; k < nopnd; k++)
-                                o.p[k] = (o.p[k] == MP3MI_FFT_DUMMY) ? o.p[k] : (unsigned) (w * N + MP3MI_FFT_SWZ((int) o.p[k]));
-                            (o.kind == 2 ? sq : rest).push_back(o);
-                        }
+                    for (size_t i = 0; i < chosen[cls].size(); i++) {
+                        const FusedOp &o = nodes[(size_t) chosen[cls][i]].o;
+                        if (o.kind != kind_order[ko]) continue;
+                        (o.kind == 2 ? sq : rest).push_back(o);
+                    }
                 /* The butterflies of a rank are independent, so their order is free: place them so that the 32
                    lanes an 8-byte LDS read is served in address 32 different bank pairs with every operand, and
                    the 16 lanes a store is served in 16 different ones.  Greedy: first what fits without any
@@ -248,6 +327,29 @@ struct FftGen {
                     placed.insert(placed.end(), group.begin(), group.end());
                 }
                 placed.insert(placed.end(), sq.begin(), sq.end());
+                /* The greedy order leaves up to twice the conflict-free cycle count in the deep ranks (many short
+                   transforms, eight operands that must all spread at once).  A long offline search (simulated
+                   annealing over swaps of butterflies of the same kind, tools/exp/fft_swz_search.cpp) does better; its
+                   result is stored as the order of the butterflies' ids (fft_placement.h) and replayed here -- if it
+                   names exactly the butterflies of this list, kind by kind; otherwise the greedy order stands. */
+                if (stored_order) {
+                    const std::vector<uint16_t> *ord = stored_order(logN, (int) rank, cls);
+                    if (ord && ord->size() == placed.size()) {
+                        std::vector<FusedOp> re(placed.size());
+                        std::vector<char> seen(placed.size() * 4 + 4, 0);
+                        bool ok = true;
+                        for (size_t i = 0; ok && i < placed.size(); i++) {
+                            size_t at = placed.size();
+                            for (size_t j = 0; j < placed.size(); j++)
+                                if (placed[j].id == (int) (*ord)[i]) { at = j; break; }
+                            ok = at < placed.size() && !seen[at];
+                            if (ok) { seen[at] = 1; re[i] = placed[at]; }
+                        }
+                        if (ok) placed = re;
+                        else if (getenv("MP3MI_FFT_INFO")) fprintf(stderr, "mp3mi: stored fft placement of rank %d class %d does not fit, greedy order kept\n", (int) rank, cls);
+                    }
+                }
+                if (placement_hook) placement_hook(logN, (int) rank, cls, placed, nopnd);
                 /* rounds of 64: block 0 = operand positions (R: 2 words per lane, C: 4), then either the
                    twiddle block(s) {cn, spc, smc, flags} (C: a second one {c3n, spc3n, smc3n, 0}) or, in a round
                    without rotations, one word of flags per lane.  flags: bit 0 rotation, bit 1 SQHALF rotation,
@@ -285,12 +387,38 @@ struct FftGen {
                     nw += words;
                 }
             }
-            if (last_round_of_rank >= 0) hdr[last_round_of_rank] |= 8u; /* the next rank reads what this one wrote */
+            if (last_round_of_rank >= 0) hdr[last_round_of_rank] |= 8u; /* the next step reads what this one wrote */
+            for (int cls = 0; cls < 2; cls++)
+                for (size_t i = 0; i < chosen[cls].size(); i++) {
+                    Node &nd = nodes[(size_t) chosen[cls][i]];
+                    nd.done = true;
+                    n_left--;
+                    for (size_t j = 0; j < nd.succ.size(); j++) nodes[(size_t) nd.succ[j]].npred--;
+                }
         }
         *n_rounds = nr;
         return nw;
     }
 };
+
+#if !defined(MP3MI_FFT_SWZ_RUNTIME)
+#include "fft_placement.h"
+/* the stored placement of one list (step, class) of the transform of 2^logN points; only for the swizzle it was made for */
+static const std::vector<uint16_t> *fft_stored_order(int logN, int step, int cls)
+{
+    static const int now[6] = {MP3MI_FFT_SWZ_COLS}, then[6] = {MP3MI_FFT_PLACEMENT_COLS};
+    for (int i = 0; i < 6; i++) if (now[i] != then[i]) return NULL;
+    static std::vector<uint16_t> v;
+    for (size_t i = 0; i < sizeof(FFT_PLACEMENT) / sizeof(FFT_PLACEMENT[0]); i++)
+        if (FFT_PLACEMENT[i].logN == logN && FFT_PLACEMENT[i].rank == step && FFT_PLACEMENT[i].cls == cls) {
+            v.assign(FFT_PLACEMENT[i].ids, FFT_PLACEMENT[i].ids + FFT_PLACEMENT[i].n);
+            return &v;
+        }
+    return NULL;
+}
+#else
+static const std::vector<uint16_t> *fft_stored_order(int, int, int) { return NULL; }
+#endif
 
 } // namespace
 
@@ -444,6 +572,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
 
     {
         FftGen *g = new FftGen();
+        g->stored_order = fft_stored_order;
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
         T->fft_nword_l = g->build(10, 1, T->fft_hdr_l, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_l, T->fft_prog_l, MP3MI_FFT_PROG_WORDS, T->fft_rd_l);
         T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS_S, T->fft_rd_s);
