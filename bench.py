@@ -302,8 +302,10 @@ def main():
         avg_launch_s = loop_ms / 1e3 / max(launches, 1)
         achieved = alg * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         lps = launches // max(args.steps, 1)
-        # (with more streams than resident wavefronts -- 16 per CU -- the library launches the queue form of the kernel)
-        kname = "k_loop_queue" if S > 16 * torch.cuda.get_device_properties(dev).multi_processor_count else "k_loop"
+        # (a batch of more streams than the kernel holds resident -- 16 wavefronts per CU -- goes through it in parts,
+        # one launch each; MP3MI_LOOP_PARTS=0 selects one launch of the queue form instead)
+        queue = os.environ.get("MP3MI_LOOP_PARTS", "1") == "0" and S > 16 * torch.cuda.get_device_properties(dev).multi_processor_count
+        kname = "k_loop_queue" if queue else "k_loop"
         traffic, traffic_src = pmc_traffic(kname, S, nf, lps) if cfg_id in (1, 2) else (None, None)
         issue = issue_roofline(kname, S, nf, avg_launch_s, lps) if cfg_id in (1, 2) else None
         result = {

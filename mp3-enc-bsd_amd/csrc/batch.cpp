@@ -53,6 +53,7 @@ struct mp3mi_batch {
     bool slot_used[2];       // ev_loop[i] has been recorded: the slot's last reader is a k_loop that may still run
     unsigned *gate_count;    // start census of k_loop's wavefronts (device memory, only ever grows), NULL = gate off
     unsigned gate_total;     // census value once every wavefront launched so far has started
+    unsigned gate_first;     // ... once the first part of the last k_loop has (encode_impl)
     int *place_order, *place_cost; // k_loop stream placement (mp3mi_loop_place), NULL = off
     unsigned *place_zero;    // taken[n] + simd_slots + simd_idx + ticket + scan, zeroed before every k_loop
     int n_simd;
@@ -87,7 +88,8 @@ struct mp3mi_batch {
     struct timing_set {
         hipEvent_t ev0, ev1;
         std::vector<hipEvent_t> loop_ev;
-        int launches;
+        int launches; // bracketed spans (one per chunk)
+        int kernels;  // k_loop launches inside them
         bool pending;
     } ts[2];
     unsigned call_no;
@@ -209,7 +211,7 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     b->hdr_flags = 0;
     b->hdr_mode = (channels == 1) ? 3 : 0;
     b->crc = 0;
-    b->gate_count = NULL; b->gate_total = 0;
+    b->gate_count = NULL; b->gate_total = 0; b->gate_first = 0;
     {
         const char *envg = getenv("MP3MI_NO_GATE");
         if (!(envg && atoi(envg))) {
@@ -389,8 +391,8 @@ static int harvest_timing(mp3mi_batch *b, int k)
         CHK(hipEventElapsedTime(&ms, ts.loop_ev[2 * c], ts.loop_ev[2 * c + 1]));
         loop += ms;
     }
-    b->last_loop_ms = loop; b->last_all_ms = tot; b->last_launches = ts.launches;
-    b->tot_loop_ms += loop; b->tot_all_ms += tot; b->tot_launches += ts.launches; b->tot_calls++;
+    b->last_loop_ms = loop; b->last_all_ms = tot; b->last_launches = ts.kernels;
+    b->tot_loop_ms += loop; b->tot_all_ms += tot; b->tot_launches += ts.kernels; b->tot_calls++;
     ts.pending = false;
     return MP3MI_OK;
 }
@@ -503,6 +505,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         ts.loop_ev.push_back(e);
     }
     ts.launches = nchunks;
+    ts.kernels = 0;
     CHK(hipEventRecord(ts.ev0, b->stream));
     // Two kinds of front-end kernels cannot share the chip with k_loop: k_fft takes a whole CU's LDS
     // per workgroup, and k_psy's wavefronts live for the whole chunk (serial over granules), so
@@ -536,13 +539,34 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipGetLastError());
         return MP3MI_OK;
     };
+    // With more streams than resident wavefronts k_loop runs in its queue form: every wavefront takes a fixed share
+    // of the streams and stays to the end, so the feed-forward kernels of the next chunk find no freed slots to run
+    // in, only cycles to take from wavefronts whose share does not shrink -- the kernel ends with its slowest
+    // wavefront, and every millisecond of work beside it cost two to four (measured at 8192 x 383 and 16384 x 278).
+    // There stage Y waits for k_loop of the chunk before.  (MP3MI_Y_AFTER_LOOP=0 / 1 overrides.)
+    // Normally it does not come to that: a batch of more streams than k_loop holds resident (4096 on an MI355X) goes
+    // through k_loop in PARTS -- contiguous stream ranges, one launch each, back to back on the loop stream -- each
+    // a launch of the one-stream-per-wavefront kernel with freed slots for the next chunk's kernels, placement and
+    // pacing as for a batch of that size.  Every buffer is stream-major, so a part is the same launch with its
+    // pointers advanced.  (MP3MI_LOOP_PARTS=0: one launch of the queue form.)
+    int loop_parts = (S + mp3mi_loop_resident() - 1) / mp3mi_loop_resident();
+    { const char *e = getenv("MP3MI_LOOP_PARTS"); if (e && !atoi(e)) loop_parts = 1; }
+    int part_streams = ((S + loop_parts - 1) / loop_parts + 63) / 64 * 64; // (whole blocks of 64 prep records)
+    { // (tests: parts of a given size, whatever the device holds)
+        const char *e = getenv("MP3MI_LOOP_PART_STREAMS");
+        if (e && atoi(e) >= 64) { part_streams = atoi(e) / 64 * 64; loop_parts = (S + part_streams - 1) / part_streams; }
+    }
+    bool y_after_loop = loop_parts == 1 && mp3mi_loop_waves(S) < S;
+    { const char *e = getenv("MP3MI_Y_AFTER_LOOP"); if (e) y_after_loop = atoi(e) != 0; }
     if (stage_x(0) != MP3MI_OK) return MP3MI_ERR_HIP;
     for (int c = 0; c < nchunks; c++) {
         const int slot = (c + b->slot_base) & 1;
         const mp3mi_geom g = geom_of(c);
         // ---- front stream: everything that does not depend on the bit reservoir ----
-        if (c >= 1 && b->gate_count) // stage Y of this chunk runs behind k_loop(c-1), once that is resident (<= 300 us)
-            mp3mi_launch_gate(b->gate_count, b->gate_total - 16u, 30000u, b->stream);
+        if (c >= 1 && y_after_loop) // (queue form of k_loop: its wavefronts stay to the end, nothing is gained beside them)
+            CHK(hipStreamWaitEvent(b->stream, b->ev_loop[slot ^ 1], 0));
+        else if (c >= 1 && b->gate_count) // stage Y of this chunk runs behind k_loop(c-1), once that is resident (<= 300 us)
+            mp3mi_launch_gate(b->gate_count, b->gate_first - 16u, 30000u, b->stream);
         mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy[slot], b->sbs, b->xr[slot], b->debug ? b->sb_dbg : NULL, b->stream);
         CHK(hipGetLastError());
         mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->prep_exact, b->stream);
@@ -552,20 +576,32 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         // ---- loop stream: the serial search and the formatter ----
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
         CHK(hipEventRecord(ts.loop_ev[2 * c], b->lstream));
-        b->gate_total += (unsigned) mp3mi_loop_waves(S);
-        mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
-        if (b->place_order) { // rank the streams by their cost in the previous chunk, hand the tables to k_loop
-            mp3mi_launch_rank(b->place_cost, b->place_order, S, b->lstream);
+        for (int part = 0; part < loop_parts; part++) {
+            const int s0 = part * part_streams, n = S - s0 < part_streams ? S - s0 : part_streams;
+            if (n <= 0) break;
+            const size_t rec0 = (size_t) s0 * 2 * (size_t) g.nf * (size_t) C; // (granule, channel) records before the part
+            mp3mi_geom gp = g;
+            gp.n_streams = n;
+            if (gp.n_samples) gp.n_samples += s0;
+            b->gate_total += (unsigned) mp3mi_loop_waves(n);
+            if (part == 0) b->gate_first = b->gate_total; // the census once the first part is resident: stage Y of the next chunk starts behind it
+            mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
+            if (b->place_order) { // rank the streams by their cost in the previous chunk, hand the tables to k_loop
+                mp3mi_launch_rank(b->place_cost + s0, b->place_order + s0, n, b->lstream);
+                CHK(hipGetLastError());
+                CHK(hipMemsetAsync(b->place_zero, 0, sizeof(unsigned) * ((size_t) S + 2 * MP3MI_PLACE_KEYS + 2), b->lstream));
+                place.order = b->place_order + s0; place.cost = b->place_cost + s0; place.taken = b->place_zero;
+                place.simd_slots = b->place_zero + S; place.simd_idx = place.simd_slots + MP3MI_PLACE_KEYS;
+                place.ticket = place.simd_idx + MP3MI_PLACE_KEYS; place.scan = place.ticket + 1;
+                place.n_simd = b->n_simd;
+            }
+            if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
+            mp3mi_launch_loop(b->T, gp, b->xr[slot] + rec0 * 576, b->psy[slot] + rec0, b->prep[slot] + rec0 / 64, b->bits_per_frame + s0,
+                              (char *) b->loop_state + (size_t) s0 * mp3mi_loop_state_size(), b->ix + rec0 * 576, b->side + (size_t) s0 * (size_t) g.nf,
+                              b->gate_count, place, b->lstream);
             CHK(hipGetLastError());
-            CHK(hipMemsetAsync(b->place_zero, 0, sizeof(unsigned) * ((size_t) S + 2 * MP3MI_PLACE_KEYS + 2), b->lstream));
-            place.order = b->place_order; place.cost = b->place_cost; place.taken = b->place_zero;
-            place.simd_slots = b->place_zero + S; place.simd_idx = place.simd_slots + MP3MI_PLACE_KEYS;
-            place.ticket = place.simd_idx + MP3MI_PLACE_KEYS; place.scan = place.ticket + 1;
-            place.n_simd = b->n_simd;
         }
-        if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
-        mp3mi_launch_loop(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->bits_per_frame, b->loop_state, b->ix, b->side, b->gate_count, place, b->lstream);
-        CHK(hipGetLastError());
+        ts.kernels += loop_parts;
         CHK(hipEventRecord(ts.loop_ev[2 * c + 1], b->lstream));
         CHK(hipEventRecord(b->ev_loop[slot], b->lstream));
         b->slot_used[slot] = true;

@@ -1227,6 +1227,9 @@ static int loop_wg_cap(void)
     return wg_cap;
 }
 
+// streams one launch of k_loop holds resident, a wavefront each
+int mp3mi_loop_resident(void) { return loop_wg_cap() * LOOP_W; }
+
 // wavefronts of a launch over n_streams streams = what the start census (gate_count[0]) grows by
 int mp3mi_loop_waves(int n_streams)
 {

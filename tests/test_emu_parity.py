@@ -39,6 +39,20 @@ def test_two_streams_mixed_bitrate_and_chunking(emu, oracle, monkeypatch):
         assert got[s] == oracle.encode(pcm[s], rate, kb, ch)[0]
 
 
+def test_loop_in_parts(emu, oracle, monkeypatch):
+    """a batch of more streams than k_loop holds resident goes through it in parts (batch.cpp): 70 mono streams in
+    parts of 64 and 6, two chunks; every stream against the oracle"""
+    monkeypatch.setenv("MP3MI_LOOP_PART_STREAMS", "64")
+    monkeypatch.setenv("MP3MI_CHUNK_FRAMES", "1")
+    S, nf, rate, ch = 70, 2, 32000, 1
+    base = np.stack([emu.synth(nf * 1152, ch, rate, 40 + s) for s in range(7)])
+    pcm = np.stack([np.round(base[s % 7].astype(np.float64) * (1 + s // 7) / 10.0).astype(np.int16) for s in range(S)])
+    kb = [(64, 96)[s % 2] for s in range(S)]
+    got = emu.encode_host(pcm, rate, ch, kb, nf)
+    for s in range(S):
+        assert got[s] == oracle.encode(pcm[s], rate, kb[s], ch)[0], "stream %d" % s
+
+
 def test_prep_exact_tier_matches_fast_tier(emu, oracle, monkeypatch):
     """k_prep decides quantanf_init's integer from plain-double logs and repeats the walk with the
     correctly rounded log only near a rounding boundary; forcing the second tier must give the
