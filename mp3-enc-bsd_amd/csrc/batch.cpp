@@ -45,6 +45,9 @@ struct mp3mi_batch {
     hipStream_t lstream;     // loop stream: k_loop + k_format
     hipEvent_t ev_front[2];  // front kernels of the chunk in slot i are done
     hipEvent_t ev_loop[2];   // k_loop of the chunk in slot i is done (slot may be overwritten)
+#define MP3MI_MAX_LOOP_PARTS 3
+    hipEvent_t ev_part[MP3MI_MAX_LOOP_PARTS]; // part p of the last k_loop is done
+    unsigned gate_part[MP3MI_MAX_LOOP_PARTS]; // census value once part p of the last k_loop has started
     hipEvent_t ev_done;      // everything of the previous encode call is done
     hipEvent_t ev_hist;      // the front stream's last work of a call (the PCM history hand-over) is enqueued
     bool have_done;
@@ -196,6 +199,7 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
         CHK(hipEventCreateWithFlags(&b->ev_loop[i], hipEventDisableTiming));
     }
     CHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
+    for (int i = 0; i < MP3MI_MAX_LOOP_PARTS; i++) { CHK(hipEventCreateWithFlags(&b->ev_part[i], hipEventDisableTiming)); b->gate_part[i] = 0; }
     CHK(hipEventCreateWithFlags(&b->ev_hist, hipEventDisableTiming));
     b->have_done = false;
     b->last_slot = 0;
@@ -322,6 +326,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
                     b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg};
     for (void *p : bufs)
         if (p) hipFree(p);
+    for (int i = 0; i < MP3MI_MAX_LOOP_PARTS; i++) hipEventDestroy(b->ev_part[i]);
     hipEvent_t evs[] = {b->ts[0].ev0, b->ts[0].ev1, b->ts[1].ev0, b->ts[1].ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done, b->ev_hist};
     for (hipEvent_t e : evs)
         if (e) hipEventDestroy(e);
@@ -529,16 +534,6 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         g.whole_file = whole_file ? 1 : 0;
         return g;
     };
-    auto stage_x = [&](int c) -> int {
-        const mp3mi_geom g = geom_of(c);
-        mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
-        CHK(hipGetLastError());
-        const int xs = (c + b->slot_base) & 1;
-        if (b->slot_used[xs]) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[xs], 0)); // the k_loop that read this slot last (two chunks ago, maybe in the call before)
-        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->fft_bins, b->cw_fix, b->psy_state, b->part_eb, b->part_cb, b->psy[xs], b->stream);
-        CHK(hipGetLastError());
-        return MP3MI_OK;
-    };
     // With more streams than resident wavefronts k_loop runs in its queue form: every wavefront takes a fixed share
     // of the streams and stays to the end, so the feed-forward kernels of the next chunk find no freed slots to run
     // in, only cycles to take from wavefronts whose share does not shrink -- the kernel ends with its slowest
@@ -558,6 +553,17 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     }
     bool y_after_loop = loop_parts == 1 && mp3mi_loop_waves(S) < S;
     { const char *e = getenv("MP3MI_Y_AFTER_LOOP"); if (e) y_after_loop = atoi(e) != 0; }
+    auto stage_x = [&](int c) -> int {
+        const mp3mi_geom g = geom_of(c);
+        const int xs = (c + b->slot_base) & 1;
+        // (k_loop in parts: holding the FFTs back until the last part has ended was tried: 471 vs 462 ms at 16384 x 278)
+        mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream);
+        CHK(hipGetLastError());
+        if (b->slot_used[xs]) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[xs], 0)); // the k_loop that read this slot last (two chunks ago, maybe in the call before)
+        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->fft_bins, b->cw_fix, b->psy_state, b->part_eb, b->part_cb, b->psy[xs], b->stream);
+        CHK(hipGetLastError());
+        return MP3MI_OK;
+    };
     if (stage_x(0) != MP3MI_OK) return MP3MI_ERR_HIP;
     for (int c = 0; c < nchunks; c++) {
         const int slot = (c + b->slot_base) & 1;
@@ -567,8 +573,26 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
             CHK(hipStreamWaitEvent(b->stream, b->ev_loop[slot ^ 1], 0));
         else if (c >= 1 && b->gate_count) // stage Y of this chunk runs behind k_loop(c-1), once that is resident (<= 300 us)
             mp3mi_launch_gate(b->gate_count, b->gate_first - 16u, 30000u, b->stream);
-        mp3mi_launch_fbmdct(b->T, g, pcm_dev, b->psy[slot], b->sbs, b->xr[slot], b->debug ? b->sb_dbg : NULL, b->stream);
+        // k_loop in parts: the three kernels of stage Y are spread over the parts -- k_filter beside the first, k_mdct
+        // beside the second, k_prep beside the third (or the last) -- each held back until ITS part is resident: the
+        // part before it has ended (an event) and the part's wavefronts have started (the census, bounded wait).
+        // Queued earlier, the single-wave workgroups take every slot the ending part frees and keep the next part's
+        // four-wave workgroups out: k_loop's second part then ran 36 ms instead of 16 at 8192 x 42.
+        auto behind_part = [&](int p) -> int {
+            if (c < 1 || y_after_loop || !b->gate_count || loop_parts < 2) return MP3MI_OK;
+            if (p > loop_parts - 1) p = loop_parts - 1;
+            if (p < 1) return MP3MI_OK;
+            CHK(hipStreamWaitEvent(b->stream, b->ev_part[p - 1], 0));
+            mp3mi_launch_gate(b->gate_count, b->gate_part[p] - 16u, 30000u, b->stream);
+            CHK(hipGetLastError());
+            return MP3MI_OK;
+        };
+        mp3mi_launch_filter(b->T, g, pcm_dev, b->sbs, b->debug ? b->sb_dbg : NULL, b->stream);
         CHK(hipGetLastError());
+        if (behind_part(1) != MP3MI_OK) return MP3MI_ERR_HIP;
+        mp3mi_launch_mdct(b->T, g, b->psy[slot], b->sbs, b->xr[slot], b->stream);
+        CHK(hipGetLastError());
+        if (loop_parts > 2 && behind_part(2) != MP3MI_OK) return MP3MI_ERR_HIP;
         mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->prep_exact, b->stream);
         CHK(hipGetLastError());
         if (c + 1 < nchunks && stage_x(c + 1) != MP3MI_OK) return MP3MI_ERR_HIP;
@@ -585,6 +609,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
             if (gp.n_samples) gp.n_samples += s0;
             b->gate_total += (unsigned) mp3mi_loop_waves(n);
             if (part == 0) b->gate_first = b->gate_total; // the census once the first part is resident: stage Y of the next chunk starts behind it
+            if (part < MP3MI_MAX_LOOP_PARTS) b->gate_part[part] = b->gate_total;
             mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
             if (b->place_order) { // rank the streams by their cost in the previous chunk, hand the tables to k_loop
                 mp3mi_launch_rank(b->place_cost + s0, b->place_order + s0, n, b->lstream);
@@ -600,6 +625,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
                               (char *) b->loop_state + (size_t) s0 * mp3mi_loop_state_size(), b->ix + rec0 * 576, b->side + (size_t) s0 * (size_t) g.nf,
                               b->gate_count, place, b->lstream);
             CHK(hipGetLastError());
+            if (part < MP3MI_MAX_LOOP_PARTS) CHK(hipEventRecord(b->ev_part[part], b->lstream));
         }
         ts.kernels += loop_parts;
         CHK(hipEventRecord(ts.loop_ev[2 * c + 1], b->lstream));

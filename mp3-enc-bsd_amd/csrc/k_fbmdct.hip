@@ -324,9 +324,12 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
 
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g) { return (size_t) g.n_streams * (size_t) (g.n_gran + 1) * (size_t) g.channels * 576 * sizeof(double); }
 
-void mp3mi_launch_fbmdct(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
-                         const mp3mi_psy_out *psy, double *sbs, double *xr, double *sb_dbg, hipStream_t st)
+void mp3mi_launch_filter(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, double *sbs, double *sb_dbg, hipStream_t st)
 {
     hipLaunchKernelGGL(k_filter, dim3((unsigned) (g.n_streams * g.channels * (((g.n_gran + 1) * 18 + FILT_SLOTS - 1) / FILT_SLOTS))), dim3(64), 0, st, T, g, pcm, sbs, sb_dbg);
+}
+
+void mp3mi_launch_mdct(const mp3mi_tables *T, const mp3mi_geom &g, const mp3mi_psy_out *psy, const double *sbs, double *xr, hipStream_t st)
+{
     hipLaunchKernelGGL(k_mdct, dim3((unsigned) (((g.n_streams * g.channels + 1) / 2) * ((g.n_gran + MDCT_RUN - 1) / MDCT_RUN))), dim3(64), 0, st, T, g, sbs, psy, xr);
 }
