@@ -7,7 +7,7 @@ f = json.load(open(src + "/pmc_fetch.json")); w = json.load(open(src + "/pmc_wri
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (two separate passes, tools/gpu_profile.sh)",
        "workload": "%d streams x %d frames, 44.1 kHz stereo 128 kbps" % (streams, frames), "streams": streams, "frames": frames,
        "units": "FETCH_SIZE/WRITE_SIZE are KiB summed over the dispatches of one step",
-       "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> hbm_read = 2*FETCH_SIZE; cross-check on a known byte count: k_mdct reads every subband granule once plus one extra per run of 11 = 1.09*28.9 GB per step (until r01l: twice, 2*28.9 GB); WRITE_SIZE is exact (k_filter writes 28.9 GB of subband samples per step).",
+       "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> hbm_read = 2*FETCH_SIZE; cross-check on a known byte count: k_mdct reads every subband granule twice (as this granule and as the next one's previous) plus one extra per run of 22 = 2.05*28.9 GB per step + 4.8 GB of block types; WRITE_SIZE is exact (k_filter writes 28.9 GB of subband samples per step).",
        "kernels": {}}
 for k in f:
     if k not in w:
