@@ -287,26 +287,6 @@ template <typename P> MP3MI_DEVFN const P *wave_uniform_here(const P *p)
     return p;
 }
 
-/* v of the lane above (up = 0: lane i takes lane i + 1's) or below (up = 1: lane i takes lane i - 1's); the last /
- * first lane keeps its own.  Two DPP moves (wave_shl:1 / wave_shr:1), no LDS. */
-MP3MI_DEVFN double wave_neighbour_f64(double v, int up)
-{
-#if defined(MP3MI_EMU)
-    return up ? __shfl_up(v, 1) : __shfl_down(v, 1);
-#else
-    union { double d; int w[2]; } a, r;
-    a.d = v;
-    if (up) {
-        r.w[0] = __builtin_amdgcn_update_dpp(a.w[0], a.w[0], 0x138, 0xf, 0xf, false);
-        r.w[1] = __builtin_amdgcn_update_dpp(a.w[1], a.w[1], 0x138, 0xf, 0xf, false);
-    } else {
-        r.w[0] = __builtin_amdgcn_update_dpp(a.w[0], a.w[0], 0x130, 0xf, 0xf, false);
-        r.w[1] = __builtin_amdgcn_update_dpp(a.w[1], a.w[1], 0x130, 0xf, 0xf, false);
-    }
-    return r.d;
-#endif
-}
-
 /* Several reductions at once, step by step in lock-step.  A DPP instruction that reads the result of
  * the previous VALU instruction needs two wait states (an s_nop each time in a lone reduction: 6 DPP +
  * 6 s_nop); interleaved, the other chains' steps fill those slots.  NSUM sums first, then NMAX maxima
