@@ -78,13 +78,18 @@ struct FusedOp {
     float tw[6];
 };
 
+/* a butterfly in the dependency DAG of a program (FftGen::build) */
+struct FftNode { FusedOp o; int lp[8]; std::vector<int> succ, pred; int npred, height; bool done; };
+/* a program's schedule: per step (a wave barrier after each) the butterflies of class 0 and of class 1 in lane order */
+typedef std::vector<std::vector<int> > FftSchedule; /* [2 * step + class] -> node ids */
+
 struct FftGen {
     Twiddle tw_rs[11], tw_sr[11];
     std::vector<std::vector<FusedOp> > rank_ops; /* [rank] */
     struct Post { int type; unsigned a, b; };
     std::vector<Post> post1, post2;
     const std::vector<uint16_t> *(*stored_order)(int logN, int rank, int cls) = NULL;
-    void (*placement_hook)(int logN, int rank, int cls, std::vector<FusedOp> &placed, int nopnd) = NULL; /* the offline search */
+    void (*schedule_hook)(int logN, const std::vector<FftNode> &nodes, FftSchedule &sched) = NULL; /* the offline search */
 
     void add(int rank, const FusedOp &o)
     {
@@ -221,7 +226,7 @@ struct FftGen {
            wave barrier; a step takes, per class, the ready butterflies in whole rounds, the longest remaining chains
            first, and a partial round only when it holds a butterfly of the longest chain (everything else can wait
            for a later step and fill its round). */
-        struct Node { FusedOp o; int lp[8]; std::vector<int> succ; int npred, height; bool done; };
+        typedef FftNode Node;
         std::vector<Node> nodes;
         for (size_t rank = 0; rank < rank_ops.size(); rank++)
             for (int w = 0; w < nwin; w++)
@@ -245,6 +250,7 @@ struct FftGen {
                     const int pr = last_writer[(size_t) e];
                     if (pr >= 0 && pr != (int) i && std::find(nodes[(size_t) pr].succ.begin(), nodes[(size_t) pr].succ.end(), (int) i) == nodes[(size_t) pr].succ.end()) {
                         nodes[(size_t) pr].succ.push_back((int) i);
+                        nodes[i].pred.push_back(pr);
                         nodes[i].npred++;
                     }
                 }
@@ -254,10 +260,9 @@ struct FftGen {
                 for (size_t j = 0; j < nodes[i].succ.size(); j++)
                     nodes[i].height = std::max(nodes[i].height, 1 + nodes[(size_t) nodes[i].succ[j]].height);
         }
+        FftSchedule sched;
         size_t n_left = nodes.size();
         for (int step = 0; n_left > 0; step++) {
-            int last_round_of_rank = -1;
-            const size_t rank = (size_t) step;
             std::vector<int> ready[2];
             int maxh = 0;
             for (size_t i = 0; i < nodes.size(); i++)
@@ -327,29 +332,53 @@ struct FftGen {
                     placed.insert(placed.end(), group.begin(), group.end());
                 }
                 placed.insert(placed.end(), sq.begin(), sq.end());
-                /* The greedy order leaves up to twice the conflict-free cycle count in the deep ranks (many short
-                   transforms, eight operands that must all spread at once).  A long offline search (simulated
-                   annealing over swaps of butterflies of the same kind, tools/exp/fft_swz_search.cpp) does better; its
-                   result is stored as the order of the butterflies' ids (fft_placement.h) and replayed here -- if it
-                   names exactly the butterflies of this list, kind by kind; otherwise the greedy order stands. */
-                if (stored_order) {
-                    const std::vector<uint16_t> *ord = stored_order(logN, (int) rank, cls);
-                    if (ord && ord->size() == placed.size()) {
-                        std::vector<FusedOp> re(placed.size());
-                        std::vector<char> seen(placed.size() * 4 + 4, 0);
-                        bool ok = true;
-                        for (size_t i = 0; ok && i < placed.size(); i++) {
-                            size_t at = placed.size();
-                            for (size_t j = 0; j < placed.size(); j++)
-                                if (placed[j].id == (int) (*ord)[i]) { at = j; break; }
-                            ok = at < placed.size() && !seen[at];
-                            if (ok) { seen[at] = 1; re[i] = placed[at]; }
-                        }
-                        if (ok) placed = re;
-                        else if (getenv("MP3MI_FFT_INFO")) fprintf(stderr, "mp3mi: stored fft placement of rank %d class %d does not fit, greedy order kept\n", (int) rank, cls);
-                    }
+                std::vector<int> ids;
+                for (size_t i = 0; i < placed.size(); i++) ids.push_back(placed[i].id);
+                sched.push_back(ids);
+            }
+            for (int cls = 0; cls < 2; cls++)
+                for (size_t i = 0; i < chosen[cls].size(); i++) {
+                    Node &nd = nodes[(size_t) chosen[cls][i]];
+                    nd.done = true;
+                    n_left--;
+                    for (size_t j = 0; j < nd.succ.size(); j++) nodes[(size_t) nd.succ[j]].npred--;
                 }
-                if (placement_hook) placement_hook(logN, (int) rank, cls, placed, nopnd);
+        }
+        /* That schedule -- list scheduling, greedy lanes -- leaves up to twice the conflict-free cycle count in the
+           deep steps (many short transforms, eight operands that must all spread at once).  A long offline search
+           (simulated annealing over swaps of butterflies of the same kind within a list and, where the dependencies
+           allow, between steps: tools/exp/fft_swz_search.cpp) does better; its result is stored as lists of butterfly
+           ids (fft_placement.h) and replayed here if it is a schedule of exactly these butterflies that respects
+           every dependency; otherwise the one above stands. */
+        if (stored_order) {
+            FftSchedule st;
+            for (size_t li = 0;; li++) {
+                const std::vector<uint16_t> *ord = stored_order(logN, (int) (li / 2), (int) (li & 1));
+                if (!ord) { if (li & 1) { st.push_back(std::vector<int>()); continue; } break; }
+                st.push_back(std::vector<int>(ord->begin(), ord->end()));
+            }
+            std::vector<int> step_of(nodes.size(), -1);
+            bool ok = !st.empty();
+            size_t count = 0;
+            for (size_t li = 0; ok && li < st.size(); li++)
+                for (size_t i = 0; ok && i < st[li].size(); i++) {
+                    const int id = st[li][i];
+                    ok = id >= 0 && (size_t) id < nodes.size() && step_of[(size_t) id] < 0 && nodes[(size_t) id].o.cls == (int) (li & 1);
+                    if (ok) { step_of[(size_t) id] = (int) (li / 2); count++; }
+                }
+            ok = ok && count == nodes.size();
+            for (size_t i = 0; ok && i < nodes.size(); i++)
+                for (size_t j = 0; ok && j < nodes[i].pred.size(); j++) ok = step_of[(size_t) nodes[i].pred[j]] < step_of[i];
+            if (ok) sched = st;
+            else if (getenv("MP3MI_FFT_INFO")) fprintf(stderr, "mp3mi: the stored fft schedule for 2^%d points does not fit, list schedule kept\n", logN);
+        }
+        if (schedule_hook) schedule_hook(logN, nodes, sched);
+        for (size_t li = 0; li < sched.size(); li += 2) {
+            int last_round_of_rank = -1;
+            for (int cls = 0; cls < 2 && li + (size_t) cls < sched.size(); cls++) {
+                const int nopnd = cls ? 8 : 4;
+                std::vector<FusedOp> placed;
+                for (size_t i = 0; i < sched[li + (size_t) cls].size(); i++) placed.push_back(nodes[(size_t) sched[li + (size_t) cls][i]].o);
                 /* rounds of 64: block 0 = operand positions (R: 2 words per lane, C: 4), then either the
                    twiddle block(s) {cn, spc, smc, flags} (C: a second one {c3n, spc3n, smc3n, 0}) or, in a round
                    without rotations, one word of flags per lane.  flags: bit 0 rotation, bit 1 SQHALF rotation,
@@ -388,13 +417,6 @@ struct FftGen {
                 }
             }
             if (last_round_of_rank >= 0) hdr[last_round_of_rank] |= 8u; /* the next step reads what this one wrote */
-            for (int cls = 0; cls < 2; cls++)
-                for (size_t i = 0; i < chosen[cls].size(); i++) {
-                    Node &nd = nodes[(size_t) chosen[cls][i]];
-                    nd.done = true;
-                    n_left--;
-                    for (size_t j = 0; j < nd.succ.size(); j++) nodes[(size_t) nd.succ[j]].npred--;
-                }
         }
         *n_rounds = nr;
         return nw;

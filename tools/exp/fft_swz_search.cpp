@@ -54,61 +54,95 @@ static int total_cost(bool verbose = false)
 
 // ---- annealing of one list ----
 static long g_sweeps = 2000;
+static bool g_quiet = false;
 static std::map<std::tuple<int, int, int>, std::vector<uint16_t>> g_orders;
 static std::mt19937_64 g_rng(20261003);
 
-static void anneal_hook(int logN, int rank, int cls, std::vector<FusedOp> &placed, int nopnd)
+// Simulated annealing over a whole program's schedule: swap two butterflies of the same class and kind -- within a
+// list (lanes / rounds) or between two steps when every dependency still points from an earlier step to a later one.
+static void anneal_hook(int logN, const std::vector<FftNode> &nodes, FftSchedule &sched)
 {
-    const size_t n = placed.size(), nround = (n + 63) / 64;
-    if (n >= 2) {
-        std::vector<unsigned> pos(nround * 8 * 64);
-        std::vector<int> cyc(nround * 8);
-        auto posof = [&](size_t i, int k) -> unsigned {
-            if (i >= n) return (unsigned) (MP3MI_FFT_DUMMY + (i & 63));
-            return placed[i].p[k] == MP3MI_FFT_DUMMY ? (unsigned) (MP3MI_FFT_DUMMY + (i & 63)) : placed[i].p[k];
-        };
-        long cur = 0;
-        for (size_t r = 0; r < nround; r++)
-            for (int k = 0; k < nopnd; k++) {
-                for (int l = 0; l < 64; l++) pos[(r * 8 + k) * 64 + l] = posof(r * 64 + l, k);
-                cur += cyc[r * 8 + k] = FftGen::round_cycles(&pos[(r * 8 + k) * 64]);
-            }
-        const long start = cur, ideal = (long) nround * nopnd * 6;
-        std::vector<FusedOp> best = placed;
-        long bestc = cur;
-        const long tries = g_sweeps * (long) n;
-        std::uniform_real_distribution<double> U(0.0, 1.0);
-        for (long t = 0; t < tries && bestc > ideal; t++) {
-            const double temp = 0.8 * pow(0.02 / 0.8, (double) t / (double) tries);
-            const size_t i = g_rng() % n, j = g_rng() % n;
-            if (i == j || placed[i].kind != placed[j].kind) continue;
-            const size_t ri = i / 64, rj = j / 64;
-            int before = 0, after = 0, ci[8], cj[8];
-            for (int k = 0; k < nopnd; k++) { before += cyc[ri * 8 + k]; if (rj != ri) before += cyc[rj * 8 + k]; }
-            std::swap(placed[i], placed[j]);
-            for (int k = 0; k < nopnd; k++) { pos[(ri * 8 + k) * 64 + (i & 63)] = posof(i, k); pos[(rj * 8 + k) * 64 + (j & 63)] = posof(j, k); }
-            for (int k = 0; k < nopnd; k++) {
-                ci[k] = FftGen::round_cycles(&pos[(ri * 8 + k) * 64]);
-                cj[k] = rj != ri ? FftGen::round_cycles(&pos[(rj * 8 + k) * 64]) : 0;
-                after += ci[k] + cj[k];
-            }
-            const int d = after - before;
-            if (d <= 0 || U(g_rng) < exp(-(double) d / temp)) {
-                for (int k = 0; k < nopnd; k++) { cyc[ri * 8 + k] = ci[k]; if (rj != ri) cyc[rj * 8 + k] = cj[k]; }
-                cur += d;
-                if (cur < bestc) { bestc = cur; best = placed; }
-            } else {
-                std::swap(placed[i], placed[j]);
-                for (int k = 0; k < nopnd; k++) { pos[(ri * 8 + k) * 64 + (i & 63)] = posof(i, k); pos[(rj * 8 + k) * 64 + (j & 63)] = posof(j, k); }
-            }
-        }
-        placed = best;
-        printf("    logN %2d rank %2d class %d: %4zu butterflies, %2zu rounds: %5ld -> %5ld cycles (conflict-free %ld)\n", logN, rank, cls, n, nround, start, bestc, ideal);
-        fflush(stdout);
+    const size_t NN = nodes.size(), NL = sched.size();
+    std::vector<int> list_of(NN), at(NN);
+    std::vector<size_t> base(NL + 1, 0); // first round of each list
+    for (size_t li = 0; li < NL; li++) {
+        base[li + 1] = base[li] + (sched[li].size() + 63) / 64;
+        for (size_t i = 0; i < sched[li].size(); i++) { list_of[(size_t) sched[li][i]] = (int) li; at[(size_t) sched[li][i]] = (int) i; }
     }
-    std::vector<uint16_t> ids;
-    for (size_t i = 0; i < n; i++) ids.push_back((uint16_t) placed[i].id);
-    g_orders[std::make_tuple(logN, rank, cls)] = ids;
+    const size_t NR = base[NL];
+    std::vector<unsigned> pos(NR * 8 * 64);
+    std::vector<int> cyc(NR * 8, 0);
+    auto nop = [&](size_t li) { return (li & 1) ? 8 : 4; };
+    auto posof = [&](size_t li, size_t i, int k) -> unsigned {
+        if (i >= sched[li].size()) return (unsigned) (MP3MI_FFT_DUMMY + (i & 63));
+        const FusedOp &o = nodes[(size_t) sched[li][i]].o;
+        return o.p[k] == MP3MI_FFT_DUMMY ? (unsigned) (MP3MI_FFT_DUMMY + (i & 63)) : o.p[k];
+    };
+    long cur = 0, ideal = 0;
+    for (size_t li = 0; li < NL; li++)
+        for (size_t r = base[li]; r < base[li + 1]; r++)
+            for (int k = 0; k < nop(li); k++) {
+                for (int l = 0; l < 64; l++) pos[(r * 8 + k) * 64 + l] = posof(li, (r - base[li]) * 64 + l, k);
+                cur += cyc[r * 8 + k] = FftGen::round_cycles(&pos[(r * 8 + k) * 64]);
+                ideal += 6;
+            }
+    const long start = cur;
+    FftSchedule best = sched;
+    long bestc = cur;
+    // pools of interchangeable butterflies
+    std::vector<int> pool[2][3];
+    for (size_t i = 0; i < NN; i++) pool[nodes[i].o.cls][nodes[i].o.kind].push_back((int) i);
+    const long tries = g_sweeps * (long) NN;
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    long cross = 0;
+    for (long t = 0; t < tries && bestc > ideal; t++) {
+        const double temp = 0.8 * pow(0.02 / 0.8, (double) t / (double) tries);
+        const int a = (int) (g_rng() % NN);
+        const std::vector<int> &pl = pool[nodes[(size_t) a].o.cls][nodes[(size_t) a].o.kind];
+        const int b = pl[g_rng() % pl.size()];
+        if (a == b) continue;
+        size_t la = (size_t) list_of[(size_t) a], lb = (size_t) list_of[(size_t) b];
+        if (la != lb) { // between steps: every dependency must still point forward
+            const int x = la < lb ? a : b, y = la < lb ? b : a; // x moves to the later step, y to the earlier one
+            const int s_early = (int) (std::min(la, lb) / 2), s_late = (int) (std::max(la, lb) / 2);
+            bool ok = true;
+            for (size_t j = 0; ok && j < nodes[(size_t) x].succ.size(); j++) ok = list_of[(size_t) nodes[(size_t) x].succ[j]] / 2 > s_late;
+            for (size_t j = 0; ok && j < nodes[(size_t) y].pred.size(); j++) ok = list_of[(size_t) nodes[(size_t) y].pred[j]] / 2 < s_early;
+            if (!ok) continue;
+        }
+        const size_t ia = (size_t) at[(size_t) a], ib = (size_t) at[(size_t) b];
+        const size_t ra = base[la] + ia / 64, rb = base[lb] + ib / 64;
+        const int n8 = nop(la);
+        int before = 0, after = 0, ca[8], cb[8];
+        for (int k = 0; k < n8; k++) { before += cyc[ra * 8 + k]; if (rb != ra) before += cyc[rb * 8 + k]; }
+        auto do_swap = [&]() {
+            std::swap(sched[la][ia], sched[lb][ib]);
+            for (int k = 0; k < n8; k++) { pos[(ra * 8 + k) * 64 + (ia & 63)] = posof(la, ia, k); pos[(rb * 8 + k) * 64 + (ib & 63)] = posof(lb, ib, k); }
+        };
+        do_swap();
+        for (int k = 0; k < n8; k++) {
+            ca[k] = FftGen::round_cycles(&pos[(ra * 8 + k) * 64]);
+            cb[k] = rb != ra ? FftGen::round_cycles(&pos[(rb * 8 + k) * 64]) : 0;
+            after += ca[k] + cb[k];
+        }
+        const int d = after - before;
+        if (d <= 0 || U(g_rng) < exp(-(double) d / temp)) {
+            for (int k = 0; k < n8; k++) { cyc[ra * 8 + k] = ca[k]; if (rb != ra) cyc[rb * 8 + k] = cb[k]; }
+            std::swap(list_of[(size_t) a], list_of[(size_t) b]);
+            std::swap(at[(size_t) a], at[(size_t) b]);
+            cur += d;
+            if (la != lb) cross++;
+            if (cur < bestc) { bestc = cur; best = sched; }
+        } else do_swap();
+    }
+    sched = best;
+    if (!g_quiet) printf("    2^%d points: %zu butterflies in %zu lists, %zu rounds: %ld -> %ld cycles (conflict-free %ld); %ld accepted moves between steps\n",
+                         logN, NN, NL, NR, start, bestc, ideal, cross);
+    for (size_t li = 0; li < NL; li++) {
+        std::vector<uint16_t> ids;
+        for (size_t i = 0; i < sched[li].size(); i++) ids.push_back((uint16_t) sched[li][i]);
+        g_orders[std::make_tuple(logN, (int) (li / 2), (int) (li & 1))] = ids;
+    }
 }
 
 int main(int argc, char **argv)
@@ -145,11 +179,44 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc >= 5 && !strcmp(argv[1], "search2")) { // hill climb on the swizzle with the ANNEALED placement as the yardstick: search2 <seconds> <sweeps> <seed> [c4..c9 to start from]
+        const double budget = atof(argv[2]);
+        g_sweeps = atol(argv[3]);
+        std::mt19937 rng((unsigned) atoi(argv[4]));
+        G->schedule_hook = anneal_hook;
+        g_quiet = true;
+        const time_t t0 = time(NULL);
+        bool first = argc >= 11;
+        int bestc = 1 << 30;
+        while (difftime(time(NULL), t0) < budget) {
+            if (first) { for (int b = 4; b < 10; b++) mp3mi_fft_swz_col[b] = (unsigned) atoi(argv[5 + b - 4]); first = false; }
+            else for (int b = 4; b < 10; b++) mp3mi_fft_swz_col[b] = rng() & (b == 4 ? 15u : 31u);
+            g_rng.seed(1); int c = total_cost();
+            for (bool improved = true; improved && difftime(time(NULL), t0) < budget;) {
+                improved = false;
+                for (int b = 4; b < 10; b++)
+                    for (int bit = 0; bit < (b == 4 ? 4 : 5); bit++) {
+                        mp3mi_fft_swz_col[b] ^= 1u << bit;
+                        g_rng.seed(1); const int c2 = total_cost();
+                        if (c2 < c) { c = c2; improved = true; }
+                        else mp3mi_fft_swz_col[b] ^= 1u << bit;
+                    }
+            }
+            if (c < bestc) {
+                bestc = c;
+                printf("annealed cost %d  cols[4..9] =", c);
+                for (int b = 4; b < 10; b++) printf(" %u", mp3mi_fft_swz_col[b]);
+                printf("\n");
+                fflush(stdout);
+            }
+        }
+        return 0;
+    }
     if (argc >= 9 && !strcmp(argv[1], "anneal")) {
         for (int b = 4; b < 10; b++) mp3mi_fft_swz_col[b] = (unsigned) atoi(argv[2 + b - 4]);
         g_sweeps = atol(argv[8]);
         printf("greedy placement: cost %d\n", total_cost(true));
-        G->placement_hook = anneal_hook;
+        G->schedule_hook = anneal_hook;
         std::map<std::tuple<int, int, int>, std::vector<uint16_t>> all;
         const int c = total_cost(true);
         printf("annealed placement: cost %d\n", c);
