@@ -19,11 +19,11 @@ import mp3common
 mp3common.EMU_SO = "$ROOT/tests/hipemu/_asan/libmp3mi_emu_asan.so"
 from mp3common import Mp3mi, BatchRun
 mp = Mp3mi(emu=True)
-for rate, ch, kbps, nf, s0 in [(44100, 2, 128, 5, 5), (48000, 2, 32, 4, 3), (32000, 1, 64, 4, 8)]:
-    run = BatchRun(mp, 2, rate, ch, kbps, nf, stream0=s0)
+for S, rate, ch, kbps, nf, s0 in [(2, 44100, 2, 128, 5, 5), (2, 48000, 2, 32, 4, 3), (2, 32000, 1, 64, 4, 8), (3, 32000, 1, 96, 3, 11)]: # (the last: an odd number of tracks)
+    run = BatchRun(mp, S, rate, ch, kbps, nf, stream0=s0)
     out, lens = run.encode()
     got = run.encode_streaming([1, nf - 1])
-    assert all(got[s] == out[s, :lens[s]].tobytes() for s in range(2))
+    assert all(got[s] == out[s, :lens[s]].tobytes() for s in range(S))
     out2, _ = run.encode(63)
     assert (out2 == out).all()
     run.close()
