@@ -193,7 +193,7 @@ def reference_baseline(pcm_sample, rate, kbps_list, channels, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="BASELINE.json workload (see the module docstring); 0 = 1, or 2 when launched on 8 GPUs")
