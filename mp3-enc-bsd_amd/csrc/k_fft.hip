@@ -542,8 +542,9 @@ extern "C" void mp3mi_debug_fft_profile(unsigned long long *out)
 #endif
 
 void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, float *energy_l,
-                      float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st)
+                      float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st, int which)
 {
+    // which: bit 0 the two transforms, bit 1 k_cw (batch.cpp launches them apart: k_cw runs beside k_loop)
     // W: as many wavefronts as fit the 160 KB of LDS next to the shared program; one workgroup per CU (that
     // is all the LDS allows), each working through its share of the batches
     const int n_task = g.n_streams * g.n_gran;
@@ -554,7 +555,8 @@ void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    if (g.channels == 2) {
+    if (!(which & 1)) {
+    } else if (g.channels == 2) {
         const int W = 12, WS = 15, nb = (n_task + W - 1) / W, nbs = (n_task + WS - 1) / WS;
         hipLaunchKernelGGL((k_fft<2, W, true>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
         hipLaunchKernelGGL((k_fft<2, WS, false>), dim3((unsigned) (nbs < n_cu ? nbs : n_cu)), dim3(64 * WS), 0, st, T, g, pcm, energy_l, energy_s, bins);
@@ -563,7 +565,7 @@ void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t 
         hipLaunchKernelGGL((k_fft<1, W, true>), dim3((unsigned) grid), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
         hipLaunchKernelGGL((k_fft<1, W, false>), dim3((unsigned) grid), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
     }
-    hipLaunchKernelGGL(k_cw, dim3((unsigned) (n_task * g.channels)), dim3(64), 0, st, bins, cw_mid, hist6, (g.test_flags >> 1) & 1, (g.test_flags >> 4) & 1);
+    if (which & 2) hipLaunchKernelGGL(k_cw, dim3((unsigned) (n_task * g.channels)), dim3(64), 0, st, bins, cw_mid, hist6, (g.test_flags >> 1) & 1, (g.test_flags >> 4) & 1);
 }
 
 // the second tier of the unpredictability for the records k_part listed (mp3mi_launch_psy)

@@ -58,7 +58,7 @@ static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_i
 }
 
 void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm,
-                      float *energy_l, float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st);
+                      float *energy_l, float *energy_s, float *bins, double *cw_mid, float *hist6, hipStream_t st, int which = 3);
 /* records whose unpredictability needs its second tier (k_part lists them, k_cw_fix and k_part's second run work
  * through the list); device memory, mp3mi_cw_fixlist_bytes(records) */
 struct mp3mi_cw_fixlist {
