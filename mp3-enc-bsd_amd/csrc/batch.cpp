@@ -1,13 +1,14 @@
 // Host side of the batched encoder: owns the device buffers, cuts the frames of a call into
 // chunks that fit the scratch budget, and enqueues the kernels of every chunk on TWO HIP streams:
 //
-//   front stream (low priority):  k_fft k_cw k_psy k_filter k_mdct k_prep   of chunk c+1
-//   loop  stream (high priority): k_loop k_format                          of chunk c
+//   front stream (low priority):  k_fft | k_cw k_part k_psy k_filter k_mdct k_prep   of chunk c+1
+//   loop  stream (high priority): k_loop k_format                                   of chunk c
 //
-// k_loop keeps one wavefront per stream resident for a whole chunk and ends when the slowest
-// stream ends (streams differ by up to 1.5x in work), so its tail leaves SIMDs idle; the
-// feed-forward kernels of the next chunk fill them.  The three buffers that cross from the front
-// stream to the loop stream (psy, xr, prep) are double-buffered; events order producer/consumer.
+// k_loop keeps one wavefront per stream resident for a whole chunk (four per SIMD) and leaves room for
+// one more wavefront per SIMD: the feed-forward kernels of the next chunk run there, behind a gate that
+// lets k_loop become resident first -- all but the FFTs, which take a whole CU's LDS per workgroup and run
+// between two k_loop launches.  The three buffers that cross from the front stream to the loop stream
+// (psy, xr, prep) are double-buffered; events order producer/consumer.  Calls overlap the same way.
 //
 //   k_fft     (stream, granule, channel)  psy FFTs                 feed-forward
 //   k_psy     (stream, channel)           thresholds / block type  serial over granules
