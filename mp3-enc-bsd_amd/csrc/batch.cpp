@@ -554,17 +554,20 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     }
     bool y_after_loop = loop_parts == 1 && mp3mi_loop_waves(S) < S;
     { const char *e = getenv("MP3MI_Y_AFTER_LOOP"); if (e) y_after_loop = atoi(e) != 0; }
-    // which: bit 0 the FFTs, bit 1 everything behind them (k_cw, k_part, k_psy)
+    // which: 1 the FFTs, 2 k_cw, 4 the partition sums (k_part), 8 k_psy
     auto stage_x = [&](int c, int which) -> int {
         const mp3mi_geom g = geom_of(c);
         const int xs = (c + b->slot_base) & 1;
         // (k_loop in parts: holding the FFTs back until the last part has ended was tried: 471 vs 462 ms at 16384 x 278)
-        mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream, which);
-        CHK(hipGetLastError());
-        if (!(which & 2)) return MP3MI_OK;
-        if (b->slot_used[xs]) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[xs], 0)); // the k_loop that read this slot last (two chunks ago, maybe in the call before)
-        mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->fft_bins, b->cw_fix, b->psy_state, b->part_eb, b->part_cb, b->psy[xs], b->stream);
-        CHK(hipGetLastError());
+        if (which & 3) {
+            mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream, which & 3);
+            CHK(hipGetLastError());
+        }
+        if ((which & 8) && b->slot_used[xs]) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[xs], 0)); // the k_loop that read this slot last (two chunks ago, maybe in the call before)
+        if (which & 12) {
+            mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->fft_bins, b->cw_fix, b->psy_state, b->part_eb, b->part_cb, b->psy[xs], b->stream, (which >> 2) & 3);
+            CHK(hipGetLastError());
+        }
         return MP3MI_OK;
     };
     // Only the FFTs (a whole CU's LDS per workgroup) have to run between two k_loop launches.  What follows them --
@@ -572,12 +575,16 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     // front of stage Y, behind the same gate: the chunk's FFTs were done before that launch started, and the slot
     // k_psy writes was read last by the launch before it.  238.2 vs 247.2 ms per 4096 x 383 step: k_loop takes 3 ms
     // longer and 9 ms of serial phase are gone.  With k_loop in parts they go beside the first part and stage Y moves
-    // on by one part -- good with four parts (16384 x 278: 453.6 vs 462.5 ms), bad with two, where all of stage Y then
-    // crowds beside the second (8192 x 383: 540 vs 502 ms): there they stay between the launches.
-    // (MP3MI_PSY_BESIDE=0 / 1 overrides.)
-    bool psy_beside = !y_after_loop && loop_parts != 2;
-    { const char *e = getenv("MP3MI_PSY_BESIDE"); if (e) psy_beside = atoi(e) != 0; }
-    if (stage_x(0, 3) != MP3MI_OK) return MP3MI_ERR_HIP;
+    // on by one part -- good with four parts (16384 x 278: 453.6 vs 462.5 ms), bad with two (8192 x 383: 540 vs 502
+    // ms: k_psy, started behind k_cw and k_part, is still running when the first part ends and keeps the second
+    // part's workgroups out).
+    // what of stage X runs beside k_loop (bits as for stage_x): all but the FFTs; with two parts k_psy only (k_cw and
+    // k_part stay between the launches: 483.7 vs 497.6 ms at 8192 x 383 with nothing beside, 540 with all three).
+    // MP3MI_PSY_BESIDE = 0 / 1 / 2: nothing / all three / k_psy only.
+    int beside = y_after_loop ? 0 : (loop_parts == 2 ? 8 : 14);
+    { const char *e = getenv("MP3MI_PSY_BESIDE"); if (e) beside = atoi(e) == 2 ? 8 : (atoi(e) ? 14 : 0); }
+    const bool psy_beside = beside != 0;
+    if (stage_x(0, 15) != MP3MI_OK) return MP3MI_ERR_HIP;
     for (int c = 0; c < nchunks; c++) {
         const int slot = (c + b->slot_base) & 1;
         const mp3mi_geom g = geom_of(c);
@@ -591,7 +598,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         // part before it has ended (an event) and the part's wavefronts have started (the census, bounded wait).
         // Queued earlier, the single-wave workgroups take every slot the ending part frees and keep the next part's
         // four-wave workgroups out: k_loop's second part then ran 36 ms instead of 16 at 8192 x 42.
-        if (psy_beside && c >= 1 && stage_x(c, 2) != MP3MI_OK) return MP3MI_ERR_HIP;
+        if (psy_beside && c >= 1 && stage_x(c, beside) != MP3MI_OK) return MP3MI_ERR_HIP;
         auto behind_part = [&](int p) -> int {
             if (c < 1 || y_after_loop || !b->gate_count || loop_parts < 2) return MP3MI_OK;
             if (p > loop_parts - 1) p = loop_parts - 1;
@@ -612,7 +619,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         if (loop_parts > 2 + shift && behind_part(2 + shift) != MP3MI_OK) return MP3MI_ERR_HIP;
         mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->prep_exact, b->stream);
         CHK(hipGetLastError());
-        if (c + 1 < nchunks && stage_x(c + 1, psy_beside ? 1 : 3) != MP3MI_OK) return MP3MI_ERR_HIP;
+        if (c + 1 < nchunks && stage_x(c + 1, 15 & ~beside) != MP3MI_OK) return MP3MI_ERR_HIP;
         CHK(hipEventRecord(b->ev_front[slot], b->stream));
         // ---- loop stream: the serial search and the formatter ----
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));

@@ -463,11 +463,13 @@ size_t mp3mi_psy_state_size(void) { return sizeof(mp3mi_psy_state); }
 // already written second-tier values everywhere and nothing is checked.
 void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l, const float *energy_s,
                       double *cw_mid, float *hist6, const float *bins, mp3mi_cw_fixlist *fix, void *psy_state, double *eb_all, float *cb_all,
-                      mp3mi_psy_out *out, hipStream_t st)
+                      mp3mi_psy_out *out, hipStream_t st, int which)
 {
+    // which: bit 0 the partition sums (k_part, with the second tier of the unpredictability), bit 1 k_psy
     const size_t n_rec = (size_t) g.n_streams * (size_t) g.n_gran * (size_t) g.channels;
     const unsigned nblk = (unsigned) ((n_rec + 63) / 64);
-    if ((g.test_flags >> 4) & 1)
+    if (!(which & 1)) {
+    } else if ((g.test_flags >> 4) & 1)
         hipLaunchKernelGGL(k_part, dim3(nblk), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all,
                            (mp3mi_cw_fixlist *) NULL, 0);
     else {
@@ -478,6 +480,7 @@ void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *e
         hipLaunchKernelGGL(k_part, dim3(nblk), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all, fix, 1);
     }
     const unsigned grid = (unsigned) ((g.n_streams * g.channels + PSY_W - 1) / PSY_W);
+    if (!(which & 2)) return;
     if (g.rate_idx == 0)
         hipLaunchKernelGGL(k_psy<true>, dim3(grid), dim3(64 * PSY_W), 0, st, T, g, eb_all, cb_all, energy_s, hist6, (mp3mi_psy_state *) psy_state, out);
     else

@@ -70,7 +70,7 @@ void mp3mi_launch_cw_fix_reset(mp3mi_cw_fixlist *fix, unsigned cap, hipStream_t 
 void mp3mi_launch_cw_fix(const mp3mi_geom &g, const float *bins, double *cw_mid, float *hist6, const mp3mi_cw_fixlist *fix, hipStream_t st);
 void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l,
                       const float *energy_s, double *cw_mid, float *hist6, const float *bins, mp3mi_cw_fixlist *fix,
-                      void *psy_state, double *eb_all, float *cb_all, mp3mi_psy_out *out, hipStream_t st);
+                      void *psy_state, double *eb_all, float *cb_all, mp3mi_psy_out *out, hipStream_t st, int which = 3);
 void mp3mi_launch_filter(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, double *sbs, double *sb_dbg, hipStream_t st);
 void mp3mi_launch_mdct(const mp3mi_tables *T, const mp3mi_geom &g, const mp3mi_psy_out *psy, const double *sbs, double *xr, hipStream_t st);
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g); /* subband samples between k_filter and k_mdct */
