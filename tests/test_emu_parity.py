@@ -39,6 +39,19 @@ def test_two_streams_mixed_bitrate_and_chunking(emu, oracle, monkeypatch):
         assert got[s] == oracle.encode(pcm[s], rate, kb, ch)[0]
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_stage_x_schedules(emu, oracle, monkeypatch, mode):
+    """what of stage X is launched beside k_loop (MP3MI_PSY_BESIDE: nothing / k_cw, k_part, k_psy / k_psy only) is a
+    matter of launch order only: four chunks under each order, against the oracle"""
+    monkeypatch.setenv("MP3MI_PSY_BESIDE", mode)
+    monkeypatch.setenv("MP3MI_CHUNK_FRAMES", "1")
+    nf, rate, ch = 4, 44100, 2
+    pcm = np.stack([emu.synth(nf * 1152, ch, rate, 60 + s) for s in range(2)])
+    got = emu.encode_host(pcm, rate, ch, [128, 96], nf)
+    for s, kb in enumerate([128, 96]):
+        assert got[s] == oracle.encode(pcm[s], rate, kb, ch)[0]
+
+
 def test_loop_in_parts(emu, oracle, monkeypatch):
     """a batch of more streams than k_loop holds resident goes through it in parts (batch.cpp): 70 mono streams in
     parts of 64 and 6, two chunks; every stream against the oracle"""
