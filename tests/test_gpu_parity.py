@@ -170,6 +170,12 @@ def test_output_independent_of_schedule(product, monkeypatch):
     monkeypatch.setenv("MP3MI_NO_PLACE", "1")
     c = product.encode_host(pcm, rate, ch, 128, nf)
     assert a == b and a == c
+    # ... and with k_cw / k_part / k_psy between the k_loop launches, or k_psy alone beside them (batch.cpp, stage X)
+    monkeypatch.delenv("MP3MI_NO_GATE")
+    monkeypatch.delenv("MP3MI_NO_PLACE")
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MP3MI_PSY_BESIDE", mode)
+        assert product.encode_host(pcm, rate, ch, 128, nf) == a, "MP3MI_PSY_BESIDE=%s" % mode
 
 
 @pytest.mark.parametrize("rate,ch,kbps,S,nf,stream0", [(44100, 2, 128, 8192, 12, 0), (32000, 1, 64, 16384, 10, 0)])
