@@ -36,9 +36,36 @@ enum {
     MP3MI_ERR_NO_DEVICE = -2, /* no usable GPU */
     MP3MI_ERR_HIP = -3,       /* a HIP call failed; message on stderr */
     MP3MI_ERR_NOMEM = -4,
-    MP3MI_ERR_TABLES = -5     /* this host's libm does not reproduce the pinned init tables (csrc/tables_pins.h):
+    MP3MI_ERR_TABLES = -5,    /* the init tables do not hash to their pinned values (csrc/tables_pins.h): a damaged build;
                                  the bitstream would not be bit-exact, so nothing is encoded */
+    MP3MI_ERR_REFERENCE_ABORT = -6 /* mp3mi_batch_sync / mp3mi_encode_host: the work completed, but for at least one stream the
+                                 REFERENCE would have died on the input (an assertion of its code fails); that stream's
+                                 out_len is 0, every other stream's output is valid -- see mp3mi_batch_stream_status */
 };
+
+/* Scheduling and scratch options of a batch.  The defaults are right for production use; the fields exist for
+ * measurements (tools/) and tests.  Zero-initialise, set struct_size = sizeof, or call mp3mi_batch_options_default. */
+typedef struct mp3mi_batch_options {
+    uint32_t struct_size;     /* sizeof(mp3mi_batch_options) of the caller's build */
+    uint32_t scratch_mb;      /* budget of the per-chunk scratch buffers in MiB (~78 KB per frame and stream); 0 = 32768 */
+    int32_t chunk_frames;     /* upper limit of a chunk's length in frames; 0 = whatever the budget allows */
+    uint32_t test_flags;      /* MP3MI_TEST_*: force the exact tier of the two-tier decisions (as mp3mi_batch_set_test_flags) */
+    int32_t call_overlap;     /* a call's feed-forward kernels may start beside the loop kernels of the call before: -1 default (on), 0, 1 */
+    int32_t gate;             /* the start census that orders the two HIP streams' kernels on the chip: -1 default (on), 0, 1 */
+    int32_t placement;        /* streams placed on SIMDs by their cost in the chunk before: -1 default (on for >= 2 streams per SIMD), 0, 1 */
+    int32_t loop_queue;       /* batches larger than the resident wavefronts: 0 default = k_loop in parts (one launch per stream range),
+                                 1 = one launch whose wavefronts take streams in turn */
+    int32_t loop_part_streams; /* streams per part (multiple of 64); 0 = the resident wavefronts of the device */
+    int32_t y_after_loop;     /* the filterbank / MDCT / prep kernels of a chunk wait for the loop kernel before it: -1 default (only with loop_queue), 0, 1 */
+    int32_t psy_beside;       /* what of the psychoacoustic stage runs beside a loop kernel: -1 default (by the number of parts),
+                                 0 nothing, 1 k_cw + k_part + k_psy, 2 k_psy only */
+} mp3mi_batch_options;
+void mp3mi_batch_options_default(mp3mi_batch_options *opt);
+/* The same, then overridden by the MP3MI_* environment variables that tools/ and tests/ use (MP3MI_SCRATCH_MB,
+ * MP3MI_CHUNK_FRAMES, MP3MI_{NOISE,PHASE,PSY,QUANT,PREP,CW}_EXACT, MP3MI_CALL_OVERLAP, MP3MI_NO_GATE, MP3MI_NO_PLACE,
+ * MP3MI_LOOP_PARTS, MP3MI_LOOP_PART_STREAMS, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE).  This is the ONLY place the library
+ * reads its environment: mp3mi_batch_create calls it once; mp3mi_batch_create_ex never does. */
+void mp3mi_batch_options_from_env(mp3mi_batch_options *opt);
 
 /* Creates an encoder for n_streams independent streams that share sample rate and channel
  * count.  rate_hz in {44100, 48000, 32000}; channels 1 or 2; kbps points to n_streams MPEG-1
@@ -47,6 +74,9 @@ enum {
  * /root/reference/src/musicin.c:456-581 (parse_args defaults, hdr_to_frps, slots per frame). */
 int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz, int channels,
                        const int *kbps, int kbps_all, int max_frames);
+/* The same with explicit options (NULL = the defaults); reads no environment variable. */
+int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_hz, int channels,
+                          const int *kbps, int kbps_all, int max_frames, const mp3mi_batch_options *opt);
 void mp3mi_batch_destroy(mp3mi_batch *b);
 
 /* Bytes to reserve per stream in the output buffer for n_frames frames. */
@@ -61,6 +91,25 @@ size_t mp3mi_batch_out_stride(const mp3mi_batch *b, int n_frames);
 int mp3mi_batch_encode(mp3mi_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev,
                        size_t out_stride, uint32_t *out_len_dev);
 int mp3mi_batch_sync(mp3mi_batch *b);
+
+/* Inputs the reference DIES on.  A few assertions of the reference's Layer III code fail on real inputs
+ * (tests/golden/coverage_notes.json, "reference_aborts", with the fixtures that reach them):
+ *   MP3MI_STREAM_ABORT_GLOBAL_GAIN  assert( cod_info->global_gain < 256 ), /root/reference/src/loop.c:358 -- a granule with
+ *                                   exact-zero lines beside a few tiny ones (a click behind digital silence)
+ *   MP3MI_STREAM_ABORT_HUFF_BITS    assert( max_bits >= 0 ) in inner_loop, src/loop.c:579 -- scalefactor bits above the
+ *                                   granule's budget (48 kHz, 32 kbps, stereo, short blocks)
+ *   MP3MI_STREAM_ABORT_FLUSH_SLOT   assert( l ) in get_side_info, src/formatBitstream.c:390, reached from BF_FlushBitstream
+ *                                   when the last main data ends exactly on a slot boundary with headers still queued
+ * The reference's process ends there and leaves no usable file.  A batch cannot end for one stream: the stream's status
+ * records the first such event, its out_len becomes 0 for that call and every later one, the other streams are not
+ * affected, and mp3mi_batch_sync returns MP3MI_ERR_REFERENCE_ABORT once.  (The drop-in symbols abort() with the
+ * reference's message, as the reference does.)
+ * mp3mi_batch_stream_status waits for the work issued so far and copies the status of every stream of the most recent
+ * streams (since the last reset / whole-file call) to status_host[n_streams]: 0, or code | frame << 8 where frame is the
+ * index of the frame it happened in (the number of frames for the final flush).  Returns the number of streams with a
+ * non-zero status, or a negative MP3MI_ERR_*. */
+enum { MP3MI_STREAM_OK = 0, MP3MI_STREAM_ABORT_GLOBAL_GAIN = 1, MP3MI_STREAM_ABORT_HUFF_BITS = 2, MP3MI_STREAM_ABORT_FLUSH_SLOT = 3 };
+int mp3mi_batch_stream_status(mp3mi_batch *b, int32_t *status_host);
 
 /* Streaming: the reference is a frame-streaming encoder (/root/reference/src/musicin.c:585-805); these calls encode
  * a stream piece by piece with everything it carries from frame to frame kept in the batch (psychoacoustic

@@ -8,7 +8,7 @@
  * batched API with n_streams = 1.  Linking the reference's unchanged musicin.o + common.o against
  * libmp3mi.so instead of l3psy.o / mdct.o / loop.o / l3bitstream.o / formatBitstream.o /
  * reservoir.o / subs.o / pow_nint.o / huffman.o (and the two filterbank functions of encode.o)
- * yields a byte-identical MP3 (tests/test_gpu_dropin.py; recipe in INTEGRATION.md).
+ * yields a byte-identical MP3 (tests/test_dropin.py; recipe in INTEGRATION.md).
  *
  * The type definitions below restate the reference's layouts (file:line cited); a translation
  * unit that already includes the reference's own headers defines

@@ -20,6 +20,30 @@ class Mp3miError(RuntimeError):
     pass
 
 
+class ReferenceAborts(Mp3miError):
+    """mp3mi_batch_sync returned MP3MI_ERR_REFERENCE_ABORT: the work is done, but the reference would have died on
+    at least one stream's input (include/mp3mi.h); that stream's out_len is 0, Batch.stream_status() says why."""
+
+
+ERR_REFERENCE_ABORT = -6
+
+
+class BatchOptions(ctypes.Structure):
+    """include/mp3mi.h: mp3mi_batch_options"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("scratch_mb", ctypes.c_uint32), ("chunk_frames", ctypes.c_int32),
+                ("test_flags", ctypes.c_uint32), ("call_overlap", ctypes.c_int32), ("gate", ctypes.c_int32),
+                ("placement", ctypes.c_int32), ("loop_queue", ctypes.c_int32), ("loop_part_streams", ctypes.c_int32),
+                ("y_after_loop", ctypes.c_int32), ("psy_beside", ctypes.c_int32)]
+
+
+def default_options(**kw):
+    o = BatchOptions()
+    lib().mp3mi_batch_options_default(ctypes.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 _lib = None
 
 
@@ -39,6 +63,11 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.mp3mi_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.mp3mi_batch_create_ex.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.mp3mi_batch_options_default.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_options_from_env.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_stream_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mp3mi_batch_destroy.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_out_stride.restype = ctypes.c_size_t
         L.mp3mi_batch_out_stride.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -80,16 +109,19 @@ def synth_pcm_device(pcm, n_per_ch, channels, rate_hz, stream0=0, seed=0x6D70336
 class Batch:
     """Batched encoder over device memory handed in as torch tensors (device pointers)."""
 
-    def __init__(self, n_streams, rate_hz, channels, kbps, max_frames):
+    def __init__(self, n_streams, rate_hz, channels, kbps, max_frames, options=None):
+        """options: a BatchOptions (mp3mi_batch_create_ex: no environment variable is read), or None
+        (mp3mi_batch_create: the defaults, overridden by the MP3MI_* variables of tools/ and tests/)"""
         import numpy as np
         self.L = lib()
         self.n_streams, self.rate_hz, self.channels, self.max_frames = n_streams, rate_hz, channels, max_frames
         self.h = ctypes.c_void_p()
-        if isinstance(kbps, int):
-            rc = self.L.mp3mi_batch_create(ctypes.byref(self.h), n_streams, rate_hz, channels, None, kbps, max_frames)
+        arr = None if isinstance(kbps, int) else np.ascontiguousarray(kbps, dtype=np.int32)
+        karg, kall = (None, kbps) if arr is None else (arr.ctypes.data, 0)
+        if options is None:
+            rc = self.L.mp3mi_batch_create(ctypes.byref(self.h), n_streams, rate_hz, channels, karg, kall, max_frames)
         else:
-            arr = np.ascontiguousarray(kbps, dtype=np.int32)
-            rc = self.L.mp3mi_batch_create(ctypes.byref(self.h), n_streams, rate_hz, channels, arr.ctypes.data, 0, max_frames)
+            rc = self.L.mp3mi_batch_create_ex(ctypes.byref(self.h), n_streams, rate_hz, channels, karg, kall, max_frames, ctypes.byref(options))
         if rc != 0:
             raise Mp3miError("mp3mi_batch_create failed with %d" % rc)
 
@@ -140,8 +172,19 @@ class Batch:
 
     def sync(self):
         rc = self.L.mp3mi_batch_sync(self.h)
+        if rc == ERR_REFERENCE_ABORT:
+            raise ReferenceAborts("the reference would have died on at least one stream's input: out_len 0 there (stream_status())")
         if rc != 0:
             raise Mp3miError("mp3mi_batch_sync failed with %d" % rc)
+
+    def stream_status(self):
+        """per stream 0, or code | frame << 8 (include/mp3mi.h, MP3MI_STREAM_ABORT_*); waits for the work issued"""
+        import numpy as np
+        st = np.zeros(self.n_streams, np.int32)
+        rc = self.L.mp3mi_batch_stream_status(self.h, st.ctypes.data)
+        if rc < 0:
+            raise Mp3miError("mp3mi_batch_stream_status failed with %d" % rc)
+        return st
 
     def last_timing(self):
         a, b, n = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()

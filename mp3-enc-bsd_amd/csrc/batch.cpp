@@ -61,7 +61,10 @@ struct mp3mi_batch {
     int *place_order, *place_cost; // k_loop stream placement (mp3mi_loop_place), NULL = off
     unsigned *place_zero;    // taken[n] + simd_slots + simd_idx + ticket + scan, zeroed before every k_loop
     int n_simd;
-    int prep_exact;          // MP3MI_PREP_EXACT=1: k_prep skips its fast first tier (tests)
+    mp3mi_batch_options opt; // as given at create time (defaults resolved where a field says "-1 default")
+    unsigned *voided;        // device counter: streams whose file a call voided (the reference dies on them), since the last sync
+    int32_t *status_dev;     // [S]: scratch of mp3mi_batch_stream_status
+    int prep_exact;          // MP3MI_TEST_PREP_EXACT: k_prep skips its fast first tier (tests)
     int test_flags;          // mp3mi_geom::test_flags
     int hdr_flags;           // copyright << 3 | original << 2 | emphasis (src/l3bitstream.c:330-334)
     int hdr_mode;            // header mode field: 0 stereo, 2 dual channel, 3 mono (src/common.h:233-236)
@@ -137,11 +140,48 @@ extern "C" const char *mp3mi_version(void)
 #endif
 }
 
+static_assert((int) MP3MI_STREAM_ABORT_GLOBAL_GAIN == MP3MI_DEV_ABORT_GLOBAL_GAIN && (int) MP3MI_STREAM_ABORT_HUFF_BITS == MP3MI_DEV_ABORT_HUFF_BITS &&
+                  (int) MP3MI_STREAM_ABORT_FLUSH_SLOT == MP3MI_DEV_ABORT_FLUSH_SLOT,
+              "status codes of mp3mi.h and mp3mi_dev.h");
+
 extern "C" void mp3mi_batch_destroy(mp3mi_batch *b);
+
+extern "C" void mp3mi_batch_options_default(mp3mi_batch_options *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t) sizeof(*o);
+    o->call_overlap = o->gate = o->placement = o->y_after_loop = o->psy_beside = -1;
+}
+
+// The one place the library reads its environment (mp3mi.h): the knobs of tools/ and tests/.
+extern "C" void mp3mi_batch_options_from_env(mp3mi_batch_options *o)
+{
+    if (!o) return;
+    mp3mi_batch_options_default(o);
+    const char *e;
+    auto on = [](const char *v) { return v && atoi(v) != 0; };
+    if ((e = getenv("MP3MI_SCRATCH_MB")) && atol(e) > 0) o->scratch_mb = (uint32_t) atol(e);
+    if ((e = getenv("MP3MI_CHUNK_FRAMES")) && atol(e) > 0) o->chunk_frames = (int32_t) atol(e);
+    if (on(getenv("MP3MI_NOISE_EXACT"))) o->test_flags |= MP3MI_TEST_NOISE_EXACT;
+    if (on(getenv("MP3MI_PHASE_EXACT"))) o->test_flags |= MP3MI_TEST_PHASE_EXACT;
+    if (on(getenv("MP3MI_PSY_EXACT"))) o->test_flags |= MP3MI_TEST_PSY_EXACT;
+    if (on(getenv("MP3MI_QUANT_EXACT"))) o->test_flags |= MP3MI_TEST_QUANT_EXACT;
+    if (on(getenv("MP3MI_PREP_EXACT"))) o->test_flags |= MP3MI_TEST_PREP_EXACT;
+    if (on(getenv("MP3MI_CW_EXACT"))) o->test_flags |= MP3MI_TEST_CW_EXACT;
+    if ((e = getenv("MP3MI_CALL_OVERLAP"))) o->call_overlap = atoi(e) != 0;
+    if (on(getenv("MP3MI_NO_GATE"))) o->gate = 0;
+    if (on(getenv("MP3MI_NO_PLACE"))) o->placement = 0;
+    if ((e = getenv("MP3MI_LOOP_PARTS")) && !atoi(e)) o->loop_queue = 1;
+    if ((e = getenv("MP3MI_LOOP_PART_STREAMS")) && atoi(e) >= 64) o->loop_part_streams = atoi(e) / 64 * 64;
+    if ((e = getenv("MP3MI_Y_AFTER_LOOP"))) o->y_after_loop = atoi(e) != 0;
+    if ((e = getenv("MP3MI_PSY_BESIDE"))) o->psy_beside = atoi(e) == 2 ? 2 : (atoi(e) ? 1 : 0);
+}
 
 // Fills *b step by step; on any failure the caller destroys the partially built object (every pointer and handle
 // starts out null, and mp3mi_batch_destroy skips what was never created).
-static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all, int max_frames)
+static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all, int max_frames,
+                       const mp3mi_batch_options &opt)
 {
     static const double s_freq[3] = {44.1, 48, 32}; // src/common.c:113
     int ri;
@@ -172,13 +212,12 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     const size_t per_gc = MP3MI_HBLK_P * 4 + MP3MI_PART_P * 12 + 3 * MP3MI_HBLK_S * 4 + MP3MI_FFT_BINS * 4 + 50 * 8 + 12 * 4 +
                           2 * (sizeof(mp3mi_psy_out) + sizeof(mp3mi_loop_prep) + 576 * 8) + 576 * 8 + 576 * 2;
     const size_t per_frame = per_gc * 2 * (size_t) channels + sizeof(mp3mi_frame_side);
-    const char *env = getenv("MP3MI_SCRATCH_MB");
-    const size_t budget = (env ? (size_t) atol(env) : (size_t) 32768) << 20;
+    b->opt = opt;
+    const size_t budget = (size_t) (opt.scratch_mb ? opt.scratch_mb : 32768u) << 20;
     long cf = (long) (budget / (per_frame * (size_t) n_streams));
     if (cf < 1) cf = 1;
     if (cf > max_frames) cf = max_frames;
-    const char *envc = getenv("MP3MI_CHUNK_FRAMES");
-    if (envc && atol(envc) > 0 && atol(envc) < cf) cf = atol(envc);
+    if (opt.chunk_frames > 0 && opt.chunk_frames < cf) cf = opt.chunk_frames;
     b->chunk_frames = (int) cf;
 
     std::vector<char> Th_store(sizeof(mp3mi_tables)); // host copy of the tables, released on every path
@@ -204,35 +243,30 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     CHK(hipEventCreateWithFlags(&b->ev_hist, hipEventDisableTiming));
     b->have_done = false;
     b->last_slot = 0;
-    { const char *e = getenv("MP3MI_CALL_OVERLAP"); b->overlap_calls = !(e && !atoi(e)); }
+    b->overlap_calls = opt.call_overlap != 0;
     b->slot_base = 0;
     b->slot_used[0] = b->slot_used[1] = false;
-    { const char *e = getenv("MP3MI_PREP_EXACT"); b->prep_exact = (e && atoi(e)) ? 1 : 0; }
-    { const char *e = getenv("MP3MI_NOISE_EXACT"); b->test_flags = (e && atoi(e)) ? 1 : 0; }
-    { const char *e = getenv("MP3MI_PHASE_EXACT"); if (e && atoi(e)) b->test_flags |= 2; }
-    { const char *e = getenv("MP3MI_PSY_EXACT"); if (e && atoi(e)) b->test_flags |= 4; }
-    { const char *e = getenv("MP3MI_QUANT_EXACT"); if (e && atoi(e)) b->test_flags |= 8; }
-    { const char *e = getenv("MP3MI_CW_EXACT"); if (e && atoi(e)) b->test_flags |= 16; }
+    b->test_flags = (int) (opt.test_flags & 15u) | ((opt.test_flags & MP3MI_TEST_CW_EXACT) ? 16 : 0);
+    b->prep_exact = (opt.test_flags & MP3MI_TEST_PREP_EXACT) ? 1 : 0;
     b->hdr_flags = 0;
     b->hdr_mode = (channels == 1) ? 3 : 0;
     b->crc = 0;
     b->gate_count = NULL; b->gate_total = 0; b->gate_first = 0;
-    {
-        const char *envg = getenv("MP3MI_NO_GATE");
-        if (!(envg && atoi(envg))) {
-            CHK(hipMalloc((void **) &b->gate_count, 2 * sizeof(unsigned))); // [0] start census, [1] frames finished in this launch
-            CHK(hipMemset(b->gate_count, 0, 2 * sizeof(unsigned)));
-        }
+    if (opt.gate != 0) {
+        CHK(hipMalloc((void **) &b->gate_count, 2 * sizeof(unsigned))); // [0] start census, [1] frames finished in this launch
+        CHK(hipMemset(b->gate_count, 0, 2 * sizeof(unsigned)));
     }
+    CHK(hipMalloc((void **) &b->voided, sizeof(unsigned)));
+    CHK(hipMemset(b->voided, 0, sizeof(unsigned)));
+    CHK(hipMalloc((void **) &b->status_dev, sizeof(int32_t) * (size_t) n_streams));
     b->place_order = NULL; b->place_cost = NULL; b->place_zero = NULL; b->n_simd = 0;
     {
-        const char *envp = getenv("MP3MI_NO_PLACE");
         hipDeviceProp_t prop;
         int dev = 0;
         CHK(hipGetDevice(&dev));
         CHK(hipGetDeviceProperties(&prop, dev));
         b->n_simd = prop.multiProcessorCount * 4;
-        if (!(envp && atoi(envp)) && n_streams >= 2 * b->n_simd) { // placement only matters when SIMDs hold several streams
+        if (opt.placement != 0 && (n_streams >= 2 * b->n_simd || opt.placement == 1)) { // placement only matters when SIMDs hold several streams
             CHK(hipMalloc((void **) &b->place_order, sizeof(int) * n_streams));
             CHK(hipMalloc((void **) &b->place_cost, sizeof(int) * n_streams));
             CHK(hipMalloc((void **) &b->place_zero, sizeof(unsigned) * ((size_t) n_streams + 2 * MP3MI_PLACE_KEYS + 2)));
@@ -289,8 +323,25 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
 extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz, int channels, const int *kbps,
                                   int kbps_all, int max_frames)
 {
+    mp3mi_batch_options opt;
+    mp3mi_batch_options_from_env(&opt); // once per batch; nothing else in the library reads the environment
+    return mp3mi_batch_create_ex(out, n_streams, rate_hz, channels, kbps, kbps_all, max_frames, &opt);
+}
+
+extern "C" int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_hz, int channels, const int *kbps,
+                                     int kbps_all, int max_frames, const mp3mi_batch_options *opt_in)
+{
     if (!out) return MP3MI_ERR_ARG;
     *out = NULL;
+    mp3mi_batch_options opt;
+    mp3mi_batch_options_default(&opt);
+    if (opt_in) {
+        if (opt_in->struct_size != sizeof(opt)) return MP3MI_ERR_ARG; // another version of the header
+        opt = *opt_in;
+        if ((opt.test_flags & ~(unsigned) MP3MI_TEST_ALL_EXACT) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||
+            (opt.loop_part_streams % 64) != 0 || opt.psy_beside > 2)
+            return MP3MI_ERR_ARG;
+    }
     // argument errors first: they are the caller's, whatever the machine
     if (rate_hz != 44100 && rate_hz != 48000 && rate_hz != 32000) return MP3MI_ERR_ARG; // src/l3psy.c:170-176 exits on anything else
     if (n_streams <= 0 || max_frames <= 0 || (channels != 1 && channels != 2)) return MP3MI_ERR_ARG;
@@ -307,7 +358,7 @@ extern "C" int mp3mi_batch_create(mp3mi_batch **out, int n_streams, int rate_hz,
         return MP3MI_ERR_NO_DEVICE;
     }
     mp3mi_batch *b = new mp3mi_batch(); // value-initialised: every pointer, handle and counter starts at zero
-    const int rc = batch_build(b, n_streams, rate_hz, channels, kbps, kbps_all, max_frames);
+    const int rc = batch_build(b, n_streams, rate_hz, channels, kbps, kbps_all, max_frames, opt);
     if (rc != MP3MI_OK) {
         mp3mi_batch_destroy(b); // frees whatever was allocated before the failure
         return rc;
@@ -324,7 +375,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     if (b->lstream) hipStreamSynchronize(b->lstream);
     void *bufs[] = {b->T, b->bits_per_frame, b->bitrate_index, b->energy_l, b->energy_s, b->hist6, b->fft_bins, b->cw_mid, b->cw_fix,
                     b->part_eb, b->part_cb, b->xr[0], b->xr[1], b->psy[0], b->psy[1], b->prep[0], b->prep[1], b->sbs, b->ix, b->side,
-                    b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg};
+                    b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg, b->voided, b->status_dev};
     for (void *p : bufs)
         if (p) hipFree(p);
     for (int i = 0; i < MP3MI_MAX_LOOP_PARTS; i++) hipEventDestroy(b->ev_part[i]);
@@ -456,8 +507,8 @@ extern "C" int mp3mi_batch_flush(mp3mi_batch *b, uint8_t *out_dev, size_t out_st
     mp3mi_geom g = mp3mi_make_geom(b->n_streams, b->channels, b->rate_idx, 0, 0, 0);
     g.fabs0 = b->frames_done;
     g.crc = b->crc;
-    mp3mi_launch_stream_tail(g, 1, (const int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->bits_per_frame, out_dev, out_stride,
-                             b->out_base, b->carry, b->carry_len, out_len_dev, b->lstream); // behind the last call's k_format
+    mp3mi_launch_stream_tail(g, 1, (int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->bits_per_frame, out_dev, out_stride,
+                             b->out_base, b->carry, b->carry_len, out_len_dev, b->voided, b->lstream); // behind the last call's k_format
     CHK(hipGetLastError());
     CHK(hipEventRecord(b->ev_done, b->lstream));
     b->have_done = true;
@@ -482,7 +533,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     // go on alternating from call to call, and a slot's writer waits for the k_loop that read it last, ev_loop).  So
     // this call's feed-forward kernels start at once and fill the chip while the last k_loop of the call before -- 4096
     // wavefronts, serial, nothing beside them -- runs out: back-to-back calls lose no pipeline fill.
-    // (MP3MI_CALL_OVERLAP=0: the front stream waits for the whole call before, as reset / flush still do.)
+    // (options.call_overlap = 0: the front stream waits for the whole call before, as reset / flush still do.)
     if (b->have_done && !b->overlap_calls) CHK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
     // a whole-file call starts every stream afresh; a streaming call continues (the first one after create / reset /
     // flush / a whole-file call starts afresh too)
@@ -546,14 +597,14 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     // pacing as for a batch of that size.  Every buffer is stream-major, so a part is the same launch with its
     // pointers advanced.  (MP3MI_LOOP_PARTS=0: one launch of the queue form.)
     int loop_parts = (S + mp3mi_loop_resident() - 1) / mp3mi_loop_resident();
-    { const char *e = getenv("MP3MI_LOOP_PARTS"); if (e && !atoi(e)) loop_parts = 1; }
+    if (b->opt.loop_queue) loop_parts = 1;
     int part_streams = ((S + loop_parts - 1) / loop_parts + 63) / 64 * 64; // (whole blocks of 64 prep records)
-    { // (tests: parts of a given size, whatever the device holds)
-        const char *e = getenv("MP3MI_LOOP_PART_STREAMS");
-        if (e && atoi(e) >= 64) { part_streams = atoi(e) / 64 * 64; loop_parts = (S + part_streams - 1) / part_streams; }
+    if (b->opt.loop_part_streams >= 64) { // (tests: parts of a given size, whatever the device holds)
+        part_streams = b->opt.loop_part_streams;
+        loop_parts = (S + part_streams - 1) / part_streams;
     }
     bool y_after_loop = loop_parts == 1 && mp3mi_loop_waves(S) < S;
-    { const char *e = getenv("MP3MI_Y_AFTER_LOOP"); if (e) y_after_loop = atoi(e) != 0; }
+    if (b->opt.y_after_loop >= 0) y_after_loop = b->opt.y_after_loop != 0;
     // which: 1 the FFTs, 2 k_cw, 4 the partition sums (k_part), 8 k_psy
     auto stage_x = [&](int c, int which) -> int {
         const mp3mi_geom g = geom_of(c);
@@ -582,7 +633,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     // k_part stay between the launches: 483.7 vs 497.6 ms at 8192 x 383 with nothing beside, 540 with all three).
     // MP3MI_PSY_BESIDE = 0 / 1 / 2: nothing / all three / k_psy only.
     int beside = y_after_loop ? 0 : (loop_parts == 2 ? 8 : 14);
-    { const char *e = getenv("MP3MI_PSY_BESIDE"); if (e) beside = atoi(e) == 2 ? 8 : (atoi(e) ? 14 : 0); }
+    if (b->opt.psy_beside >= 0) beside = b->opt.psy_beside == 2 ? 8 : (b->opt.psy_beside ? 14 : 0);
     const bool psy_beside = beside != 0;
     if (stage_x(0, 15) != MP3MI_OK) return MP3MI_ERR_HIP;
     for (int c = 0; c < nchunks; c++) {
@@ -656,7 +707,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipEventRecord(b->ev_loop[slot], b->lstream));
         b->slot_used[slot] = true;
         mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,
-                            out_len_dev, b->lstream);
+                            out_len_dev, (int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->voided, b->lstream);
         CHK(hipGetLastError());
         b->last_nf = g.nf;
         b->last_slot = slot;
@@ -667,8 +718,8 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         mp3mi_launch_hist_save(g, pcm_dev, b->pcm_hist, b->stream);
         CHK(hipGetLastError());
         if (!whole_file) {
-            mp3mi_launch_stream_tail(g, 0, (const int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->bits_per_frame, out_dev,
-                                     out_stride, b->out_base, b->carry, b->carry_len, out_len_dev, b->lstream);
+            mp3mi_launch_stream_tail(g, 0, (int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->bits_per_frame, out_dev,
+                                     out_stride, b->out_base, b->carry, b->carry_len, out_len_dev, b->voided, b->lstream);
             CHK(hipGetLastError());
         }
         CHK(hipEventRecord(b->ev_hist, b->stream));
@@ -692,7 +743,29 @@ extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
     CHK(hipStreamSynchronize(b->stream));
     CHK(hipStreamSynchronize(b->lstream));
     CHK(hipGetLastError());
+    // streams whose file was voided since the last sync: the reference dies on those inputs (mp3mi.h)
+    unsigned voided = 0;
+    CHK(hipMemcpy(&voided, b->voided, sizeof(voided), hipMemcpyDeviceToHost));
+    if (voided) {
+        CHK(hipMemset(b->voided, 0, sizeof(unsigned)));
+        return MP3MI_ERR_REFERENCE_ABORT;
+    }
     return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_stream_status(mp3mi_batch *b, int32_t *status_host)
+{
+    if (!b || !status_host) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    // (the state of the most recent streams: a whole-file call leaves it behind, the next call's reset clears it)
+    mp3mi_launch_status_gather(b->n_streams, (const int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->status_dev, b->lstream);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(b->stream));
+    CHK(hipStreamSynchronize(b->lstream));
+    CHK(hipMemcpy(status_host, b->status_dev, sizeof(int32_t) * (size_t) b->n_streams, hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int s = 0; s < b->n_streams; s++) n += status_host[s] != 0;
+    return n;
 }
 
 extern "C" int mp3mi_batch_debug_cw_fixups(mp3mi_batch *b, int *n_listed, int *n_records)

@@ -42,7 +42,7 @@ struct loop_state_host {
     int32_t ResvSize;
     int32_t sc_en_tot[2][2], sc_en[2][2][21], sc_xm[2][2][21], sc_xrmax[2][2];
     int32_t addr[2][2][3];
-    int32_t pad;
+    int32_t ref_abort;
 };
 
 struct DropIn {
@@ -281,6 +281,10 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
     HIPOK(hipMemcpyAsync(&sd, D.side_d, sizeof(sd), hipMemcpyDeviceToHost, D.st));
     HIPOK(hipMemcpyAsync(&ls, D.loop_state, sizeof(ls), hipMemcpyDeviceToHost, D.st));
     HIPOK(hipStreamSynchronize(D.st));
+    // inputs the reference dies on: so does this call, with the reference's own words (its assert() prints the
+    // expression and abort()s)
+    if ((ls.ref_abort & 255) == MP3MI_DEV_ABORT_GLOBAL_GAIN) DIE("iteration_loop: Assertion `cod_info->global_gain < 256' failed (src/loop.c:358)");
+    if ((ls.ref_abort & 255) == MP3MI_DEV_ABORT_HUFF_BITS) DIE("inner_loop: Assertion `max_bits >= 0' failed (src/loop.c:579)");
     l3_side->resvDrain = sd.resvDrain;
     for (int ch = 0; ch < C; ch++)
         for (int b = 0; b < 4; b++) l3_side->scfsi[ch][b] = (unsigned) sd.scfsi[ch][b];
@@ -396,7 +400,7 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
     g.hdr_mode = info->mode;
     g.crc = crc;
     g.hdr_flags = ((info->mode_ext & 3) << 4) | ((info->copyright & 1) << 3) | ((info->original & 1) << 2) | (info->emphasis & 3);
-    mp3mi_launch_format(D.T, g, D.ix_d, D.side_d, D.bits_d, D.bri_d, D.win_d, D.win_bytes, D.len_d, D.st);
+    mp3mi_launch_format(D.T, g, D.ix_d, D.side_d, D.bits_d, D.bri_d, D.win_d, D.win_bytes, D.len_d, NULL, 0, NULL, D.st);
     HIPOK(hipStreamSynchronize(D.st));
     // bytes that are final now = everything up to the end of this frame's main data
     long bits = sd.resvDrain;
@@ -416,6 +420,11 @@ extern "C" void III_FlushBitstream(void)
     if (!D.ready || D.frames_done == 0) return;
     const int slot = D.frame_bytes - D.si_bytes;
     const long rem = ((D.m_end + slot - 1) / slot) * slot - D.m_end;
+    {   // BF_FlushBitstream's remainder call asks for a header the queue no longer has (k_format.hip, fmt_flush_dies)
+        const long written = (D.m_end + slot - 1) / slot, queued = D.frames_done - written;
+        if (queued >= 1 && written * slot == D.m_end && ((queued * (long) slot * 8) % 32) == 0)
+            DIE("get_side_info: Assertion `l' failed (src/formatBitstream.c:390, from BF_FlushBitstream)");
+    }
     const long total = D.frames_done * (long) D.frame_bytes - rem;
     const long widx = D.frames_done - 1 < WIN_FRAMES ? D.frames_done - 1 : WIN_FRAMES;
     const long base = (D.frames_done - 1 - widx) * (long) D.frame_bytes;

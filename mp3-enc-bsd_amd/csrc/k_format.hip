@@ -98,13 +98,28 @@ MP3MI_DEVFN void fmt_pair(const mp3mi_tables *T, int t, int x, int y, unsigned *
     }
 }
 
+// BF_FlushBitstream (src/formatBitstream.c:87-105) writes sum(frameLength - SILength) zero bits over the queued headers in
+// words of 32 and ends with WriteMainDataBits(0, bits % 32).  When the main data written so far ends exactly on a slot
+// boundary (nothing left in the current slot) with k >= 1 headers still queued and k * slot bits are a multiple of 32, that
+// last call has nothing to write but finds BitCount == ThisFrameSize, asks for another header and get_side_info's
+// assert( l ) fails (src/formatBitstream.c:225-230, 381-390): the reference dies in its flush.  n_done frames encoded,
+// m_end bytes of main data written, slot = main-data bytes per frame.
+MP3MI_DEVFN bool fmt_flush_dies(long n_done, long m_end, int slot)
+{
+    if (n_done <= 0) return false;
+    const long written = (m_end + slot - 1) / slot; // headers written so far: one per slot the main data has entered
+    const long queued = n_done - written;
+    return queued >= 1 && written * slot == m_end && ((queued * (long) slot * 8) % 32) == 0;
+}
+
 __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                const int16_t *__restrict__ ix_all,
                                                const mp3mi_frame_side *__restrict__ side_all,
                                                const int32_t *__restrict__ bits_per_frame,
                                                const int32_t *__restrict__ bitrate_index,
                                                uint8_t *__restrict__ out, size_t out_stride,
-                                               uint32_t *__restrict__ out_len)
+                                               uint32_t *__restrict__ out_len, int32_t *__restrict__ loop_state,
+                                               int loop_state_words, unsigned *__restrict__ voided)
 {
     __shared__ fmt_lds L;
     const int lane = wave_lane();
@@ -288,7 +303,16 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
         // byte under construction as well
         const long mend = (long) n_abs * (long) slot - (long) mdb + nbytes; // once per stream
         const long rem = ((mend + slot - 1) / slot) * slot - mend;
-        out_len[s] = (uint32_t) (n_frames_s * frame_bytes - rem + 1);
+        uint32_t len = (uint32_t) (n_frames_s * frame_bytes - rem + 1);
+        if (loop_state) {
+            int32_t *st = &loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)];
+            if (*st == 0 && fmt_flush_dies(n_frames_s, mend, slot)) *st = MP3MI_DEV_ABORT_FLUSH_SLOT | (int32_t) (n_frames_s << 8);
+            if (*st != 0) { // the reference died on this stream: there is no file
+                len = 0;
+                if (voided) atomicAdd(voided, 1u);
+            }
+        }
+        out_len[s] = len;
     }
 }
 
@@ -314,10 +338,11 @@ __global__ void __launch_bounds__(64) k_carry_in(const uint8_t *__restrict__ car
 // After the call's frames are formatted (flush = 0): how much of the row is final, what stays in the carry.
 // flush = 1 (III_FlushBitstream + close_bit_stream_w, src/formatBitstream.c:87-120, src/common.c:843-868, 968):
 // the carry goes out up to where the last main data ends, plus the byte under construction.
-__global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, const int32_t *__restrict__ loop_state, int loop_state_words,
+__global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, int32_t *__restrict__ loop_state, int loop_state_words,
                                                     const int32_t *__restrict__ bits_per_frame, uint8_t *__restrict__ out, size_t out_stride,
                                                     int64_t *__restrict__ out_base, uint8_t *__restrict__ carry,
-                                                    int32_t *__restrict__ carry_len, uint32_t *__restrict__ out_len)
+                                                    int32_t *__restrict__ carry_len, uint32_t *__restrict__ out_len,
+                                                    unsigned *__restrict__ voided)
 {
     const int s = (int) blockIdx.x, lane = (int) threadIdx.x;
     const int C = geo.channels;
@@ -333,7 +358,8 @@ __global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, c
         const int keep = (int) (end - fin); // <= 511 bytes of open slots plus the headers in between
         for (int i = lane; i < keep && i < MP3MI_CARRY_BYTES; i += 64) cr[i] = row[fin - base + i];
         if (lane == 0) {
-            out_len[s] = (uint32_t) (fin - base);
+            // (a stream the reference died on delivers nothing more; mp3mi_batch_stream_status says why)
+            out_len[s] = loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)] ? 0u : (uint32_t) (fin - base);
             carry_len[s] = keep < MP3MI_CARRY_BYTES ? keep : MP3MI_CARRY_BYTES;
             out_base[s] = fin;
         }
@@ -346,11 +372,25 @@ __global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, c
         const int n = (int) (total - base), have = carry_len[s];
         for (int i = lane; i < n; i += 64) row[i] = i < have ? cr[i] : (uint8_t) 0;
         if (lane == 0) {
-            out_len[s] = (uint32_t) (n > 0 ? n : 0);
+            int32_t *st = &loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)];
+            if (*st == 0 && fmt_flush_dies(n_done, m_end, slot)) *st = MP3MI_DEV_ABORT_FLUSH_SLOT | (int32_t) (n_done << 8);
+            if (*st != 0 && voided) atomicAdd(voided, 1u);
+            out_len[s] = *st ? 0u : (uint32_t) (n > 0 ? n : 0);
             carry_len[s] = 0;
             out_base[s] = total;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_status_gather(int n_streams, const int32_t *__restrict__ loop_state, int loop_state_words, int32_t *__restrict__ status)
+{
+    const int s = (int) (blockIdx.x * 256 + threadIdx.x);
+    if (s < n_streams) status[s] = loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)];
+}
+
+void mp3mi_launch_status_gather(int n_streams, const int32_t *loop_state, int loop_state_words, int32_t *status, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_status_gather, dim3((unsigned) ((n_streams + 255) / 256)), dim3(256), 0, st, n_streams, loop_state, loop_state_words, status);
 }
 
 // the last MP3MI_PCM_HIST samples of the call (a frame has 1152 > MP3MI_PCM_HIST) are the next call's history
@@ -368,12 +408,12 @@ void mp3mi_launch_carry_in(int n_streams, const uint8_t *carry, const int32_t *c
     hipLaunchKernelGGL(k_carry_in, dim3((unsigned) n_streams), dim3(64), 0, st, carry, carry_len, out, out_stride);
 }
 
-void mp3mi_launch_stream_tail(const mp3mi_geom &g, int flush, const int32_t *loop_state, int loop_state_words, const int32_t *bits_per_frame,
+void mp3mi_launch_stream_tail(const mp3mi_geom &g, int flush, int32_t *loop_state, int loop_state_words, const int32_t *bits_per_frame,
                               uint8_t *out, size_t out_stride, int64_t *out_base, uint8_t *carry, int32_t *carry_len, uint32_t *out_len,
-                              hipStream_t st)
+                              unsigned *voided, hipStream_t st)
 {
     hipLaunchKernelGGL(k_stream_tail, dim3((unsigned) g.n_streams), dim3(64), 0, st, g, flush, loop_state, loop_state_words, bits_per_frame,
-                       out, out_stride, out_base, carry, carry_len, out_len);
+                       out, out_stride, out_base, carry, carry_len, out_len, voided);
 }
 
 void mp3mi_launch_hist_save(const mp3mi_geom &g, const int16_t *pcm, int16_t *hist, hipStream_t st)
@@ -383,9 +423,9 @@ void mp3mi_launch_hist_save(const mp3mi_geom &g, const int16_t *pcm, int16_t *hi
 
 void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix, const mp3mi_frame_side *side,
                          const int32_t *bits_per_frame, const int32_t *bitrate_index, uint8_t *out,
-                         size_t out_stride, uint32_t *out_len, hipStream_t st)
+                         size_t out_stride, uint32_t *out_len, int32_t *loop_state, int loop_state_words, unsigned *voided, hipStream_t st)
 {
     const unsigned grid = (unsigned) (g.n_streams * g.nf);
     hipLaunchKernelGGL(k_format, dim3(grid), dim3(64), 0, st, T, g, ix, side, bits_per_frame, bitrate_index, out,
-                       out_stride, out_len);
+                       out_stride, out_len, loop_state, loop_state_words, voided);
 }

@@ -33,7 +33,7 @@ typedef struct {
     int32_t ResvSize;
     int32_t sc_en_tot[2][2], sc_en[2][2][21], sc_xm[2][2][21], sc_xrmax[2][2];
     int32_t addr[2][2][3];
-    int32_t pad;
+    int32_t ref_abort; // last word (MP3MI_LOOP_STATE_ABORT_WORD): 0, or MP3MI_DEV_ABORT_* | frame << 8 -- an input the reference dies on
 } mp3mi_loop_state;
 
 struct loop_gr { // wave-uniform working copy of gr_info (src/l3side.h:60-87)
@@ -64,6 +64,12 @@ struct loop_lds {
     int p23[2][2];      // part2_3_length (ResvFrameEnd adds the stuffing bits, src/reservoir.c:190-224)
     int preflag0[2];    // granule 0's preflag (src/loop.c:1172-1176)
 };
+
+// The reference DIES on some inputs (an assert fails: tests/golden/coverage_notes.json, "reference_aborts").  A batch cannot
+// die for one stream: the first such event is recorded in the stream's state (code | frame index << 8; wave-uniform, so
+// it lives in a scalar register until the state goes back to memory), the search goes on with something harmless, and
+// k_format / k_stream_tail void the stream's output (mp3mi.h, mp3mi_batch_stream_status).
+#define LOOP_REF_ABORT(code, frame) do { if (ref_abort == 0) ref_abort = (code) | (int) ((frame) << 8); } while (0)
 
 // Wavefronts (streams) per workgroup.  They share nothing but the code-length tables in LDS (1.9 KB that every stream
 // would otherwise hold a copy of) and synchronise only per wavefront.
@@ -712,6 +718,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
     if (lane < 8) L.ix[576 + lane] = 0;
     if (lane == 0) L.xr[576] = 0.0;
     wave_sync();
+    int ref_abort = __builtin_amdgcn_readfirstlane(L.st.ref_abort); // (sticky: the first event of the stream stands)
 
     // ragged batch: frames of this stream beyond its last (zero-filled) one are not encoded
     const int nf_s = geo.n_samples ? loop_frames_here(geo, geo.n_samples[s]) : geo.nf;
@@ -837,7 +844,15 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                         iteration++;
                         work += 5;
                         g.part2_length = loop_part2_length(g, scfsi_m);
-                        const int huff_bits = max_bits - g.part2_length;
+                        int huff_bits = max_bits - g.part2_length;
+                        if (huff_bits < 0) {
+                            // assert( max_bits >= 0 ) of inner_loop (src/loop.c:579): the scalefactors alone exceed the
+                            // granule's budget and the reference dies.  Without the assert its loop -- and the one below --
+                            // would raise the step for ever: no count is <= a negative budget.  The stream is void from
+                            // here on; any budget lets the search run out.
+                            LOOP_REF_ABORT(MP3MI_DEV_ABORT_HUFF_BITS, geo.fabs0 + geo.f0 + fl);
+                            huff_bits = max_bits;
+                        }
                         // bin_search_StepSize (src/loop.c:2119-2140, first iteration only) and inner_loop (src/loop.c:569-606)
                         // as ONE loop around ONE copy of the quantise+count pass (the pass is ~3 k instructions; a second
                         // inlined copy is instruction-cache pressure for nothing).  The bisection probes (top + bot) / 2
@@ -1040,6 +1055,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 // ResvAdjust (src/reservoir.c:141-145), global_gain (src/loop.c:357)
                 ResvSize += (mean_bits / C) - g.part2_3_length;
                 const int global_gain = loop_nint((double) g.q + 210.0);
+                if (global_gain >= 256) LOOP_REF_ABORT(MP3MI_DEV_ABORT_GLOBAL_GAIN, geo.fabs0 + geo.f0 + fl); // assert, src/loop.c:358
 
                 PROF(6);
                 // ---- hand the granule over: signed ix (src/l3bitstream.c:115-125) and side info ----
@@ -1130,6 +1146,8 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
     }
     {
         const int ln = wave_lane_here(); // (not the address the state was loaded through, kept alive across the whole kernel)
+        if (ln == 0) L.st.ref_abort = ref_abort;
+        wave_sync();
         for (int i = ln; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &state[s])[i] = ((const int *) &L.st)[i];
     }
     if (place.cost && lane == 0) place.cost[s] = work;
@@ -1212,15 +1230,14 @@ extern "C" void mp3mi_debug_loop_waves(unsigned long long *out, int n_streams)
 size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 
 // workgroups that are resident together: four of LOOP_W = 4 wavefronts per CU (four wavefronts per SIMD: what stays
-// resident beside the feed-forward kernels, batch.cpp); MP3MI_LOOP_WGS_PER_CU overrides (experiments)
+// resident beside the feed-forward kernels, batch.cpp)
 static int loop_wg_cap(void)
 {
     static int wg_cap = 0;
     if (!wg_cap) {
-        int dev = 0, per_cu = 4;
+        int dev = 0;
+        const int per_cu = 4;
         hipDeviceProp_t prop;
-        const char *e = getenv("MP3MI_LOOP_WGS_PER_CU");
-        if (e && atoi(e) > 0) per_cu = atoi(e);
         wg_cap = 256 * per_cu;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) wg_cap = prop.multiProcessorCount * per_cu;
     }

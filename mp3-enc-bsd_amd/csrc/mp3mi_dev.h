@@ -64,6 +64,13 @@ static inline int mp3mi_fft_swz_rt(int p)
 #define MP3MI_STEP_MIN (-400)
 #define MP3MI_STEP_N 801
 
+/* Inputs the reference dies on (an assertion fails; tests/golden/coverage_notes.json): status codes, the public names
+ * are MP3MI_STREAM_* in include/mp3mi.h (batch.cpp checks that they agree).  A stream's status word is the LAST word of
+ * its mp3mi_loop_state: code | index of the frame it happened in << 8 (the number of frames: in the final flush). */
+#define MP3MI_DEV_ABORT_GLOBAL_GAIN 1 /* assert( cod_info->global_gain < 256 ), src/loop.c:358 */
+#define MP3MI_DEV_ABORT_HUFF_BITS 2   /* assert( max_bits >= 0 ), src/loop.c:579 */
+#define MP3MI_DEV_ABORT_FLUSH_SLOT 3  /* assert( l ), src/formatBitstream.c:390, from BF_FlushBitstream's remainder call */
+
 /* Data movement the reference's FFT ends with; folded into the read-out tables fft_rd_* (tables_host.cpp) */
 enum {
     FOP_NEG = 1,    /* x[a]=-x[a]                                        (src/subs.c:523) */

@@ -100,14 +100,19 @@ void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_tick
    part of the bit reservoir's slots and the headers in between, at most MP3MI_CARRY_BYTES -- wait in `carry` */
 #define MP3MI_CARRY_BYTES 2048
 void mp3mi_launch_carry_in(int n_streams, const uint8_t *carry, const int32_t *carry_len, uint8_t *out, size_t out_stride, hipStream_t st);
-void mp3mi_launch_stream_tail(const mp3mi_geom &g, int flush, const int32_t *loop_state, int loop_state_words, const int32_t *bits_per_frame,
+/* loop_state: the streams' mp3mi_loop_state records (k_loop.hip) as words -- word 0 is ResvSize, the last word the
+   stream's status (MP3MI_DEV_ABORT_*); voided: counts the streams whose file a call voided because of it */
+void mp3mi_launch_stream_tail(const mp3mi_geom &g, int flush, int32_t *loop_state, int loop_state_words, const int32_t *bits_per_frame,
                               uint8_t *out, size_t out_stride, int64_t *out_base, uint8_t *carry, int32_t *carry_len, uint32_t *out_len,
-                              hipStream_t st);
+                              unsigned *voided, hipStream_t st);
+/* status[s] = the status word of stream s (a gather out of the strided state records) */
+void mp3mi_launch_status_gather(int n_streams, const int32_t *loop_state, int loop_state_words, int32_t *status, hipStream_t st);
 void mp3mi_launch_hist_save(const mp3mi_geom &g, const int16_t *pcm, int16_t *hist, hipStream_t st);
+/* loop_state / voided as for mp3mi_launch_stream_tail (a whole-file call ends the streams in k_format); NULL: no status */
 void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix,
                          const mp3mi_frame_side *side, const int32_t *bits_per_frame,
                          const int32_t *bitrate_index, uint8_t *out, size_t out_stride,
-                         uint32_t *out_len, hipStream_t st);
+                         uint32_t *out_len, int32_t *loop_state, int loop_state_words, unsigned *voided, hipStream_t st);
 #endif
 
 #endif

@@ -1,8 +1,11 @@
 // Host-side construction of the read-only table block (mp3mi_tables).
 //
-// Every value that the reference computes once at start-up with libm is computed here the
-// same way with the host's libm (identical glibc on the GPU box), so the kernels never
-// evaluate an init-time transcendental themselves:
+// Every value that the reference computes once at start-up with libm is computed the same way with glibc's libm --
+// but NOT on the machine that encodes: the expressions below marked LIBM_TABLE are compiled only into the generator
+// (-DMP3MI_TABLE_GEN, `make blob`), which runs in the environment the golden vectors come from and writes their values,
+// bit for bit, into tables_blob.bin; the library links that file (build/tables_blob.o) and copies the values out of it.
+// The product therefore calls no transcendental of the host's libm at all, and a host with another libm emits the
+// same stream (tests/test_table_pins.py::test_tables_do_not_depend_on_this_hosts_libm).  What comes out of libm:
 //   Hann windows            src/l3psy.c:194-195      spreading matrix   src/l3psy.c:818-848
 //   FFT twiddles            src/subs.c:278-286,452-457
 //   analysis filter matrix  src/encode.c:331-345     MDCT windows/cos   src/mdct.c:129-171
@@ -21,9 +24,82 @@
 #include "mp3mi_tables_gen.h"
 #include "mdct_shape.h"
 
+#if defined(MP3MI_FFT_INFO) /* -DMP3MI_FFT_INFO: print the round headers the generator produces (after changing it) */
+#define MP3MI_FFT_INFO_ON 1
+#else
+#define MP3MI_FFT_INFO_ON 0
+#endif
 #define R_PI 3.14159265358979
 #define R_LN_TO_LOG10 0.2302585093
 #define R_TWOPI 6.28318530717958647692
+
+/* ---- tables_blob.bin: the values that come out of libm, as the reference environment computes them ----
+ * "MP3MITB1", n entries {id, rate index or -1 for all rates, offset, size}, the data, FNV-1a 64 of all before. */
+enum {
+    TB_WINDOW = 1, TB_WINDOW_S, TB_S3_L, TB_EXP_SNR_S, TB_FILT, TB_MDCT_WIN, TB_COS_S, TB_COS_L, TB_CA, TB_CS,
+    TB_POW_NINT, TB_POW43, TB_STEP, TB_PRETAB_XR, TB_PRETAB_XMIN, TB_SQRT2, TB_LOG2,
+    TB_TWIDDLE = 64 /* + 2 * logm + three */
+};
+struct tb_entry { uint32_t id; int32_t rate; uint32_t offset, size; };
+struct tb_header { char magic[8]; uint32_t n_entries, pad; };
+
+static uint64_t tb_fnv(const void *p, size_t n)
+{
+    const unsigned char *b = (const unsigned char *) p;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+#if defined(MP3MI_TABLE_GEN)
+/* generator: compute with libm, record */
+static std::vector<tb_entry> tb_entries;
+static std::vector<unsigned char> tb_data;
+static void tb_put(uint32_t id, int rate, const void *src, size_t bytes)
+{
+    for (const tb_entry &e : tb_entries)
+        if (e.id == id && e.rate == rate) return; /* (the tables of a rate are built more than once) */
+    tb_entry e = {id, rate, (uint32_t) tb_data.size(), (uint32_t) bytes};
+    tb_entries.push_back(e);
+    tb_data.insert(tb_data.end(), (const unsigned char *) src, (const unsigned char *) src + bytes);
+    while (tb_data.size() % 8) tb_data.push_back(0);
+}
+#define LIBM_TABLE(id, rate, dst, bytes, ...) do { __VA_ARGS__; tb_put((id), (rate), (dst), (bytes)); } while (0)
+#else
+/* product: copy out of the linked blob */
+extern "C" const unsigned char _binary_tables_blob_bin_start[], _binary_tables_blob_bin_end[];
+static int tb_failed = 0; /* some entry was missing or the blob is damaged: build_tables_unpinned reports it */
+static int tb_get(uint32_t id, int rate, void *dst, size_t bytes)
+{
+    const unsigned char *b = _binary_tables_blob_bin_start;
+    const size_t total = (size_t) (_binary_tables_blob_bin_end - _binary_tables_blob_bin_start);
+    static int checked = 0; /* 0 not yet, 1 good, -1 bad */
+    if (!checked) {
+        uint64_t h = 0;
+        checked = -1;
+        if (total > sizeof(tb_header) + 8 && !memcmp(b, "MP3MITB1", 8)) {
+            memcpy(&h, b + total - 8, 8);
+            if (h == tb_fnv(b, total - 8)) checked = 1;
+        }
+        if (checked < 0) fprintf(stderr, "mp3mi: the linked table blob (csrc/tables_blob.bin) is damaged\n");
+    }
+    if (checked < 0) { tb_failed = 1; return -1; }
+    tb_header hd;
+    memcpy(&hd, b, sizeof(hd));
+    for (uint32_t i = 0; i < hd.n_entries; i++) {
+        tb_entry e;
+        memcpy(&e, b + sizeof(hd) + (size_t) i * sizeof(e), sizeof(e));
+        if (e.id != id || (e.rate != rate && e.rate != -1)) continue;
+        if (e.size != bytes || (size_t) e.offset + e.size > total) break;
+        memcpy(dst, b + sizeof(hd) + (size_t) hd.n_entries * sizeof(tb_entry) + e.offset, bytes);
+        return 0;
+    }
+    fprintf(stderr, "mp3mi: table blob has no entry %u for rate index %d of %zu bytes -- regenerate it (make -C csrc blob)\n", id, rate, bytes);
+    tb_failed = 1;
+    return -1;
+}
+#define LIBM_TABLE(id, rate, dst, bytes, ...) do { if (tb_get((id), (rate), (dst), (bytes))) return -7; } while (0)
+#endif
 
 static const int SFB_L[3][23] = {
     {0,4,8,12,16,20,24,30,36,44,52,62,74,90,110,134,162,196,238,288,342,418,576},
@@ -45,6 +121,11 @@ Twiddle make_twiddle(int logm, bool three)
     Twiddle tw;
     tw.nel = nel;
     tw.t.assign((size_t) (three ? 6 : 3) * (nel > 0 ? nel : 1), 0.0f);
+#if !defined(MP3MI_TABLE_GEN)
+    (void) tb_get((uint32_t) (TB_TWIDDLE + 2 * logm + (three ? 1 : 0)), -1, tw.t.data(), tw.t.size() * sizeof(float)); /* (a failure is remembered: tb_failed) */
+    (void) m8; (void) e;
+    return tw;
+#else
     for (int n = 1; n < m4; n++) {
         if (n == m8) continue;
         float ang = (float) (n * R_TWOPI / m);
@@ -62,7 +143,9 @@ Twiddle make_twiddle(int logm, bool three)
         }
         e++;
     }
+    tb_put((uint32_t) (TB_TWIDDLE + 2 * logm + (three ? 1 : 0)), -1, tw.t.data(), tw.t.size() * sizeof(float));
     return tw;
+#endif
 }
 
 /* One fused butterfly of the flattened FFT.  cls 0 ("R", four operands a b c d):
@@ -370,7 +453,7 @@ struct FftGen {
             for (size_t i = 0; ok && i < nodes.size(); i++)
                 for (size_t j = 0; ok && j < nodes[i].pred.size(); j++) ok = step_of[(size_t) nodes[i].pred[j]] < step_of[i];
             if (ok) sched = st;
-            else if (getenv("MP3MI_FFT_INFO")) fprintf(stderr, "mp3mi: the stored fft schedule for 2^%d points does not fit, list schedule kept\n", logN);
+            else if (MP3MI_FFT_INFO_ON) fprintf(stderr, "mp3mi: the stored fft schedule for 2^%d points does not fit, list schedule kept\n", logN);
         }
         if (schedule_hook) schedule_hook(logN, nodes, sched);
         for (size_t li = 0; li < sched.size(); li += 2) {
@@ -513,8 +596,10 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
         }
     }
 
-    for (unsigned i = 0; i < 1024; i++) T->window[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 1024)));
-    for (unsigned i = 0; i < 256; i++) T->window_s[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 256)));
+    LIBM_TABLE(TB_WINDOW, -1, T->window, sizeof(T->window),
+               for (unsigned i = 0; i < 1024; i++) T->window[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 1024))));
+    LIBM_TABLE(TB_WINDOW_S, -1, T->window_s, sizeof(T->window_s),
+               for (unsigned i = 0; i < 256; i++) T->window_s[i] = (float) (0.5 * (1 - cos(2.0 * R_PI * (i - 0.5) / 256))));
 
     const int cb_l = T_PL_COUNT[ri], cb_s = T_PS_COUNT[ri];
     double bval_l[MP3MI_CBANDS];
@@ -533,17 +618,19 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
        i.e. they are summed into partition 0 after its own lines (src/l3psy.c:131, 808-809) */
     T->part_l_covered = k2;
     if (k2 > MP3MI_HBLK) return -2;
-    for (int i = 0; i < cb_l; i++)
-        for (int j = 0; j < cb_l; j++) {
-            double tempx, x, tempy, temp;
-            if (j >= i) tempx = (bval_l[i] - bval_l[j]) * 3.0;
-            else tempx = (bval_l[i] - bval_l[j]) * 1.5;
-            if (tempx >= 0.5 && tempx <= 2.5) { temp = tempx - 0.5; x = 8.0 * (temp * temp - 2.0 * temp); }
-            else x = 0.0;
-            tempx += 0.474;
-            tempy = 15.811389 + 7.5 * tempx - 17.5 * sqrt(1.0 + tempx * tempx);
-            T->s3_l[i][j] = (tempy <= -60.0) ? 0.0 : exp((x + tempy) * R_LN_TO_LOG10);
-        }
+    (void) bval_l;
+    LIBM_TABLE(TB_S3_L, ri, T->s3_l, sizeof(T->s3_l),
+               for (int i = 0; i < cb_l; i++)
+                   for (int j = 0; j < cb_l; j++) {
+                       double tempx; double x; double tempy; double temp;
+                       if (j >= i) tempx = (bval_l[i] - bval_l[j]) * 3.0;
+                       else tempx = (bval_l[i] - bval_l[j]) * 1.5;
+                       if (tempx >= 0.5 && tempx <= 2.5) { temp = tempx - 0.5; x = 8.0 * (temp * temp - 2.0 * temp); }
+                       else x = 0.0;
+                       tempx += 0.474;
+                       tempy = 15.811389 + 7.5 * tempx - 17.5 * sqrt(1.0 + tempx * tempx);
+                       T->s3_l[i][j] = (tempy <= -60.0) ? 0.0 : exp((x + tempy) * R_LN_TO_LOG10);
+                   });
     memset(T->s3_lt, 0, sizeof(T->s3_lt));
     for (int i = 0; i < MP3MI_CBANDS; i++)
         for (int j = 0; j < MP3MI_CBANDS; j++) T->s3_lt[j][i] = T->s3_l[i][j];
@@ -556,14 +643,15 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
         T->part_s_start[i] = k2;
         k2 += T_PS_NUMLINES[ri][i];
         T->qthr_s[i] = T_PS_QTHR[ri][i];
-        T->exp_snr_s[i] = exp((double) T_PS_SNR[ri][i] * R_LN_TO_LOG10);
     }
     for (int i = cb_s; i <= MP3MI_CBANDS_S; i++) T->part_s_start[i] = k2;
     T->part_s_covered = k2;
     if (k2 > MP3MI_HBLK_S) return -2;
     /* entries of qthr_s/exp_snr_s beyond cb_s: the reference loops b < 42 over statics that
        were never written there: qthr_s = 0, SNR_s = 0 -> exp(0) = 1 */
-    for (int i = cb_s; i < MP3MI_CBANDS_S; i++) T->exp_snr_s[i] = exp(0.0 * R_LN_TO_LOG10);
+    LIBM_TABLE(TB_EXP_SNR_S, ri, T->exp_snr_s, sizeof(T->exp_snr_s),
+               for (int i = 0; i < cb_s; i++) T->exp_snr_s[i] = exp((double) T_PS_SNR[ri][i] * R_LN_TO_LOG10);
+               for (int i = cb_s; i < MP3MI_CBANDS_S; i++) T->exp_snr_s[i] = exp(0.0 * R_LN_TO_LOG10));
     for (int i = 0; i < MP3MI_CBANDS; i++) { T->s3_lo[i] = T_S3_LO[i]; T->s3_hi[i] = T_S3_HI[i]; }
     for (int i = 0; i < 21; i++) {
         T->bu_l[i] = T_SL_BU[ri][i]; T->bo_l[i] = T_SL_BO[ri][i];
@@ -603,7 +691,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
             bool same = T->fft_nround_l == (int) sizeof(hl) && T->fft_nround_s == (int) sizeof(hs);
             for (int i = 0; same && i < T->fft_nround_l; i++) same = T->fft_hdr_l[i] == hl[i];
             for (int i = 0; same && i < T->fft_nround_s; i++) same = T->fft_hdr_s[i] == hs[i];
-            if (getenv("MP3MI_FFT_INFO")) {
+            if (MP3MI_FFT_INFO_ON) {
                 fprintf(stderr, "#define MP3MI_FFT_HDRS_L");
                 for (int i = 0; i < T->fft_nround_l; i++) fprintf(stderr, "%s %u", i ? "," : "", T->fft_hdr_l[i]);
                 fprintf(stderr, "\n#define MP3MI_FFT_HDRS_S");
@@ -612,51 +700,53 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
             }
             if (!same) { fprintf(stderr, "mp3mi: fft program does not match MP3MI_FFT_HDRS_* (mp3mi_dev.h)\n"); delete g; return -6; }
         }
-        if (getenv("MP3MI_FFT_INFO")) fprintf(stderr, "mp3mi: fft program long %d rounds %d words, short %d rounds %d words\n", T->fft_nround_l, T->fft_nword_l, T->fft_nround_s, T->fft_nword_s);
+        if (MP3MI_FFT_INFO_ON) fprintf(stderr, "mp3mi: fft program long %d rounds %d words, short %d rounds %d words\n", T->fft_nround_l, T->fft_nword_l, T->fft_nround_s, T->fft_nword_s);
         delete g;
     }
 
     for (int i = 0; i < 512; i++) T->enwindow[i] = T_ENWINDOW[i];
-    for (int i = 0; i < 32; i++) {
-        double row[64];
-        for (int k = 0; k < 64; k++) {
-            double f = 1e9 * cos((double) ((2 * i + 1) * (16 - k) * R_PI / 64));
-            if (f >= 0) modf(f + 0.5, &f);
-            else modf(f - 0.5, &f);
-            row[k] = f * 1e-9;
-        }
-        for (int j = 0; j < 16; j++) T->filt[i][j] = row[j];
-        for (int j = 0; j < 15; j++) T->filt[i][16 + j] = row[33 + j];
-        T->filt[i][31] = 0.0;
-    }
+    LIBM_TABLE(TB_FILT, -1, T->filt, sizeof(T->filt),
+               for (int i = 0; i < 32; i++) {
+                   double row[64];
+                   for (int k = 0; k < 64; k++) {
+                       double f = 1e9 * cos((double) ((2 * i + 1) * (16 - k) * R_PI / 64));
+                       if (f >= 0) modf(f + 0.5, &f);
+                       else modf(f - 0.5, &f);
+                       row[k] = f * 1e-9;
+                   }
+                   for (int j = 0; j < 16; j++) T->filt[i][j] = row[j];
+                   for (int j = 0; j < 15; j++) T->filt[i][16 + j] = row[33 + j];
+                   T->filt[i][31] = 0.0;
+               });
 
     double (*win)[36] = T->mdct_win;
-    for (int i = 0; i < 36; i++) win[0][i] = sin(R_PI / 36 * (i + 0.5));
-    for (int i = 0; i < 18; i++) win[1][i] = sin(R_PI / 36 * (i + 0.5));
-    for (int i = 18; i < 24; i++) win[1][i] = 1.0;
-    for (int i = 24; i < 30; i++) win[1][i] = sin(R_PI / 12 * (i + 0.5 - 18));
-    for (int i = 30; i < 36; i++) win[1][i] = 0.0;
-    for (int i = 0; i < 6; i++) win[3][i] = 0.0;
-    for (int i = 6; i < 12; i++) win[3][i] = sin(R_PI / 12 * (i + 0.5 - 6));
-    for (int i = 12; i < 18; i++) win[3][i] = 1.0;
-    for (int i = 18; i < 36; i++) win[3][i] = sin(R_PI / 36 * (i + 0.5));
-    for (int i = 0; i < 12; i++) win[2][i] = sin(R_PI / 12 * (i + 0.5));
-    for (int i = 12; i < 36; i++) win[2][i] = 0.0;
-    {
-        int N = 12;
-        for (int m = 0; m < N / 2; m++)
-            for (int k = 0; k < N; k++)
-                T->cos_s[m][k] = cos((R_PI / (2 * N)) * (2 * k + 1 + N / 2) * (2 * m + 1)) / (N / 4);
-        N = 36;
-        for (int m = 0; m < N / 2; m++)
-            for (int k = 0; k < N; k++)
-                T->cos_l[m][k] = cos((R_PI / (2 * N)) * (2 * k + 1 + N / 2) * (2 * m + 1)) / (N / 4);
-    }
-    for (int k = 0; k < 8; k++) {
-        double sq = sqrt(1.0 + ALIAS_C[k] * ALIAS_C[k]);
-        T->ca[k] = ALIAS_C[k] / sq;
-        T->cs[k] = 1.0 / sq;
-    }
+    LIBM_TABLE(TB_MDCT_WIN, -1, T->mdct_win, sizeof(T->mdct_win),
+               for (int i = 0; i < 36; i++) win[0][i] = sin(R_PI / 36 * (i + 0.5));
+               for (int i = 0; i < 18; i++) win[1][i] = sin(R_PI / 36 * (i + 0.5));
+               for (int i = 18; i < 24; i++) win[1][i] = 1.0;
+               for (int i = 24; i < 30; i++) win[1][i] = sin(R_PI / 12 * (i + 0.5 - 18));
+               for (int i = 30; i < 36; i++) win[1][i] = 0.0;
+               for (int i = 0; i < 6; i++) win[3][i] = 0.0;
+               for (int i = 6; i < 12; i++) win[3][i] = sin(R_PI / 12 * (i + 0.5 - 6));
+               for (int i = 12; i < 18; i++) win[3][i] = 1.0;
+               for (int i = 18; i < 36; i++) win[3][i] = sin(R_PI / 36 * (i + 0.5));
+               for (int i = 0; i < 12; i++) win[2][i] = sin(R_PI / 12 * (i + 0.5));
+               for (int i = 12; i < 36; i++) win[2][i] = 0.0);
+    (void) win;
+    LIBM_TABLE(TB_COS_S, -1, T->cos_s, sizeof(T->cos_s),
+               const int N = 12;
+               for (int m = 0; m < N / 2; m++)
+                   for (int k = 0; k < N; k++)
+                       T->cos_s[m][k] = cos((R_PI / (2 * N)) * (2 * k + 1 + N / 2) * (2 * m + 1)) / (N / 4));
+    LIBM_TABLE(TB_COS_L, -1, T->cos_l, sizeof(T->cos_l),
+               const int N = 36;
+               for (int m = 0; m < N / 2; m++)
+                   for (int k = 0; k < N; k++)
+                       T->cos_l[m][k] = cos((R_PI / (2 * N)) * (2 * k + 1 + N / 2) * (2 * m + 1)) / (N / 4));
+    LIBM_TABLE(TB_CA, -1, T->ca, sizeof(T->ca),
+               for (int k = 0; k < 8; k++) T->ca[k] = ALIAS_C[k] / sqrt(1.0 + ALIAS_C[k] * ALIAS_C[k]));
+    LIBM_TABLE(TB_CS, -1, T->cs, sizeof(T->cs),
+               for (int k = 0; k < 8; k++) T->cs[k] = 1.0 / sqrt(1.0 + ALIAS_C[k] * ALIAS_C[k]));
     /* Long-block MDCT in shared-subexpression form.  Every bracketed operand group of
        src/mdct.c:205-508 is one of 26 per-band values V: d1[j] = fin[j]-fin[17-j], s2[j] =
        fin[18+j]+fin[35-j] (j<9), six 6-operand groups and two 18-operand groups -- or the exact
@@ -730,17 +820,20 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
         }
     }
 
-    T->pow_nint_tab[0] = 0.0;
-    for (int i = 1; i < 2048; i++) T->pow_nint_tab[i] = pow((double) i - 0.4054, 4.0 / 3.0);
-    T->pow_nint_tab[2048] = HUGE_VAL;
-    for (int i = 0; i < MP3MI_POW43_N; i++) T->pow43[i] = pow((double) i, 4.0 / 3.0);
-    for (int i = 0; i < MP3MI_STEP_N; i++) T->step[i] = pow(2.0, (double) (MP3MI_STEP_MIN + i) * 0.25);
-    for (int n = 0; n < 4; n++) {
-        T->pretab_xr[n] = pow(sqrt(2.), (double) n);
-        T->pretab_xmin[n] = pow(sqrt(2.), 2.0 * (double) n);
-    }
-    T->sqrt2 = sqrt(2.0);
-    T->log2 = log(2.0);
+    LIBM_TABLE(TB_POW_NINT, -1, T->pow_nint_tab, sizeof(T->pow_nint_tab),
+               T->pow_nint_tab[0] = 0.0;
+               for (int i = 1; i < 2048; i++) T->pow_nint_tab[i] = pow((double) i - 0.4054, 4.0 / 3.0);
+               T->pow_nint_tab[2048] = HUGE_VAL);
+    LIBM_TABLE(TB_POW43, -1, T->pow43, sizeof(T->pow43),
+               for (int i = 0; i < MP3MI_POW43_N; i++) T->pow43[i] = pow((double) i, 4.0 / 3.0));
+    LIBM_TABLE(TB_STEP, -1, T->step, sizeof(T->step),
+               for (int i = 0; i < MP3MI_STEP_N; i++) T->step[i] = pow(2.0, (double) (MP3MI_STEP_MIN + i) * 0.25));
+    LIBM_TABLE(TB_PRETAB_XR, -1, T->pretab_xr, sizeof(T->pretab_xr),
+               for (int n = 0; n < 4; n++) T->pretab_xr[n] = pow(sqrt(2.), (double) n));
+    LIBM_TABLE(TB_PRETAB_XMIN, -1, T->pretab_xmin, sizeof(T->pretab_xmin),
+               for (int n = 0; n < 4; n++) T->pretab_xmin[n] = pow(sqrt(2.), 2.0 * (double) n));
+    LIBM_TABLE(TB_SQRT2, -1, &T->sqrt2, sizeof(T->sqrt2), T->sqrt2 = sqrt(2.0));
+    LIBM_TABLE(TB_LOG2, -1, &T->log2, sizeof(T->log2), T->log2 = log(2.0));
 
     size_t n_ht = sizeof(T_HT_PACKED) / sizeof(T_HT_PACKED[0]);
     if (n_ht > 1440) return -3;
@@ -776,16 +869,19 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
         T->ht_linbits[i] = T_HT_LINBITS[i];
         T->ht_linmax[i] = T_HT_LINMAX[i];
     }
+#if !defined(MP3MI_TABLE_GEN)
+    if (tb_failed) return -7;
+#endif
     return 0;
 }
 
 /* ---- pins: the tables as the reference-equivalent environment builds them ----
- * Every member above that comes out of libm (windows, twiddles, spreading function, MDCT cosines, the power
- * tables) changes the bitstream if one bit of it changes.  tables_pins.h holds an FNV-1a hash of every member
- * for each sampling rate, generated where the golden vectors were generated (tools/gen_table_pins.py: glibc
- * 2.35, the build the reference's goldens come from); mp3mi_build_tables recomputes them and refuses to hand
- * out a table block that differs -- a host with another libm fails loudly instead of silently emitting a
- * different stream.  MP3MI_TABLE_PINS=off skips the check (used only to generate the pins). */
+ * One changed bit in a member that came out of libm (windows, twiddles, spreading function, MDCT cosines, the power
+ * tables) changes the bitstream.  tables_pins.h holds an FNV-1a hash of every member for each sampling rate, generated
+ * where the golden vectors were generated (tools/gen_table_pins.py: glibc 2.35, the build the reference's goldens come
+ * from).  The generator refuses to write a blob whose tables do not hash to the pins (another libm); the library
+ * checks the tables it assembled from the blob against them on every build -- a damaged or mismatched blob fails
+ * loudly (MP3MI_ERR_TABLES) instead of emitting a different stream.  There is no switch to turn the check off. */
 #define MP3MI_TABLE_MEMBERS(X) \
     X(rate_idx) X(sfb_l) X(sfb_s) X(sfb_of_line_l) X(sfb_of_line_s) X(nj_first) X(nj_count) X(nj_job0) X(nj_njobs) X(nj_max) \
     X(nj_seg) X(lane_bands) X(lane_jobs) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
@@ -839,9 +935,8 @@ extern "C" int mp3mi_tables_digest(int rate_idx, uint64_t *hashes, const char **
 extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
 {
     const int rc = build_tables_unpinned(T, rate_idx);
+    if (rc == -7) return -8; /* the blob lacks an entry or is damaged: reported as MP3MI_ERR_TABLES */
     if (rc != 0) return rc;
-    const char *env = getenv("MP3MI_TABLE_PINS");
-    if (env && !strcmp(env, "off")) return 0;
     if (MP3MI_TABLE_PINS_N != MP3MI_N_TABLE_MEMBERS) {
         fprintf(stderr, "mp3mi: tables_pins.h lists %d members, mp3mi_tables has %d -- regenerate it (tools/gen_table_pins.py)\n",
                 (int) MP3MI_TABLE_PINS_N, (int) MP3MI_N_TABLE_MEMBERS);
@@ -852,10 +947,51 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
     int bad = 0;
     for (int i = 0; i < MP3MI_N_TABLE_MEMBERS; i++)
         if (h[i] != MP3MI_TABLE_PINS[rate_idx][i]) {
-            fprintf(stderr, "mp3mi: table member '%s' (rate index %d) differs from its pinned value: this host's libm does not "
-                            "reproduce the reference environment's tables; the bitstream would not be bit-exact\n",
+            fprintf(stderr, "mp3mi: table member '%s' (rate index %d) differs from its pinned value (csrc/tables_pins.h): the table blob and "
+                            "the table code do not belong together; the bitstream would not be bit-exact\n",
                     TABLE_MEMBER_NAMES[i], rate_idx);
             bad++;
         }
     return bad ? -8 : 0;
 }
+
+#if defined(MP3MI_TABLE_GEN)
+/* The generator (make -C csrc blob): builds the tables of the three rates with THIS host's libm, checks them against the
+ * pins -- this host must be the environment the goldens come from -- and writes tables_blob.bin.
+ *   gen_table_blob out.bin [--no-pin-check]     (the latter only to bootstrap new pins after a layout change) */
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s out.bin [--no-pin-check]\n", argv[0]); return 2; }
+    const bool check = !(argc > 2 && !strcmp(argv[2], "--no-pin-check"));
+    mp3mi_tables *T = (mp3mi_tables *) calloc(1, sizeof(mp3mi_tables));
+    for (int ri = 0; ri < 3; ri++) {
+        const int rc = build_tables_unpinned(T, ri);
+        if (rc != 0) { fprintf(stderr, "table build failed for rate index %d: %d\n", ri, rc); return 1; }
+        if (check) {
+            uint64_t h[MP3MI_N_TABLE_MEMBERS];
+            table_hashes(T, h);
+            for (int i = 0; i < MP3MI_N_TABLE_MEMBERS; i++)
+                if (MP3MI_TABLE_PINS_N != MP3MI_N_TABLE_MEMBERS || h[i] != MP3MI_TABLE_PINS[ri][i]) {
+                    fprintf(stderr, "member '%s' (rate index %d) differs from its pin: this host's libm is not the reference environment's; "
+                                    "no blob written\n", TABLE_MEMBER_NAMES[i], ri);
+                    return 1;
+                }
+        }
+    }
+    free(T);
+    tb_header hd;
+    memset(&hd, 0, sizeof(hd));
+    memcpy(hd.magic, "MP3MITB1", 8);
+    hd.n_entries = (uint32_t) tb_entries.size();
+    std::vector<unsigned char> out((const unsigned char *) &hd, (const unsigned char *) &hd + sizeof(hd));
+    out.insert(out.end(), (const unsigned char *) tb_entries.data(), (const unsigned char *) (tb_entries.data() + tb_entries.size()));
+    out.insert(out.end(), tb_data.begin(), tb_data.end());
+    const uint64_t h = tb_fnv(out.data(), out.size());
+    out.insert(out.end(), (const unsigned char *) &h, (const unsigned char *) &h + 8);
+    FILE *f = fopen(argv[1], "wb");
+    if (!f || fwrite(out.data(), 1, out.size(), f) != out.size()) { perror(argv[1]); return 1; }
+    fclose(f);
+    printf("%s: %zu entries, %zu bytes\n", argv[1], tb_entries.size(), out.size());
+    return 0;
+}
+#endif

@@ -21,6 +21,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mp3common import STAGE_DT, SEED  # noqa: E402
 
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import crafted_inputs  # noqa: E402
+
 GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = [
     # name, rate, channels, kbps, stream, seconds, dumped frames
@@ -31,6 +34,42 @@ CASES = [
     ("m32_064", 32000, 1, 64, 8, 0.55, 8),
     ("s44_032_starved", 44100, 2, 32, 14, 0.30, 6),
 ]
+# Round 3: inputs made for the branches of the reference that the synthetic family above never takes
+# (tools/ref_coverage.py, tools/cov_search.py; generators in oracle/crafted_inputs.py).  mode = the driver's -m letter
+# plus e / c / o for -e, -c, -o (oracle/ref_harness.c); frames = which frames' stage dumps are kept.
+CRAFTED = [
+    # name, rate, channels, kbps, mode, generator spec, kept frames, what it is for
+    ("x44_128_loud_tone", 44100, 2, 128, "s", {"gen": "loud_tone"}, (0, 1, 2, 5),
+     "scfsi set and used (loop.c:676-711, 759-770, 1177-1180, 1264-1311; l3bitstream.c:236-248), calc_noise with ix >= 1024 (loop.c:1061-1062)"),
+    ("x44_128_tones_scfsi", 44100, 2, 128, "s", {"gen": "stationary_tones", "frames": 10}, (2, 3, 4),
+     "quantanf_init's floor (loop.c:392-393), scfsi on a chord"),
+    ("x32m_320_silence_noise", 32000, 1, 320, "m", {"gen": "silence_then_noise", "silent_frames": 3, "loud_frames": 3, "tail_silent": 2}, (0, 1, 3, 6),
+     "mean_bits above 4095 (reservoir.c:109-110), frame longer than 7680 bits (:81-82), stuffing plan b and the drain into ancillary data (:197-216, l3bitstream.c:132-133, 493-509), all-zero granules (loop.c:347)"),
+    ("x48_032_lag", 48000, 2, 32, "s", {"gen": "silence_then_noise", "silent_frames": 8, "loud_frames": 4, "tail_silent": 6, "amp": 3000.0, "lowpass": 8}, (7, 8, 9, 12),
+     "main data lagging several frames: headers queued in the formatter (formatBitstream.c:292-296, 366-374), flush with queued headers and the zero-bit remainder call (:98-104, 229-230)"),
+    ("x48_192_click", 48000, 2, 192, "s", {"gen": "click_after_silence", "at": (2 * 1152 + 200, 3 * 1152 + 800), "width": 60}, (2, 3, 4),
+     "exact-zero spectral lines beside non-zero ones (loop.c:381), STOP -> SHORT (l3psy.c:693-694), the second 4095 cap of ResvMaxBits (reservoir.c:131-132)"),
+    ("x44_128_crc_dual", 44100, 2, 128, "de", {"gen": "bursts", "frames": 6}, (0, 1, 2, 3, 4, 5),
+     "error protection: the zero CRC word and the smaller mean_bits (l3bitstream.c:338-341, musicin.c:744-745), dual-channel header"),
+    ("x44_128_faint_after_silence", 44100, 2, 128, "s", {"gen": "silence_then_tones", "amp": 3.0, "noise": 0.0, "f": (1000.0,)}, (3, 4),
+     "a full reservoir and modest perceptual entropy: add_bits = more_bits (reservoir.c:121-124); the energy floor of enphinew (subs.c:70-74); cw = 0 for r + |r'| = 0 (l3psy.c:508-511)"),
+    ("x48_320_transients", 48000, 2, 320, "s", {"gen": "full_scale_transients", "period": 1300, "width": 300}, (0, 1, 2),
+     "reservoir of size 0 (reservoir.c:81-82), full-scale short blocks at the highest bitrate"),
+    ("x44_320_silence_noise", 44100, 2, 320, "s", {"gen": "silence_then_noise", "silent_frames": 2, "loud_frames": 3, "tail_silent": 2}, (1, 2, 5),
+     "stereo stuffing plan b (reservoir.c:197-212) with frames longer than 7680 bits"),
+    ("x44_128_phase_pair", 44100, 2, 128, "s", {"gen": "phase_pair", "frames": 12, "skip": 24}, (6, 7),
+     "the scfsi decision failing on the allowed distortions alone (loop.c:704, second operand)"),
+    ("x32m_064_bursts", 32000, 1, 64, "m", {"gen": "bursts", "period": 2 * 576 + 500, "width": 200}, (1, 2, 3, 4),
+     "mono block switching with bursts two granules apart"),
+]
+# Inputs on which the REFERENCE DIES (an assertion fails): no bitstream exists, the expectation is the status the product
+# reports for the stream (include/mp3mi.h, mp3mi_batch_stream_status).  where = the failing assertion.
+ABORTING = [
+    ("abort_global_gain", 44100, 2, 128, "s", {"gen": "click_after_silence", "at": (3 * 1152 + 400, 4 * 1152 + 900), "width": 20},
+     {"where": "loop.c:358", "status": 1, "frame": 4}),
+    ("abort_flush_slot", 48000, 2, 64, "s", {"gen": "random_blocks", "frames": 5, "seed": 1100},
+     {"where": "formatBitstream.c:390", "status": 3, "frame": 5}),
+]
 
 
 def wav_bytes(pcm, ch, rate):
@@ -39,7 +78,31 @@ def wav_bytes(pcm, ch, rate):
             struct.pack("<IHHIIHH", 16, 1, ch, rate, rate * ch * 2, ch * 2, 16) + b"data" + struct.pack("<I", len(data)) + data)
 
 
+def run_reference(pcm, rate, ch, kbps, mode, want_dump=True):
+    """(mp3 bytes, stage dumps, return code, stderr) of the unmodified reference on this input"""
+    with tempfile.TemporaryDirectory() as td:
+        wav, mp3, dump = (os.path.join(td, x) for x in ("a.wav", "a.mp3", "a.dump"))
+        open(wav, "wb").write(wav_bytes(pcm, ch, rate))
+        r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_harness"), wav, mp3, str(rate), str(kbps), mode] + ([dump] if want_dump else []),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        data = open(mp3, "rb").read() if os.path.exists(mp3) else b""
+        d = np.fromfile(dump, dtype=STAGE_DT) if want_dump and os.path.exists(dump) else None
+    return data, d, r.returncode, r.stderr.decode(errors="replace")
+
+
+def run_reference_cli(pcm, rate, ch, kbps, mode):
+    """the reference's own driver (oracle/_ref/encode) with the options the mode string stands for"""
+    with tempfile.TemporaryDirectory() as td:
+        wav, mp3 = os.path.join(td, "a.wav"), os.path.join(td, "a.mp3")
+        open(wav, "wb").write(wav_bytes(pcm, ch, rate))
+        opts = ["-m", mode[0]] + [x for c, x in (("e", "-e"), ("c", "-c"), ("o", "-o")) if c in mode[1:]]
+        subprocess.run([os.path.join(ROOT, "oracle", "_ref", "encode"), "-s", "%g" % (rate / 1000.0), "-b", str(kbps)] + opts + [wav, mp3],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return open(mp3, "rb").read()
+
+
 def main():
+    only_new = "--only-new" in sys.argv  # keep the round-1 entries of the manifest as they are, (re)make the crafted ones
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
     import ctypes
     synth_so = os.path.join(tempfile.mkdtemp(), "libsynth.so")
@@ -49,7 +112,9 @@ def main():
     synth = ctypes.CDLL(synth_so)
     os.makedirs(GOLD, exist_ok=True)
     manifest = []
-    for name, rate, ch, kbps, stream, secs, ndump in CASES:
+    if only_new:
+        manifest = [c for c in json.load(open(os.path.join(GOLD, "MANIFEST.json"))) if c["name"] in [x[0] for x in CASES]]
+    for name, rate, ch, kbps, stream, secs, ndump in ([] if only_new else CASES):
         n = int(rate * secs)
         pcm = np.zeros(n * ch, np.int16)
         synth.mp3mi_synth_pcm(ctypes.c_void_p(pcm.ctypes.data), ctypes.c_long(n), ch, rate, ctypes.c_uint32(stream), ctypes.c_uint32(SEED))
@@ -69,6 +134,31 @@ def main():
             entry["pcm_file"] = name + ".pcm.npy"
             entry["mp3_file"] = name + ".mp3"
         np.savez_compressed(os.path.join(GOLD, name + ".stages.npz"), dumps=d[:ndump])
+        manifest.append(entry)
+        print(entry)
+    for name, rate, ch, kbps, mode, spec, keep, what in CRAFTED:
+        pcm = crafted_inputs.make(spec, rate, ch)
+        data, d, rc, err = run_reference(pcm, rate, ch, kbps, mode)
+        assert rc == 0, (name, err)
+        assert data == run_reference_cli(pcm, rate, ch, kbps, mode), name + ": harness and the reference's own driver disagree"
+        keep = [f for f in keep if f < len(d)]
+        entry = {"name": name, "rate": rate, "channels": ch, "kbps": kbps, "mode": mode, "generator": spec, "n_samples_per_ch": len(pcm) // ch,
+                 "frames": len(d), "pcm_md5": hashlib.md5(pcm.tobytes()).hexdigest(), "mp3_md5": hashlib.md5(data).hexdigest(),
+                 "mp3_len": len(data), "dump_frames": len(keep), "dump_frame_indices": keep, "covers": what,
+                 "source": "reference via oracle/_ref/ref_harness (== oracle/_ref/encode)", "pcm_file": name + ".pcm.npy", "mp3_file": name + ".mp3"}
+        np.save(os.path.join(GOLD, name + ".pcm.npy"), pcm)
+        open(os.path.join(GOLD, name + ".mp3"), "wb").write(data)
+        np.savez_compressed(os.path.join(GOLD, name + ".stages.npz"), dumps=d[keep])
+        manifest.append(entry)
+        print(entry)
+    for name, rate, ch, kbps, mode, spec, ab in ABORTING:
+        pcm = crafted_inputs.make(spec, rate, ch)
+        data, d, rc, err = run_reference(pcm, rate, ch, kbps, mode, want_dump=False)
+        assert rc != 0 and ("/" + ab["where"] + ":") in err, (name, rc, err)
+        entry = {"name": name, "rate": rate, "channels": ch, "kbps": kbps, "mode": mode, "generator": spec, "n_samples_per_ch": len(pcm) // ch,
+                 "frames": len(pcm) // ch // 1152, "pcm_md5": hashlib.md5(pcm.tobytes()).hexdigest(), "reference_aborts": dict(ab, message=err.strip().split(": ", 1)[-1]),
+                 "source": "the reference dies on this input (oracle/_ref/ref_harness)", "pcm_file": name + ".pcm.npy"}
+        np.save(os.path.join(GOLD, name + ".pcm.npy"), pcm)
         manifest.append(entry)
         print(entry)
     json.dump(manifest, open(os.path.join(GOLD, "MANIFEST.json"), "w"), indent=1)

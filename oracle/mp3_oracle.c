@@ -88,6 +88,8 @@ typedef struct {
 
 struct mp3o_stream {
     int rate_idx, rate_hz, kbps, bitrate_index, channels, mode;
+    int crc, copyright, original, emphasis; /* the driver's -e -c -o -d (src/musicin.c:263-275) */
+    int ref_abort;                          /* MP3O_ABORT_*: the reference would have died here (see mp3_oracle.h) */
     int bitsPerFrame, mean_bits;
     tables_t *T;
     /* psy model state (function statics of src/l3psy.c:57-131 and the caller's sam[]) */
@@ -1113,7 +1115,10 @@ static void bin_search_StepSize(const mp3o_stream *s, int desired_rate, double s
 static int inner_loop(const mp3o_stream *s, const double *xrs, int *ix, int max_bits, gr_info_t *g)
 { /* src/loop.c:569-606 */
     int bits;
-    assert(max_bits >= 0);
+    if (max_bits < 0) { /* assert( max_bits >= 0 ), src/loop.c:579: the reference dies here (and the loop below would not end) */
+        if (!((mp3o_stream *) s)->ref_abort) ((mp3o_stream *) s)->ref_abort = MP3O_ABORT_HUFF_BITS;
+        return 0;
+    }
     g->quantizerStepSize -= 1.0;
     do {
         do {
@@ -1376,7 +1381,7 @@ static void iteration_loop(mp3o_stream *s, double pe[2][2], double xr_org[2][2][
             }
             s->ResvSize += (mean_bits / s->channels) - (int) g->part2_3_length; /* ResvAdjust */
             g->global_gain = (unsigned) r_nint(g->quantizerStepSize + 210.0);
-            assert(g->global_gain < 256);
+            if (g->global_gain >= 256 && !s->ref_abort) s->ref_abort = MP3O_ABORT_GLOBAL_GAIN; /* assert, src/loop.c:358 */
         }
     ResvFrameEnd(s, mean_bits);
 }
@@ -1417,16 +1422,17 @@ static void queue_side_info(mp3o_stream *s)
     bb_put(&b, 0xfff, 12);
     bb_put(&b, 1, 1);                       /* version: MPEG-1 */
     bb_put(&b, 4 - 3, 2);                   /* layer III */
-    bb_put(&b, 1, 1);                       /* !error_protection */
+    bb_put(&b, s->crc ? 0u : 1u, 1);        /* !error_protection (src/l3bitstream.c:325) */
     bb_put(&b, (unsigned) s->bitrate_index, 4);
     bb_put(&b, (unsigned) s->rate_idx, 2);
     bb_put(&b, 0, 1);                       /* padding: never (src/musicin.c:566-581) */
     bb_put(&b, 0, 1);                       /* extension: uninitialised in the reference, observed 0 */
     bb_put(&b, (unsigned) s->mode, 2);
     bb_put(&b, 0, 2);                       /* mode_ext */
-    bb_put(&b, 0, 1);                       /* copyright */
-    bb_put(&b, 0, 1);                       /* original */
-    bb_put(&b, 0, 2);                       /* emphasis */
+    bb_put(&b, (unsigned) s->copyright, 1);
+    bb_put(&b, (unsigned) s->original, 1);
+    bb_put(&b, (unsigned) s->emphasis, 2);
+    if (s->crc) bb_put(&b, 0, 16);          /* the CRC word, never computed for Layer III (src/l3bitstream.c:312, 338-342) */
     bb_put(&b, (unsigned) s->side.main_data_begin, 9);
     bb_put(&b, s->side.private_bits, s->channels == 2 ? 3 : 5);
     for (ch = 0; ch < s->channels; ch++)
@@ -1456,14 +1462,17 @@ static void queue_side_info(mp3o_stream *s)
         }
     e->frameLength = s->bitsPerFrame;
     e->SILength = b.nbits;
-    assert(b.nbits == 32 + (s->channels == 2 ? 256 : 136));
+    assert(b.nbits == 32 + (s->channels == 2 ? 256 : 136) + (s->crc ? 16 : 0));
 }
 
 static int write_side_info(mp3o_stream *s)
 { /* src/formatBitstream.c:250-270 + get_side_info :369 */
     si_entry_t *e;
     int i;
-    assert(s->q_len > 0);
+    if (s->q_len <= 0) { /* get_side_info's assert( l ), src/formatBitstream.c:390: the reference dies here */
+        if (!s->ref_abort) s->ref_abort = MP3O_ABORT_FLUSH_SLOT;
+        return 0;
+    }
     e = &s->queue[s->q_head];
     s->q_head = (s->q_head + 1) % s->q_cap;
     s->q_len--;
@@ -1651,6 +1660,22 @@ mp3o_stream *mp3o_open(int rate_hz, int kbps, int channels)
     return s;
 }
 
+int mp3o_set_options(mp3o_stream *s, int mode, int error_protection, int copyright, int original, int emphasis)
+{ /* the driver's -m -e -c -o -d (src/musicin.c:226-275); before the first frame */
+    if (mode == 1) return -1; /* joint stereo: refused for Layer III (src/musicin.c:548-552) */
+    if ((s->channels == 1) != (mode == 3)) return -1;
+    s->mode = mode;
+    s->crc = error_protection != 0;
+    s->copyright = copyright != 0;
+    s->original = original != 0;
+    s->emphasis = emphasis & 3;
+    /* src/musicin.c:728-746 */
+    s->mean_bits = (s->bitsPerFrame - (32 + (s->channels == 1 ? 136 : 256) + (s->crc ? 16 : 0))) / 2;
+    return 0;
+}
+
+int mp3o_ref_abort(const mp3o_stream *s) { return s->ref_abort; }
+
 void mp3o_close(mp3o_stream *s)
 {
     if (!s) return;
@@ -1755,13 +1780,33 @@ const uint8_t *mp3o_output(const mp3o_stream *s, size_t *len)
 size_t mp3o_encode_pcm(int rate_hz, int kbps, int channels, const int16_t *pcm, size_t n_total,
                        uint8_t **out, stage_dump_t *dumps, int max_dumps)
 {
+    int ab = 0;
+    size_t n = mp3o_encode_pcm_ex(rate_hz, kbps, channels, NULL, pcm, n_total, out, dumps, max_dumps, &ab);
+    if (ab) { /* callers of the plain entry do not expect inputs the reference dies on */
+        fprintf(stderr, "mp3_oracle: the reference aborts on this input (MP3O_ABORT_* = %d)\n", ab);
+        abort();
+    }
+    return n;
+}
+
+size_t mp3o_encode_pcm_ex(int rate_hz, int kbps, int channels, const char *mode, const int16_t *pcm, size_t n_total,
+                          uint8_t **out, stage_dump_t *dumps, int max_dumps, int *ref_abort)
+{
     mp3o_stream *s = mp3o_open(rate_hz, kbps, channels);
     size_t per_frame = (size_t) 1152 * (size_t) channels, pos = 0, len;
     int16_t buf[2][1152];
     int frame = 0, j;
     const uint8_t *p;
     *out = NULL;
+    *ref_abort = 0;
     if (!s) return 0;
+    if (mode && mode[0]) { /* as oracle/ref_harness.c: the -m letter, then e / c / o */
+        const int m = mode[0] == 'm' ? 3 : mode[0] == 'd' ? 2 : mode[0] == 'j' ? 1 : 0;
+        if (mp3o_set_options(s, m, strchr(mode + 1, 'e') != NULL, strchr(mode + 1, 'c') != NULL, strchr(mode + 1, 'o') != NULL, 0)) {
+            mp3o_close(s);
+            return 0;
+        }
+    }
     while (pos < n_total) { /* get_audio / read_samples, src/encode.c:123-256 */
         size_t n = n_total - pos < per_frame ? n_total - pos : per_frame;
         memset(buf, 0, sizeof(buf));
@@ -1775,9 +1820,16 @@ size_t mp3o_encode_pcm(int rate_hz, int kbps, int channels, const int16_t *pcm, 
         pos += n;
         mp3o_encode_frame(s, (const int16_t (*)[1152]) buf, (dumps && frame < max_dumps) ? &dumps[frame] : NULL);
         if (dumps && frame < max_dumps) dumps[frame].frame_index = frame;
+        if (s->ref_abort) break; /* the reference is dead: nothing after this frame exists */
         frame++;
     }
-    mp3o_flush(s);
+    if (!s->ref_abort) mp3o_flush(s);
+    if (s->ref_abort) {
+        *ref_abort = s->ref_abort | (frame << 8); /* the frame it died in (the number of frames: in the final flush) */
+        *out = (uint8_t *) malloc(1);
+        mp3o_close(s);
+        return 0;
+    }
     p = mp3o_output(s, &len);
     *out = (uint8_t *) malloc(len ? len : 1);
     memcpy(*out, p, len);

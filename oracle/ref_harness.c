@@ -6,7 +6,8 @@
  * stage_dump_t per frame, so the CPU restatement (oracle/mp3_oracle.c) can be
  * pinned stage by stage against the real reference.
  *
- * usage: ref_harness in.wav out.mp3 <rate_hz> <kbps> <s|m> [dump.bin]
+ * usage: ref_harness in.wav out.mp3 <rate_hz> <kbps> <s|m|d>[e][c][o] [dump.bin]
+ *        (the mode letter as the driver's -m; e / c / o = its -e, -c, -o options, src/musicin.c:263-275)
  *
  * Only compiled when /root/reference exists (this container); nothing here
  * travels as source of the reference.
@@ -58,7 +59,7 @@ int main(int argc, char **argv)
     long rate;
 
     if (argc < 6) {
-        fprintf(stderr, "usage: %s in.wav out.mp3 rate_hz kbps s|m [dump.bin]\n", argv[0]);
+        fprintf(stderr, "usage: %s in.wav out.mp3 rate_hz kbps s|m|d[e][c][o] [dump.bin]\n", argv[0]);
         return 2;
     }
     rate = atol(argv[3]);
@@ -69,8 +70,11 @@ int main(int argc, char **argv)
     fr_ps.tab_num = -1;
     fr_ps.alloc = NULL;
     info.lay = 3;
-    info.mode = (argv[5][0] == 'm') ? MPG_MD_MONO : MPG_MD_STEREO;
+    info.mode = (argv[5][0] == 'm') ? MPG_MD_MONO : (argv[5][0] == 'd') ? MPG_MD_DUAL_CHANNEL : MPG_MD_STEREO;
     info.mode_ext = 0;
+    info.error_protection = strchr(argv[5] + 1, 'e') != NULL;
+    info.copyright = strchr(argv[5] + 1, 'c') != NULL;
+    info.original = strchr(argv[5] + 1, 'o') != NULL;
     info.sampling_frequency = SmpFrqIndex(rate, &info.version);
     info.bitrate_index = BitrateIndex(3, kbps, info.version);
     if (info.sampling_frequency < 0 || info.bitrate_index < 0 || info.version != 1) return 2;
@@ -91,7 +95,7 @@ int main(int argc, char **argv)
 
     while (get_audio(musicin, buffer, num_samples, stereo, &info) > 0) {
         int bitsPerFrame = 8 * whole_SpF;
-        int sideinfo_len = 32 + (stereo == 1 ? 136 : 256);
+        int sideinfo_len = 32 + (stereo == 1 ? 136 : 256) + (info.error_protection ? 16 : 0); /* src/musicin.c:728-746 */
         int mean_bits = (bitsPerFrame - sideinfo_len) / 2;
         memset(&d, 0, sizeof(d));
         d.magic = STAGE_DUMP_MAGIC;

@@ -24,4 +24,16 @@ def case_pcm(case, synth):
 
 
 def case_stages(case):
-    return np.load(os.path.join(GOLD, case["name"] + ".stages.npz"))["dumps"]
+    """(stage dumps, the frame index of each): the first dump_frames frames, or the frames the case names"""
+    d = np.load(os.path.join(GOLD, case["name"] + ".stages.npz"))["dumps"]
+    return d, case.get("dump_frame_indices", list(range(len(d))))
+
+
+def encoding_cases():
+    """fixtures the reference encodes"""
+    return [c for c in manifest() if not c.get("reference_aborts")]
+
+
+def aborting_cases():
+    """fixtures the reference dies on (an assertion fails): the expectation is the status"""
+    return [c for c in manifest() if c.get("reference_aborts")]

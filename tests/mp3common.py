@@ -45,33 +45,67 @@ def build_emu():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu")], check=True)
 
 
+class ReferenceAborts(Exception):
+    """The reference dies on this input (an assertion fails): .status is the MP3O_ABORT_* / MP3MI_STREAM_* code,
+    .frame the index of the frame it died in, the number of frames for the final flush (oracle/mp3_oracle.h)."""
+
+    def __init__(self, code):
+        Exception.__init__(self, "the reference aborts on this input: status %d in frame %d" % (code & 255, code >> 8))
+        self.status, self.frame = code & 255, code >> 8
+
+
 class Oracle:
     def __init__(self):
         if not os.path.exists(ORACLE_SO):
             build_oracle()
         self.lib = ctypes.CDLL(ORACLE_SO)
-        self.lib.mp3o_encode_pcm.restype = ctypes.c_size_t
-        self.lib.mp3o_encode_pcm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                             ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int]
+        self.lib.mp3o_encode_pcm_ex.restype = ctypes.c_size_t
+        self.lib.mp3o_encode_pcm_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p,
+                                                ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_int)]
         self.libc = ctypes.CDLL("libc.so.6")
         self.libc.free.argtypes = [ctypes.c_void_p]
 
-    def encode(self, pcm, rate, kbps, channels, dumps=0):
-        """pcm: int16 array, interleaved.  Returns (mp3 bytes, stage dumps or None)."""
+    def encode(self, pcm, rate, kbps, channels, dumps=0, mode=None):
+        """pcm: int16 array, interleaved; mode: None or the driver's -m letter (s / d / m) followed by e / c / o for
+        its -e / -c / -o options.  Returns (mp3 bytes, stage dumps or None); raises ReferenceAborts where the reference
+        dies, ValueError where it refuses the configuration."""
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
         out = ctypes.c_void_p()
+        ab = ctypes.c_int(0)
         d = np.zeros(dumps, dtype=STAGE_DT) if dumps else None
-        n = self.lib.mp3o_encode_pcm(rate, kbps, channels, pcm.ctypes.data, pcm.size, ctypes.byref(out),
-                                     d.ctypes.data if dumps else None, dumps)
+        n = self.lib.mp3o_encode_pcm_ex(rate, kbps, channels, mode.encode() if mode else None, pcm.ctypes.data, pcm.size,
+                                        ctypes.byref(out), d.ctypes.data if dumps else None, dumps, ctypes.byref(ab))
         if not out.value:
             raise ValueError("oracle refused configuration")
         data = ctypes.string_at(out.value, n)
         self.libc.free(out)
+        if ab.value:
+            raise ReferenceAborts(ab.value)
         return data, d
+
+
+ERR_REFERENCE_ABORT = -6  # include/mp3mi.h
+
+
+class BatchOptions(ctypes.Structure):
+    """include/mp3mi.h: mp3mi_batch_options"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("scratch_mb", ctypes.c_uint32), ("chunk_frames", ctypes.c_int32),
+                ("test_flags", ctypes.c_uint32), ("call_overlap", ctypes.c_int32), ("gate", ctypes.c_int32),
+                ("placement", ctypes.c_int32), ("loop_queue", ctypes.c_int32), ("loop_part_streams", ctypes.c_int32),
+                ("y_after_loop", ctypes.c_int32), ("psy_beside", ctypes.c_int32)]
 
 
 class Mp3mi:
     """The product library (emu=False) or its emulated CPU test build (emu=True)."""
+
+    def options(self, **kw):
+        """mp3mi_batch_options with the defaults, fields overridden by keyword"""
+        o = BatchOptions()
+        self.lib.mp3mi_batch_options_default(ctypes.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
 
     def __init__(self, emu=False):
         path = EMU_SO if emu else PRODUCT_SO
@@ -81,6 +115,11 @@ class Mp3mi:
         L = self.lib
         L.mp3mi_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.mp3mi_batch_create_ex.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.mp3mi_batch_options_default.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_options_from_env.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_stream_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mp3mi_batch_destroy.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_out_stride.restype = ctypes.c_size_t
         L.mp3mi_batch_out_stride.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -209,19 +248,33 @@ class BatchRun:
     """One batch of S streams on device memory through the C ABI: PCM synthesised on the device (or uploaded),
     encoded as often as wanted (e.g. once per test-flag setting), outputs fetched per stream."""
 
-    def __init__(self, mp, S, rate, channels, kbps, n_frames, stream0=0, pcm=None, seed=SEED, mode=None, crc=0):
+    def __init__(self, mp, S, rate, channels, kbps, n_frames, stream0=0, pcm=None, seed=SEED, mode=None, crc=0, options=None,
+                 copyright=0, original=0):
+        """mode: the header mode field (0 stereo, 2 dual channel, 3 mono) or the driver's option string as
+        oracle/ref_harness.c takes it (-m letter, then e / c / o); options: a BatchOptions (mp3mi_batch_create_ex)"""
         self.mp, self.S, self.rate, self.ch, self.nf = mp, S, rate, channels, n_frames
         L = mp.lib
         self.mem = DevMem(mp)
         self.b = ctypes.c_void_p()
         karr = None if np.isscalar(kbps) else np.ascontiguousarray(kbps, dtype=np.int32)
-        rc = L.mp3mi_batch_create(ctypes.byref(self.b), S, rate, channels, karr.ctypes.data if karr is not None else None,
-                                  int(kbps) if karr is None else 0, n_frames)
+        if options is None:
+            rc = L.mp3mi_batch_create(ctypes.byref(self.b), S, rate, channels, karr.ctypes.data if karr is not None else None,
+                                      int(kbps) if karr is None else 0, n_frames)
+        else:
+            rc = L.mp3mi_batch_create_ex(ctypes.byref(self.b), S, rate, channels, karr.ctypes.data if karr is not None else None,
+                                         int(kbps) if karr is None else 0, n_frames, ctypes.byref(options))
         assert rc == 0, "mp3mi_batch_create -> %d" % rc
+        if isinstance(mode, str):
+            crc = crc or ("e" in mode[1:])
+            copyright = copyright or ("c" in mode[1:])
+            original = original or ("o" in mode[1:])
+            mode = {"s": 0, "d": 2, "m": 3}[mode[0]]
         if mode is not None:
             assert L.mp3mi_batch_set_mode(self.b, mode) == 0
         if crc:
             assert L.mp3mi_batch_set_error_protection(self.b, 1) == 0
+        if copyright or original:
+            assert L.mp3mi_batch_set_header(self.b, int(bool(copyright)), int(bool(original)), 0) == 0
         self.stride = L.mp3mi_batch_out_stride(self.b, n_frames)
         self.n_per_ch = n_frames * 1152
         self.pcm_bytes = S * self.n_per_ch * channels * 2
@@ -241,15 +294,23 @@ class BatchRun:
         n = self.n_per_ch * self.ch
         return self.mem.download(self.d_pcm + s * n * 2, (n,), np.int16)
 
-    def encode(self, flags=0):
+    def encode(self, flags=0, expect_abort=False):
         L = self.mp.lib
         assert L.mp3mi_batch_set_test_flags(self.b, flags) == 0
         rc = L.mp3mi_batch_encode(self.b, self.d_pcm, self.nf, self.d_out, self.stride, self.d_len)
         assert rc == 0, "mp3mi_batch_encode -> %d" % rc
-        assert L.mp3mi_batch_sync(self.b) == 0
+        rc = L.mp3mi_batch_sync(self.b)
+        assert rc == (ERR_REFERENCE_ABORT if expect_abort else 0), "mp3mi_batch_sync -> %d" % rc
         out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
         lens = self.mem.download(self.d_len, (self.S,), np.uint32)
         return out, lens
+
+    def status(self):
+        """mp3mi_batch_stream_status: per stream 0 or code | frame << 8"""
+        st = np.zeros(self.S, np.int32)
+        rc = self.mp.lib.mp3mi_batch_stream_status(self.b, st.ctypes.data)
+        assert rc >= 0, "mp3mi_batch_stream_status -> %d" % rc
+        return st
 
     def cw_fixups(self):
         """(records listed for the second tier of the unpredictability, records) of the last call's last chunk"""

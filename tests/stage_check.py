@@ -6,8 +6,11 @@ import numpy as np
 from mp3common import GI, PSY_DT, SIDE_DT
 
 
-def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames):
-    """pcm: int16 [S, n_frames*1152*channels].  Returns (bytes per stream, stages dict)."""
+def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames, mode=None, expect_abort=False):
+    """pcm: int16 [S, n_frames*1152*channels]; mode: None or the driver's option string as oracle/ref_harness.c
+    takes it (the -m letter s / d / m, then e / c / o for -e / -c / -o).  Returns (bytes per stream, stages dict);
+    with expect_abort (inputs the reference dies on) mp3mi_batch_sync must say so and the stages dict carries the
+    per-stream status under "status"."""
     L = lib.lib
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     S = pcm.shape[0]
@@ -16,7 +19,12 @@ def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames):
     rc = L.mp3mi_batch_create(ctypes.byref(b), S, rate, channels, karr.ctypes.data if karr is not None else None,
                               int(kbps) if karr is None else 0, n_frames)
     assert rc == 0, "mp3mi_batch_create -> %d" % rc
+    want_sync = -6 if expect_abort else 0  # MP3MI_ERR_REFERENCE_ABORT
     try:
+        if mode:
+            assert L.mp3mi_batch_set_mode(b, {"s": 0, "d": 2, "m": 3}[mode[0]]) == 0
+            assert L.mp3mi_batch_set_error_protection(b, 1 if "e" in mode[1:] else 0) == 0
+            assert L.mp3mi_batch_set_header(b, 1 if "c" in mode[1:] else 0, 1 if "o" in mode[1:] else 0, 0) == 0
         L.mp3mi_batch_debug_enable(b, 1)
         stride = L.mp3mi_batch_out_stride(b, n_frames)
         is_emu = b"emulator" in L.mp3mi_version()
@@ -25,6 +33,8 @@ def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames):
             lens = np.zeros(S, np.uint32)
             rc = L.mp3mi_batch_encode(b, pcm.ctypes.data, n_frames, out.ctypes.data, stride, lens.ctypes.data)
             assert rc == 0
+            rc = L.mp3mi_batch_sync(b)
+            assert rc == want_sync, "mp3mi_batch_sync -> %d" % rc
         else:
             hip = ctypes.CDLL("libamdhip64.so")
             hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
@@ -37,7 +47,8 @@ def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames):
             assert hip.hipMemcpy(dp, pcm.ctypes.data, pcm.nbytes, 1) == 0
             rc = L.mp3mi_batch_encode(b, dp, n_frames, do, stride, dl)
             assert rc == 0, rc
-            assert L.mp3mi_batch_sync(b) == 0
+            rc = L.mp3mi_batch_sync(b)
+            assert rc == want_sync, "mp3mi_batch_sync -> %d" % rc
             out = np.zeros((S, stride), np.uint8)
             lens = np.zeros(S, np.uint32)
             assert hip.hipMemcpy(out.ctypes.data, do, S * stride, 2) == 0
@@ -54,21 +65,24 @@ def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames):
         for what, key in ((0, "psy"), (1, "xr"), (2, "ix"), (3, "side"), (4, "sb")):
             n = L.mp3mi_batch_debug_fetch(b, what, st[key].ctypes.data, st[key].nbytes)
             assert n == st[key].nbytes, (key, n, st[key].nbytes)
+        st["status"] = np.zeros(S, np.int32)
+        assert L.mp3mi_batch_stream_status(b, st["status"].ctypes.data) >= 0
         return [out[s, :lens[s]].tobytes() for s in range(S)], st
     finally:
         L.mp3mi_batch_destroy(b)
 
 
-def compare_stages(st, s, dumps, channels):
-    """Returns a list of mismatch descriptions (empty = identical)."""
+def compare_stages(st, s, dumps, channels, frames=None):
+    """dumps[k] is the reference's / the oracle's record of frame frames[k] (default: k).  Returns a list of mismatch
+    descriptions (empty = identical)."""
     bad = []
 
     def chk(where, name, a, b):
         if not np.array_equal(np.asarray(a), np.asarray(b)):
             bad.append("%s %s" % (where, name))
 
-    for f in range(len(dumps)):
-        d = dumps[f]
+    for k, f in enumerate(frames if frames is not None else range(len(dumps))):
+        d = dumps[k]
         for gr in range(2):
             for c in range(channels):
                 g = 2 * f + gr
@@ -80,8 +94,12 @@ def compare_stages(st, s, dumps, channels):
                 chk(w, "ratio_s", p["ratio_s"], d["ratio_s"][gr, c])
                 chk(w, "subband samples", st["sb"][s, g, c], d["sb"][c, gr])
                 chk(w, "xr", st["xr"][s, g, c], d["xr"][gr, c])
-                chk(w, "|ix|", np.abs(st["ix"][s, g, c].astype(np.int32)), d["l3_enc"][gr, c])
                 sg, gi = st["side"][s, f]["gr"][gr, c], d["gi"][gr, c]
+                # the lines the side information declares (2 * big_values + 4 * count1): an all-zero granule skips the
+                # search in the reference and leaves the PREVIOUS frame's values in its static l3_enc (src/loop.c:346-349),
+                # which nothing reads; the product hands zeros on
+                coded = 2 * int(gi[GI["big_values"]]) + 4 * int(gi[GI["count1"]])
+                chk(w, "|ix|", np.abs(st["ix"][s, g, c].astype(np.int32))[:coded], d["l3_enc"][gr, c][:coded])
                 for nm in ("part2_3_length", "big_values", "count1", "global_gain", "scalefac_compress",
                            "window_switching_flag", "block_type", "region0_count", "region1_count", "preflag",
                            "count1table_select", "part2_length"):

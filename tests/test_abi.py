@@ -50,7 +50,45 @@ def test_fails_loudly_without_gpu(product):
 
 
 def test_argument_errors_do_not_need_a_gpu(product):
+    """what the reference refuses the product refuses (MP3MI_ERR_ARG): the MPEG-2 LSF rates L3psycho_anal exits on
+    (src/l3psy.c:170-176), bitrates outside the Layer III table (src/common.c:118-125, 460-481), channel counts"""
     b = ctypes.c_void_p()
-    assert product.lib.mp3mi_batch_create(ctypes.byref(b), 4, 22050, 2, None, 128, 8) == -1
+    for rate in (22050, 24000, 16000, 8000, 96000):
+        assert product.lib.mp3mi_batch_create(ctypes.byref(b), 4, rate, 2, None, 128, 8) == -1
+    for kbps in (0, 16, 100, 384):
+        assert product.lib.mp3mi_batch_create(ctypes.byref(b), 4, 44100, 2, None, kbps, 8) == -1
     assert product.lib.mp3mi_batch_create(ctypes.byref(b), 4, 44100, 3, None, 128, 8) == -1
     assert product.lib.mp3mi_batch_create(ctypes.byref(b), 0, 44100, 2, None, 128, 8) == -1
+
+
+def test_options_struct(product):
+    """mp3mi_batch_options: defaults, the environment overlay (the one place the library reads its environment), and
+    a struct of another size refused"""
+    import subprocess
+    import sys
+    o = product.options()
+    assert o.struct_size == ctypes.sizeof(o) and o.scratch_mb == 0 and o.chunk_frames == 0 and o.test_flags == 0
+    assert (o.call_overlap, o.gate, o.placement, o.y_after_loop, o.psy_beside, o.loop_queue) == (-1, -1, -1, -1, -1, 0)
+    code = ("import sys, ctypes; sys.path.insert(0, %r); from mp3common import Mp3mi, BatchOptions; m = Mp3mi(); o = BatchOptions(); "
+            "m.lib.mp3mi_batch_options_from_env(ctypes.byref(o)); "
+            "print(o.chunk_frames, o.scratch_mb, o.test_flags, o.gate, o.placement, o.loop_queue, o.loop_part_streams, o.psy_beside)" % os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MP3MI_CHUNK_FRAMES="7", MP3MI_SCRATCH_MB="100", MP3MI_PSY_EXACT="1", MP3MI_CW_EXACT="1", MP3MI_NO_GATE="1",
+               MP3MI_NO_PLACE="1", MP3MI_LOOP_PARTS="0", MP3MI_LOOP_PART_STREAMS="200", MP3MI_PSY_BESIDE="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert [int(x) for x in out] == [7, 100, 4 | 32, 0, 0, 1, 192, 2]
+    b = ctypes.c_void_p()
+    o.struct_size = 8
+    assert product.lib.mp3mi_batch_create_ex(ctypes.byref(b), 4, 44100, 2, None, 128, 8, ctypes.byref(o)) == -1
+
+
+def test_product_reads_its_environment_in_one_place_only():
+    """getenv appears in mp3mi_batch_options_from_env and nowhere else in the product sources"""
+    src_dir = os.path.join(ROOT, "mp3-enc-bsd_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(src_dir)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            text = open(os.path.join(src_dir, f), errors="replace").read()
+            for m in re.finditer(r"getenv\s*\(", text):
+                fn = re.findall(r"^[\w\" ].*?\b(\w+)\s*\([^;{}]*\)\s*\{", text[:m.start()], flags=re.M)
+                hits.append((f, fn[-1] if fn else "?"))
+    assert hits and all(h == ("batch.cpp", "mp3mi_batch_options_from_env") for h in hits), sorted(set(hits))

@@ -4,7 +4,9 @@ the emulator runs every lane as a fiber.  (The real HIP build is covered by the 
 import numpy as np
 import pytest
 
-from golden_util import case_pcm, case_stages, manifest
+import hashlib
+
+from golden_util import aborting_cases, case_pcm, case_stages, encoding_cases, manifest
 from mp3common import pad_frames
 from stage_check import compare_stages, run_batch_with_stages
 
@@ -22,12 +24,56 @@ def test_emulated_kernels_match_oracle(emu, oracle, rate, channels, kbps, stream
 def test_emulated_kernels_match_reference_golden(emu):
     """straight against the reference's own stage dumps (no oracle in between)"""
     case = [c for c in manifest() if c["name"] == "s44_128_bursty"][0]
-    gold = case_stages(case)[:6]
+    gold = case_stages(case)[0][:6]
     pcm, nf = pad_frames(case_pcm(case, emu.synth), case["channels"])
     nf = 6
     got, st = run_batch_with_stages(emu, pcm[None, :nf * 1152 * case["channels"]], case["rate"], case["channels"], case["kbps"], nf)
     bad = compare_stages(st, 0, gold, case["channels"])
     assert not bad, bad[:8]
+
+
+CRAFTED = [c for c in encoding_cases() if c["name"].startswith("x")]
+
+
+@pytest.mark.parametrize("case", CRAFTED, ids=[c["name"] for c in CRAFTED])
+def test_emulated_kernels_reproduce_the_crafted_goldens(emu, case):
+    """the fixtures made for the reference's rarely taken branches (tests/golden/coverage_notes.json,
+    oracle/crafted_inputs.py): scfsi, reservoir caps and the drain into ancillary data, queued headers, exact-zero
+    lines, error protection -- md5 of the whole file and the stage seams of the dumped frames"""
+    pcm, nf = pad_frames(case_pcm(case, emu.synth), case["channels"])
+    got, st = run_batch_with_stages(emu, pcm[None, :], case["rate"], case["channels"], case["kbps"], nf, mode=case.get("mode"))
+    assert len(got[0]) == case["mp3_len"] and hashlib.md5(got[0]).hexdigest() == case["mp3_md5"]
+    gold, frames = case_stages(case)
+    bad = compare_stages(st, 0, gold, case["channels"], frames)
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("case", aborting_cases(), ids=[c["name"] for c in aborting_cases()])
+def test_emulated_kernels_report_where_the_reference_dies(emu, case):
+    pcm, nf = pad_frames(case_pcm(case, emu.synth), case["channels"])
+    got, st = run_batch_with_stages(emu, pcm[None, :], case["rate"], case["channels"], case["kbps"], nf, mode=case.get("mode"),
+                                    expect_abort=True)
+    assert got[0] == b""
+    assert (st["status"][0] & 255, st["status"][0] >> 8) == (case["reference_aborts"]["status"], case["reference_aborts"]["frame"])
+
+
+def test_an_aborting_stream_leaves_its_neighbours_alone(emu, oracle):
+    """one stream of a batch is an input the reference dies on: its file is voided, the other streams' bytes are the
+    oracle's, and the status survives until the next reset"""
+    from mp3common import BatchRun
+    case = [c for c in aborting_cases() if c["name"] == "abort_global_gain"][0]
+    bad, nf = pad_frames(case_pcm(case, emu.synth), 2)
+    good = emu.synth(nf * 1152, 2, 44100, 77)
+    run = BatchRun(emu, 3, 44100, 2, 128, nf, pcm=np.stack([good, bad, good]))
+    try:
+        out, lens = run.encode(expect_abort=True)
+        ref = oracle.encode(good, 44100, 128, 2)[0]
+        assert lens[1] == 0 and out[0, :lens[0]].tobytes() == ref and out[2, :lens[2]].tobytes() == ref
+        st = run.status()
+        assert st[0] == 0 and st[2] == 0 and st[1] & 255 == 1
+        assert emu.lib.mp3mi_batch_sync(run.b) == 0  # reported once
+    finally:
+        run.close()
 
 
 def test_two_streams_mixed_bitrate_and_chunking(emu, oracle, monkeypatch):

@@ -9,10 +9,11 @@ import tempfile
 import numpy as np
 import pytest
 
-from golden_util import case_pcm, case_stages, manifest
-from mp3common import ROOT, STAGE_DT
+from golden_util import aborting_cases, case_pcm, case_stages, encoding_cases
+from mp3common import ROOT, STAGE_DT, ReferenceAborts
 
-CASES = manifest()
+CASES = encoding_cases()
+ABORTS = aborting_cases()
 
 
 @pytest.fixture(scope="module")
@@ -33,15 +34,25 @@ def synth():
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_oracle_reproduces_reference(oracle, synth, case):
     pcm = case_pcm(case, synth)
-    gold = case_stages(case)
-    data, dumps = oracle.encode(pcm, case["rate"], case["kbps"], case["channels"], dumps=len(gold))
+    gold, frames = case_stages(case)
+    data, dumps = oracle.encode(pcm, case["rate"], case["kbps"], case["channels"], dumps=max(frames) + 1, mode=case.get("mode"))
     assert len(data) == case["mp3_len"]
     assert hashlib.md5(data).hexdigest() == case["mp3_md5"]
-    for f in range(len(gold)):
+    for k, f in enumerate(frames):
         for name in STAGE_DT.names:
             if name in ("magic", "frame_index"):
                 continue
-            assert np.array_equal(dumps[f][name], gold[f][name]), "frame %d field %s" % (f, name)
+            assert np.array_equal(dumps[f][name], gold[k][name]), "frame %d field %s" % (f, name)
+
+
+@pytest.mark.parametrize("case", ABORTS, ids=[c["name"] for c in ABORTS])
+def test_oracle_reports_where_the_reference_dies(oracle, synth, case):
+    """inputs on which an assertion of the reference fails (tests/golden/coverage_notes.json): the oracle says which"""
+    pcm = case_pcm(case, synth)
+    with pytest.raises(ReferenceAborts) as e:
+        oracle.encode(pcm, case["rate"], case["kbps"], case["channels"], mode=case.get("mode"))
+    assert e.value.status == case["reference_aborts"]["status"]
+    assert e.value.frame == case["reference_aborts"]["frame"]
 
 
 def test_oracle_refuses_what_the_reference_refuses(oracle):
