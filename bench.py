@@ -7,8 +7,7 @@ The workloads are BASELINE.json's configs, selected with --conf
 
   1  4096 streams x 383 frames, 44.1 kHz stereo, 128 kbps            (configs[1]; the default, the metric's config)
   2  8192 streams x 383 frames per GPU, 44.1 kHz stereo, 128 kbps    (configs[2]: 65 536 streams on 8 GPUs, plain
-                                                                      stereo -- the reference refuses joint stereo;
-                                                                      the default when launched on 8 GPUs)
+                                                                      stereo -- the reference refuses joint stereo)
   3  4096 streams x 417 frames, 48 kHz stereo, stream s at {64,96,128,192,256,320}[s mod 6] kbps   (configs[3])
   4  16384 streams x 278 frames, 32 kHz mono, 64 kbps                (configs[4])
 
@@ -23,7 +22,6 @@ makes the run FAIL (exit 1, value null).  tools/full_parity.py compares every st
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
-import glob
 import importlib
 import json
 import os
@@ -84,62 +82,60 @@ class Workload:
         self.batch.close()
 
 
-def newest_profile(pattern, pred):
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.getmtime, reverse=True):
-        try:
-            d = json.load(open(f))
-            r = pred(d)
-            if r is not None:
-                return r, os.path.basename(f)
-        except Exception:
-            continue
-    return None, None
+# What bounds each kernel (measured stand-alone durations against bytes moved and instructions
+# issued).  A label, not a measurement: the measurements are in the profile the bench line names.
+KERNEL_BOUND = {
+    "k_loop": "valu+salu issue (4 wavefronts per SIMD, serial per stream)", "k_loop_queue": "valu+salu issue",
+    "k_fft": "lds pipe (bank conflicts of the butterfly program)", "k_cw": "valu issue (f64)", "k_cw_fix": "valu issue (f64)",
+    "k_part": "hbm (one lane per record, 2 KB rows)", "k_psy": "latency (one wavefront per track, serial over granules)",
+    "k_filter": "valu issue (f64) + hbm", "k_mdct": "hbm", "k_prep": "hbm", "k_format": "latency (bit scatter)",
+}
 
 
-def pmc_traffic(kernel, streams, frames, launches_per_step):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary of this workload
-    (profiles/*_pmc_hbm_*.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    command, gfx950 correction applied there).  Counters cannot be read from inside the timed run,
-    so this is the figure of the profiling pass, or None when no summary matches the workload."""
-    def pred(d):
-        k = d["kernels"][kernel]
-        if d.get("streams") == streams and d.get("frames") == frames and k["dispatches"] == launches_per_step:
-            return k["hbm_bytes_per_launch"]
-        return None
-    return newest_profile("*_pmc_hbm_*.json", pred)
+def current_profile(source_hash, streams, frames):
+    """The committed counter profile this build may quote: profiles/CURRENT names it (written when a profile is
+    committed: tools/gpu_round_profile.sh, tools/make_profile_json.py); it is used only if it was taken on the same
+    sources (mp3mi_source_hash) and the same workload.  Returns (profile dict or None, reason)."""
+    ptr = os.path.join(ROOT, "profiles", "CURRENT")
+    if not os.path.exists(ptr):
+        return None, "no profiles/CURRENT"
+    name = open(ptr).read().strip()
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception as e:
+        return None, "profiles/%s unreadable: %s" % (name, e)
+    if d.get("source_hash") != source_hash:
+        return None, "profiles/%s was taken on sources %s, this library is %s: counters not quoted" % (name, d.get("source_hash"), source_hash)
+    if d.get("streams") != streams or d.get("frames") != frames:
+        return None, "profiles/%s is of %s x %s, this run of %d x %d" % (name, d.get("streams"), d.get("frames"), streams, frames)
+    d["file"] = name
+    return d, None
 
 
-def issue_roofline(kernel, streams, frames, kernel_s_per_launch, launches_per_step):
-    """The bound the kernel actually runs against: VALU issue.  From the newest committed SQ counter passes of this
-    workload (profiles/*_insts_<S>x<F>.json, tools/gpu_insts.sh; counters are per-wave quad-cycles, MI355X_MICROARCH.md):
+def issue_roofline(k, streams, kernel_s_per_launch):
+    """The bound the kernel actually runs against: VALU issue.  From the SQ counter passes of the profile (per-wave
+    quad-cycles, MI355X_MICROARCH.md):
       achieved = SQ_ACTIVE_INST_VALU  -- quad-cycles in which a wavefront of the kernel was issuing a vector instruction
       peak     = SQ_WAVE_CYCLES / waves resident per SIMD -- the quad-cycles the SIMDs were held by the kernel (a SIMD's
                  vector port serves one of its resident wavefronts at a time)
     so frac is the share of the SIMDs' vector issue capacity the launch used; what is left is waitcnt / issue stalls.
     The instruction mix per launch goes along (what there is to remove: the kernel gets faster by executing fewer
-    vector instructions, not by moving fewer bytes)."""
-    def pred(d):
-        k = d[kernel]
-        if k["dispatches"] != launches_per_step or "SQ_ACTIVE_INST_VALU" not in k:
-            return None
-        n = float(k["dispatches"])
-        waves_per_simd = max(1.0, min(4.0, streams / 1024.0))
-        achieved, peak = k["SQ_ACTIVE_INST_VALU"] / n, k["SQ_WAVE_CYCLES"] / n / waves_per_simd
-        f64 = sum(k.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) / n
-        f32 = sum(k.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")) / n
-        vmem = (k.get("SQ_INSTS_VMEM_RD", 0) + k.get("SQ_INSTS_VMEM_WR", 0)) / n
-        r = {"bound": "valu-issue", "achieved": int(achieved), "peak": int(peak), "unit": "SIMD quad-cycles per launch", "frac": round(achieved / peak, 4),
-             "waves_per_simd": waves_per_simd,
-             "wave_time_split": {c: round(k[c] / k["SQ_WAVE_CYCLES"], 4) for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if c in k},
-             "instructions_per_launch": {"valu": int(k["SQ_INSTS_VALU"] / n), "valu_f64": int(f64), "valu_f32": int(f32),
-                                         "valu_int32": int(k.get("SQ_INSTS_VALU_INT32", 0) / n), "salu": int(k["SQ_INSTS_SALU"] / n),
-                                         "branch": int(k.get("SQ_INSTS_BRANCH", 0) / n), "lds": int(k["SQ_INSTS_LDS"] / n), "vmem": int(vmem)},
-             "effective_clock_ghz": round(4.0 * peak / 1024.0 / kernel_s_per_launch / 1e9, 3) if kernel_s_per_launch > 0 else None}
-        return r
-    r, src = newest_profile("*_insts_%dx%d.json" % (streams, frames), pred)
-    if r is not None:
-        r["source"] = src
-    return r
+    instructions, not by moving fewer bytes)."""
+    if not k or "SQ_ACTIVE_INST_VALU" not in k:
+        return None
+    n = float(k["dispatches"])
+    waves_per_simd = max(1.0, min(4.0, streams / 1024.0))
+    achieved, peak = k["SQ_ACTIVE_INST_VALU"] / n, k["SQ_WAVE_CYCLES"] / n / waves_per_simd
+    f64 = sum(k.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) / n
+    f32 = sum(k.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")) / n
+    vmem = (k.get("SQ_INSTS_VMEM_RD", 0) + k.get("SQ_INSTS_VMEM_WR", 0)) / n
+    return {"bound": "valu-issue", "achieved": int(achieved), "peak": int(peak), "unit": "SIMD quad-cycles per launch", "frac": round(achieved / peak, 4),
+            "waves_per_simd": waves_per_simd,
+            "wave_time_split": {c: round(k[c] / k["SQ_WAVE_CYCLES"], 4) for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if c in k},
+            "instructions_per_launch": {"valu": int(k["SQ_INSTS_VALU"] / n), "valu_f64": int(f64), "valu_f32": int(f32),
+                                        "valu_int32": int(k.get("SQ_INSTS_VALU_INT32", 0) / n), "salu": int(k["SQ_INSTS_SALU"] / n),
+                                        "branch": int(k.get("SQ_INSTS_BRANCH", 0) / n), "lds": int(k["SQ_INSTS_LDS"] / n), "vmem": int(vmem)},
+            "effective_clock_ghz": round(4.0 * peak / 1024.0 / kernel_s_per_launch / 1e9, 3) if kernel_s_per_launch > 0 else None}
 
 
 def cpu_baseline(pcm_sample, rate, kbps_list, channels, cores):
@@ -195,8 +191,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                    help="BASELINE.json workload (see the module docstring); 0 = 1, or 2 when launched on 8 GPUs")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="BASELINE.json workload (see the module docstring); the default is configs[1] for every N, so that the "
+                         "1 / 2 / 4 / 8-GPU series is one per-GPU workload")
     ap.add_argument("--streams", type=int, default=0, help="override: streams per GPU")
     ap.add_argument("--frames", type=int, default=0, help="override: frames per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true",
@@ -224,7 +221,7 @@ def main():
     cdev = torch.device("cpu") if (distributed and one_gpu) else dev  # where the collectives' tensors live
 
     mp3 = importlib.import_module("mp3-enc-bsd_amd")
-    cfg_id = args.config or (2 if world == 8 else 1)
+    cfg_id = args.config
     cfg = dict(CONFIGS[cfg_id])
     default_size = not (args.streams or args.frames)
     if args.streams:
@@ -290,9 +287,15 @@ def main():
                    "sample": "%d of this batch's streams x %d frames, oracle/_ref/encode (unmodified reference, gcc -O2), one process per stream" % (len(idx), nf),
                    "port_value": round(fps, 1)}
     n_bad = torch.tensor([len(bad)], dtype=torch.int64, device=cdev)
+    # which streams each rank encoded, and a digest of what it produced (the ranks' ranges must be disjoint, their bytes differ)
+    import hashlib
+    mine = torch.tensor([rank, rank * S, S, int(hashlib.md5(b"".join(got)).hexdigest()[:15], 16)], dtype=torch.int64, device=cdev)
+    per_rank = [mine.clone() for _ in range(world)]
     if distributed:
         dist.all_reduce(n_bad, op=dist.ReduceOp.SUM)
+        dist.all_gather(per_rank, mine)
     parity_ok = int(n_bad.item()) == 0
+    ranks = [{"rank": int(t[0]), "first_stream": int(t[1]), "streams": int(t[2]), "sample_digest": "%015x" % int(t[3])} for t in per_rank]
 
     frames_total = S * nf * args.steps * world
     if rank == 0:
@@ -306,13 +309,28 @@ def main():
         # one launch each; MP3MI_LOOP_PARTS=0 selects one launch of the queue form instead)
         queue = os.environ.get("MP3MI_LOOP_PARTS", "1") == "0" and S > 16 * torch.cuda.get_device_properties(dev).multi_processor_count
         kname = "k_loop_queue" if queue else "k_loop"
-        traffic, traffic_src = pmc_traffic(kname, S, nf, lps) if cfg_id in (1, 2) else (None, None)
-        issue = issue_roofline(kname, S, nf, avg_launch_s, lps) if cfg_id in (1, 2) else None
+        # Counter figures cannot be read from inside the timed run: they come from the committed profile that
+        # profiles/CURRENT names -- if, and only if, it was taken on the sources this library was built from.
+        src_hash = mp3.lib().mp3mi_source_hash().decode()
+        prof, prof_why = current_profile(src_hash, S, nf)
+        traffic = issue = pipeline = kernels = None
+        if prof is not None:
+            pk = prof["kernels"]
+            if kname in pk and pk[kname].get("dispatches") == lps:
+                traffic = pk[kname].get("hbm_bytes_per_launch")
+                issue = issue_roofline(pk[kname], S, avg_launch_s)
+            hbm_step = sum(v.get("hbm_bytes_per_launch", 0) * v.get("dispatches", 0) for v in pk.values())
+            pipeline = {"alg_bytes_per_step": int(alg * S * nf), "hbm_bytes_per_step": int(hbm_step),
+                        "ratio": round(hbm_step / (alg * S * nf), 2), "hbm_gbs_over_the_step": round(hbm_step / (dt / args.steps) / 1e9, 1)}
+            kernels = {k: {"bound": KERNEL_BOUND.get(k.split("<")[0], "?"), "launches_per_step": v.get("dispatches"),
+                           "avg_ms_per_launch": v.get("avg_ms"), "hbm_bytes_per_launch": v.get("hbm_bytes_per_launch")}
+                       for k, v in sorted(pk.items())}
         result = {
             "metric": "stereo 44.1 kHz frames/s @128 kbps (bit-exact), 1/2/4/8 MI355X + %HBM roofline",
             "value": round(frames_total / dt, 1) if parity_ok else None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "timing": "sync_each" if sync_each else "pipelined (the K timed calls are issued back to back; ms_per_step = wall time / K)",
             "config": {"workload": "batch of %d synthetic %.1f kHz %s streams x %d frames per GPU, %s kbps CBR (%s%s)"
                        % (S, rate / 1000.0, "stereo" if C == 2 else "mono", nf,
                           "64-320 mixed" if cfg["kbps"] == "mix48" else str(cfg["kbps"]), cfg["name"],
@@ -322,13 +340,18 @@ def main():
                        "parallelism": "streams sharded across GPUs, no collective"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+                         "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
+                         "traffic_source": ("profiles/" + prof["file"]) if prof is not None else None,
+                         "traffic_unavailable_because": prof_why,
                          "algorithmic_bytes_per_frame": round(alg, 1),
                          "kernel_ms_per_launch": round(avg_launch_s * 1e3, 3), "launches_per_step": lps,
-                         "all_kernels_ms_per_step": round(all_ms / max(args.steps, 1), 3),
-                         "limited_by": "vector instruction issue, not HBM (see issue: share of the SIMDs' VALU issue capacity in use)",
-                         "issue": issue},
+                         # (HIP-event span of a call from its first to its last kernel; calls overlap when pipelined, so
+                         # it is only reported where every call was synchronised)
+                         "all_kernels_ms_per_step": round(all_ms / max(args.steps, 1), 3) if sync_each else None,
+                         "limited_by": "instruction issue of the dominant kernel, not HBM (issue: share of the SIMDs' VALU issue capacity in use; kernels: what bounds each)",
+                         "issue": issue, "pipeline": pipeline, "kernels": kernels, "source_hash": src_hash},
             "cpu_baseline": cpu,
+            "ranks": ranks,
             "parity_spot_check": {"streams_per_rank": len(idx), "bit_exact": parity_ok, "mismatching_streams_rank0": bad,
                                   "witness": "oracle/liboracle.so" + (" + oracle/_ref/encode" if cpu and cpu["kind"] == "reference" else "")},
         }

@@ -226,6 +226,9 @@ int mp3mi_batch_debug_cw_fixups(mp3mi_batch *b, int *n_listed, int *n_records);
 
 /* Library / device identification string for logs. */
 const char *mp3mi_version(void);
+/* sha256 (first 16 hex digits) over the sources the library was built from (csrc/Makefile): measurements carry it, and
+ * bench.py only quotes counter figures of a committed profile that was taken on the same sources. */
+const char *mp3mi_source_hash(void);
 
 #ifdef __cplusplus
 }

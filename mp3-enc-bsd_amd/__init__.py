@@ -88,6 +88,7 @@ def lib():
         L.mp3mi_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.mp3mi_version.restype = ctypes.c_char_p
+        L.mp3mi_source_hash.restype = ctypes.c_char_p
         _lib = L
     return _lib
 

@@ -131,6 +131,11 @@ static int have_device(void)
     return 1;
 }
 
+#if !defined(MP3MI_SOURCE_HASH)
+#define MP3MI_SOURCE_HASH "unknown"
+#endif
+extern "C" const char *mp3mi_source_hash(void) { return MP3MI_SOURCE_HASH; }
+
 extern "C" const char *mp3mi_version(void)
 {
 #if defined(MP3MI_EMU)

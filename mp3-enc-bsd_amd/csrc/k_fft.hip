@@ -503,6 +503,11 @@ MP3MI_DEVFN void cw_record(const float *__restrict__ bins, double *__restrict__ 
         const double t3 = r2 + __builtin_fabs(r_prime);
         double cw = 0.0;
         if (t3 != 0.0) cw = __builtin_sqrt(t1 * t1 + t2 * t2) / t3;
+        // Predicted and actual line bit for bit alike (digital silence: every energy at its floor, every phase 0; a
+        // stationary bin): the reference subtracts a product from itself, whatever its libm returns for the sine --
+        // its c_w is +0 exactly, as ours is.  -0.0 tells k_part that this zero is not a first-tier estimate (it adds
+        // like +0.0 there): without it every record of a silent stream would go through the second tier.
+        if (FASTSC && r2 == r_prime && phi2 == phi_prime) cw = -0.0;
         cw_mid[rec * 50 + lane] = cw;
     } else if (lane < 56 && FASTSC) { // (the same in both tiers: written once)
         hist6[rec * 12 + lane - 50] = (float) __builtin_sqrt((double) e[0]); // r, src/l3psy.c:500

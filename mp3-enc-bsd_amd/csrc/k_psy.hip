@@ -103,7 +103,8 @@ MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, i
     if (j < T->part_l_covered) {
         W.eb = W.eb + e;
         const double d = (double) W.cb + cw * e;
-        if (CHECK && !part_cw_safe(d, e)) *amb = true;
+        // (cw == -0.0: k_cw's mark for a c_w that is exactly zero in the reference as well -- nothing to check)
+        if (CHECK && dm_bits(cw) != (long long) 0x8000000000000000ull && !part_cw_safe(d, e)) *amb = true;
         W.cb = (float) d;
         while (W.b < MP3MI_CBANDS && j + 1 == W.pend) { // closes this partition and any empty ones after it
             if (W.b == 0) { W.eb0 = W.eb; W.cb0 = W.cb; }

@@ -76,6 +76,24 @@ def test_an_aborting_stream_leaves_its_neighbours_alone(emu, oracle):
         run.close()
 
 
+def test_silence_does_not_take_the_second_tier(emu, oracle):
+    """digital silence: every unpredictability is an exact zero in the reference too (k_cw marks it), so no record is
+    listed for the correctly rounded sines -- it used to be all of them"""
+    from mp3common import BatchRun
+    nf = 3
+    pcm = np.zeros((2, nf * 1152 * 2), np.int16)
+    pcm[1, 2 * 1152 * 2:] = emu.synth(1152, 2, 44100, 9)  # the second stream wakes up in its last frame
+    run = BatchRun(emu, 2, 44100, 2, 128, nf, pcm=pcm)
+    try:
+        out, lens = run.encode()
+        listed, records = run.cw_fixups()
+        assert records == 2 * nf * 2 * 2 and listed <= 2, (listed, records)
+        for s in range(2):
+            assert out[s, :lens[s]].tobytes() == oracle.encode(pcm[s], 44100, 128, 2)[0]
+    finally:
+        run.close()
+
+
 def test_two_streams_mixed_bitrate_and_chunking(emu, oracle, monkeypatch):
     monkeypatch.setenv("MP3MI_CHUNK_FRAMES", "2")
     nf, rate, ch = 5, 48000, 2

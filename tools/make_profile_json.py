@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Merges what tools/gpu_round_profile.sh collected under gpurun_out/<tag>/ into profile.json: per kernel the calls and
+average duration of the kernel trace, the HBM bytes per launch of the FETCH_SIZE / WRITE_SIZE passes (gfx950: FETCH_SIZE
+tallies 128-byte requests at 64 B -> read bytes = 2 * FETCH_SIZE KiB; MI355X_MICROARCH.md, HBM section) and the SQ
+counters of the four instruction passes -- stamped with the library's source hash, the workload and the bench line
+measured under the kernel trace.  bench.py quotes counter figures only from the profile that profiles/CURRENT names and
+only while the hash matches the library it runs on.
+
+    python3 tools/make_profile_json.py gpurun_out/<tag> <tag>
+"""
+import csv
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(src, tag):
+    L = ctypes.CDLL(os.path.join(ROOT, "mp3-enc-bsd_amd", "libmp3mi.so"))
+    L.mp3mi_source_hash.restype = ctypes.c_char_p
+    bench = None
+    for line in open(os.path.join(src, "bench_under_rocprof.json")):
+        if line.startswith("{"):
+            bench = json.loads(line)
+    assert bench is not None, "no bench line under the kernel trace"
+    steps, warm = bench["steps"], bench["warmup"]
+    kernels = {}
+    for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
+        n = r["Name"].split("(")[0].replace("void ", "")
+        if n.startswith("k_"):
+            kernels[n] = {"calls_in_trace": int(r["Calls"]), "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
+                          "total_ms_in_trace": round(float(r["TotalDurationNs"]) / 1e6, 3)}
+    f = json.load(open(os.path.join(src, "pmc_fetch.json")))
+    w = json.load(open(os.path.join(src, "pmc_write.json")))
+    for k in f:
+        if k in w:
+            d = f[k]["dispatches"]
+            kernels.setdefault(k, {}).update({
+                "dispatches": d, "FETCH_SIZE_KiB": f[k]["FETCH_SIZE"], "WRITE_SIZE_KiB": w[k]["WRITE_SIZE"],
+                "hbm_read_GB_per_step": round(2 * f[k]["FETCH_SIZE"] * 1024 / 1e9, 2), "hbm_write_GB_per_step": round(w[k]["WRITE_SIZE"] * 1024 / 1e9, 2),
+                "hbm_bytes_per_launch": int((2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024 / d)})
+    for p in "abcd":
+        fn = os.path.join(src, "pmc_%s.json" % p)
+        if os.path.exists(fn):
+            for k, v in json.load(open(fn)).items():
+                kernels.setdefault(k, {}).update({c: x for c, x in v.items() if c != "dispatches"})
+    tot_r = sum(v.get("hbm_read_GB_per_step", 0) for v in kernels.values())
+    tot_w = sum(v.get("hbm_write_GB_per_step", 0) for v in kernels.values())
+    out = {"tag": tag, "source_hash": L.mp3mi_source_hash().decode(), "streams": bench["config"]["streams_per_gpu"],
+           "frames": bench["config"]["frames_per_stream"], "config_id": bench["config"]["config_id"],
+           "commands": ["rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline  (steps %d, warmup %d: calls_in_trace / (steps + warmup) per step)" % (steps, warm),
+                        "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline  (one pass each)",
+                        "rocprofv3 --pmc <8 SQ counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline  (four passes)"],
+           "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section): hbm_read = 2 * FETCH_SIZE KiB; WRITE_SIZE is exact",
+           "hbm_GB_per_step": {"read": round(tot_r, 1), "write": round(tot_w, 1), "total": round(tot_r + tot_w, 1)},
+           "bench_line_under_kernel_trace": bench, "kernels": kernels}
+    json.dump(out, open(os.path.join(src, "profile.json"), "w"), indent=1)
+    print("source %s, %d x %d: %.1f GB read + %.1f GB written per step" % (out["source_hash"], out["streams"], out["frames"], tot_r, tot_w))
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1].get("total_ms_in_trace", 0)):
+        print("%-14s avg %8.3f ms  x %3d per step   read %7.2f GB  write %7.2f GB per step" % (
+            k, v.get("avg_ms", 0), v.get("dispatches", 0), v.get("hbm_read_GB_per_step", 0), v.get("hbm_write_GB_per_step", 0)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
