@@ -12,7 +12,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmp3mi.so")
+# MP3MI_LIB: another build of the same library (tools/gpu_ab.sh: A/B of two builds on one device; tools/gpu_loop_profile.sh:
+# a diagnostic build) -- so that measurements never overwrite the product library
+LIB_PATH = os.environ.get("MP3MI_LIB") or os.path.join(_HERE, "libmp3mi.so")
 FRAME_SAMPLES = 1152
 
 

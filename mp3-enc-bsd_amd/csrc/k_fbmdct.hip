@@ -159,10 +159,15 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
 // the next track; the wavefront walks a run of MDCT_RUN consecutive granules.  A band's 36 inputs, its 26 operand
 // groups and its 18 outputs live in the lane's registers; every window value and every transform coefficient is the
 // same for all lanes -- scalar loads, SGPR operands of the f64 multiplies --; LDS holds the finished [band][18]
-// blocks only: for the alias butterflies' neighbour values and for coalesced stores.  (A wavefront per granule with the inputs in LDS, as before, spent two thirds of its
+// blocks -- for the alias butterflies' neighbour values and for coalesced stores -- and the previous granule's samples.  (A wavefront per granule with the inputs in LDS, as before, spent two thirds of its
 // instructions on LDS traffic and its addresses, and waited on the LDS pipe.)
 #define MDCT_RUN 22 // <= 32: lane k of a half holds the block type of the run's granule k
-struct mdct_out_lds { double x[2][576]; };
+// x: the finished [band][18] blocks of the two tracks.  prev: the band's 18 samples of the granule BEFORE the one being
+// transformed, element k of lane l at prev[k][l] (every lane reads and writes its own column only: no barrier, no bank
+// conflict).  A granule's samples come from memory ONCE, as "cur", and are parked here on the way for their second use
+// as the next granule's "prev" -- until round 3 they were read from memory twice (65 GB of the step's reads instead of
+// 36), because 36 more doubles do not fit the registers beside the transform.
+struct mdct_out_lds { double x[2][576]; double prev[18][64]; };
 
 // ordered signed sum of windowed inputs: ops[i] = index | 0x80 (subtract / negate)   (src/mdct.c:205-508)
 template <int N> MP3MI_DEVFN double mdct_group_reg(const double (&fin)[36], const uint8_t *ops)
@@ -173,14 +178,22 @@ template <int N> MP3MI_DEVFN double mdct_group_reg(const double (&fin)[36], cons
     return acc;
 }
 
-// long window (src/mdct.c:199-509): prev / cur = the band's 18 samples of the previous granule and of this one (stride 32)
-MP3MI_DEVFN void mdct_long_reg(const double *prev, const double *cur, const mp3mi_tables *T, double (&o)[18])
+// long window (src/mdct.c:199-509): prev = the band's 18 samples of the previous granule (this lane's column of an LDS
+// block, stride 64), cur = those of this one (memory, stride 32); park = where cur goes for its second use (the same
+// column -- it takes prev's place -- or, for a pass that is not the last one over these inputs, scratch)
+MP3MI_DEVFN void mdct_long_reg(const double *prev, const double *cur, double *park, const mp3mi_tables *T, double (&o)[18])
 {
     double V[26];
     {
-        double fin[36];
+        double fin[36], c[18];
 #pragma unroll
-        for (int k = 0; k < 18; k++) { fin[k] = T->mdct_win[0][k] * prev[32 * k]; fin[18 + k] = T->mdct_win[0][18 + k] * cur[32 * k]; }
+        for (int k = 0; k < 18; k++) c[k] = cur[32 * k]; // all in flight together
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+            fin[k] = T->mdct_win[0][k] * prev[64 * k];
+            fin[18 + k] = T->mdct_win[0][18 + k] * c[k];
+            park[64 * k] = c[k];
+        }
 #pragma unroll
         for (int j = 0; j < 9; j++) { V[j] = fin[j] - fin[17 - j]; V[9 + j] = fin[18 + j] + fin[35 - j]; }
 #pragma unroll
@@ -210,11 +223,16 @@ MP3MI_DEVFN void mdct_long_reg(const double *prev, const double *cur, const mp3m
 }
 
 // the other block types; bt (1, 2, 3) is the same for all lanes that keep the result
-MP3MI_DEVFN void mdct_other_reg(const double *prev, const double *cur, const mp3mi_tables *T, int bt, double (&o)[18])
+MP3MI_DEVFN void mdct_other_reg(const double *prev, const double *cur, double *park, const mp3mi_tables *T, int bt, double (&o)[18])
 {
     double in[36];
 #pragma unroll
-    for (int k = 0; k < 18; k++) { in[k] = prev[32 * k]; in[18 + k] = cur[32 * k]; }
+    for (int k = 0; k < 18; k++) in[18 + k] = cur[32 * k];
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        in[k] = prev[64 * k];
+        park[64 * k] = in[18 + k];
+    }
     if (bt == 2) { // three short transforms, out[3*mm + l]   (src/mdct.c:173-185)
         double w[3][12];
 #pragma unroll
@@ -267,10 +285,12 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
     const int btv = band < n ? psy[rec0 + (size_t) band * C].block_type : 0;
     const size_t pitch = (size_t) C * 576;
     const double *blk = sbs + (((size_t) s * (G + 1) + g_lo) * C + ch) * 576 + band; // granule slot g_lo: the one before granule g_lo
+    double *prev = &L.prev[0][lane];
+#pragma unroll
+    for (int k = 0; k < 18; k++) prev[64 * k] = blk[32 * k]; // the run's first "previous granule"
     for (int kk = 0; kk < n; kk++) {
-        // (the inputs are read where they are used, every granule twice -- as this granule and as the next one's
-        // previous; the second time from the cache: 36 values held across the transform do not fit the registers)
-        const double *prev = blk + (size_t) kk * pitch, *cur = prev + pitch;
+        // (this granule's samples are read where they are used, once, and parked in LDS for the next granule)
+        const double *cur = blk + (size_t) (kk + 1) * pitch;
         const int bt0 = wave_readlane_i32(btv, kk), bt1 = wave_readlane_i32(btv, 32 + kk);
         const int bt = h ? bt1 : bt0;
         double o[18];
@@ -280,8 +300,12 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
         for (int pass = 0; pass < (mixed ? 2 : 1); pass++) {
             const int v = pass ? bt1 : bt0;
             const mp3mi_tables *Tk = wave_uniform_here(T);
-            if (v == 0) mdct_long_reg(prev, cur, Tk, o);
-            else mdct_other_reg(prev, cur, Tk, v, o);
+            // the last pass over these inputs parks them in prev's place; the first of two parks into L.x, which is
+            // scratch until the pass writes its results there (same layout: [18][64] doubles)
+            double *park = (pass == (mixed ? 1 : 0)) ? prev : &L.x[0][0] + lane;
+            if (v == 0) mdct_long_reg(prev, cur, park, Tk, o);
+            else mdct_other_reg(prev, cur, park, Tk, v, o);
+            if (mixed) __syncthreads(); // (every lane is done with L.x as scratch before results go there)
             if (bt == v) {
 #pragma unroll
                 for (int m = 0; m < 18; m++) own[m] = o[m];

@@ -1084,6 +1084,16 @@ static int bigv_bitcount(const mp3o_stream *s, const int *ix, const gr_info_t *g
     return bits;
 }
 
+#if defined(MP3O_CENSUS)
+/* tools/pass_census.py: how the search spends its quantise + count passes (build with -DMP3O_CENSUS; single-threaded) */
+long long mp3o_census[16];
+enum { CEN_GC, CEN_BISECT, CEN_BISECT_OVER, CEN_BISECT_EQUAL, CEN_OUTER, CEN_INNER_FIRST, CEN_INNER_EXTRA, CEN_PASS_ALLZERO,
+       CEN_OUTER_NO_AMP, CEN_BISECT_ALLZERO, CEN_SHORT_GC };
+#define CENSUS(i, n) (mp3o_census[i] += (n))
+#else
+#define CENSUS(i, n) ((void) 0)
+#endif
+
 static int count_bits(const mp3o_stream *s, const int *ix, gr_info_t *g)
 { /* src/loop.c:2099-2113 */
     int bits;
@@ -1107,6 +1117,8 @@ static void bin_search_StepSize(const mp3o_stream *s, int desired_rate, double s
         g->quantizerStepSize = next;
         quantize(s, xrs, ix, g);
         bit = count_bits(s, ix, g);
+        CENSUS(CEN_BISECT, 1); CENSUS(CEN_BISECT_OVER, bit > desired_rate); CENSUS(CEN_BISECT_EQUAL, bit == desired_rate);
+        CENSUS(CEN_BISECT_ALLZERO, ix_max(ix, 0, 576) == 0);
         if (bit > desired_rate) top = next;
         else bot = next;
     } while (bit != desired_rate && fabs(last - next) > 1.0);
@@ -1120,11 +1132,13 @@ static int inner_loop(const mp3o_stream *s, const double *xrs, int *ix, int max_
         return 0;
     }
     g->quantizerStepSize -= 1.0;
+    CENSUS(CEN_INNER_FIRST, 1); CENSUS(CEN_INNER_EXTRA, -1);
     do {
         do {
             g->quantizerStepSize += 1.0;
             quantize(s, xrs, ix, g);
         } while (ix_max(ix, 0, 576) > 8191 + 14);
+        CENSUS(CEN_INNER_EXTRA, 1); CENSUS(CEN_PASS_ALLZERO, ix_max(ix, 0, 576) == 0);
         calc_runlen(ix, g);
         bits = count1_bitcount(ix, g);
         subdivide(s, g);
@@ -1271,8 +1285,10 @@ static int outer_loop(mp3o_stream *s, double *xr, int max_bits, xmin_t *xm, int 
     int scalesave_l[21], scalesave_s[13][3];
     int sfb, i, bits, huff_bits, save_preflag, save_compress, over, status, iteration = 0;
     double xfsf[4][21];
+    CENSUS(CEN_GC, 1); CENSUS(CEN_SHORT_GC, g->window_switching_flag && g->block_type == 2);
     do {
         iteration += 1;
+        CENSUS(CEN_OUTER, 1);
         g->part2_length = (unsigned) part2_length(s, gr, ch);
         huff_bits = max_bits - (int) g->part2_length;
         if (iteration == 1) bin_search_StepSize(s, max_bits, g->quantizerStepSize, ix, xr, g);
@@ -1285,6 +1301,7 @@ static int outer_loop(mp3o_stream *s, double *xr, int max_bits, xmin_t *xm, int 
         save_compress = (int) g->scalefac_compress;
         preemphasis(s, xr, xfsf, xm, gr, ch);
         over = amp_scalefac_bands(s, xr, xfsf, xm, gr, ch, iteration);
+        CENSUS(CEN_OUTER_NO_AMP, over == 0);
         if ((status = loop_break(s, g, gr, ch)) == 0) status = scale_bitcount(s, gr, ch);
     } while (status == 0 && over > 0);
     g->preflag = (unsigned) save_preflag;

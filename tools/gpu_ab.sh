@@ -1,19 +1,20 @@
 #!/bin/bash
 # Runs on the GPU box: A/B of two prebuilt product libraries ON THE SAME DEVICE (boxes differ by several per cent, so
-# numbers from two gpurun calls do not compare).  The libraries are mp3-enc-bsd_amd/ab/lib<name>.so (built here with
-# tools/ab_build.sh <name>; *.so files travel with the snapshot).  Alternates A B A B; for every run prints the bench
+# numbers from two gpurun calls do not compare).  The libraries are mp3-enc-bsd_amd/ab_now/lib<name>.so (built here with
+# tools/ab_build.sh <name>; that directory travels with the snapshot and is emptied by `tools/ab_build.sh --clean`).  The
+# library under test is selected with MP3MI_LIB (mp3-enc-bsd_amd/__init__.py); the product library is never overwritten.
+# Alternates A B A B; for every run prints the bench
 # line's ms per step and, from a kernel trace of one more step, the time of the step's last k_loop launch (the one
 # that runs alone) and the per-kernel averages.
 # Usage: tools/gpu_ab.sh <nameA> <nameB> [rounds, default 2] [bench args...]
-A=$1; B=$2; R=${3:-2}; shift 3 2>/dev/null
+A=$1; B=$2; R=${3:-2}; shift $(( $# < 3 ? $# : 3 ))
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/ab_${A}_${B}
 mkdir -p $out
-cp mp3-enc-bsd_amd/libmp3mi.so /tmp/libmp3mi_keep.so
 export TMPDIR=/tmp
 for r in $(seq 1 $R); do
   for n in $A $B; do
-    cp mp3-enc-bsd_amd/ab/lib$n.so mp3-enc-bsd_amd/libmp3mi.so
+    export MP3MI_LIB=$GRAFT_REPO_ROOT/mp3-enc-bsd_amd/ab_now/lib$n.so
     python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $out/bench_${n}_$r.json 2> $out/bench_${n}_$r.err || { echo "bench failed for $n"; tail -5 $out/bench_${n}_$r.err; }
     ms=$(python3 -c "import json;d=json.loads(open('$out/bench_${n}_$r.json').read().strip().splitlines()[-1]);print('%.2f ms/step  value %s  exact %s' % (d['ms_per_step'], d['value'], d['parity_spot_check']['bit_exact']))" 2>/dev/null)
     rm -rf /tmp/ab_tl
@@ -34,4 +35,3 @@ print("%-10s round %s  %s  | last k_loop alone %.3f ms | " % (sys.argv[1], sys.a
 PY
   done
 done
-cp /tmp/libmp3mi_keep.so mp3-enc-bsd_amd/libmp3mi.so

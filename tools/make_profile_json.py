@@ -29,13 +29,13 @@ def main(src, tag):
     kernels = {}
     for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
         n = r["Name"].split("(")[0].replace("void ", "")
-        if n.startswith("k_"):
+        if n.startswith("k_") and n != "k_synth":  # (k_synth generates the workload: not part of a step)
             kernels[n] = {"calls_in_trace": int(r["Calls"]), "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
                           "total_ms_in_trace": round(float(r["TotalDurationNs"]) / 1e6, 3)}
     f = json.load(open(os.path.join(src, "pmc_fetch.json")))
     w = json.load(open(os.path.join(src, "pmc_write.json")))
     for k in f:
-        if k in w:
+        if k in w and k != "k_synth":
             d = f[k]["dispatches"]
             kernels.setdefault(k, {}).update({
                 "dispatches": d, "FETCH_SIZE_KiB": f[k]["FETCH_SIZE"], "WRITE_SIZE_KiB": w[k]["WRITE_SIZE"],
@@ -45,6 +45,8 @@ def main(src, tag):
         fn = os.path.join(src, "pmc_%s.json" % p)
         if os.path.exists(fn):
             for k, v in json.load(open(fn)).items():
+                if k == "k_synth":
+                    continue
                 kernels.setdefault(k, {}).update({c: x for c, x in v.items() if c != "dispatches"})
     tot_r = sum(v.get("hbm_read_GB_per_step", 0) for v in kernels.values())
     tot_w = sum(v.get("hbm_write_GB_per_step", 0) for v in kernels.values())
