@@ -44,20 +44,21 @@ struct mp3mi_batch {
     int max_frame_bytes;
     hipStream_t stream;      // front stream: feed-forward kernels (and the initial memsets)
     hipStream_t lstream;     // loop stream: k_loop + k_format
-    hipEvent_t ev_front[2];  // front kernels of the chunk in slot i are done
-    hipEvent_t ev_loop[2];   // k_loop of the chunk in slot i is done (slot may be overwritten)
-#define MP3MI_MAX_LOOP_PARTS 4
-    hipEvent_t ev_part[MP3MI_MAX_LOOP_PARTS]; // part p of the last k_loop is done
-    unsigned gate_part[MP3MI_MAX_LOOP_PARTS]; // census value once part p of the last k_loop has started
+    // A batch of more streams than k_loop holds resident is cut into PARTS (contiguous stream ranges); a part's frames of
+    // one chunk are an "item", and the items go through the two HIP streams one after the other (encode_impl).
+    // Per (double-buffer slot, part), index slot * n_parts + part:
+    std::vector<hipEvent_t> ev_front; // the item's front kernels are done
+    std::vector<hipEvent_t> ev_loop;  // its k_loop is done (the slot's region of this part may be overwritten)
+    std::vector<char> slot_used;      // ev_loop has been recorded: the region's last reader is a k_loop that may still run
+    int n_parts, part_streams;
     hipEvent_t ev_done;      // everything of the previous encode call is done
     hipEvent_t ev_hist;      // the front stream's last work of a call (the PCM history hand-over) is enqueued
     bool have_done;
     bool overlap_calls;      // a call's front stream does not wait for the call before it (MP3MI_CALL_OVERLAP=0: it does)
     int slot_base;           // parity of the double-buffer slot the next call's chunk 0 takes
-    bool slot_used[2];       // ev_loop[i] has been recorded: the slot's last reader is a k_loop that may still run
     unsigned *gate_count;    // start census of k_loop's wavefronts (device memory, only ever grows), NULL = gate off
     unsigned gate_total;     // census value once every wavefront launched so far has started
-    unsigned gate_first;     // ... once the first part of the last k_loop has (encode_impl)
+    unsigned gate_first;     // ... the same (kept for the gate's target: the census once the LAST launch is resident)
     int *place_order, *place_cost; // k_loop stream placement (mp3mi_loop_place), NULL = off
     unsigned *place_zero;    // taken[n] + simd_slots + simd_idx + ticket + scan, zeroed before every k_loop
     int n_simd;
@@ -239,18 +240,30 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
         CHK(hipStreamCreateWithPriority(&b->stream, hipStreamDefault, least));
         CHK(hipStreamCreateWithPriority(&b->lstream, hipStreamDefault, greatest));
     }
-    for (int i = 0; i < 2; i++) {
-        CHK(hipEventCreateWithFlags(&b->ev_front[i], hipEventDisableTiming));
-        CHK(hipEventCreateWithFlags(&b->ev_loop[i], hipEventDisableTiming));
+    {   // parts: as few as hold the batch with at most mp3mi_loop_resident() streams each, equal in size (a multiple of
+        // 64: the prep records come in blocks); options.loop_part_streams overrides (tests); options.loop_queue: one
+        // part whatever the size, k_loop in its queue form
+        const int resident = mp3mi_loop_resident();
+        int np = (n_streams + resident - 1) / resident;
+        int ps = ((n_streams + np - 1) / np + 63) / 64 * 64;
+        if (opt.loop_part_streams >= 64) ps = opt.loop_part_streams;
+        if (opt.loop_queue) ps = (n_streams + 63) / 64 * 64;
+        b->part_streams = ps;
+        b->n_parts = (n_streams + ps - 1) / ps;
+        b->ev_front.assign(2 * (size_t) b->n_parts, (hipEvent_t) 0);
+        b->ev_loop.assign(2 * (size_t) b->n_parts, (hipEvent_t) 0);
+        b->slot_used.assign(2 * (size_t) b->n_parts, 0);
+        for (size_t i = 0; i < b->ev_front.size(); i++) {
+            CHK(hipEventCreateWithFlags(&b->ev_front[i], hipEventDisableTiming));
+            CHK(hipEventCreateWithFlags(&b->ev_loop[i], hipEventDisableTiming));
+        }
     }
     CHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
-    for (int i = 0; i < MP3MI_MAX_LOOP_PARTS; i++) { CHK(hipEventCreateWithFlags(&b->ev_part[i], hipEventDisableTiming)); b->gate_part[i] = 0; }
     CHK(hipEventCreateWithFlags(&b->ev_hist, hipEventDisableTiming));
     b->have_done = false;
     b->last_slot = 0;
     b->overlap_calls = opt.call_overlap != 0;
     b->slot_base = 0;
-    b->slot_used[0] = b->slot_used[1] = false;
     b->test_flags = (int) (opt.test_flags & 15u) | ((opt.test_flags & MP3MI_TEST_CW_EXACT) ? 16 : 0);
     b->prep_exact = (opt.test_flags & MP3MI_TEST_PREP_EXACT) ? 1 : 0;
     b->hdr_flags = 0;
@@ -383,8 +396,9 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
                     b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg, b->voided, b->status_dev};
     for (void *p : bufs)
         if (p) hipFree(p);
-    for (int i = 0; i < MP3MI_MAX_LOOP_PARTS; i++) hipEventDestroy(b->ev_part[i]);
-    hipEvent_t evs[] = {b->ts[0].ev0, b->ts[0].ev1, b->ts[1].ev0, b->ts[1].ev1, b->ev_front[0], b->ev_front[1], b->ev_loop[0], b->ev_loop[1], b->ev_done, b->ev_hist};
+    for (hipEvent_t e : b->ev_front) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_loop) if (e) hipEventDestroy(e);
+    hipEvent_t evs[] = {b->ts[0].ev0, b->ts[0].ev1, b->ts[1].ev0, b->ts[1].ev1, b->ev_done, b->ev_hist};
     for (hipEvent_t e : evs)
         if (e) hipEventDestroy(e);
     for (int k = 0; k < 2; k++)
@@ -559,24 +573,158 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipGetLastError());
     }
     const int nchunks = (n_frames + b->chunk_frames - 1) / b->chunk_frames;
+    const int P = b->n_parts, n_items = nchunks * P;
     if (harvest_timing(b, (int) (b->call_no & 1)) != MP3MI_OK) return MP3MI_ERR_HIP; // (the call before the last one)
     mp3mi_batch::timing_set &ts = b->ts[b->call_no & 1];
-    while ((int) ts.loop_ev.size() < 2 * nchunks) {
+    while ((int) ts.loop_ev.size() < 2 * n_items) {
         hipEvent_t e;
         CHK(hipEventCreate(&e));
         ts.loop_ev.push_back(e);
     }
-    ts.launches = nchunks;
+    ts.launches = n_items;
     ts.kernels = 0;
     CHK(hipEventRecord(ts.ev0, b->stream));
-    // Two kinds of front-end kernels cannot share the chip with k_loop: k_fft takes a whole CU's LDS
-    // per workgroup, and k_psy's wavefronts live for the whole chunk (serial over granules), so
-    // whichever is in flight when k_loop is launched keeps k_loop's wavefronts from starting.  Both
-    // therefore run one chunk ahead, BEFORE k_loop of the previous chunk starts (stage X); what
-    // overlaps with k_loop(c) is stage Y of chunk c+1: k_filter, k_mdct, k_prep -- short-lived
-    // single-wave workgroups that fit next to k_loop's and yield freed slots to it.
+    // The unit of scheduling is an ITEM: the frames of one chunk of one PART of the streams (a batch of at most
+    // mp3mi_loop_resident() streams -- 4096 on an MI355X -- is one part).  Items go through the pipeline one after the
+    // other, chunk by chunk and within a chunk part by part, exactly as the chunks of a one-part batch do: every buffer
+    // is stream-major, so an item is the same kernels with their pointers advanced to the part's first stream.
+    //
+    //   front stream:  FFT(k+1) | gate | k_cw k_part k_psy (k+1) | k_filter k_mdct k_prep (k+1) | FFT(k+2) ...
+    //   loop stream:              k_rank k_loop(k) ................................................ k_format(k)
+    //
+    // Two kinds of front-end kernels cannot share the chip with k_loop as it starts: k_fft takes a whole CU's LDS per
+    // workgroup, and k_psy's wavefronts live long (serial over granules), so whichever is in flight when a k_loop is
+    // launched keeps its workgroups from starting.  The FFTs of item k+1 therefore run BETWEEN two k_loop launches; all
+    // the rest of item k+1 runs beside k_loop(k), behind a gate that lets k_loop become resident first, in the order of
+    // how little each loses at one wavefront per SIMD; what does not fit beside k_loop (the tail of k_mdct, k_prep)
+    // runs behind it, alone and fast.  (Until round 3 the feed-forward kernels ran over ALL streams of a chunk and only
+    // k_loop was cut into parts, with a hand-made assignment of kernels to parts for two and for four parts; with three
+    // parts k_psy was still running when the second part started and that part took 65 ms instead of 37:
+    // profiles/r03_experiments.txt.  12 288 / 16 384 / 20 000 streams: 5.8 -> ... M frames/s.)
     const int cfr = (n_frames + nchunks - 1) / nchunks; // equal chunks: a short last one would run without overlap
-    auto geom_of = [&](int c) {
+    struct item_view {
+        mp3mi_geom g;      // of the part: n_streams, n_samples / hist / out_base advanced
+        int slot, ev;      // double-buffer slot of the chunk; index of the (slot, part) events
+        size_t s0, rec0;   // first stream; (granule, channel) records of the chunk before the part
+    };
+    auto view = [&](int k) {
+        item_view v;
+        const int c = k / P, part = k % P;
+        const int f0 = c * cfr;
+        const int nf = (n_frames - f0 < cfr) ? n_frames - f0 : cfr;
+        v.s0 = (size_t) part * (size_t) b->part_streams;
+        const int n = S - (int) v.s0 < b->part_streams ? S - (int) v.s0 : b->part_streams;
+        mp3mi_geom g = mp3mi_make_geom(n, C, b->rate_idx, n_frames, f0, nf);
+        g.test_flags = b->test_flags;
+        g.n_samples = n_samples_dev ? n_samples_dev + v.s0 : NULL;
+        g.hdr_flags |= b->hdr_flags;
+        g.hdr_mode = b->hdr_mode;
+        g.crc = b->crc;
+        g.fabs0 = fabs0;
+        g.hist = b->pcm_hist + v.s0 * MP3MI_PCM_HIST * (size_t) C;
+        g.out_base = whole_file ? NULL : b->out_base + v.s0;
+        g.whole_file = whole_file ? 1 : 0;
+        v.g = g;
+        v.slot = (c + b->slot_base) & 1;
+        v.ev = v.slot * P + part;
+        v.rec0 = v.s0 * 2 * (size_t) nf * (size_t) C;
+        return v;
+    };
+    const size_t pcm_pitch = (size_t) n_frames * 1152 * (size_t) C; // int16 per stream in the caller's buffer
+    const size_t psy_state_bytes = mp3mi_psy_state_size() * (size_t) C, loop_state_bytes = mp3mi_loop_state_size();
+    // which: 1 the FFTs, 2 k_cw, 4 the partition sums (k_part), 8 k_psy
+    auto stage_x = [&](int k, int which) -> int {
+        const item_view v = view(k);
+        const size_t r = v.rec0;
+        if (which & 3) {
+            mp3mi_launch_fft(b->T, v.g, pcm_dev + v.s0 * pcm_pitch, b->energy_l + r * MP3MI_HBLK_P, b->energy_s + r * 3 * MP3MI_HBLK_S,
+                             b->fft_bins + r * MP3MI_FFT_BINS, b->cw_mid + r * 50, b->hist6 + r * 12, b->stream, which & 3);
+            CHK(hipGetLastError());
+        }
+        // the k_loop that read this region of the slot last (two chunks ago, maybe in the call before)
+        if ((which & 8) && b->slot_used[v.ev]) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[v.ev], 0));
+        if (which & 12) {
+            mp3mi_launch_psy(b->T, v.g, b->energy_l + r * MP3MI_HBLK_P, b->energy_s + r * 3 * MP3MI_HBLK_S, b->cw_mid + r * 50, b->hist6 + r * 12,
+                             b->fft_bins + r * MP3MI_FFT_BINS, b->cw_fix, (char *) b->psy_state + v.s0 * psy_state_bytes, b->part_eb + r * MP3MI_PART_P,
+                             b->part_cb + r * MP3MI_PART_P, b->psy[v.slot] + r, b->stream, (which >> 2) & 3);
+            CHK(hipGetLastError());
+        }
+        return MP3MI_OK;
+    };
+    if (stage_x(0, 15) != MP3MI_OK) return MP3MI_ERR_HIP;
+    for (int k = 0; k < n_items; k++) {
+        const item_view v = view(k);
+        const mp3mi_geom &g = v.g;
+        const size_t r = v.rec0;
+        // A part larger than the resident wavefronts (options.loop_queue) runs k_loop in its queue form: every wavefront
+        // takes a fixed share of the streams and stays to the end, so the feed-forward kernels of the next item find no
+        // freed slots beside it, only cycles to take from wavefronts whose share does not shrink (every millisecond of
+        // work beside it cost two to four, measured at 8192 x 383 and 16384 x 278): there stage Y waits for k_loop.
+        bool y_after_loop = mp3mi_loop_waves(g.n_streams) < g.n_streams;
+        if (b->opt.y_after_loop >= 0) y_after_loop = b->opt.y_after_loop != 0;
+        // what of stage X runs beside k_loop (bits as for stage_x): all but the FFTs -- k_cw, k_part, k_psy are small in
+        // registers and LDS, the item's FFTs were done before that launch started, and the region k_psy writes was read
+        // last by the launch before it: 238.2 vs 247.2 ms per 4096 x 383 step with them between the launches.
+        // options.psy_beside = 0 / 1 / 2: nothing / all three / k_psy only.
+        int beside = y_after_loop ? 0 : 14;
+        if (b->opt.psy_beside >= 0) beside = b->opt.psy_beside == 2 ? 8 : (b->opt.psy_beside ? 14 : 0);
+        // ---- front stream: everything that does not depend on the bit reservoir ----
+        if (k >= 1 && y_after_loop) { // (the k_loop before this item's: view(k - 1))
+            const item_view pv = view(k - 1);
+            CHK(hipStreamWaitEvent(b->stream, b->ev_loop[pv.ev], 0));
+        } else if (k >= 1 && b->gate_count) // this item's kernels run behind k_loop(k - 1), once that is resident (<= 300 us)
+            mp3mi_launch_gate(b->gate_count, b->gate_first - 16u, 30000u, b->stream);
+        if (beside && k >= 1 && stage_x(k, beside) != MP3MI_OK) return MP3MI_ERR_HIP;
+        mp3mi_launch_filter(b->T, g, pcm_dev + v.s0 * pcm_pitch, b->sbs + v.s0 * (size_t) (g.n_gran + 1) * (size_t) C * 576,
+                            b->debug ? b->sb_dbg + r * 576 : NULL, b->stream);
+        CHK(hipGetLastError());
+        mp3mi_launch_mdct(b->T, g, b->psy[v.slot] + r, b->sbs + v.s0 * (size_t) (g.n_gran + 1) * (size_t) C * 576, b->xr[v.slot] + r * 576, b->stream);
+        CHK(hipGetLastError());
+        mp3mi_launch_prep(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r / 64, b->prep_exact, b->stream);
+        CHK(hipGetLastError());
+        if (k + 1 < n_items) {
+            const item_view nv = view(k + 1);
+            const bool ny = b->opt.y_after_loop >= 0 ? b->opt.y_after_loop != 0 : mp3mi_loop_waves(nv.g.n_streams) < nv.g.n_streams;
+            int nbeside = ny ? 0 : 14;
+            if (b->opt.psy_beside >= 0) nbeside = b->opt.psy_beside == 2 ? 8 : (b->opt.psy_beside ? 14 : 0);
+            if (stage_x(k + 1, 15 & ~nbeside) != MP3MI_OK) return MP3MI_ERR_HIP;
+        }
+        CHK(hipEventRecord(b->ev_front[v.ev], b->stream));
+        // ---- loop stream: the serial search and the formatter ----
+        CHK(hipStreamWaitEvent(b->lstream, b->ev_front[v.ev], 0));
+        CHK(hipEventRecord(ts.loop_ev[2 * k], b->lstream));
+        {
+            const int n = g.n_streams;
+            b->gate_total += (unsigned) mp3mi_loop_waves(n);
+            b->gate_first = b->gate_total; // the census once this launch is resident: the next item's kernels start behind it
+            mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
+            if (b->place_order) { // rank the part's streams by their cost in the previous chunk, hand the tables to k_loop
+                mp3mi_launch_rank(b->place_cost + v.s0, b->place_order + v.s0, n, b->lstream);
+                CHK(hipGetLastError());
+                CHK(hipMemsetAsync(b->place_zero, 0, sizeof(unsigned) * ((size_t) S + 2 * MP3MI_PLACE_KEYS + 2), b->lstream));
+                place.order = b->place_order + v.s0; place.cost = b->place_cost + v.s0; place.taken = b->place_zero;
+                place.simd_slots = b->place_zero + S; place.simd_idx = place.simd_slots + MP3MI_PLACE_KEYS;
+                place.ticket = place.simd_idx + MP3MI_PLACE_KEYS; place.scan = place.ticket + 1;
+                place.n_simd = b->n_simd;
+            }
+            if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
+            mp3mi_launch_loop(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r / 64, b->bits_per_frame + v.s0,
+                              (char *) b->loop_state + v.s0 * loop_state_bytes, b->ix + r * 576, b->side + v.s0 * (size_t) g.nf,
+                              b->gate_count, place, b->lstream);
+            CHK(hipGetLastError());
+        }
+        ts.kernels += 1;
+        CHK(hipEventRecord(ts.loop_ev[2 * k + 1], b->lstream));
+        CHK(hipEventRecord(b->ev_loop[v.ev], b->lstream));
+        b->slot_used[v.ev] = 1;
+        mp3mi_launch_format(b->T, g, b->ix + r * 576, b->side + v.s0 * (size_t) g.nf, b->bits_per_frame + v.s0, b->bitrate_index + v.s0,
+                            out_dev + v.s0 * out_stride, out_stride, out_len_dev + v.s0, (int32_t *) ((char *) b->loop_state + v.s0 * loop_state_bytes),
+                            (int) (loop_state_bytes / 4), b->voided, b->lstream);
+        CHK(hipGetLastError());
+        b->last_nf = g.nf;
+        b->last_slot = v.slot;
+    }
+    auto geom_of = [&](int c) { // the whole batch's geometry of chunk c (hand-over kernels below)
         const int f0 = c * cfr;
         const int nf = (n_frames - f0 < cfr) ? n_frames - f0 : cfr;
         mp3mi_geom g = mp3mi_make_geom(S, C, b->rate_idx, n_frames, f0, nf);
@@ -591,132 +739,6 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         g.whole_file = whole_file ? 1 : 0;
         return g;
     };
-    // With more streams than resident wavefronts k_loop runs in its queue form: every wavefront takes a fixed share
-    // of the streams and stays to the end, so the feed-forward kernels of the next chunk find no freed slots to run
-    // in, only cycles to take from wavefronts whose share does not shrink -- the kernel ends with its slowest
-    // wavefront, and every millisecond of work beside it cost two to four (measured at 8192 x 383 and 16384 x 278).
-    // There stage Y waits for k_loop of the chunk before.  (MP3MI_Y_AFTER_LOOP=0 / 1 overrides.)
-    // Normally it does not come to that: a batch of more streams than k_loop holds resident (4096 on an MI355X) goes
-    // through k_loop in PARTS -- contiguous stream ranges, one launch each, back to back on the loop stream -- each
-    // a launch of the one-stream-per-wavefront kernel with freed slots for the next chunk's kernels, placement and
-    // pacing as for a batch of that size.  Every buffer is stream-major, so a part is the same launch with its
-    // pointers advanced.  (MP3MI_LOOP_PARTS=0: one launch of the queue form.)
-    int loop_parts = (S + mp3mi_loop_resident() - 1) / mp3mi_loop_resident();
-    if (b->opt.loop_queue) loop_parts = 1;
-    int part_streams = ((S + loop_parts - 1) / loop_parts + 63) / 64 * 64; // (whole blocks of 64 prep records)
-    if (b->opt.loop_part_streams >= 64) { // (tests: parts of a given size, whatever the device holds)
-        part_streams = b->opt.loop_part_streams;
-        loop_parts = (S + part_streams - 1) / part_streams;
-    }
-    bool y_after_loop = loop_parts == 1 && mp3mi_loop_waves(S) < S;
-    if (b->opt.y_after_loop >= 0) y_after_loop = b->opt.y_after_loop != 0;
-    // which: 1 the FFTs, 2 k_cw, 4 the partition sums (k_part), 8 k_psy
-    auto stage_x = [&](int c, int which) -> int {
-        const mp3mi_geom g = geom_of(c);
-        const int xs = (c + b->slot_base) & 1;
-        // (k_loop in parts: holding the FFTs back until the last part has ended was tried: 471 vs 462 ms at 16384 x 278)
-        if (which & 3) {
-            mp3mi_launch_fft(b->T, g, pcm_dev, b->energy_l, b->energy_s, b->fft_bins, b->cw_mid, b->hist6, b->stream, which & 3);
-            CHK(hipGetLastError());
-        }
-        if ((which & 8) && b->slot_used[xs]) CHK(hipStreamWaitEvent(b->stream, b->ev_loop[xs], 0)); // the k_loop that read this slot last (two chunks ago, maybe in the call before)
-        if (which & 12) {
-            mp3mi_launch_psy(b->T, g, b->energy_l, b->energy_s, b->cw_mid, b->hist6, b->fft_bins, b->cw_fix, b->psy_state, b->part_eb, b->part_cb, b->psy[xs], b->stream, (which >> 2) & 3);
-            CHK(hipGetLastError());
-        }
-        return MP3MI_OK;
-    };
-    // Only the FFTs (a whole CU's LDS per workgroup) have to run between two k_loop launches.  What follows them --
-    // k_cw, k_part, k_psy: 4.8 ms per chunk, small in registers and LDS -- runs BESIDE the k_loop launch before, in
-    // front of stage Y, behind the same gate: the chunk's FFTs were done before that launch started, and the slot
-    // k_psy writes was read last by the launch before it.  238.2 vs 247.2 ms per 4096 x 383 step: k_loop takes 3 ms
-    // longer and 9 ms of serial phase are gone.  With k_loop in parts they go beside the first part and stage Y moves
-    // on by one part -- good with four parts (16384 x 278: 453.6 vs 462.5 ms), bad with two (8192 x 383: 540 vs 502
-    // ms: k_psy, started behind k_cw and k_part, is still running when the first part ends and keeps the second
-    // part's workgroups out).
-    // what of stage X runs beside k_loop (bits as for stage_x): all but the FFTs; with two parts k_psy only (k_cw and
-    // k_part stay between the launches: 483.7 vs 497.6 ms at 8192 x 383 with nothing beside, 540 with all three).
-    // MP3MI_PSY_BESIDE = 0 / 1 / 2: nothing / all three / k_psy only.
-    int beside = y_after_loop ? 0 : (loop_parts == 2 ? 8 : 14);
-    if (b->opt.psy_beside >= 0) beside = b->opt.psy_beside == 2 ? 8 : (b->opt.psy_beside ? 14 : 0);
-    const bool psy_beside = beside != 0;
-    if (stage_x(0, 15) != MP3MI_OK) return MP3MI_ERR_HIP;
-    for (int c = 0; c < nchunks; c++) {
-        const int slot = (c + b->slot_base) & 1;
-        const mp3mi_geom g = geom_of(c);
-        // ---- front stream: everything that does not depend on the bit reservoir ----
-        if (c >= 1 && y_after_loop) // (queue form of k_loop: its wavefronts stay to the end, nothing is gained beside them)
-            CHK(hipStreamWaitEvent(b->stream, b->ev_loop[slot ^ 1], 0));
-        else if (c >= 1 && b->gate_count) // stage Y of this chunk runs behind k_loop(c-1), once that is resident (<= 300 us)
-            mp3mi_launch_gate(b->gate_count, b->gate_first - 16u, 30000u, b->stream);
-        // k_loop in parts: the three kernels of stage Y are spread over the parts -- k_filter beside the first, k_mdct
-        // beside the second, k_prep beside the third (or the last) -- each held back until ITS part is resident: the
-        // part before it has ended (an event) and the part's wavefronts have started (the census, bounded wait).
-        // Queued earlier, the single-wave workgroups take every slot the ending part frees and keep the next part's
-        // four-wave workgroups out: k_loop's second part then ran 36 ms instead of 16 at 8192 x 42.
-        if (psy_beside && c >= 1 && stage_x(c, beside) != MP3MI_OK) return MP3MI_ERR_HIP;
-        auto behind_part = [&](int p) -> int {
-            if (c < 1 || y_after_loop || !b->gate_count || loop_parts < 2) return MP3MI_OK;
-            if (p > loop_parts - 1) p = loop_parts - 1;
-            if (p < 1) return MP3MI_OK;
-            CHK(hipStreamWaitEvent(b->stream, b->ev_part[p - 1], 0));
-            mp3mi_launch_gate(b->gate_count, b->gate_part[p] - 16u, 30000u, b->stream);
-            CHK(hipGetLastError());
-            return MP3MI_OK;
-        };
-        // (with k_cw / k_part / k_psy beside the first part, the others move on by one: k_filter beside the second, ...)
-        const int shift = (psy_beside && c >= 1) ? 1 : 0;
-        if (shift && behind_part(1) != MP3MI_OK) return MP3MI_ERR_HIP;
-        mp3mi_launch_filter(b->T, g, pcm_dev, b->sbs, b->debug ? b->sb_dbg : NULL, b->stream);
-        CHK(hipGetLastError());
-        if (loop_parts > 1 + shift && behind_part(1 + shift) != MP3MI_OK) return MP3MI_ERR_HIP;
-        mp3mi_launch_mdct(b->T, g, b->psy[slot], b->sbs, b->xr[slot], b->stream);
-        CHK(hipGetLastError());
-        if (loop_parts > 2 + shift && behind_part(2 + shift) != MP3MI_OK) return MP3MI_ERR_HIP;
-        mp3mi_launch_prep(b->T, g, b->xr[slot], b->psy[slot], b->prep[slot], b->prep_exact, b->stream);
-        CHK(hipGetLastError());
-        if (c + 1 < nchunks && stage_x(c + 1, 15 & ~beside) != MP3MI_OK) return MP3MI_ERR_HIP;
-        CHK(hipEventRecord(b->ev_front[slot], b->stream));
-        // ---- loop stream: the serial search and the formatter ----
-        CHK(hipStreamWaitEvent(b->lstream, b->ev_front[slot], 0));
-        CHK(hipEventRecord(ts.loop_ev[2 * c], b->lstream));
-        for (int part = 0; part < loop_parts; part++) {
-            const int s0 = part * part_streams, n = S - s0 < part_streams ? S - s0 : part_streams;
-            if (n <= 0) break;
-            const size_t rec0 = (size_t) s0 * 2 * (size_t) g.nf * (size_t) C; // (granule, channel) records before the part
-            mp3mi_geom gp = g;
-            gp.n_streams = n;
-            if (gp.n_samples) gp.n_samples += s0;
-            b->gate_total += (unsigned) mp3mi_loop_waves(n);
-            if (part == 0) b->gate_first = b->gate_total; // the census once the first part is resident: stage Y of the next chunk starts behind it
-            if (part < MP3MI_MAX_LOOP_PARTS) b->gate_part[part] = b->gate_total;
-            mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
-            if (b->place_order) { // rank the streams by their cost in the previous chunk, hand the tables to k_loop
-                mp3mi_launch_rank(b->place_cost + s0, b->place_order + s0, n, b->lstream);
-                CHK(hipGetLastError());
-                CHK(hipMemsetAsync(b->place_zero, 0, sizeof(unsigned) * ((size_t) S + 2 * MP3MI_PLACE_KEYS + 2), b->lstream));
-                place.order = b->place_order + s0; place.cost = b->place_cost + s0; place.taken = b->place_zero;
-                place.simd_slots = b->place_zero + S; place.simd_idx = place.simd_slots + MP3MI_PLACE_KEYS;
-                place.ticket = place.simd_idx + MP3MI_PLACE_KEYS; place.scan = place.ticket + 1;
-                place.n_simd = b->n_simd;
-            }
-            if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
-            mp3mi_launch_loop(b->T, gp, b->xr[slot] + rec0 * 576, b->psy[slot] + rec0, b->prep[slot] + rec0 / 64, b->bits_per_frame + s0,
-                              (char *) b->loop_state + (size_t) s0 * mp3mi_loop_state_size(), b->ix + rec0 * 576, b->side + (size_t) s0 * (size_t) g.nf,
-                              b->gate_count, place, b->lstream);
-            CHK(hipGetLastError());
-            if (part < MP3MI_MAX_LOOP_PARTS) CHK(hipEventRecord(b->ev_part[part], b->lstream));
-        }
-        ts.kernels += loop_parts;
-        CHK(hipEventRecord(ts.loop_ev[2 * c + 1], b->lstream));
-        CHK(hipEventRecord(b->ev_loop[slot], b->lstream));
-        b->slot_used[slot] = true;
-        mp3mi_launch_format(b->T, g, b->ix, b->side, b->bits_per_frame, b->bitrate_index, out_dev, out_stride,
-                            out_len_dev, (int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->voided, b->lstream);
-        CHK(hipGetLastError());
-        b->last_nf = g.nf;
-        b->last_slot = slot;
-    }
     {   // hand over to the next call: PCM history (front stream: behind the last kernels that read the old one) and,
         // for a streaming call, what became final / what waits (loop stream: behind the last k_format)
         const mp3mi_geom g = geom_of(0);
