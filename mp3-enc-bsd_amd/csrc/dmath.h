@@ -528,5 +528,11 @@ DM_FN int dm_float_rounding_safe_ulps(double v, long long ulps) /* ulps of v (2^
     return (d < 0 ? -d : d) > ulps;
 }
 DM_FN int dm_float_rounding_safe(double v) { return dm_float_rounding_safe_ulps(v, 64); }
+/* distance of v from the nearest midpoint of two floats, in ulps of v (diagnostics) */
+DM_FN long long dm_float_midpoint_distance_ulps(double v)
+{
+    const long long d = (dm_bits(v) & 0x1fffffffLL) - 0x10000000LL;
+    return d < 0 ? -d : d;
+}
 
 #endif

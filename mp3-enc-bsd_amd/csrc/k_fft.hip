@@ -442,6 +442,12 @@ MP3MI_DEVFN void cw_bin(float re, float im, bool exact, float *energy, float *ph
     float ph = 0.0f;
     if (!low) {
         const double y = -(double) im, x = (double) re;
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        if (!EXACT && y != 0.0 && x != 0.0) { // site 1: phi = (float) atan2(-im, re); a libm within one ulp of the exact value
+            const long long dd = dm_float_midpoint_distance_ulps(dm_atan2(y, x));
+            ULP_CENSUS(UC_PHASE, dd <= 1, dd <= (1LL << 20));
+        }
+#endif
         if (EXACT || y == 0.0 || x == 0.0) ph = (float) dm_atan2(y, x);
         else {
             const double v = dm_atan2_fast(y, x);
@@ -507,7 +513,7 @@ MP3MI_DEVFN void cw_record(const float *__restrict__ bins, double *__restrict__ 
         // stationary bin): the reference subtracts a product from itself, whatever its libm returns for the sine --
         // its c_w is +0 exactly, as ours is.  -0.0 tells k_part that this zero is not a first-tier estimate (it adds
         // like +0.0 there): without it every record of a silent stream would go through the second tier.
-        if (FASTSC && r2 == r_prime && phi2 == phi_prime) cw = -0.0;
+        if (r2 == r_prime && phi2 == phi_prime) cw = -0.0;
         cw_mid[rec * 50 + lane] = cw;
     } else if (lane < 56 && FASTSC) { // (the same in both tiers: written once)
         hist6[rec * 12 + lane - 50] = (float) __builtin_sqrt((double) e[0]); // r, src/l3psy.c:500
@@ -582,3 +588,5 @@ void mp3mi_launch_cw_fix(const mp3mi_geom &g, const float *bins, double *cw_mid,
 {
     hipLaunchKernelGGL(k_cw_fix, dim3(2048), dim3(64), 0, st, bins, cw_mid, hist6, (g.test_flags >> 1) & 1, fix);
 }
+
+ULP_CENSUS_ACCESSOR(mp3mi_debug_ulp_census_fft)

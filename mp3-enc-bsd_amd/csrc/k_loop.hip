@@ -813,6 +813,12 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                     max_bits = mb > 4095 ? 4095 : mb;
                     if (ResvMax != 0) {
                         const int more_bits = (int) (po->pe * 3.1 - (double) mb);
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+                        if (lane == 0) { // site 3b: (int)(pe * 3.1 - mean_bits); pe within 1.8e-12 of the reference's (k_psy.hip)
+                            const double t = po->pe * 3.1 - (double) mb, fr = __builtin_fabs(t - __builtin_rint(t));
+                            ULP_CENSUS(UC_PE_RESV, fr <= 6e-12, fr <= 6e-12 * 1048576.0);
+                        }
+#endif
                         int add_bits = 0;
                         if (more_bits > 100) {
                             const int frac = (ResvSize * 6) / 10;
@@ -1287,3 +1293,5 @@ void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_tick
 {
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, count, target, max_ticks);
 }
+
+ULP_CENSUS_ACCESSOR(mp3mi_debug_ulp_census_loop)

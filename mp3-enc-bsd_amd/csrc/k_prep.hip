@@ -39,6 +39,12 @@ struct __attribute__((aligned(16))) prep_d2 { double x, y; };
 
 MP3MI_DEVFN int prep_ilog2(const mp3mi_tables *T, double v) // (int)(log(v)/log(2)), src/loop.c:633-667
 {
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+    if (v != 0.0) { // site 5: (int)(log(v) / log(2)): a log one ulp off moves the quotient by two of its ulps
+        const double q = dm_log(v) / T->log2, fr = __builtin_fabs(q - __builtin_rint(q)), u = __builtin_fabs(q) * 0x1p-52;
+        ULP_CENSUS(UC_SCFSI_LOG, fr <= 2.0 * u, fr <= 2.0 * u * 1048576.0);
+    }
+#endif
     return (v == 0.0) ? 0 : (int) (dm_log(v) / T->log2);
 }
 
@@ -153,6 +159,12 @@ __global__ void __launch_bounds__(64, 3) k_prep(const mp3mi_tables *__restrict__
             const double sfm = dm_exp(S.slog / 576.0) / (S.tot / 576.0);
             const double v = 8.0 * dm_log(sfm);
             tp = (v < 0) ? (int) (v - 0.5) : (int) (v + 0.5); // nint, src/loop.c:2020
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+            if (exact && live) { // site 4: nint(8 ln sfm) from 576 logs, an exp and a log, each one ulp off: < 1e-12 absolute (k_prep.hip, header)
+                const double av = __builtin_fabs(v), fr = __builtin_fabs((av - __builtin_floor(av)) - 0.5);
+                ULP_CENSUS(UC_QUANTANF, fr <= 1e-12, fr <= 1e-12 * 1048576.0);
+            }
+#endif
             if (tp < -100) tp = -100;
             if (!exact) { // is nint(v) independent of the last bits of the logs?
                 const double av = __builtin_fabs(v), fr = av - __builtin_floor(av);
@@ -191,3 +203,5 @@ void mp3mi_launch_prep(const mp3mi_tables *T, const mp3mi_geom &g, const double 
     const size_t n_rec = (size_t) g.n_streams * (size_t) g.n_gran * (size_t) g.channels;
     hipLaunchKernelGGL(k_prep, dim3((unsigned) ((n_rec + 63) / 64)), dim3(64), 0, st, T, g, xr, psy, prep, force_exact);
 }
+
+ULP_CENSUS_ACCESSOR(mp3mi_debug_ulp_census_prep)

@@ -105,6 +105,23 @@ MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, i
         const double d = (double) W.cb + cw * e;
         // (cw == -0.0: k_cw's mark for a c_w that is exactly zero in the reference as well -- nothing to check)
         if (CHECK && dm_bits(cw) != (long long) 0x8000000000000000ull && !part_cw_safe(d, e)) *amb = true;
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        // site 6: the float this step rounds to, with c_w from correctly rounded sines (lines 0..5, and the records that
+        // went through the second tier): could the reference's own sines, one ulp off, round it the other way?
+        if (dm_bits(cw) != (long long) 0x8000000000000000ull && cw != 0.4 && e != 0.0 && Lt.rec[wave_lane_here()] != PART_NO_REC) { // (0.4: the constant of lines 206.., src/l3psy.c:555-556 -- no libm in it; e == 0: d == cb whatever c_w is)
+            const long long bb = dm_bits(d);
+            long long dist = (bb & 0x1fffffffLL) - 0x10000000LL;
+            dist = dist < 0 ? -dist : dist;
+            const bool range = bb >= 0x3810000000000000LL && bb < 0x47f0000000000000LL;
+            // (the band: the reference performs the same operations in the same order, so only its four libm results differ,
+            // by at most one ulp each: c_w moves by < 5e-16 -- 1.6e-16 through t1, t2, the root and the quotient, plus a
+            // few flipped roundings on the way --, d by < 5e-16 e + an ulp of d = (4.5 e / d + 1) ulps; 4.5 e + 2 d is counted)
+            ULP_CENSUS(UC_CW_STEP, !CHECK && range && !((double) dist * d > 4.5 * e + 2.0 * d), !CHECK && range && !((double) dist * d > (4.5 * e + 2.0 * d) * 1048576.0));
+            // (sums below the floats' normal range -- a line-0 energy of next to nothing -- are counted apart: the grid there
+            // is absolute, 2^-149, and a relative 1e-16 does not reach a midpoint; k_part sends them to the second tier all the same)
+            if (!CHECK && !range) ULP_CENSUS(UC_CW_RANGE, 0, 0);
+        }
+#endif
         W.cb = (float) d;
         while (W.b < MP3MI_CBANDS && j + 1 == W.pend) { // closes this partition and any empty ones after it
             if (W.b == 0) { W.eb0 = W.eb; W.cb0 = W.cb; }
@@ -178,7 +195,8 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
         const double t1 = (double) rn * cn - r_prime * cp;
         const double t2 = (double) rn * sn - r_prime * sp;
         const double t3 = (double) rn + __builtin_fabs(r_prime);
-        const double cw = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
+        double cw = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
+        if ((double) rn == r_prime && (double) pn == phi_prime) cw = -0.0; // an exact zero in the reference too (k_fft.hip, cw_record)
         part_line<false>(T, W, Lt, j, er[j], cw, eb_all, cb_all, &amb); // (correctly rounded sines: nothing to check)
     }
     // lines 6..511 in blocks of 32 = one 128-byte line of the energy row; the unpredictability of lines
@@ -367,6 +385,21 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
             }
             if (tier == 0 && !wave_any(pr != 0.0 && !dm_float_rounding_safe_ulps(pr, 256))) break;
         }
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        if (b < MP3MI_CBANDS && (double) ecb != 0.0) { // site 2: nb = (float)(ecb norm exp(-snr ln10/10)), log and exp one ulp off: 20 ulps of the product
+            double cbb = ctb / (double) ecb;
+            if (cbb < 0.01) cbb = 0.01;
+            cbb = dm_log(cbb);
+            double tbb = -0.299 - 0.43 * cbb;
+            tbb = (0.0 > tbb) ? 0.0 : tbb;
+            tbb = (1.0 < tbb) ? 1.0 : tbb;
+            double snr = 29.0 * tbb + 6.0 * (1.0 - tbb);
+            snr = (minval > snr) ? minval : snr;
+            const double prx = ((double) ecb * norm_l) * dm_exp(-snr * R_LN_TO_LOG10);
+            const long long dd = dm_float_midpoint_distance_ulps(prx);
+            ULP_CENSUS(UC_NB, dd <= 20, dd <= (20LL << 20));
+        }
+#endif
         if (b < MP3MI_CBANDS) {
             const double a2 = 2.0 * nb_1, a16 = 16.0 * nb_2;
             const double inner = (a2 < a16) ? a2 : a16;
@@ -389,6 +422,10 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
         wave_sync();
         const double pe = L.pe;
         const bool attack = !(pe < 1800.0);
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        // site 3a: pe is a sum of 63 terms numlines * log(..); every log one ulp off moves it by < 513 * 2^-48 = 1.8e-12
+        if (lane == 0) ULP_CENSUS(UC_PE_ATTACK, __builtin_fabs(pe - 1800.0) <= 2e-12, __builtin_fabs(pe - 1800.0) <= 2e-12 * 1048576.0);
+#endif
 
         // block type state machine (src/l3psy.c:651-668, 689-694, 732-739)
         int blocktype, bt_out;
@@ -487,3 +524,5 @@ void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *e
     else
         hipLaunchKernelGGL(k_psy<false>, dim3(grid), dim3(64 * PSY_W), 0, st, T, g, eb_all, cb_all, energy_s, hist6, (mp3mi_psy_state *) psy_state, out);
 }
+
+ULP_CENSUS_ACCESSOR(mp3mi_debug_ulp_census_psy)

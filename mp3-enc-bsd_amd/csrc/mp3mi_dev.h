@@ -205,6 +205,31 @@ typedef struct {
 #define LOOP_FAST_EXP2F(x) __builtin_amdgcn_exp2f(x) /* |x| < 80 here: no denormal range to care for */
 #endif
 
+/* Diagnostic build only (-DMP3MI_ULP_CENSUS, tools/gpu_ulp_census.sh; never the product build): how often does a
+ * value that came out of a transcendental sit so close to the rounding or comparison it feeds that a libm which is off by
+ * one ulp -- as glibc's may be -- could decide it differently?  Per site three counters: calls, calls within the band a
+ * one-ulp error of every libm result involved can move the value by ("near"), calls within a band 2^20 times wider
+ * ("wide": the statistics behind an estimate where "near" is too rare to be seen).  DESIGN.md section 2. */
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+enum { UC_PHASE, UC_NB, UC_PE_ATTACK, UC_PE_RESV, UC_QUANTANF, UC_SCFSI_LOG, UC_CW_STEP, UC_CW_RANGE, UC_N };
+static __device__ unsigned long long g_ulp_census[UC_N][3]; /* (one copy per translation unit: no relocatable device code here) */
+/* adds this translation unit's counters to out[UC_N][3] and clears them */
+#define ULP_CENSUS_ACCESSOR(name)                                                                       \
+    extern "C" void name(unsigned long long *out)                                                       \
+    {                                                                                                   \
+        unsigned long long h[UC_N][3], z[UC_N][3] = {};                                                 \
+        hipDeviceSynchronize();                                                                         \
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ulp_census), sizeof(h));                                    \
+        hipMemcpyToSymbol(HIP_SYMBOL(g_ulp_census), z, sizeof(z));                                      \
+        for (int i = 0; i < UC_N; i++) for (int j = 0; j < 3; j++) out[3 * i + j] += h[i][j];          \
+    }
+#define ULP_CENSUS(site, near_, wide_) do { atomicAdd(&g_ulp_census[site][0], 1ull); if (wide_) atomicAdd(&g_ulp_census[site][2], 1ull); \
+                                            if (near_) atomicAdd(&g_ulp_census[site][1], 1ull); } while (0)
+#else
+#define ULP_CENSUS(site, near_, wide_) do { } while (0)
+#define ULP_CENSUS_ACCESSOR(name)
+#endif
+
 /* ---- wave helpers (64 lanes) ---- */
 MP3MI_DEVFN int wave_lane(void) { return (int) (threadIdx.x & 63); }
 /* The lane index behind an optimisation barrier: everything derived from it (addresses, masks) is
