@@ -135,3 +135,36 @@ def test_sincos_fast_error_bound(dm):
     for name in ("sin", "cos"):
         exact, fast = call1(dm, name, x), call1(dm, name + "_fast", x)
         assert np.abs(fast - exact).max() <= 2.0 ** -51
+
+
+def test_sincos_fast_on_the_arguments_k_cw_really_has(dm):
+    """dm_sincos_fast is only ever called with phi2 = a float phase in [-pi, pi] and phi' = 2 phi0 - phi2 (|.| <= 3 pi),
+    both float-derived (k_fft.hip, cw_record).  Instead of random doubles: (a) float phases on a stride through ALL
+    floats of [0, pi] by their bit patterns (every 509th: ~2.1 M), both signs, with the phi' they form with another one;
+    (b) a dense grid around every multiple of pi/2 up to 3 pi, where the argument reduction cancels most; (c) the
+    floats next to those multiples.  The bound part_cw_safe builds on is 2^-51 absolute (it assumes twelve times that)."""
+    import mpmath
+    rng = np.random.default_rng(23)
+    hi = int(np.float32(np.pi).view(np.int32))
+    pos = np.arange(0, hi + 1, 509, dtype=np.int64).astype(np.int32).view(np.float32).astype(np.float64)
+    phases = np.concatenate([pos, -pos])
+    partner = rng.permutation(phases)
+    args = [phases, 2.0 * partner - phases]
+    edges = []
+    for k in range(-6, 7):
+        c = k * np.pi / 2
+        args.append(c + np.linspace(-2.0 ** -9, 2.0 ** -9, 20001))
+        f = np.float32(c)
+        near = np.array([np.nextafter(f, np.float32(np.inf)), f, np.nextafter(f, np.float32(-np.inf))], dtype=np.float32).astype(np.float64)
+        edges += [near, 2.0 * near - near[::-1]]
+    x = np.concatenate(args + edges)
+    x = x[np.abs(x) <= 3 * np.pi + 1e-6]
+    for name in ("sin", "cos"):
+        exact, fast = call1(dm, name, x), call1(dm, name + "_fast", x)
+        assert np.abs(fast - exact).max() <= 2.0 ** -51, name
+    # the judge itself (dm_sin / dm_cos, correctly rounded) against mpmath where cancellation is worst
+    mpmath.mp.prec = 200
+    e = np.concatenate(edges)
+    got = call1(dm, "sin", e)
+    worst = max(abs(float(mpmath.sin(mpmath.mpf(float(v))) - mpmath.mpf(float(g)))) / max(abs(float(g)), 2.0 ** -1000) for v, g in zip(e, got))
+    assert worst <= 2.0 ** -53, worst
