@@ -72,8 +72,15 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
     __shared__ filter_lds L;
     const int lane = wave_lane();
     const int C = geo.channels, G1 = geo.n_gran + 1, NS = G1 * 18, NB = (NS + FILT_SLOTS - 1) / FILT_SLOTS;
-    int bid = (int) blockIdx.x;
-    const int ch = bid % C; bid /= C;
+    // The two channels of a stereo stream sit interleaved in the same cache lines, and consecutive workgroups go to
+    // different XCDs (eight L2 caches): the channel is therefore bit 3 of the workgroup index -- workgroups w and w + 8
+    // read the same lines, land on the same XCD a moment apart, and the second finds them in that XCD's L2.
+    int bid = (int) blockIdx.x, ch = 0;
+    if (C == 2) {
+        const int total = (int) gridDim.x, full = total & ~15; // (the last, partial group of 16 falls back to the plain order)
+        if (bid < full) { ch = (bid >> 3) & 1; bid = ((bid >> 4) << 3) | (bid & 7); }
+        else { ch = (bid - full) & 1; bid = (full >> 1) + ((bid - full) >> 1); }
+    }
     const int blk = bid % NB;
     const int s = bid / NB;
     const long n_pitch = (long) geo.n_frames * 1152; // row pitch of the PCM buffer
