@@ -1853,3 +1853,7 @@ size_t mp3o_encode_pcm_ex(int rate_hz, int kbps, int channels, const char *mode,
     mp3o_close(s);
     return len;
 }
+
+/* Layers I and II: the same translation unit, because they share the window, the FFT, the
+ * filterbank and the bit writer above -- as the reference's layers do */
+#include "mp12_oracle.inc"
