@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
     }
     const int blk = bid % NB;
     const int s = bid / NB;
-    const long n_pitch = (long) geo.n_frames * 1152; // row pitch of the PCM buffer
+    const long n_pitch = geo.pcm_pitch ? geo.pcm_pitch : (long) geo.n_frames * 1152; // row pitch of the PCM buffer
     const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch; // valid samples: the rest reads as zero (src/encode.c:162-166)
     const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
     const int16_t *hist = geo.hist ? geo.hist + (size_t) s * MP3MI_PCM_HIST * (size_t) C : NULL;

@@ -16,6 +16,7 @@
 // Algorithmic HBM bytes: 2304 B PCM in (1344-sample window, 58 % shared with neighbours),
 // 4048 B out.
 #include "mp3mi_host.h"
+#include "l12_dev.h"
 #include "dmath.h"
 
 #define R_SQHALF 0.707106781186547524401 /* src/subs.c:27 */
@@ -540,6 +541,129 @@ __global__ void __launch_bounds__(64) k_cw_fix(const float *__restrict__ bins, d
 __global__ void __launch_bounds__(64) k_cw_fix_reset(mp3mi_cw_fixlist *fix, unsigned cap)
 {
     if (threadIdx.x == 0) { fix->count = 0; fix->cap = cap; }
+}
+
+// Layers I and II (l12_dev.h): the 1024-point transform of every PASS of the psychoacoustic model for Layers I / II
+// (src/psy.c:258-270: the same Hann window, the same fft() as Layer III's long transform), one wavefront per
+// (stream, pass) task and all channels, with the same resident butterfly program.  Out: the raw bins of all 513
+// lines, (re, im) rows per (pass, channel) record -- these layers take phase and magnitude of EVERY line
+// (src/psy.c:282-292), not of 156 of them.  Passes before the stream's first sample (q < 0) are not transformed:
+// k12_phase gives them the reference's initial r = phi = 0.
+template <int C, int W>
+__global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict__ T, l12_geom geo,
+                                                  const int16_t *__restrict__ pcm_all, float *__restrict__ bins)
+{
+    __shared__ fft_lds<C, W, MP3MI_FFT_PROG_WORDS> LL;
+    const int lane = wave_lane(), tid = (int) threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    fft_wave_lds<C> &L = LL.w[wv];
+    const int NP = geo.np, n_task = geo.n_streams * NP;
+    const long n_pitch = (long) geo.n_frames * geo.spf;
+    const int lane_swz = MP3MI_FFT_SWZ(lane);
+    {
+        const int nw4 = T->fft_nword_l / 4;
+        const uint4 *src = (const uint4 *) T->fft_prog_l;
+        for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = src[i];
+    }
+    __syncthreads();
+    for (int batch = (int) blockIdx.x; batch * W < n_task; batch += (int) gridDim.x) {
+        int task = batch * W + wv;
+        const bool valid = task < n_task;
+        task = valid ? task : n_task - 1;
+        const int qi = task % NP, s = task / NP;
+        const size_t rec0 = ((size_t) s * NP + qi) * C;
+        const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
+        const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch;
+        const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
+        const long t0 = (long) geo.spp * (q + 1) - geo.span; // time of savebuf[0]  (src/psy.c:258-262)
+        {
+            float wl[16];
+            uint32_t smp[16];
+            fft_load_pcm<C, 16>(pcm, NULL, t0, n_per_ch, lane, smp);
+#pragma unroll
+            for (int k = 0; k < 16; k++) wl[k] = T->window[lane + 64 * k];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                fft_pair<C> v;
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    v.c[c] = wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16)); // src/psy.c:264
+                *(fft_pair<C> *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(64 * k)) * C) = v;
+            }
+        }
+        wave_sync();
+        fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
+        // bins 0 and 512 are real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x) (src/subs.c:58, 93)
+#pragma unroll 3
+        for (int i = lane; i < L12_HBLK; i += 64) {
+            fft_pair<C> re, im;
+            fft_bin<C>(L.x, T->fft_rd_l[i], &re, &im);
+            if (valid && q >= 0) {
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    float *o = bins + (rec0 + c) * (2 * L12_ROW);
+                    o[i] = re.c[c];
+                    o[L12_ROW + i] = (i == 0 || i == 512) ? -0.0f : im.c[c];
+                }
+            }
+        }
+        wave_sync(); // the spectrum is dead: the next task's samples take its place
+    }
+}
+
+// energy, magnitude and phase of every line of a (pass, channel) record (src/subs.c:53-123, src/psy.c:285-286), one
+// wavefront per record: erp[rec] = {energy, r = (float) sqrt((double) energy), phi}, rows of L12_ROW floats.  The phases
+// in two tiers, as k_cw's (cw_bin).  A pass before the stream's first sample has the reference's initial r = phi = 0
+// (src/psy.c:158-162; its energy is never looked at).
+__global__ void __launch_bounds__(64) k12_phase(l12_geom geo, const float *__restrict__ bins, float *__restrict__ erp)
+{
+    const int lane = wave_lane();
+    const size_t rec = blockIdx.x;
+    const int qi = (int) ((rec / (size_t) geo.channels) % (size_t) geo.np);
+    const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
+    const float *b = bins + rec * (2 * L12_ROW);
+    float *o = erp + rec * (3 * L12_ROW);
+    const int force_exact = (geo.test_flags >> 1) & 1;
+    if (q < 0) {
+        for (int i = lane; i < L12_HBLK; i += 64) { o[i] = 0.0f; o[L12_ROW + i] = 0.0f; o[2 * L12_ROW + i] = 0.0f; }
+        return;
+    }
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+        const int i = lane + 64 * k;
+        const bool on = i < L12_HBLK; // (k = 8: line 512 only)
+        if (!wave_any(on)) break;
+        const float re = on ? b[i] : 1.0f, im = on ? b[L12_ROW + i] : 0.0f;
+        float e, ph;
+        bool unsafe = force_exact != 0;
+        if (!unsafe) cw_bin<false>(re, im, i == 0 || i == 512, &e, &ph, &unsafe);
+        if (wave_any(unsafe)) cw_bin<true>(re, im, i == 0 || i == 512, &e, &ph, &unsafe);
+        if (on) {
+            o[i] = e;
+            o[L12_ROW + i] = (float) __builtin_sqrt((double) e);
+            o[2 * L12_ROW + i] = ph;
+        }
+    }
+}
+
+void mp3mi_launch_l12_phase(const l12_geom &g, const float *bins, float *erp, hipStream_t st)
+{
+    hipLaunchKernelGGL(k12_phase, dim3((unsigned) ((size_t) g.n_streams * g.np * g.channels)), dim3(64), 0, st, g, bins, erp);
+}
+
+void mp3mi_launch_fft12(const mp3mi_tables *T, const l12_geom &g, const int16_t *pcm, float *bins, hipStream_t st)
+{
+    const int n_task = g.n_streams * g.np;
+    int n_cu = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    if (g.channels == 2) {
+        const int W = 12, nb = (n_task + W - 1) / W;
+        hipLaunchKernelGGL((k_fft12<2, W>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, bins);
+    } else {
+        const int W = 16, nb = (n_task + W - 1) / W;
+        hipLaunchKernelGGL((k_fft12<1, W>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, bins);
+    }
 }
 
 #if defined(MP3MI_FFT_PROFILE) && !defined(MP3MI_EMU)

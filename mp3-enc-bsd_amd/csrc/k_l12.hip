@@ -1,0 +1,713 @@
+// Layers I and II (l12_dev.h): psychoacoustic model 2 behind the FFT, and the frame encoder.
+//
+//   k12_psy    one wavefront per (stream, pass, channel) record: the unpredictability of all 513 lines, the partition
+//              sums, spreading, tonality, masking threshold per line and -- Layer II -- the signal-to-mask ratio of
+//              the 32 subbands (src/psy.c:282-386).  Layer I's threshold also looks at the pass before (pre-echo
+//              control, src/psy.c:355-359): k12_psy stores the per-line thresholds and k12_snr1 finishes.
+//   k12_alloc  one wavefront per (stream, frame), a lane per (subband, channel): scale factors, transmission pattern,
+//              joint-stereo bound, the greedy bit allocation, CRC, quantisation, and the frame's bits assembled in LDS
+//              (src/encode.c:512-1416, src/common.c:1251-1327).
+//
+// Floating point: the reference's types expression by expression (FLOAT = float, FLT_EVAL_METHOD 0, no contraction).
+// Run-time transcendentals (sin cos log exp on data) come from dmath.h in two tiers, as on the Layer III path: a plain
+// double value with a proven error bound decides every FLOAT rounding it can, and the rest is repeated with the
+// correctly rounded function.
+#include "mp3mi_host.h"
+#include "l12_dev.h"
+#include "dmath.h"
+
+#define R_LN_TO_LOG10 0.2302585093
+
+// does every value within err of v round to the same float?  (rounding is monotone: the two ends decide)
+MP3MI_DEVFN bool l12_float_decided(double v, double err) { return (float) (v - err) == (float) (v + err); }
+
+struct psy12_lds {
+    float e[L12_ROW], c[L12_ROW], thr[L12_ROW];
+    float ge[64], gc[64], nb[64];
+};
+
+// c[j] of src/psy.c:283-292 for one line.  FAST: sines and cosines from dm_sincos_fast (|error| < 2^-51 each); the
+// quotient is then within 2^-49 of what correctly rounded ones give (t1, t2 are off by at most (r + |r'|) 1.5 2^-51,
+// their root by sqrt 2 times that, and the divisor IS r + |r'|), and *unsafe says whether the float could differ.
+template <bool FAST>
+MP3MI_DEVFN float psy12_c(float r_new, float phi_new, float r_old, float r_oldest, float phi_old, float phi_oldest, bool *unsafe)
+{
+    const float r_prime = (float) (2.0 * (double) r_old - (double) r_oldest);
+    const float phi_prime = (float) (2.0 * (double) phi_old - (double) phi_oldest);
+    const double rn = (double) r_new, rp = (double) r_prime;
+    double s2, c2, sp, cp;
+    if (FAST) {
+        dm_sincos_fast((double) phi_new, &s2, &c2);
+        dm_sincos_fast((double) phi_prime, &sp, &cp);
+    } else {
+        dm_sincos((double) phi_new, &s2, &c2);
+        dm_sincos((double) phi_prime, &sp, &cp);
+    }
+    const double t1 = rn * c2 - rp * cp;
+    const double t2 = rn * s2 - rp * sp;
+    const double t3 = rn + __builtin_fabs(rp);
+    double cw = 0.0;
+    if (t3 != 0.0) cw = __builtin_sqrt(t1 * t1 + t2 * t2) / t3;
+    // predicted == actual bit for bit (digital silence, a stationary bin): the reference subtracts a product from
+    // itself whatever its libm returns -- exactly 0, as here
+    const bool same = r_new == r_prime && phi_new == phi_prime;
+    if (FAST && t3 != 0.0 && !same && !l12_float_decided(cw, 0x1p-49)) *unsafe = true;
+    return (float) cw;
+}
+
+// the signal-to-mask ratio of subband sb from the energies and thresholds of its lines, src/psy.c:367-386.
+// The logarithm in two tiers: dm_log_fast is within 2^-50 max(1, |log x|) of the logarithm.
+MP3MI_DEVFN float psy12_snr_band(const float *e, const float *fthr, int sb, bool exact)
+{
+    const int j = 16 * sb;
+    float x;
+    if (sb < 13) {
+        float minthres = 60802371420160.0f, sum_energy = 0.0f;
+        for (int k = 0; k < 17; k++) {
+            const float f = fthr[j + k];
+            if (minthres > f) minthres = f;
+            sum_energy = sum_energy + e[j + k];
+        }
+        x = (float) ((double) sum_energy / ((double) minthres * 17.0));
+    } else {
+        float minthres = 0.0f, sum_energy = 0.0f;
+        for (int k = 0; k < 17; k++) {
+            minthres = minthres + fthr[j + k];
+            sum_energy = sum_energy + e[j + k];
+        }
+        x = sum_energy / minthres;
+    }
+    const bool normal = x >= 0x1p-126f && x < __builtin_inff();
+    if (!exact && normal) {
+        const double lv = dm_log_fast((double) x), v = 4.342944819 * lv;
+        const double al = __builtin_fabs(lv);
+        if (l12_float_decided(v, 0x1p-47 * (al > 1.0 ? al : 1.0))) return (float) v;
+    }
+    return (float) (4.342944819 * dm_log((double) x));
+}
+
+__global__ void __launch_bounds__(64) k12_psy(const mp3mi_tables_l12 *__restrict__ T, l12_geom geo,
+                                              const float *__restrict__ erp, float *__restrict__ thr1, float *__restrict__ snr)
+{
+    __shared__ psy12_lds L;
+    const int lane = wave_lane();
+    const int C = geo.channels, NP = geo.np;
+    // records of this launch: the chunk's own passes, and for Layer I the one before them (its threshold is the
+    // next one's lthr)
+    const int qi0 = geo.lb - (geo.layer == 1 ? 1 : 0), nq = NP - qi0;
+    const int ch = (int) (blockIdx.x % (unsigned) C);
+    const int ql = (int) ((blockIdx.x / (unsigned) C) % (unsigned) nq);
+    const int s = (int) (blockIdx.x / (unsigned) (C * nq));
+    const int qi = qi0 + ql;
+    const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
+    if (q < 0) return; // (Layer I, first chunk: the pass before the stream has the initial lthr, k12_snr1)
+    const size_t rec = ((size_t) s * NP + qi) * C + ch;
+    const float *r_n = erp + rec * (3 * L12_ROW);               // this pass: energy, r, phi
+    const float *r_o = erp + (rec - (size_t) C) * (3 * L12_ROW);     // the pass before ("old")
+    const float *r_oo = erp + (rec - 2 * (size_t) C) * (3 * L12_ROW); // two before ("oldest" = the slot "new" overwrites)
+    const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1;
+
+    // ---- unpredictability of every line, src/psy.c:282-292
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+        const int i = lane + 64 * k;
+        const bool on = i < L12_HBLK;
+        if (!wave_any(on)) break;
+        const int ii = on ? i : 0;
+        const float en = r_n[ii], rn = r_n[L12_ROW + ii], pn = r_n[2 * L12_ROW + ii];
+        const float ro = r_o[L12_ROW + ii], po = r_o[2 * L12_ROW + ii];
+        const float roo = r_oo[L12_ROW + ii], poo = r_oo[2 * L12_ROW + ii];
+        bool unsafe = cw_exact;
+        float c = 0.0f;
+        if (!unsafe) c = psy12_c<true>(rn, pn, ro, roo, po, poo, &unsafe);
+        if (wave_any(unsafe && on)) {
+            const float cx = psy12_c<false>(rn, pn, ro, roo, po, poo, &unsafe);
+            c = unsafe ? cx : c;
+        }
+        if (on) { L.e[i] = en; L.c[i] = c; }
+    }
+    wave_sync();
+
+    // ---- partition sums in line order, src/psy.c:297-306: a lane per partition
+    {
+        float ge = 0.0f, gc = 0.0f;
+        if (lane < T->npart) {
+            const int j0 = T->part_first[lane], j1 = T->part_first[lane + 1];
+            for (int j = j0; j < j1; j++) {
+                const float ev = L.e[j];
+                ge = ge + ev;
+                gc = gc + ev * L.c[j];
+            }
+        }
+        L.ge[lane] = ge;
+        L.gc[lane] = gc;
+    }
+    wave_sync();
+
+    // ---- spreading, tonality, masking level of partition j = lane, src/psy.c:312-348
+    {
+        float nbv = 0.0f;
+        const int j = lane < L12_CB ? lane : 0;
+        float ecb = 0.0f, cb = 0.0f;
+        for (int k = 0; k < L12_CB; k++) {
+            const float sv = T->spread_t[k][j]; // (the reference skips s == 0: adding 0 * x changes nothing)
+            ecb = ecb + sv * L.ge[k];
+            cb = cb + sv * L.gc[k];
+        }
+        if (ecb != 0.0f) cb = cb / ecb;
+        else cb = 0.0f;
+        if ((double) cb < .05) cb = (float) 0.05;
+        else if ((double) cb > .5) cb = (float) 0.5;
+        const double tmn = T->tmn[j], nmt = 5.5;
+        float bc;
+        {
+            bool done = false;
+            bc = 0.0f;
+            if (!psy_exact) { // log within 3 2^-50 on [0.05, 0.5]: v within 2^-44
+                const double tb = -0.434294482 * dm_log_fast((double) cb) - 0.301029996;
+                const double v = tmn * tb + nmt * (1.0 - tb);
+                if (l12_float_decided(v, 0x1p-44)) { bc = (float) v; done = true; }
+            }
+            if (wave_any(!done)) {
+                const double tb = -0.434294482 * dm_log((double) cb) - 0.301029996;
+                const float bx = (float) (tmn * tb + nmt * (1.0 - tb));
+                bc = done ? bc : bx;
+            }
+        }
+        const float bm = T->bmaxv[j];
+        bc = (bc > bm) ? bc : bm;
+        {
+            const double arg = (double) -bc * R_LN_TO_LOG10;
+            bool done = false;
+            float bx = 0.0f;
+            if (!psy_exact) { // exp within 2^-50 relative
+                const double v = dm_exp_fast(arg);
+                if (l12_float_decided(v, v * 0x1p-48)) { bx = (float) v; done = true; }
+            }
+            if (wave_any(!done)) {
+                const float by = (float) dm_exp(arg);
+                bx = done ? bx : by;
+            }
+            bc = bx;
+        }
+        const float rn = T->rn_nl[j];
+        if (rn != 0.0f) nbv = ecb * bc / rn;
+        L.nb[lane] = lane < L12_CB ? nbv : 0.0f;
+    }
+    wave_sync();
+
+    // ---- threshold of every line before pre-echo control, src/psy.c:349-353 ("temp1": the larger of two floats)
+    for (int i = lane; i < L12_HBLK; i += 64) {
+        const float t = L.nb[T->partition[i]], a = T->absthr[i];
+        const float v = (t > a) ? t : a;
+        L.thr[i] = v;
+        if (geo.layer == 1) thr1[rec * L12_ROW + i] = v;
+    }
+    if (geo.layer == 1) return;
+    wave_sync();
+    if (lane < 32) snr[rec * 32 + lane] = psy12_snr_band(L.e, L.thr, lane, psy_exact);
+}
+
+// Layer I: the threshold of a line is limited by 32 x the threshold of the pass before and floored at 0.00316 x its
+// own value (pre-echo control, src/psy.c:355-361; lthr starts at 60802371420160.0, :161-162)
+__global__ void __launch_bounds__(64) k12_snr1(l12_geom geo, const float *__restrict__ erp, const float *__restrict__ thr1,
+                                               float *__restrict__ snr)
+{
+    __shared__ psy12_lds L;
+    const int lane = wave_lane();
+    const int C = geo.channels, NP = geo.np, nq = NP - geo.lb;
+    const int ch = (int) (blockIdx.x % (unsigned) C);
+    const int ql = (int) ((blockIdx.x / (unsigned) C) % (unsigned) nq);
+    const int s = (int) (blockIdx.x / (unsigned) (C * nq));
+    const int qi = geo.lb + ql;
+    const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
+    const size_t rec = ((size_t) s * NP + qi) * C + ch;
+    for (int i = lane; i < L12_HBLK; i += 64) {
+        const double temp1 = (double) thr1[rec * L12_ROW + i];
+        const float lthr = q >= 1 ? (float) (32.0 * (double) thr1[(rec - (size_t) C) * L12_ROW + i]) : 60802371420160.0f;
+        float f = (temp1 < (double) lthr) ? (float) temp1 : lthr;
+        const double temp2 = temp1 * 0.00316;
+        f = (temp2 > (double) f) ? (float) temp2 : f;
+        L.thr[i] = f;
+        L.e[i] = erp[rec * (3 * L12_ROW) + i];
+    }
+    wave_sync();
+    if (lane < 32) snr[rec * 32 + lane] = psy12_snr_band(L.e, L.thr, lane, (geo.test_flags >> 2) & 1);
+}
+
+void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *thr1, float *snr, hipStream_t st)
+{
+    const int nq = g.np - g.lb + (g.layer == 1 ? 1 : 0);
+    hipLaunchKernelGGL(k12_psy, dim3((unsigned) ((size_t) g.n_streams * nq * g.channels)), dim3(64), 0, st, T, g, erp, thr1, snr);
+    if (g.layer == 1)
+        hipLaunchKernelGGL(k12_snr1, dim3((unsigned) ((size_t) g.n_streams * (g.np - g.lb) * g.channels)), dim3(64), 0, st, g, erp, thr1, snr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the frame encoder
+// ------------------------------------------------------------------------------------------------------------------
+// pattern[class0][class1] of II_transmission_pattern (src/encode.c:647-651) as a code:
+// 0 = 0x123, 1 = 0x122, 2 = 0x133, 3 = 0x113, 4 = 0x111, 5 = 0x222, 6 = 0x333, 7 = 0x444
+__device__ static const uint8_t L12_PATTERN[5][5] = {{0, 1, 1, 2, 0}, {3, 4, 4, 7, 3}, {4, 4, 4, 6, 3}, {5, 5, 5, 6, 0}, {0, 1, 1, 2, 0}};
+#define L12_IMG_WORDS 448 /* 1792 bytes: the largest frame is 1728 (Layer II, 384 kbps at 32 kHz) */
+struct alloc12_lds {
+    unsigned img[L12_IMG_WORDS];
+    double multiple[64];
+    uint16_t al[32][16][4];
+    int ba[2][32], sf[2][32];
+    unsigned crc;
+};
+
+MP3MI_DEVFN void l12_or(unsigned *w, unsigned v)
+{
+#if defined(MP3MI_EMU)
+    *w |= v;
+#else
+    atomicOr(w, v);
+#endif
+}
+// the low n bits of val at bit position pos (MSB first) of a word image, src/common.c:1134-1161
+MP3MI_DEVFN void l12_put(unsigned *img, int pos, unsigned val, int n)
+{
+    if (n <= 0) return;
+    if (n < 32) val &= (1u << n) - 1u;
+    const int wi = pos >> 5, off = pos & 31;
+    if (off + n <= 32) l12_or(&img[wi], val << (32 - off - n));
+    else {
+        const int n2 = off + n - 32;
+        l12_or(&img[wi], val >> n2);
+        l12_or(&img[wi + 1], val << (32 - n2));
+    }
+}
+// exclusive prefix sum over the wave in lane order; *total = the wave's sum
+MP3MI_DEVFN int l12_scan(int v, int *total)
+{
+    const int lane = wave_lane();
+    int incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, (unsigned) d);
+        if (lane >= d) incl += o;
+    }
+    *total = __shfl(incl, 63);
+    return incl - v;
+}
+// index of the scalefactor just above the peak m: the largest j <= 62 with m <= multiple[j], 0 if there is none
+// (src/encode.c:529-534, 551-556; multiple[] falls with j)
+MP3MI_DEVFN int l12_scale_index(const double *mult, double m)
+{
+    int lo = 0, hi = 63; // count of j in [0, 63) with multiple[j] >= m lies in [lo, hi]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1; // is multiple[mid - 1] >= m ?
+        if (mult[mid - 1] >= m) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo > 0 ? lo - 1 : 0;
+}
+MP3MI_DEVFN double l12_wave_min_f64(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
+MP3MI_DEVFN void l12_update_crc(unsigned data, unsigned length, unsigned *crc)
+{ // src/common.c:1309-1323
+    unsigned masking = 1u << length;
+    while ((masking >>= 1)) {
+        const unsigned carry = *crc & 0x8000u;
+        *crc <<= 1;
+        if (!carry ^ !(data & masking)) *crc ^= 0x8005u;
+    }
+    *crc &= 0xffffu;
+}
+
+// LAYER 1 or 2; NPART = parts of 12 samples per subband and frame (1 or 3)
+template <int LAYER>
+__global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restrict__ T, l12_geom geo,
+                                                const l12_stream_cfg *__restrict__ cfg, const double *__restrict__ sbs,
+                                                const float *__restrict__ snr, uint8_t *__restrict__ out, size_t out_stride,
+                                                uint32_t *__restrict__ out_len, l12_frame_dbg *__restrict__ dbg)
+{
+    constexpr int NPART = LAYER == 1 ? 1 : 3, NSLOT = 12 * NPART;
+    __shared__ alloc12_lds L;
+    const int lane = wave_lane();
+    const int C = geo.channels, stereo = C;
+    const int fl = (int) (blockIdx.x % (unsigned) geo.nf), s = (int) (blockIdx.x / (unsigned) geo.nf);
+    const long n = (long) geo.f0 + fl; // frame index in the stream
+    const long n_frames_s = geo.n_samples ? ((long) geo.n_samples[s] + geo.spf - 1) / geo.spf : (long) geo.n_frames;
+    if (n >= n_frames_s) {
+        if (n_frames_s == 0 && n == 0 && lane == 0) { out[(size_t) s * out_stride] = 0; out_len[s] = 1; }
+        return;
+    }
+    const l12_stream_cfg cf = cfg[s];
+    const int sblimit = cf.sblimit, frame_bytes = cf.frame_bits / 8;
+    const int sb = C == 2 ? lane >> 1 : lane, ch = C == 2 ? lane & 1 : 0;
+    const bool act = sb < sblimit && lane < 32 * C; // a (subband, channel) the layer codes
+    const int sbc = sb < 32 ? sb : 31;
+
+    for (int i = lane; i < L12_IMG_WORDS; i += 64) L.img[i] = 0;
+    L.multiple[lane] = T->multiple[lane];
+    if (LAYER == 2)
+        for (int i = lane; i < 32 * 16 * 4 / 2; i += 64) ((uint32_t *) L.al)[i] = ((const uint32_t *) T->alloc[cf.table])[i];
+    wave_sync();
+
+    // ---- the frame's subband samples of this lane's (subband, channel), src/musicin.c:622-626, 662-666.  k_filter
+    // stored them for Layer III's MDCT: odd slots of odd subbands negated (src/mdct.c:57-60) -- undone here, exactly.
+    double x[NSLOT];
+    {
+        const int G1 = geo.n_gran + 1;
+        const double *base = sbs + ((size_t) s * G1 * C + (lane < 32 * C ? ch : 0)) * 576 + sbc;
+        int sg = geo.slot0 + fl * NSLOT, gi = sg / 18, qq = sg - 18 * gi;
+#pragma unroll
+        for (int u = 0; u < NSLOT; u++) {
+            const double v = base[(size_t) gi * C * 576 + qq * 32];
+            x[u] = ((sbc & 1) && (qq & 1)) ? -v : v;
+            qq++;
+            if (qq == 18) { qq = 0; gi++; }
+        }
+    }
+
+    // ---- scale factors, src/encode.c:512-561; joint stereo: of the channels' mean as well (:469-494, musicin.c:629-632)
+    unsigned scalar[3] = {0, 0, 0}, j_scale[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NPART; t++) {
+        double m = __builtin_fabs(x[12 * t]);
+#pragma unroll
+        for (int j = 1; j < 12; j++) { const double a = __builtin_fabs(x[12 * t + j]); m = a > m ? a : m; }
+        scalar[t] = sb < sblimit ? (unsigned) l12_scale_index(L.multiple, m) : 63u;
+    }
+    if (geo.actual_mode == 1) {
+#pragma unroll
+        for (int t = 0; t < NPART; t++) {
+            double m = 0.0;
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const double o = __shfl_xor(x[12 * t + j], 1);
+                const double a = __builtin_fabs(.5 * ((ch ? o : x[12 * t + j]) + (ch ? x[12 * t + j] : o)));
+                m = (j == 0 || a > m) ? a : m;
+            }
+            j_scale[t] = sb < sblimit ? (unsigned) l12_scale_index(L.multiple, m) : 63u;
+        }
+    }
+
+    // ---- signal-to-mask ratios of this frame, src/musicin.c:639-643, 681-686 and src/psy.c:391-395
+    double smr = 0.0;
+    if (lane < 32 * C) {
+        const size_t rec = ((size_t) s * geo.np + geo.lb + (size_t) fl * LAYER) * C + ch;
+        float v = snr[rec * 32 + sbc];
+        if (LAYER == 2) { const float w = snr[(rec + (size_t) C) * 32 + sbc]; v = (v > w) ? v : w; }
+        smr = (double) v;
+    }
+
+    // ---- Layer II: transmission pattern, src/encode.c:638-691
+    unsigned scfsi = 0;
+    if (LAYER == 2 && act) {
+        const int d0 = (int) (scalar[0] - scalar[1]), d1 = (int) (scalar[1] - scalar[2]);
+        const int c0 = d0 <= -3 ? 0 : d0 < 0 ? 1 : d0 == 0 ? 2 : d0 < 3 ? 3 : 4;
+        const int c1 = d1 <= -3 ? 0 : d1 < 0 ? 1 : d1 == 0 ? 2 : d1 < 3 ? 3 : 4;
+        switch (L12_PATTERN[c0][c1]) {
+        case 0: scfsi = 0; break;
+        case 1: scfsi = 3; scalar[2] = scalar[1]; break;
+        case 2: scfsi = 3; scalar[1] = scalar[2]; break;
+        case 3: scfsi = 1; scalar[1] = scalar[0]; break;
+        case 4: scfsi = 2; scalar[1] = scalar[2] = scalar[0]; break;
+        case 5: scfsi = 2; scalar[0] = scalar[2] = scalar[1]; break;
+        case 6: scfsi = 2; scalar[0] = scalar[1] = scalar[2]; break;
+        default:
+            scfsi = 2;
+            if (scalar[0] > scalar[2]) scalar[0] = scalar[2];
+            scalar[1] = scalar[2] = scalar[0];
+        }
+    }
+    const int sfs = scfsi == 0 ? 3 : scfsi == 2 ? 1 : 2;                 // sfsPerScfsi, src/encode.c:825
+    const int sfs_o = __shfl_xor(sfs, 1);                                // the other channel's (C == 2)
+    const double smr_o = __shfl_xor(smr, 1);
+    const double *snrt = T->snr;
+    const int maxAlloc = LAYER == 2 ? (1 << L.al[sbc][0][1]) - 1 : 15;   // src/encode.c:838
+
+    // ---- joint stereo: how many subbands stay stereo, src/encode.c:882-948
+    int mode = geo.actual_mode, mode_ext = 0, jsbound = sblimit;
+    if (geo.actual_mode == 1) {
+        mode = 0;
+        for (int me = 4;;) { // me == 4: plain stereo; then mode_ext 3, 2, 1, 0
+            const int jsb = me == 4 ? sblimit : (me == 3 ? 16 : me == 2 ? 12 : me == 1 ? 8 : 4); // js_bound, src/common.c:320-331 (Layers I and II alike)
+            int bits = 0;
+            if (act && (sb < jsb || ch == 0)) { // *_bits_for_nonoise, src/encode.c:782-860
+                if (LAYER == 1) {
+                    int k = 0;
+                    for (; k < 14; ++k)
+                        if ((-smr + snrt[k]) >= 0.0) break;
+                    if (stereo == 2 && sb >= jsb)
+                        for (; k < 14; ++k)
+                            if ((-smr_o + snrt[k]) >= 0.0) break;
+                    if (k > 0) bits = (k + 1) * 12 + 6 * ((sb >= jsb) ? stereo : 1);
+                } else {
+                    int ba = 0;
+                    for (; ba < maxAlloc - 1; ++ba)
+                        if ((-smr + snrt[L.al[sbc][ba][3] + ((ba > 0) ? 1 : 0)]) >= 0.0) break;
+                    if (stereo == 2 && sb >= jsb)
+                        for (; ba < maxAlloc - 1; ++ba)
+                            if ((-smr_o + snrt[L.al[sbc][ba][3] + ((ba > 0) ? 1 : 0)]) >= 0.0) break;
+                    if (ba > 0) {
+                        bits = 12 * (L.al[sbc][ba][2] * L.al[sbc][ba][1]) + 2 + 6 * sfs;
+                        if (stereo == 2 && sb >= jsb) bits += 2 + 6 * sfs_o;
+                    }
+                }
+            }
+            int hdr; // bits of the header and of the allocation fields
+            if (LAYER == 1) hdr = 32 + 4 * ((jsb * stereo) + (32 - jsb));
+            else {
+                const int bb = (act && (sb < jsb || ch == 0)) ? L.al[sbc][0][1] : 0;
+                hdr = 32 + (geo.crc ? 16 : 0) + wave_sum_i32(bb);
+            }
+            const int rq = hdr + wave_sum_i32(bits);
+            if (me == 4) {
+                if (!(rq > cf.frame_bits)) break;
+                mode = 1;
+                me = 3;
+                continue;
+            }
+            jsbound = jsb;
+            mode_ext = me;
+            if (!((rq > cf.frame_bits) && (me > 0))) break;
+            --me;
+        }
+    }
+
+    // ---- *_a_bit_allocation, src/encode.c:974-1172: the band with the smallest mask-to-noise ratio gets the next step,
+    // the first in (subband, channel) order among equals -- lane order
+    int ba = 0, used = 0, adb = cf.frame_bits;
+    double mnr = snrt[0] - smr;
+    {
+        const bool code = act && (sb < jsbound || ch == 0); // has an allocation field of its own
+        int bbal;
+        if (LAYER == 1) bbal = 4 * ((jsbound * stereo) + (32 - jsbound));
+        else bbal = wave_sum_i32(code ? (int) L.al[sbc][0][1] : 0);
+        adb -= bbal + (geo.crc ? 16 : 0) + 32;
+        const int ad = adb;
+        int bspl = 0, bscf = 0, bsel = 0;
+        for (;;) {
+            const double lim = LAYER == 1 ? wave_bcast_f64(mnr, 0) + 1 : 999999.0;
+            const bool cand = act && used != 2 && lim > mnr;
+            const double small = l12_wave_min_f64(cand ? mnr : __builtin_inf());
+            const unsigned long long tie = __ballot(cand && mnr == small);
+            if (!tie) break;
+            const int win = __ffsll((long long) tie) - 1;
+            const int wsb = C == 2 ? win >> 1 : win;
+            const bool me_win = lane == win, me_oth = C == 2 && lane == (win ^ 1) && wsb >= jsbound;
+            // the winner's figures (computed by every lane for itself; the winner's are read)
+            int increment, scale, seli;
+            if (LAYER == 1) {
+                increment = used ? 12 : 24;
+                scale = used ? 0 : 6;
+                seli = 0;
+                if (sb >= jsbound) scale *= stereo;
+            } else {
+                const int nx = ba + 1 < 16 ? ba + 1 : 15;
+                increment = 12 * (L.al[sbc][nx][2] * L.al[sbc][nx][1]);
+                if (used) increment -= 12 * (L.al[sbc][ba][2] * L.al[sbc][ba][1]);
+                if (used) scale = seli = 0;
+                else {
+                    seli = 2;
+                    scale = 6 * sfs;
+                    if (stereo == 2 && sb >= jsbound) { seli += 2; scale += 6 * sfs_o; }
+                }
+            }
+            const int need = wave_readlane_i32(increment + scale + seli, win);
+            const bool fits = ad >= bspl + bscf + bsel + need;
+            if (fits) {
+                bspl += wave_readlane_i32(increment, win);
+                bscf += wave_readlane_i32(scale, win);
+                bsel += wave_readlane_i32(seli, win);
+            }
+            if (me_win) {
+                if (fits) {
+                    ba++;
+                    used = 1;
+                    if (LAYER == 1) {
+                        mnr = -smr + snrt[ba];
+                        if (ba == 14) used = 2;
+                    } else {
+                        mnr = -smr + snrt[L.al[sbc][ba][3] + 1];
+                        if (ba >= maxAlloc) used = 2;
+                    }
+                } else used = 2;
+            }
+            const int wba = wave_readlane_i32(ba, win), wused = wave_readlane_i32(used, win);
+            if (me_oth) { // above the joint-stereo bound the allocation applies to both channels
+                ba = wba;
+                used = wused;
+                mnr = -smr + (LAYER == 1 ? snrt[ba] : snrt[L.al[sbc][ba][3] + 1]);
+            }
+        }
+        adb = ad - (bspl + bscf + bsel);
+    }
+    if (!act) ba = 0;
+
+    // ---- CRC over header and allocation (Layer II: and scfsi), src/common.c:1251-1307
+    unsigned crc = 0;
+    if (geo.crc || dbg) {
+        if (lane < 32 * C) { L.ba[ch][sbc] = ba; L.sf[ch][sbc] = (int) scfsi; }
+        wave_sync();
+    }
+    if (geo.crc) {
+        if (lane == 0) {
+            unsigned c = 0xffff;
+            l12_update_crc((unsigned) cf.bitrate_index, 4, &c);
+            l12_update_crc((unsigned) geo.rate_idx, 2, &c);
+            l12_update_crc(0, 1, &c);
+            l12_update_crc(0, 1, &c);
+            l12_update_crc((unsigned) mode, 2, &c);
+            l12_update_crc((unsigned) mode_ext, 2, &c);
+            l12_update_crc((unsigned) (geo.hdr_flags >> 3) & 1u, 1, &c);
+            l12_update_crc((unsigned) (geo.hdr_flags >> 2) & 1u, 1, &c);
+            l12_update_crc((unsigned) geo.hdr_flags & 3u, 2, &c);
+            const int nsb = LAYER == 1 ? 32 : sblimit;
+            for (int i = 0; i < nsb; i++)
+                for (int k = 0; k < ((i < jsbound) ? stereo : 1); k++)
+                    l12_update_crc((unsigned) L.ba[k][i], LAYER == 1 ? 4u : (unsigned) L.al[i][0][1], &c);
+            if (LAYER == 2)
+                for (int i = 0; i < sblimit; i++)
+                    for (int k = 0; k < stereo; k++)
+                        if (L.ba[k][i]) l12_update_crc((unsigned) L.sf[k][i], 2, &c);
+            L.crc = c;
+        }
+        wave_sync();
+        crc = L.crc;
+    }
+
+    if (dbg) { // the seams of oracle/stage_dump_l12.h
+        l12_frame_dbg *d = dbg + (size_t) s * geo.nf + fl;
+        if (lane < 32 * C) {
+            d->ltmin[ch][sbc] = smr;
+            for (int t = 0; t < 3; t++) d->scalar[ch][t][sbc] = t < NPART ? (int) scalar[t] : 0;
+            d->scfsi[ch][sbc] = (int) scfsi;
+            d->bit_alloc[ch][sbc] = ba;
+            if (ch == 0)
+                for (int t = 0; t < 3; t++) d->j_scale[t][sbc] = (t < NPART && geo.actual_mode == 1) ? (int) j_scale[t] : 0;
+        }
+        if (C == 1 && lane >= 32) {
+            const int b2 = lane - 32;
+            d->ltmin[1][b2] = 0.0;
+            for (int t = 0; t < 3; t++) d->scalar[1][t][b2] = 0;
+            d->scfsi[1][b2] = 0;
+            d->bit_alloc[1][b2] = 0;
+        }
+        if (lane == 0) {
+            d->mode = mode; d->mode_ext = mode_ext; d->jsbound = jsbound; d->sblimit = sblimit;
+            d->adb_left = adb; d->crc = (int) crc;
+        }
+    }
+
+    // ---- the frame's bits, src/encode.c:418-437, 708-748, 1328-1416
+    const bool own = act && (sb < jsbound || ch == 0); // writes allocation field and samples (above the bound: channel 0's lane)
+    int pos = 0, tot;
+    if (lane == 0) {
+        unsigned h = 0xfffu << 20;           // syncword
+        h |= 1u << 19;                       // ID: MPEG-1
+        h |= (unsigned) (4 - LAYER) << 17;
+        h |= (geo.crc ? 0u : 1u) << 16;      // protection bit: set = no CRC
+        h |= (unsigned) cf.bitrate_index << 12;
+        h |= (unsigned) geo.rate_idx << 10;  // (padding 0, private 0: src/musicin.c:566-581)
+        h |= (unsigned) mode << 6;
+        h |= (unsigned) mode_ext << 4;
+        h |= (unsigned) geo.hdr_flags & 15u;
+        L.img[0] = h;
+        if (geo.crc) L.img[1] = crc << 16;
+    }
+    wave_sync(); // (plain stores before the atomic ORs)
+    pos = 32 + (geo.crc ? 16 : 0);
+    {   // allocation fields
+        const int nb = LAYER == 1 ? ((lane < 32 * C && (sb < jsbound || ch == 0)) ? 4 : 0) : (own ? (int) L.al[sbc][0][1] : 0);
+        const int ofs = l12_scan(nb, &tot);
+        if (nb) l12_put(L.img, pos + ofs, (unsigned) ba, nb);
+        pos += tot;
+    }
+    if (LAYER == 2) { // scfsi, then the scale factors it selects
+        const int nb = (act && ba) ? 2 : 0;
+        int ofs = l12_scan(nb, &tot);
+        if (nb) l12_put(L.img, pos + ofs, scfsi, 2);
+        pos += tot;
+        const int ns = (act && ba) ? 6 * sfs : 0;
+        ofs = l12_scan(ns, &tot);
+        if (ns) {
+            int p = pos + ofs;
+            l12_put(L.img, p, scalar[0], 6); p += 6;
+            if (scfsi == 0) { l12_put(L.img, p, scalar[1], 6); p += 6; }
+            if (scfsi != 2) l12_put(L.img, p, scalar[2], 6);
+        }
+        pos += tot;
+    } else {
+        const int ns = (lane < 32 * C && ba) ? 6 : 0;
+        const int ofs = l12_scan(ns, &tot);
+        if (ns) l12_put(L.img, pos + ofs, scalar[0], 6);
+        pos += tot;
+    }
+    {   // samples: quantised (src/encode.c:1207-1325) and written group by group
+        const bool joint = stereo == 2 && sb >= jsbound;
+        const bool wr = own && ba > 0;
+        int nbits, grp = 3, steps = 0, qn = 0, qnt;
+        if (LAYER == 1) { nbits = ba + 1; qn = ba; qnt = ba > 0 ? ba - 1 : 0; }
+        else {
+            const uint16_t *e = L.al[sbc][ba];
+            steps = e[0]; nbits = e[1]; grp = e[2]; qnt = e[3];
+            while ((1L << qn) < (long) steps) qn++;
+            qn--;
+            if (qn < 0) qn = 0; // (a lane without allocation: nothing of it is written)
+        }
+        const double qa = T->qa[qnt], qb = T->qb[qnt];
+        const int per = LAYER == 1 ? nbits : (grp == 3 ? 3 * nbits : nbits); // bits of this lane per row of the sample section
+        int rowbits;
+        const int ofs = l12_scan(wr ? per : 0, &rowbits);
+#pragma unroll
+        for (int t = 0; t < NPART; t++) {
+            const double div = L.multiple[joint ? j_scale[t] : scalar[t]];
+#pragma unroll
+            for (int j0 = 0; j0 < 12; j0 += (LAYER == 1 ? 1 : 3)) {
+                unsigned q3[3];
+#pragma unroll
+                for (int jj = 0; jj < (LAYER == 1 ? 1 : 3); jj++) {
+                    double v = x[12 * t + j0 + jj];
+                    if (geo.actual_mode == 1) { // (the shuffle runs on every lane, the value is used above the bound)
+                        const double o = __shfl_xor(v, 1);
+                        if (joint) v = .5 * ((ch ? o : v) + (ch ? v : o));
+                    }
+                    double d = v / div;
+                    d = d * qa + qb;
+                    unsigned sig = 1;
+                    if (!(d >= 0)) { sig = 0; d += 1.0; }
+                    unsigned qv = (unsigned) (d * (double) (1L << qn));
+                    if (sig) qv |= 1u << qn;
+                    q3[jj] = qv;
+                }
+                if (wr) {
+                    const int row = LAYER == 1 ? j0 : (t * 4 + j0 / 3);
+                    const int p = pos + row * rowbits + ofs;
+                    if (LAYER == 1) l12_put(L.img, p, q3[0], nbits);
+                    else if (grp == 3) {
+                        l12_put(L.img, p, q3[0], nbits);
+                        l12_put(L.img, p + nbits, q3[1], nbits);
+                        l12_put(L.img, p + 2 * nbits, q3[2], nbits);
+                    } else l12_put(L.img, p, q3[0] + q3[1] * (unsigned) steps + q3[2] * (unsigned) steps * (unsigned) steps, nbits);
+                }
+            }
+        }
+    }
+    wave_sync();
+    // ---- the frame goes to byte n * frame_bytes of the stream's row; what is left of it is zero (src/musicin.c:657, 703).
+    // The file carries one byte beyond its last frame (close_bit_stream_w, src/common.c:843-868): the last frame's wavefront adds it.
+    {
+        uint8_t *o = out + (size_t) s * out_stride + (size_t) n * (size_t) frame_bytes;
+        for (int i = lane; i < frame_bytes; i += 64) o[i] = (uint8_t) (L.img[i >> 2] >> (24 - 8 * (i & 3)));
+        if (n == n_frames_s - 1 && lane == 0) {
+            o[frame_bytes] = 0;
+            out_len[s] = (uint32_t) (n_frames_s * frame_bytes + 1);
+        }
+    }
+}
+
+void mp3mi_launch_l12_alloc(const mp3mi_tables_l12 *T, const l12_geom &g, const l12_stream_cfg *cfg, const double *sbs,
+                            const float *snr, uint8_t *out, size_t out_stride, uint32_t *out_len, l12_frame_dbg *dbg, hipStream_t st)
+{
+    const unsigned grid = (unsigned) ((size_t) g.n_streams * g.nf);
+    if (g.layer == 1) hipLaunchKernelGGL(k12_alloc<1>, dim3(grid), dim3(64), 0, st, T, g, cfg, sbs, snr, out, out_stride, out_len, dbg);
+    else hipLaunchKernelGGL(k12_alloc<2>, dim3(grid), dim3(64), 0, st, T, g, cfg, sbs, snr, out, out_stride, out_len, dbg);
+}

@@ -36,6 +36,8 @@ struct mp3mi_geom {
                            start of a stream), or NULL: nothing precedes the call */
     const int64_t *out_base; /* device, [n_streams]: file position of byte 0 of the stream's output row, or NULL: 0 */
     int whole_file;     /* the call is the whole stream: k_format also finishes the file (length incl. flush + close) */
+    long pcm_pitch;     /* samples per channel in a stream's row of the PCM buffer; 0 = n_frames * 1152 (Layers I / II frames are
+                           not 1152 samples: l12_batch.cpp sets it for k_filter) */
     int test_flags;     /* bit 0: k_loop takes the exact (sequential) noise sums only (MP3MI_NOISE_EXACT=1, tests);
                            bit 1: k_cw takes the correctly rounded atan2 only (MP3MI_PHASE_EXACT=1, tests);
                            bit 2: k_psy takes dm_log / dm_exp only (MP3MI_PSY_EXACT=1, tests);
@@ -53,6 +55,7 @@ static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_i
     g.crc = 0;
     g.fabs0 = 0; g.hist = NULL; g.out_base = NULL; g.whole_file = 1;
     g.test_flags = 0;
+    g.pcm_pitch = 0;
     g.n_samples = NULL;
     return g;
 }

@@ -23,6 +23,8 @@
 #include "mp3mi_host.h"
 #include "mp3mi_tables_gen.h"
 #include "mdct_shape.h"
+#include "l12_dev.h"
+#include "mp3mi_tables_l12_gen.h"
 
 #if defined(MP3MI_FFT_INFO) /* -DMP3MI_FFT_INFO: print the round headers the generator produces (after changing it) */
 #define MP3MI_FFT_INFO_ON 1
@@ -38,6 +40,7 @@
 enum {
     TB_WINDOW = 1, TB_WINDOW_S, TB_S3_L, TB_EXP_SNR_S, TB_FILT, TB_MDCT_WIN, TB_COS_S, TB_COS_L, TB_CA, TB_CS,
     TB_POW_NINT, TB_POW43, TB_STEP, TB_PRETAB_XR, TB_PRETAB_XMIN, TB_SQRT2, TB_LOG2,
+    TB_L12_SPREAD, /* Layers I / II: the spreading function of src/psy.c:200-216 */
     TB_TWIDDLE = 64 /* + 2 * logm + three */
 };
 struct tb_entry { uint32_t id; int32_t rate; uint32_t offset, size; };
@@ -898,6 +901,7 @@ enum { MP3MI_N_TABLE_MEMBERS = 0 MP3MI_TABLE_MEMBERS(X) };
 #define X(m) #m,
 static const char *const TABLE_MEMBER_NAMES[MP3MI_N_TABLE_MEMBERS] = {MP3MI_TABLE_MEMBERS(X)};
 #undef X
+#include "tables_l12_pins.h"
 #include "tables_pins.h" /* MP3MI_TABLE_PINS_N, MP3MI_TABLE_PINS[3][MP3MI_TABLE_PINS_N] */
 
 static uint64_t fnv1a64(const void *p, size_t n)
@@ -955,6 +959,134 @@ extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
     return bad ? -8 : 0;
 }
 
+
+/* ---- Layers I and II (l12_dev.h): psychoacoustic model 2 of src/psy.c and the coding tables ----
+ * Everything but the spreading function is plain float / double arithmetic on constants (the FLOAT intermediates of
+ * src/psy.c:151-198 kept as the reference declares them); the spreading function takes a square root and an
+ * exponential and comes out of the blob like the Layer III tables.  Pinned by its hash per sampling rate. */
+static const uint64_t L12_SPREAD_PINS[3] = {L12_SPREAD_PIN_0, L12_SPREAD_PIN_1, L12_SPREAD_PIN_2};
+
+static int build_tables_l12_unpinned(mp3mi_tables_l12 *T, int ri, int layer, float (*s)[L12_CB])
+{
+    static const float crit_band[27] = {0, 100, 200, 300, 400, 510, 630, 770, 920, 1080, 1270, 1480, 1720, 2000, 2320, 2700,
+                                        3150, 3700, 4400, 5300, 6400, 7700, 9500, 12000, 15500, 25000, 30000};
+    static const float bmax[27] = {20.0, 20.0, 20.0, 20.0, 20.0, 17.0, 15.0, 10.0, 7.0, 4.4, 4.5, 4.5, 4.5, 4.5,
+                                   4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 3.5, 3.5, 3.5};
+    static const double rates[3] = {44100.0, 48000.0, 32000.0};
+    static const double SNR[18] = {0.00, 7.00, 11.00, 16.00, 20.84, 25.28, 31.59, 37.75, 43.84, /* src/encode.c:777-780 */
+                                   49.89, 55.93, 61.96, 67.98, 74.01, 80.03, 86.05, 92.01, 98.01};
+    static const double QA[17] = {0.750000000, 0.625000000, 0.875000000, 0.562500000, 0.937500000, /* src/encode.c:1195-1199 */
+                                  0.968750000, 0.984375000, 0.992187500, 0.996093750, 0.998046875,
+                                  0.999023438, 0.999511719, 0.999755859, 0.999877930, 0.999938965,
+                                  0.999969482, 0.999984741};
+    static const double QB[17] = {-0.250000000, -0.375000000, -0.125000000, -0.437500000, -0.062500000, /* :1201-1205 */
+                                  -0.031250000, -0.015625000, -0.007812500, -0.003906250, -0.001953125,
+                                  -0.000976563, -0.000488281, -0.000244141, -0.000122070, -0.000061035,
+                                  -0.000030518, -0.000015259};
+    if (ri < 0 || ri > 2 || (layer != 1 && layer != 2)) return -1;
+    memset(T, 0, sizeof(*T));
+    T->rate_idx = ri;
+    T->layer = layer;
+    float fthr[L12_HBLK], cbval[L12_CB], rnorm[L12_CB], freq_mult, bval_lo;
+    int numlines[L12_CB], partition[L12_HBLK];
+    double temp1, temp2;
+    unsigned i, j;
+    memset(cbval, 0, sizeof(cbval)); memset(numlines, 0, sizeof(numlines)); /* mem_alloc zero-fills, src/common.c:541 */
+    /* src/psy.c:165-198 */
+    freq_mult = rates[ri] / 1024;
+    for (i = 0; i < L12_HBLK; i++) {
+        temp1 = i * freq_mult;
+        j = 1;
+        while (temp1 > crit_band[j]) j++;
+        fthr[i] = j - 1 + (temp1 - crit_band[j - 1]) / (crit_band[j] - crit_band[j - 1]);
+    }
+    partition[0] = 0;
+    temp2 = 1;
+    cbval[0] = fthr[0];
+    bval_lo = fthr[0];
+    for (i = 1; i < L12_HBLK; i++) {
+        if ((fthr[i] - bval_lo) > 0.33) {
+            partition[i] = partition[i - 1] + 1;
+            if (partition[i] >= L12_CB) return -2;
+            cbval[partition[i - 1]] = cbval[partition[i - 1]] / temp2;
+            cbval[partition[i]] = fthr[i];
+            bval_lo = fthr[i];
+            numlines[partition[i - 1]] = temp2;
+            temp2 = 1;
+        } else {
+            partition[i] = partition[i - 1];
+            cbval[partition[i]] += fthr[i];
+            temp2++;
+        }
+    }
+    numlines[partition[i - 1]] = temp2;
+    cbval[partition[i - 1]] = cbval[partition[i - 1]] / temp2;
+    T->npart = partition[L12_HBLK - 1] + 1;
+    /* the spreading function, src/psy.c:200-216 */
+    LIBM_TABLE(TB_L12_SPREAD, ri, s, sizeof(float) * L12_CB * L12_CB,
+        for (int jj = 0; jj < L12_CB; jj++)
+            for (int ii = 0; ii < L12_CB; ii++) {
+                double t1 = (cbval[ii] - cbval[jj]) * 1.05, t2, t3;
+                if (t1 >= 0.5 && t1 <= 2.5) {
+                    t2 = t1 - 0.5;
+                    t2 = 8.0 * (t2 * t2 - 2.0 * t2);
+                } else t2 = 0;
+                t1 += 0.474;
+                t3 = 15.811389 + 7.5 * t1 - 17.5 * sqrt((double) (1.0 + t1 * t1));
+                if (t3 <= -100) s[ii][jj] = 0;
+                else {
+                    t3 = (t2 + t3) * R_LN_TO_LOG10;
+                    s[ii][jj] = exp(t3);
+                }
+            });
+    for (j = 0; j < L12_CB; j++) { /* src/psy.c:219-228 */
+        temp1 = 15.5 + cbval[j];
+        T->tmn[j] = (temp1 > 24.5) ? temp1 : 24.5;
+        rnorm[j] = 0;
+        for (i = 0; i < L12_CB; i++) rnorm[j] += s[j][i];
+    }
+    for (j = 0; j < L12_CB; j++) {
+        for (i = 0; i < L12_CB; i++) T->spread_t[i][j] = s[j][i];
+        T->cbval[j] = cbval[j];
+        T->rnorm[j] = rnorm[j];
+        unsigned k = cbval[j] + 0.5; /* src/psy.c:336 */
+        if (k >= 27) return -2;
+        T->bmaxv[j] = bmax[k];
+        T->rn_nl[j] = (rnorm[j] && numlines[j]) ? rnorm[j] * numlines[j] : 0.0f; /* src/psy.c:346-347 */
+    }
+    for (i = 0; i < L12_HBLK; i++) {
+        T->absthr[i] = T12_ABSTHR[ri][i];
+        T->partition[i] = (uint8_t) partition[i];
+        if (i == 0 || partition[i] != partition[i - 1]) T->part_first[partition[i]] = (int16_t) i;
+    }
+    for (int b = T->npart; b <= 64; b++) T->part_first[b] = L12_HBLK;
+    memcpy(T->multiple, T12_MULTIPLE, sizeof(T->multiple));
+    memcpy(T->snr, SNR, sizeof(SNR)); memcpy(T->qa, QA, sizeof(QA)); memcpy(T->qb, QB, sizeof(QB));
+    if (layer == 1) { /* what the layer's first frame does to the shared statics, src/encode.c:900-905, 1226-1231 */
+        T->snr[2] = T->snr[3];
+        for (i = 3; i < 16; i++) T->snr[i] = T->snr[i + 2];
+        T->qa[1] = T->qa[2]; T->qb[1] = T->qb[2];
+        for (i = 2; i < 15; i++) { T->qa[i] = T->qa[i + 2]; T->qb[i] = T->qb[i + 2]; }
+    }
+    memcpy(T->alloc, T12_ALLOC, sizeof(T->alloc));
+    for (i = 0; i < 4; i++) T->sblimit[i] = T12_ALLOC_SBLIMIT[i];
+    return 0;
+}
+
+extern "C" int mp3mi_build_tables_l12(mp3mi_tables_l12 *T, int rate_idx, int layer)
+{
+    static float s[L12_CB][L12_CB];
+    const int rc = build_tables_l12_unpinned(T, rate_idx, layer, s);
+    if (rc == -7) return -8;
+    if (rc != 0) return rc;
+    if (fnv1a64(s, sizeof(s)) != L12_SPREAD_PINS[rate_idx]) {
+        fprintf(stderr, "mp3mi: the Layer I/II spreading function (rate index %d) differs from its pinned value: the table blob and the "
+                        "table code do not belong together\n", rate_idx);
+        return -8;
+    }
+    return 0;
+}
+
 #if defined(MP3MI_TABLE_GEN)
 /* The generator (make -C csrc blob): builds the tables of the three rates with THIS host's libm, checks them against the
  * pins -- this host must be the environment the goldens come from -- and writes tables_blob.bin.
@@ -979,6 +1111,17 @@ int main(int argc, char **argv)
         }
     }
     free(T);
+    {   /* Layers I / II: the spreading function of the three rates */
+        static mp3mi_tables_l12 T12;
+        static float sp[L12_CB][L12_CB];
+        for (int ri = 0; ri < 3; ri++) {
+            const int rc = build_tables_l12_unpinned(&T12, ri, 2, sp);
+            if (rc != 0) { fprintf(stderr, "Layer I/II table build failed for rate index %d: %d\n", ri, rc); return 1; }
+            const uint64_t h = fnv1a64(sp, sizeof(sp));
+            printf("L12_SPREAD_PIN_%d 0x%016llxull\n", ri, (unsigned long long) h);
+            if (check && h != L12_SPREAD_PINS[ri]) { fprintf(stderr, "Layer I/II spreading function (rate index %d) differs from its pin; no blob written\n", ri); return 1; }
+        }
+    }
     tb_header hd;
     memset(&hd, 0, sizeof(hd));
     memcpy(hd.magic, "MP3MITB1", 8);

@@ -392,3 +392,181 @@ class BatchRun:
             self.mp.lib.mp3mi_batch_destroy(self.b)
             self.b = ctypes.c_void_p()
         self.mem.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Layers I and II: oracle/mp12_oracle.inc, oracle/ref_harness_l12.c, include/mp3mi_l12.h
+# ---------------------------------------------------------------------------------------------------------------------
+REF_HARNESS_L12 = os.path.join(ROOT, "oracle", "_ref", "ref_harness_l12")
+REF_ENCODE = os.path.join(ROOT, "oracle", "_ref", "encode")
+# oracle/stage_dump_l12.h
+L12_DT = np.dtype([("sb", "<f8", (2, 3, 12, 32)), ("ltmin", "<f8", (2, 32)), ("scalar", "<i4", (2, 3, 32)), ("j_scale", "<i4", (3, 32)),
+                   ("scfsi", "<i4", (2, 32)), ("bit_alloc", "<i4", (2, 32)), ("mode", "<i4"), ("mode_ext", "<i4"), ("jsbound", "<i4"),
+                   ("sblimit", "<i4"), ("adb_left", "<i4"), ("crc", "<i4"), ("magic", "<i4"), ("frame_index", "<i4")])
+# include/mp3mi_l12.h: mp3mi_l12_frame_seams
+L12_SEAM_DT = np.dtype([("ltmin", "<f8", (2, 32)), ("scalar", "<i4", (2, 3, 32)), ("j_scale", "<i4", (3, 32)), ("scfsi", "<i4", (2, 32)),
+                        ("bit_alloc", "<i4", (2, 32)), ("mode", "<i4"), ("mode_ext", "<i4"), ("jsbound", "<i4"), ("sblimit", "<i4"),
+                        ("adb_left", "<i4"), ("crc", "<i4"), ("pad", "<i4", (2,))])
+L12_SEAMS = ["ltmin", "scalar", "j_scale", "scfsi", "bit_alloc", "mode", "mode_ext", "jsbound", "sblimit", "adb_left", "crc"]
+L12_BITRATES = {1: [32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 416, 448],
+                2: [32, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384]}
+L12_MODES = {"s": 0, "j": 1, "d": 2, "m": 3}
+
+
+def l12_spf(layer):
+    return 384 if layer == 1 else 1152
+
+
+def oracle_l12(orc, layer, rate, kbps, mode, pcm, dumps=0):
+    """orc: an Oracle; mode: the driver's -m letter (s / d / j / m) followed by e / c / o.  Returns (bytes, dumps or None)."""
+    L = orc.lib
+    L.mp3o_encode_pcm_l12.restype = ctypes.c_size_t
+    L.mp3o_encode_pcm_l12.argtypes = [ctypes.c_int] * 4 + [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                            ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int]
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = ctypes.c_void_p()
+    d = np.zeros(dumps, L12_DT) if dumps else None
+    ch = 1 if mode[0] == "m" else 2
+    n = L.mp3o_encode_pcm_l12(layer, rate, kbps, ch, mode.encode(), pcm.ctypes.data, pcm.size, ctypes.byref(out),
+                              d.ctypes.data if dumps else None, dumps)
+    if not out.value:
+        raise ValueError("oracle refused configuration")
+    data = ctypes.string_at(out.value, n)
+    orc.libc.free(out)
+    return data, d
+
+
+def ref_l12(layer, rate, kbps, mode, pcm, workdir, dumps=True):
+    """the UNMODIFIED reference through oracle/_ref/ref_harness_l12 (bytes, stage_dump_l12 records)"""
+    wav, mpg, dmp = (os.path.join(workdir, n) for n in ("in.wav", "out.mpg", "dump.bin"))
+    with open(wav, "wb") as f:
+        f.write(b"\0" * 44)
+        f.write(np.ascontiguousarray(pcm, dtype="<i2").tobytes())
+    r = subprocess.run([REF_HARNESS_L12, wav, mpg, str(layer), str(rate), str(kbps), mode] + ([dmp] if dumps else []),
+                       capture_output=True, cwd=workdir)
+    assert r.returncode == 0, (r.returncode, r.stderr[-300:])
+    return open(mpg, "rb").read(), (np.fromfile(dmp, L12_DT) if dumps else None)
+
+
+def l12_signal(n_per_ch, ch, seed, rate=44100):
+    """a sweep, noise and a burst per channel (test input of the Layer I / II parity tests)"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_per_ch)
+    x = np.zeros((n_per_ch, ch))
+    for c in range(ch):
+        f0 = rng.uniform(100, 4000)
+        x[:, c] = rng.uniform(2000, 12000) * np.sin(2 * np.pi * f0 * t / rate * (1 + t / max(n_per_ch, 1))) + rng.uniform(100, 3000) * rng.standard_normal(n_per_ch)
+        a = n_per_ch // 3
+        x[a:a + 200, c] += rng.uniform(0, 15000) * rng.standard_normal(len(x[a:a + 200, c]))
+    return np.clip(x, -32768, 32767).astype(np.int16).reshape(-1)
+
+
+class L12Run:
+    """One Layer I / II batch through the C ABI (include/mp3mi_l12.h) on device memory (or the emulated test build's
+    host memory): pcm_list = interleaved int16 arrays, one per stream (ragged lengths allowed)."""
+
+    def __init__(self, mp, layer, rate, kbps, mode, pcm_list=None, n_frames=None, scratch_mb=0, flags=0, seams=False,
+                 synth=None):
+        """synth = (S, stream0): PCM synthesised on the device by mp3mi_synth_pcm_device instead of pcm_list"""
+        L = mp.lib
+        self.mp, self.layer, self.rate, self.mode = mp, layer, rate, mode
+        self.ch = ch = 1 if mode[0] == "m" else 2
+        spf = l12_spf(layer)
+        if synth:
+            S = synth[0]
+        else:
+            S = len(pcm_list)
+            n_frames = n_frames or max((len(p) // ch + spf - 1) // spf for p in pcm_list)
+        self.S, self.nf = S, n_frames
+        L.mp3mi_l12_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+        L.mp3mi_l12_batch_out_stride.restype = ctypes.c_size_t
+        L.mp3mi_l12_batch_out_stride.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_l12_batch_encode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_l12_batch_sync.argtypes = [ctypes.c_void_p]
+        L.mp3mi_l12_batch_destroy.argtypes = [ctypes.c_void_p]
+        L.mp3mi_l12_batch_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_l12_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_l12_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.mp3mi_l12_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.mp3mi_l12_batch_debug_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_l12_batch_debug_fetch.restype = ctypes.c_long
+        L.mp3mi_l12_batch_debug_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        L.mp3mi_l12_batch_total_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+        self.b = ctypes.c_void_p()
+        karr = None if np.isscalar(kbps) else np.ascontiguousarray(kbps, dtype=np.int32)
+        rc = L.mp3mi_l12_batch_create(ctypes.byref(self.b), layer, S, rate, ch, karr.ctypes.data if karr is not None else None,
+                                      int(kbps) if karr is None else 0, n_frames, scratch_mb)
+        assert rc == 0, "mp3mi_l12_batch_create -> %d" % rc
+        assert L.mp3mi_l12_batch_set_mode(self.b, L12_MODES[mode[0]]) == 0
+        assert L.mp3mi_l12_batch_set_error_protection(self.b, int("e" in mode[1:])) == 0
+        assert L.mp3mi_l12_batch_set_header(self.b, int("c" in mode[1:]), int("o" in mode[1:]), 0) == 0
+        assert L.mp3mi_l12_batch_set_test_flags(self.b, flags) == 0
+        if seams:
+            L.mp3mi_l12_batch_debug_enable(self.b, 1)
+        self.mem = DevMem(mp)
+        self.stride = L.mp3mi_l12_batch_out_stride(self.b, n_frames)
+        row = n_frames * spf * ch
+        self.row = row
+        self.d_pcm = self.mem.alloc(S * row * 2)
+        self.d_out = self.mem.alloc(S * self.stride)
+        self.d_len = self.mem.alloc(4 * S)
+        self.d_ns = None
+        if synth:
+            rc = L.mp3mi_synth_pcm_device(self.d_pcm, S, n_frames * spf, ch, rate, synth[1], SEED)
+            assert rc == 0, "mp3mi_synth_pcm_device -> %d" % rc
+        else:
+            pcm = np.zeros((S, row), np.int16)
+            ns = np.zeros(S, np.int32)
+            for i, p in enumerate(pcm_list):
+                pcm[i, :len(p)] = p
+                ns[i] = len(p) // ch
+            self.mem.upload(self.d_pcm, pcm)
+            self.d_ns = self.mem.alloc(4 * S)
+            self.mem.upload(self.d_ns, ns)
+
+    def pcm_of(self, s):
+        return self.mem.download(self.d_pcm + s * self.row * 2, (self.row,), np.int16)
+
+    def set_flags(self, flags):
+        assert self.mp.lib.mp3mi_l12_batch_set_test_flags(self.b, flags) == 0
+
+    def encode(self):
+        L = self.mp.lib
+        rc = L.mp3mi_l12_batch_encode(self.b, self.d_pcm, self.d_ns, self.nf, self.d_out, self.stride, self.d_len)
+        assert rc == 0, "mp3mi_l12_batch_encode -> %d" % rc
+        assert L.mp3mi_l12_batch_sync(self.b) == 0
+        out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
+        lens = self.mem.download(self.d_len, (self.S,), np.uint32)
+        return [out[i, :lens[i]].tobytes() for i in range(self.S)]
+
+    def seams(self):
+        """(records [S][frames of the last chunk], first frame of that chunk)"""
+        d = np.zeros((self.S * self.nf,), L12_SEAM_DT)
+        f0, nf = ctypes.c_int(), ctypes.c_int()
+        n = self.mp.lib.mp3mi_l12_batch_debug_fetch(self.b, d.ctypes.data, d.nbytes, ctypes.byref(f0), ctypes.byref(nf))
+        assert n > 0, n
+        return d[:self.S * nf.value].reshape(self.S, nf.value), f0.value
+
+    def kernel_ms(self):
+        ms, calls = ctypes.c_double(), ctypes.c_long()
+        assert self.mp.lib.mp3mi_l12_batch_total_timing(self.b, ctypes.byref(ms), ctypes.byref(calls)) == 0
+        return ms.value, calls.value
+
+    def close(self):
+        if self.b:
+            self.mp.lib.mp3mi_l12_batch_destroy(self.b)
+            self.b = ctypes.c_void_p()
+        self.mem.free()
+
+
+def l12_compare_seams(ref_dumps, got, f0):
+    """names of the seams of `got` ([frames of a chunk] L12_SEAM_DT, first frame f0) that differ from the stage_dump_l12
+    records of the same frames"""
+    bad = []
+    for k in range(len(got)):
+        if f0 + k >= len(ref_dumps):
+            break
+        for name in L12_SEAMS:
+            if not np.array_equal(ref_dumps[f0 + k][name], got[k][name]):
+                bad.append((f0 + k, name))
+    return bad
