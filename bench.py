@@ -17,6 +17,10 @@ csrc/pcm_synth_core.h run on the device (md5-pinned by tests/test_synth.py).  A 
 streams is compared byte for byte with the CPU oracle and with the unmodified reference binary; a mismatch
 makes the run FAIL (exit 1, value null).  tools/full_parity.py compares every stream.
 
+--layer 1|2 runs the same contract over the Layer I / Layer II path (include/mp3mi_l12.h) at the
+reference's default bitrate for the layer (src/musicin.c:371-372: 288 / 160 kbps): 4096 streams x 10 s of 44.1 kHz stereo.
+The default (--layer 3) is the metric of BASELINE.json.
+
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -151,7 +155,7 @@ def cpu_baseline(pcm_sample, rate, kbps_list, channels, cores):
     return frames / dt, outs
 
 
-def reference_baseline(pcm_sample, rate, kbps_list, channels, cores):
+def reference_baseline(pcm_sample, rate, kbps_list, channels, cores, layer=3):
     """The UNMODIFIED reference encoder (oracle/_ref/encode, compiled from /root/reference/src by
     oracle/Makefile where the sources exist; the binary travels with the repository) on the same
     sample, one process per stream.  Returns (frames/s, outputs) or None when the binary is absent."""
@@ -171,9 +175,9 @@ def reference_baseline(pcm_sample, rate, kbps_list, channels, cores):
                     struct.pack("<I", len(data)) + data)
 
     def run(k):
-        args = [exe, "-s", "%g" % (rate / 1000.0), "-b", str(kbps_list[k])] + (["-m", "m"] if channels == 1 else [])
+        args = [exe, "-l", str(layer), "-s", "%g" % (rate / 1000.0), "-b", str(kbps_list[k])] + (["-m", "m"] if channels == 1 else [])
         subprocess.run(args + [os.path.join(tmp, "%d.wav" % k), os.path.join(tmp, "%d.mp3" % k)], check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp)  # (psycho_anal writes "out.dat" where it runs)
         return open(os.path.join(tmp, "%d.mp3" % k), "rb").read()
 
     run(0)  # warm the page cache
@@ -181,9 +185,131 @@ def reference_baseline(pcm_sample, rate, kbps_list, channels, cores):
     with ThreadPoolExecutor(max_workers=cores) as ex:
         outs = list(ex.map(run, range(len(pcm_sample))))
     dt = time.perf_counter() - t0
-    frames = sum(len(p) // (1152 * channels) for p in pcm_sample)
+    spf = 384 if layer == 1 else 1152
+    frames = sum(len(p) // (spf * channels) for p in pcm_sample)
     shutil.rmtree(tmp, ignore_errors=True)
     return frames / dt, outs
+
+
+L12_KERNEL_BOUND = {
+    "k12_alloc": "valu+salu issue (a wave minimum per granted step, serial per frame)", "k12_psy": "latency + hbm (serial partition / spreading sums, 14 KB of rows per record)",
+    "k12_phase": "valu issue (f64 atan2) + hbm", "k_filter": "valu issue (f64) + hbm", "k_fft12": "lds pipe (bank conflicts of the butterfly program)",
+}
+
+
+def main_l12(args, mp3, dev, cdev, rank, world, distributed):
+    """The Layer I / II path under the same contract: a step = one mp3mi_l12_batch_encode call over the batch."""
+    import hashlib
+    from mp3common import Oracle, oracle_l12
+    if distributed:
+        import torch.distributed as dist
+    layer = args.layer
+    spf = 384 if layer == 1 else 1152
+    rate, C, mode = 44100, 2, "s"
+    kbps = 288 if layer == 1 else 160  # the driver's default: bitrate[version][lay - 1][9], src/musicin.c:371-372
+    S = args.streams or 4096
+    nf = args.frames or (1149 if layer == 1 else 383)  # 10 s of audio, as BASELINE configs[0] / [1]
+    batch = mp3.BatchL12(layer, S, rate, C, kbps, nf)
+    pcm = torch.empty((S, nf * spf * C), dtype=torch.int16, device=dev)
+    mp3.synth_pcm_device(pcm, nf * spf, C, rate, stream0=rank * S, seed=SEED)
+    out = torch.zeros((S, batch.out_stride(nf)), dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(S, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.encode(pcm, nf, out, out_len)
+        batch.sync()
+    barrier()
+    k_before = batch.kernel_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.encode(pcm, nf, out, out_len)
+    batch.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    k_after = batch.kernel_timing()
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    timed_baseline = rank == 0 and world == 1 and not args.no_cpu_baseline
+    n_sample = max(4, cores * 2) if timed_baseline else 8
+    idx = sorted(set(np.linspace(0, S - 1, n_sample).astype(int).tolist()))
+    pcm_sample = [pcm[i].cpu().numpy() for i in idx]
+    out_h, len_h = out[idx].cpu().numpy(), out_len[idx].cpu().numpy()
+    got = [out_h[k, : len_h[k]].tobytes() for k in range(len(idx))]
+    orc = Oracle()
+    oracle_l12(orc, layer, rate, kbps, mode, pcm_sample[0][: spf * C * 4])
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        refs = list(ex.map(lambda p: oracle_l12(orc, layer, rate, kbps, mode, p)[0], pcm_sample))
+    fps = len(idx) * nf / (time.perf_counter() - t1)
+    bad = [int(idx[k]) for k in range(len(idx)) if got[k] != refs[k]]
+    cpu = None
+    if timed_baseline:
+        cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d of this batch's streams x %d frames, oracle/liboracle.so (mp12_oracle.inc), one thread per stream" % (len(idx), nf)}
+        ref = reference_baseline(pcm_sample, rate, [kbps] * len(idx), C, cores, layer=layer)
+        if ref is not None:
+            rfps, routs = ref
+            bad += [int(idx[k]) for k in range(len(idx)) if got[k] != routs[k] and int(idx[k]) not in bad]
+            cpu = {"value": round(rfps, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
+                   "sample": "%d of this batch's streams x %d frames, oracle/_ref/encode -l %d (unmodified reference, gcc -O2), one process per stream" % (len(idx), nf, layer),
+                   "port_value": round(fps, 1)}
+    n_bad = torch.tensor([len(bad)], dtype=torch.int64, device=cdev)
+    mine = torch.tensor([rank, rank * S, S, int(hashlib.md5(b"".join(got)).hexdigest()[:15], 16)], dtype=torch.int64, device=cdev)
+    per_rank = [mine.clone() for _ in range(world)]
+    if distributed:
+        dist.all_reduce(n_bad, op=dist.ReduceOp.SUM)
+        dist.all_gather(per_rank, mine)
+    parity_ok = int(n_bad.item()) == 0
+    ranks = [{"rank": int(t[0]), "first_stream": int(t[1]), "streams": int(t[2]), "sample_digest": "%015x" % int(t[3])} for t in per_rank]
+    if rank == 0:
+        fb = mp3.frame_bytes_l12(layer, rate, kbps)
+        alg = spf * C * 2 + fb  # PCM in + frame out
+        kt = {k: (k_after[k][0] - k_before[k][0], k_after[k][1] - k_before[k][1]) for k in k_after}
+        dom = max(kt, key=lambda k: kt[k][0])
+        dom_ms, dom_n = kt[dom]
+        avg_launch_s = dom_ms / 1e3 / max(dom_n, 1)
+        frames_per_launch = S * nf * args.steps / max(dom_n, 1)
+        achieved = alg * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        result = {
+            "metric": "Layer %s stereo 44.1 kHz frames/s @%d kbps (bit-exact), MI355X" % ("I" if layer == 1 else "II", kbps),
+            "value": round(S * nf * args.steps * world / dt, 1) if parity_ok else None, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "timing": "the K timed calls are issued back to back; ms_per_step = wall time / K",
+            "config": {"workload": "batch of %d synthetic 44.1 kHz stereo streams x %d Layer %s frames (%d samples) per GPU, %d kbps CBR, "
+                                   "psychoacoustic model 2 (SURVEY 8(f) row 4; not a BASELINE.json config)" % (S, nf, "I" if layer == 1 else "II", spf, kbps),
+                       "layer": layer, "streams_per_gpu": S, "frames_per_stream": nf,
+                       "pcm": "mp3mi_synth_pcm_device, seed 0x%08x, streams rank*S .." % SEED,
+                       "parallelism": "streams sharded across GPUs, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_frame": alg, "kernel_ms_per_launch": round(avg_launch_s * 1e3, 3),
+                         "launches_per_step": dom_n // max(args.steps, 1),
+                         "limited_by": "instruction issue and latency of the frame kernels, not HBM (kernels: what bounds each)",
+                         "kernels": {k: {"bound": L12_KERNEL_BOUND.get(k, "?"), "launches_per_step": kt[k][1] // max(args.steps, 1),
+                                         "avg_ms_per_launch": round(kt[k][0] / max(kt[k][1], 1), 3)} for k in sorted(kt)},
+                         "source_hash": mp3.lib().mp3mi_source_hash().decode()},
+            "cpu_baseline": cpu, "ranks": ranks,
+            "parity_spot_check": {"streams_per_rank": len(idx), "bit_exact": parity_ok, "mismatching_streams_rank0": bad,
+                                  "witness": "oracle/liboracle.so" + (" + oracle/_ref/encode" if cpu and cpu["kind"] == "reference" else "")},
+        }
+        print(json.dumps(result), flush=True)
+    batch.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit("bench.py: PARITY FAILURE -- the GPU bitstream differs from the reference on %d sampled streams" % int(n_bad.item()))
 
 
 def main():
@@ -194,6 +320,8 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
                     help="BASELINE.json workload (see the module docstring); the default is configs[1] for every N, so that the "
                          "1 / 2 / 4 / 8-GPU series is one per-GPU workload")
+    ap.add_argument("--layer", type=int, default=3, choices=[1, 2, 3],
+                    help="3: the Layer III path (BASELINE.json's metric, the default); 1 / 2: the Layer I / II path of SURVEY 8(f) row 4")
     ap.add_argument("--streams", type=int, default=0, help="override: streams per GPU")
     ap.add_argument("--frames", type=int, default=0, help="override: frames per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true",
@@ -221,6 +349,8 @@ def main():
     cdev = torch.device("cpu") if (distributed and one_gpu) else dev  # where the collectives' tensors live
 
     mp3 = importlib.import_module("mp3-enc-bsd_amd")
+    if args.layer != 3:
+        return main_l12(args, mp3, dev, cdev, rank, world, distributed)
     cfg_id = args.config
     cfg = dict(CONFIGS[cfg_id])
     default_size = not (args.streams or args.frames)

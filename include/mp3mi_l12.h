@@ -75,6 +75,9 @@ long mp3mi_l12_batch_debug_fetch(mp3mi_l12_batch *b, void *host_dst, size_t cap,
 
 /* milliseconds inside the kernels of all encode calls since create (HIP events on the batch's stream), and the calls */
 int mp3mi_l12_batch_total_timing(mp3mi_l12_batch *b, double *all_kernels_ms, long *calls);
+/* the same per kernel, HIP events around every launch: [0] k_fft12, [1] k12_phase, [2] k12_psy (Layer I: + k12_snr1),
+ * [3] k_filter, [4] k12_alloc -- milliseconds and launches since create */
+int mp3mi_l12_batch_kernel_timing(mp3mi_l12_batch *b, double ms[5], long launches[5]);
 
 /* Host-buffer convenience wrapper (tests, smoke): pcm [n_streams][n_frames * frame * channels], n_samples may be NULL;
  * mode MP3MI_MODE_* or -1 = by the channel count. */

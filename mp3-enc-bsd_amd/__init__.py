@@ -89,6 +89,19 @@ def lib():
         L.mp3mi_batch_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        # Layers I and II (include/mp3mi_l12.h)
+        L.mp3mi_l12_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+        L.mp3mi_l12_batch_destroy.argtypes = [ctypes.c_void_p]
+        L.mp3mi_l12_batch_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_l12_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_l12_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.mp3mi_l12_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.mp3mi_l12_batch_out_stride.restype = ctypes.c_size_t
+        L.mp3mi_l12_batch_out_stride.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mp3mi_l12_batch_encode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_l12_batch_sync.argtypes = [ctypes.c_void_p]
+        L.mp3mi_l12_batch_total_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+        L.mp3mi_l12_batch_kernel_timing.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.mp3mi_version.restype = ctypes.c_char_p
         L.mp3mi_source_hash.restype = ctypes.c_char_p
         _lib = L
@@ -208,6 +221,74 @@ class Batch:
     def close(self):
         if self.h:
             self.L.mp3mi_batch_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+L12_KERNELS = ("k_fft12", "k12_phase", "k12_psy", "k_filter", "k12_alloc")
+L12_FRAME_SAMPLES = {1: 384, 2: 1152}
+
+
+def frame_bytes_l12(layer, rate_hz, kbps):
+    """slots per frame times the slot size, never padded (reference: src/musicin.c:562-581)"""
+    if layer == 1:
+        return 4 * int((384.0 / (rate_hz / 1000.0)) * (kbps / 32.0))
+    return int((1152.0 / (rate_hz / 1000.0)) * (kbps / 8.0))
+
+
+class BatchL12:
+    """Layer I / II batched encoder (include/mp3mi_l12.h) over device memory handed in as torch tensors."""
+
+    def __init__(self, layer, n_streams, rate_hz, channels, kbps, max_frames, mode=None, error_protection=False, scratch_mb=0):
+        import numpy as np
+        self.L = lib()
+        self.layer, self.n_streams, self.rate_hz, self.channels, self.max_frames = layer, n_streams, rate_hz, channels, max_frames
+        self.h = ctypes.c_void_p()
+        arr = None if isinstance(kbps, int) else np.ascontiguousarray(kbps, dtype=np.int32)
+        karg, kall = (None, kbps) if arr is None else (arr.ctypes.data, 0)
+        rc = self.L.mp3mi_l12_batch_create(ctypes.byref(self.h), layer, n_streams, rate_hz, channels, karg, kall, max_frames, scratch_mb)
+        if rc != 0:
+            raise Mp3miError("mp3mi_l12_batch_create failed with %d" % rc)
+        if mode is not None:
+            self._check(self.L.mp3mi_l12_batch_set_mode(self.h, mode), "mp3mi_l12_batch_set_mode")
+        if error_protection:
+            self._check(self.L.mp3mi_l12_batch_set_error_protection(self.h, 1), "mp3mi_l12_batch_set_error_protection")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise Mp3miError("%s failed with %d" % (what, rc))
+
+    def out_stride(self, n_frames):
+        return self.L.mp3mi_l12_batch_out_stride(self.h, n_frames)
+
+    def encode(self, pcm, n_frames, out, out_len, n_samples=None):
+        assert pcm.is_cuda and out.is_cuda and out_len.is_cuda and pcm.is_contiguous() and out.is_contiguous()
+        self._check(self.L.mp3mi_l12_batch_encode(self.h, pcm.data_ptr(), n_samples.data_ptr() if n_samples is not None else None,
+                                                  n_frames, out.data_ptr(), out.stride(0), out_len.data_ptr()), "mp3mi_l12_batch_encode")
+
+    def sync(self):
+        self._check(self.L.mp3mi_l12_batch_sync(self.h), "mp3mi_l12_batch_sync")
+
+    def total_timing(self):
+        """(ms inside all kernels, calls) since create; waits for the work issued so far"""
+        a, k = ctypes.c_double(), ctypes.c_long()
+        self._check(self.L.mp3mi_l12_batch_total_timing(self.h, ctypes.byref(a), ctypes.byref(k)), "mp3mi_l12_batch_total_timing")
+        return a.value, k.value
+
+    def kernel_timing(self):
+        """{kernel: (ms, launches)} since create (HIP events around every launch)"""
+        ms, n = (ctypes.c_double * 5)(), (ctypes.c_long * 5)()
+        self._check(self.L.mp3mi_l12_batch_kernel_timing(self.h, ms, n), "mp3mi_l12_batch_kernel_timing")
+        return {L12_KERNELS[i]: (ms[i], n[i]) for i in range(5)}
+
+    def close(self):
+        if self.h:
+            self.L.mp3mi_l12_batch_destroy(self.h)
             self.h = ctypes.c_void_p()
 
     def __del__(self):

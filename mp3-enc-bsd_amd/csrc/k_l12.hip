@@ -23,7 +23,8 @@ MP3MI_DEVFN bool l12_float_decided(double v, double err) { return (float) (v - e
 
 struct psy12_lds {
     float e[L12_ROW], c[L12_ROW], thr[L12_ROW];
-    float ge[64], gc[64], nb[64];
+    float2 g2[64]; // grouped_e, grouped_c of partition k
+    float nb[64];
 };
 
 // c[j] of src/psy.c:283-292 for one line.  FAST: sines and cosines from dm_sincos_fast (|error| < 2^-51 each); the
@@ -86,26 +87,33 @@ MP3MI_DEVFN float psy12_snr_band(const float *e, const float *fthr, int sb, bool
     return (float) (4.342944819 * dm_log((double) x));
 }
 
-__global__ void __launch_bounds__(64) k12_psy(const mp3mi_tables_l12 *__restrict__ T, l12_geom geo,
+__global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restrict__ T, l12_geom geo,
                                               const float *__restrict__ erp, float *__restrict__ thr1, float *__restrict__ snr)
 {
     __shared__ psy12_lds L;
     const int lane = wave_lane();
     const int C = geo.channels, NP = geo.np;
     // records of this launch: the chunk's own passes, and for Layer I the one before them (its threshold is the
-    // next one's lthr)
+    // next one's lthr).  The wavefronts are persistent: each walks through every gridDim.x-th record.
     const int qi0 = geo.lb - (geo.layer == 1 ? 1 : 0), nq = NP - qi0;
-    const int ch = (int) (blockIdx.x % (unsigned) C);
-    const int ql = (int) ((blockIdx.x / (unsigned) C) % (unsigned) nq);
-    const int s = (int) (blockIdx.x / (unsigned) (C * nq));
+    const unsigned n_rec = (unsigned) geo.n_streams * (unsigned) nq * (unsigned) C;
+    const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1;
+    const double tmn = T->tmn[lane < L12_CB ? lane : 0];
+    const float bm = T->bmaxv[lane < L12_CB ? lane : 0], rn_nl = T->rn_nl[lane < L12_CB ? lane : 0];
+    const int pj0 = lane < T->npart ? T->part_first[lane] : 0, pj1 = lane < T->npart ? T->part_first[lane + 1] : 0;
+#pragma unroll 1
+    for (unsigned bid = blockIdx.x; bid < n_rec; bid += gridDim.x) {
+    const int ch = (int) (bid % (unsigned) C);
+    const int ql = (int) ((bid / (unsigned) C) % (unsigned) nq);
+    const int s = (int) (bid / (unsigned) (C * nq));
     const int qi = qi0 + ql;
     const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
-    if (q < 0) return; // (Layer I, first chunk: the pass before the stream has the initial lthr, k12_snr1)
+    if (q < 0) continue; // (Layer I, first chunk: the pass before the stream has the initial lthr, k12_snr1)
     const size_t rec = ((size_t) s * NP + qi) * C + ch;
     const float *r_n = erp + rec * (3 * L12_ROW);               // this pass: energy, r, phi
     const float *r_o = erp + (rec - (size_t) C) * (3 * L12_ROW);     // the pass before ("old")
     const float *r_oo = erp + (rec - 2 * (size_t) C) * (3 * L12_ROW); // two before ("oldest" = the slot "new" overwrites)
-    const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1;
+    wave_sync(); // the record before is done with the LDS
 
     // ---- unpredictability of every line, src/psy.c:282-292
 #pragma unroll 1
@@ -131,16 +139,15 @@ __global__ void __launch_bounds__(64) k12_psy(const mp3mi_tables_l12 *__restrict
     // ---- partition sums in line order, src/psy.c:297-306: a lane per partition
     {
         float ge = 0.0f, gc = 0.0f;
-        if (lane < T->npart) {
-            const int j0 = T->part_first[lane], j1 = T->part_first[lane + 1];
-            for (int j = j0; j < j1; j++) {
+        {
+#pragma unroll 4
+            for (int j = pj0; j < pj1; j++) {
                 const float ev = L.e[j];
                 ge = ge + ev;
                 gc = gc + ev * L.c[j];
             }
         }
-        L.ge[lane] = ge;
-        L.gc[lane] = gc;
+        L.g2[lane] = make_float2(ge, gc);
     }
     wave_sync();
 
@@ -149,16 +156,35 @@ __global__ void __launch_bounds__(64) k12_psy(const mp3mi_tables_l12 *__restrict
         float nbv = 0.0f;
         const int j = lane < L12_CB ? lane : 0;
         float ecb = 0.0f, cb = 0.0f;
-        for (int k = 0; k < L12_CB; k++) {
-            const float sv = T->spread_t[k][j]; // (the reference skips s == 0: adding 0 * x changes nothing)
-            ecb = ecb + sv * L.ge[k];
-            cb = cb + sv * L.gc[k];
+        // row j of the spreading function in two halves of 32 (8 loads of 16 bytes each, served by the CU's vector
+        // cache: the table is 16 KB), fetched here and not kept: 64 registers for the whole kernel otherwise
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float srow[32];
+            const float4 *rp = (const float4 *) (T->spread_r[j] + 32 * h);
+#if !defined(MP3MI_EMU)
+            __asm__ volatile("" : "+v"(rp));
+#endif
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float4 v = rp[k];
+                srow[4 * k] = v.x; srow[4 * k + 1] = v.y; srow[4 * k + 2] = v.z; srow[4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 32; k++) { // (the reference skips s == 0: adding 0 * x changes nothing; k = 63 is padding: 0 * 0)
+                const float2 g = L.g2[32 * h + k];
+                ecb = ecb + srow[k] * g.x;
+                cb = cb + srow[k] * g.y;
+#if !defined(MP3MI_EMU)
+                if ((k & 7) == 7) __asm__ volatile("" ::: "memory"); // (eight broadcast reads in flight, not all: registers)
+#endif
+            }
         }
         if (ecb != 0.0f) cb = cb / ecb;
         else cb = 0.0f;
         if ((double) cb < .05) cb = (float) 0.05;
         else if ((double) cb > .5) cb = (float) 0.5;
-        const double tmn = T->tmn[j], nmt = 5.5;
+        const double nmt = 5.5;
         float bc;
         {
             bool done = false;
@@ -174,7 +200,6 @@ __global__ void __launch_bounds__(64) k12_psy(const mp3mi_tables_l12 *__restrict
                 bc = done ? bc : bx;
             }
         }
-        const float bm = T->bmaxv[j];
         bc = (bc > bm) ? bc : bm;
         {
             const double arg = (double) -bc * R_LN_TO_LOG10;
@@ -190,8 +215,7 @@ __global__ void __launch_bounds__(64) k12_psy(const mp3mi_tables_l12 *__restrict
             }
             bc = bx;
         }
-        const float rn = T->rn_nl[j];
-        if (rn != 0.0f) nbv = ecb * bc / rn;
+        if (rn_nl != 0.0f) nbv = ecb * bc / rn_nl;
         L.nb[lane] = lane < L12_CB ? nbv : 0.0f;
     }
     wave_sync();
@@ -203,9 +227,10 @@ __global__ void __launch_bounds__(64) k12_psy(const mp3mi_tables_l12 *__restrict
         L.thr[i] = v;
         if (geo.layer == 1) thr1[rec * L12_ROW + i] = v;
     }
-    if (geo.layer == 1) return;
+    if (geo.layer == 1) continue;
     wave_sync();
     if (lane < 32) snr[rec * 32 + lane] = psy12_snr_band(L.e, L.thr, lane, psy_exact);
+    }
 }
 
 // Layer I: the threshold of a line is limited by 32 x the threshold of the pass before and floored at 0.00316 x its
@@ -238,7 +263,15 @@ __global__ void __launch_bounds__(64) k12_snr1(l12_geom geo, const float *__rest
 void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *thr1, float *snr, hipStream_t st)
 {
     const int nq = g.np - g.lb + (g.layer == 1 ? 1 : 0);
-    hipLaunchKernelGGL(k12_psy, dim3((unsigned) ((size_t) g.n_streams * nq * g.channels)), dim3(64), 0, st, T, g, erp, thr1, snr);
+    const size_t n_rec = (size_t) g.n_streams * nq * g.channels;
+    static int n_wave = 0; // resident wavefronts: 16 per CU at the kernel's 128 registers
+    if (!n_wave) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_wave = 256 * 16;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_wave = prop.multiProcessorCount * 16;
+    }
+    hipLaunchKernelGGL(k12_psy, dim3((unsigned) (n_rec < (size_t) n_wave ? n_rec : (size_t) n_wave)), dim3(64), 0, st, T, g, erp, thr1, snr);
     if (g.layer == 1)
         hipLaunchKernelGGL(k12_snr1, dim3((unsigned) ((size_t) g.n_streams * (g.np - g.lb) * g.channels)), dim3(64), 0, st, g, erp, thr1, snr);
 }
@@ -303,10 +336,37 @@ MP3MI_DEVFN int l12_scale_index(const double *mult, double m)
     }
     return lo > 0 ? lo - 1 : 0;
 }
-MP3MI_DEVFN double l12_wave_min_f64(double v)
+// a double as a 64-bit key whose unsigned order is the doubles' order (no NaN; -0 never occurs here)
+MP3MI_DEVFN unsigned long long l12_key(double d)
 {
-    for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(v, m); v = o < v ? o : v; }
+    const long long b = dm_bits(d);
+    return (unsigned long long) (b ^ ((b >> 63) | (long long) 0x8000000000000000ull));
+}
+// wave minimum of 64-bit keys: DPP steps inside the rows, row broadcasts across them (lanes without a source keep their own)
+MP3MI_DEVFN unsigned long long l12_wave_min_u64(unsigned long long v)
+{
+#if defined(MP3MI_EMU)
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(v, m); v = o < v ? o : v; }
     return v;
+#else
+    unsigned lo = (unsigned) v, hi = (unsigned) (v >> 32);
+#define L12_MIN_STEP(ctrl)                                                                                  \
+    {                                                                                                       \
+        const unsigned olo = (unsigned) __builtin_amdgcn_update_dpp((int) lo, (int) lo, ctrl, 0xf, 0xf, false); \
+        const unsigned ohi = (unsigned) __builtin_amdgcn_update_dpp((int) hi, (int) hi, ctrl, 0xf, 0xf, false); \
+        const bool lt = ohi < hi || (ohi == hi && olo < lo);                                                \
+        lo = lt ? olo : lo;                                                                                 \
+        hi = lt ? ohi : hi;                                                                                 \
+    }
+    L12_MIN_STEP(0xB1)  /* quad_perm [1,0,3,2] */
+    L12_MIN_STEP(0x4E)  /* quad_perm [2,3,0,1] */
+    L12_MIN_STEP(0x141) /* row_half_mirror */
+    L12_MIN_STEP(0x140) /* row_mirror */
+    L12_MIN_STEP(0x142) /* row_bcast15 */
+    L12_MIN_STEP(0x143) /* row_bcast31 */
+#undef L12_MIN_STEP
+    return ((unsigned long long) (unsigned) __builtin_amdgcn_readlane((int) hi, 63) << 32) | (unsigned) __builtin_amdgcn_readlane((int) lo, 63);
+#endif
 }
 MP3MI_DEVFN void l12_update_crc(unsigned data, unsigned length, unsigned *crc)
 { // src/common.c:1309-1323
@@ -473,7 +533,9 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
     }
 
     // ---- *_a_bit_allocation, src/encode.c:974-1172: the band with the smallest mask-to-noise ratio gets the next step,
-    // the first in (subband, channel) order among equals -- lane order
+    // the first in (subband, channel) order among equals -- lane order.  Every lane keeps its ratio as a 64-bit key
+    // whose unsigned order is the doubles' order (all ones: not a candidate) and the bits its next step would cost;
+    // one wave minimum per step, and only the winner (and, above the joint-stereo bound, its other channel) recomputes.
     int ba = 0, used = 0, adb = cf.frame_bits;
     double mnr = snrt[0] - smr;
     {
@@ -483,41 +545,38 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
         else bbal = wave_sum_i32(code ? (int) L.al[sbc][0][1] : 0);
         adb -= bbal + (geo.crc ? 16 : 0) + 32;
         const int ad = adb;
-        int bspl = 0, bscf = 0, bsel = 0;
+        int spent = 0; // bspl + bscf + bsel
+        // what the lane's next step costs: sample bits, and with its first step scale factor (and scfsi) bits
+        auto next_cost = [&]() -> int {
+            if (LAYER == 1) {
+                int scale = used ? 0 : 6;
+                if (sb >= jsbound) scale *= stereo;
+                return (used ? 12 : 24) + scale;
+            }
+            const int nx = ba + 1 < 16 ? ba + 1 : 15;
+            int inc = 12 * (L.al[sbc][nx][2] * L.al[sbc][nx][1]);
+            if (used) return inc - 12 * (L.al[sbc][ba][2] * L.al[sbc][ba][1]);
+            inc += 2 + 6 * sfs;
+            if (stereo == 2 && sb >= jsbound) inc += 2 + 6 * sfs_o;
+            return inc;
+        };
+        int need = next_cost();
+        unsigned long long key = (act && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : ~0ull;
         for (;;) {
-            const double lim = LAYER == 1 ? wave_bcast_f64(mnr, 0) + 1 : 999999.0;
-            const bool cand = act && used != 2 && lim > mnr;
-            const double small = l12_wave_min_f64(cand ? mnr : __builtin_inf());
-            const unsigned long long tie = __ballot(cand && mnr == small);
-            if (!tie) break;
+            unsigned long long k = key;
+            if (LAYER == 1) { // src/encode.c:1012: small starts at mnr[0][0] + 1, whatever state that band is in
+                const double lim = wave_bcast_f64(mnr, 0) + 1;
+                if (!(lim > mnr)) k = ~0ull;
+            }
+            const unsigned long long small = l12_wave_min_u64(k);
+            if (small == ~0ull) break;
+            const unsigned long long tie = __ballot(k == small);
             const int win = __ffsll((long long) tie) - 1;
             const int wsb = C == 2 ? win >> 1 : win;
             const bool me_win = lane == win, me_oth = C == 2 && lane == (win ^ 1) && wsb >= jsbound;
-            // the winner's figures (computed by every lane for itself; the winner's are read)
-            int increment, scale, seli;
-            if (LAYER == 1) {
-                increment = used ? 12 : 24;
-                scale = used ? 0 : 6;
-                seli = 0;
-                if (sb >= jsbound) scale *= stereo;
-            } else {
-                const int nx = ba + 1 < 16 ? ba + 1 : 15;
-                increment = 12 * (L.al[sbc][nx][2] * L.al[sbc][nx][1]);
-                if (used) increment -= 12 * (L.al[sbc][ba][2] * L.al[sbc][ba][1]);
-                if (used) scale = seli = 0;
-                else {
-                    seli = 2;
-                    scale = 6 * sfs;
-                    if (stereo == 2 && sb >= jsbound) { seli += 2; scale += 6 * sfs_o; }
-                }
-            }
-            const int need = wave_readlane_i32(increment + scale + seli, win);
-            const bool fits = ad >= bspl + bscf + bsel + need;
-            if (fits) {
-                bspl += wave_readlane_i32(increment, win);
-                bscf += wave_readlane_i32(scale, win);
-                bsel += wave_readlane_i32(seli, win);
-            }
+            const int wneed = wave_readlane_i32(need, win);
+            const bool fits = ad >= spent + wneed;
+            if (fits) spent += wneed;
             if (me_win) {
                 if (fits) {
                     ba++;
@@ -530,15 +589,21 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
                         if (ba >= maxAlloc) used = 2;
                     }
                 } else used = 2;
+                need = next_cost();
+                key = (used != 2 && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : ~0ull;
             }
-            const int wba = wave_readlane_i32(ba, win), wused = wave_readlane_i32(used, win);
-            if (me_oth) { // above the joint-stereo bound the allocation applies to both channels
-                ba = wba;
-                used = wused;
-                mnr = -smr + (LAYER == 1 ? snrt[ba] : snrt[L.al[sbc][ba][3] + 1]);
+            if (C == 2 && wsb >= jsbound) { // above the joint-stereo bound the allocation applies to both channels
+                const int wba = wave_readlane_i32(ba, win), wused = wave_readlane_i32(used, win);
+                if (me_oth) {
+                    ba = wba;
+                    used = wused;
+                    mnr = -smr + (LAYER == 1 ? snrt[ba] : snrt[L.al[sbc][ba][3] + 1]);
+                    need = next_cost();
+                    key = (used != 2 && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : ~0ull;
+                }
             }
         }
-        adb = ad - (bspl + bscf + bsel);
+        adb = ad - spent;
     }
     if (!act) ba = 0;
 

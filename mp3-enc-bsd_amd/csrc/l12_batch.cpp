@@ -37,6 +37,10 @@ struct mp3mi_l12_batch {
     std::vector<l12_stream_cfg> cfg_h;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
+    std::vector<hipEvent_t> kev; // six per chunk of the last call: around the five launches
+    int kev_chunks;
+    double kernel_ms[5];
+    long kernel_launches[5];
     bool timing_open;
     double total_ms;
     long calls;
@@ -103,7 +107,8 @@ extern "C" int mp3mi_l12_batch_create(mp3mi_l12_batch **out, int layer, int n_st
     b->lb = layer == 1 ? 3 : 2;
     b->mode = channels == 1 ? MP3MI_MODE_MONO : MP3MI_MODE_STEREO;
     b->crc = 0; b->hdr_flags = 0; b->test_flags = 0; b->debug = 0;
-    b->timing_open = false; b->total_ms = 0.0; b->calls = 0;
+    b->timing_open = false; b->total_ms = 0.0; b->calls = 0; b->kev_chunks = 0;
+    for (int i = 0; i < 5; i++) { b->kernel_ms[i] = 0.0; b->kernel_launches[i] = 0; }
     b->ev0 = b->ev1 = 0; b->T3 = NULL; b->T = NULL; b->cfg = NULL;
     b->bins = b->erp = b->thr1 = b->snr = NULL; b->sbs = NULL; b->dbg = NULL; b->dbg_f0 = b->dbg_nf = 0;
     if (hipGetDevice(&b->device) != hipSuccess) { delete b; return MP3MI_ERR_HIP; }
@@ -184,6 +189,7 @@ extern "C" void mp3mi_l12_batch_destroy(mp3mi_l12_batch *b)
         (void) hipFree(b->thr1); (void) hipFree(b->snr); (void) hipFree(b->sbs); (void) hipFree(b->dbg);
         if (b->ev0) (void) hipEventDestroy(b->ev0);
         if (b->ev1) (void) hipEventDestroy(b->ev1);
+        for (hipEvent_t e : b->kev) (void) hipEventDestroy(e);
         if (b->stream) (void) hipStreamDestroy(b->stream);
     }
     delete b;
@@ -228,6 +234,13 @@ static int l12_close_timing(mp3mi_l12_batch *b)
     CHK(hipEventSynchronize(b->ev1));
     CHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     b->total_ms += (double) ms;
+    for (int c = 0; c < b->kev_chunks; c++)
+        for (int k = 0; k < 5; k++) {
+            CHK(hipEventElapsedTime(&ms, b->kev[(size_t) c * 6 + k], b->kev[(size_t) c * 6 + k + 1]));
+            b->kernel_ms[k] += (double) ms;
+            b->kernel_launches[k]++;
+        }
+    b->kev_chunks = 0;
     b->timing_open = false;
     return MP3MI_OK;
 }
@@ -242,7 +255,17 @@ extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev
     const int S = b->n_streams, C = b->channels, layer = b->layer;
     if (b->debug && !b->dbg) CHK(hipMalloc((void **) &b->dbg, sizeof(l12_frame_dbg) * (size_t) S * (size_t) b->chunk_frames));
     CHK(hipEventRecord(b->ev0, b->stream));
-    for (int f0 = 0; f0 < n_frames; f0 += b->chunk_frames) {
+    {
+        const size_t want = 6 * (size_t) ((n_frames + b->chunk_frames - 1) / b->chunk_frames);
+        while (b->kev.size() < want) {
+            hipEvent_t e;
+            CHK(hipEventCreate(&e));
+            b->kev.push_back(e);
+        }
+    }
+    int chunk = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += b->chunk_frames, chunk++) {
+        hipEvent_t *ke = &b->kev[(size_t) chunk * 6];
         const int nf = n_frames - f0 < b->chunk_frames ? n_frames - f0 : b->chunk_frames;
         l12_geom g;
         memset(&g, 0, sizeof(g));
@@ -263,14 +286,21 @@ extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev
         fg.g0 = g.g0; fg.n_gran = g.n_gran;
         fg.pcm_pitch = (long) n_frames * b->spf;
         fg.n_samples = n_samples_dev;
+        CHK(hipEventRecord(ke[0], b->stream));
         mp3mi_launch_fft12(b->T3, g, pcm_dev, b->bins, b->stream);
+        CHK(hipEventRecord(ke[1], b->stream));
         mp3mi_launch_l12_phase(g, b->bins, b->erp, b->stream);
+        CHK(hipEventRecord(ke[2], b->stream));
         mp3mi_launch_l12_psy(b->T, g, b->erp, b->thr1, b->snr, b->stream);
+        CHK(hipEventRecord(ke[3], b->stream));
         mp3mi_launch_filter(b->T3, fg, pcm_dev, b->sbs, NULL, b->stream);
+        CHK(hipEventRecord(ke[4], b->stream));
         mp3mi_launch_l12_alloc(b->T, g, b->cfg, b->sbs, b->snr, out_dev, out_stride, out_len_dev, b->debug ? b->dbg : NULL, b->stream);
+        CHK(hipEventRecord(ke[5], b->stream));
         b->dbg_f0 = f0; b->dbg_nf = nf;
     }
     CHK(hipEventRecord(b->ev1, b->stream));
+    b->kev_chunks = chunk;
     b->timing_open = true;
     b->calls++;
     CHK(hipGetLastError());
@@ -293,6 +323,16 @@ extern "C" int mp3mi_l12_batch_total_timing(mp3mi_l12_batch *b, double *all_kern
     { const int rc = l12_close_timing(b); if (rc != MP3MI_OK) return rc; }
     if (all_kernels_ms) *all_kernels_ms = b->total_ms;
     if (calls) *calls = b->calls;
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_l12_batch_kernel_timing(mp3mi_l12_batch *b, double ms[5], long launches[5])
+{
+    if (!b || !ms || !launches) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    CHK(hipStreamSynchronize(b->stream));
+    { const int rc = l12_close_timing(b); if (rc != MP3MI_OK) return rc; }
+    for (int i = 0; i < 5; i++) { ms[i] = b->kernel_ms[i]; launches[i] = b->kernel_launches[i]; }
     return MP3MI_OK;
 }
 

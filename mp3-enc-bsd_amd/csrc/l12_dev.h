@@ -31,7 +31,7 @@
 typedef struct {
     int32_t rate_idx, layer, npart, pad0;
     /* psychoacoustic model 2, src/psy.c:151-228 */
-    float spread_t[L12_CB][64];   /* spread_t[k][j] = s[j][k]: what the lanes j read together in step k */
+    float spread_r[64][64];       /* spread_r[j][k] = s[j][k]: lane j of k12_psy keeps its row in registers */
     float cbval[64], rnorm[64], bmaxv[64]; /* bmaxv[j] = bmax[(unsigned) (cbval[j] + 0.5)] */
     float rn_nl[64];              /* rnorm[j] * numlines[j] (float product, src/psy.c:347), 0 where the reference takes nb = 0 */
     double tmn[64];

@@ -1046,7 +1046,7 @@ static int build_tables_l12_unpinned(mp3mi_tables_l12 *T, int ri, int layer, flo
         for (i = 0; i < L12_CB; i++) rnorm[j] += s[j][i];
     }
     for (j = 0; j < L12_CB; j++) {
-        for (i = 0; i < L12_CB; i++) T->spread_t[i][j] = s[j][i];
+        for (i = 0; i < L12_CB; i++) T->spread_r[j][i] = s[j][i];
         T->cbval[j] = cbval[j];
         T->rnorm[j] = rnorm[j];
         unsigned k = cbval[j] + 0.5; /* src/psy.c:336 */

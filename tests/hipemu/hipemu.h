@@ -26,6 +26,9 @@ struct dim3 {
 };
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
+struct float2 { float x, y; };
+struct __attribute__((aligned(16))) float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 
 typedef int hipError_t;
 typedef void *hipStream_t;
