@@ -193,7 +193,7 @@ def reference_baseline(pcm_sample, rate, kbps_list, channels, cores, layer=3):
 
 L12_KERNEL_BOUND = {
     "k12_alloc": "valu+salu issue (a wave minimum per granted step, serial per frame)", "k12_psy": "latency + hbm (serial partition / spreading sums, 14 KB of rows per record)",
-    "k12_phase": "valu issue (f64 atan2) + hbm", "k_filter": "valu issue (f64) + hbm", "k_fft12": "lds pipe (bank conflicts of the butterfly program)",
+    "k_filter": "valu issue (f64) + hbm", "k_fft12": "lds pipe (butterfly program) with the phases' f64 chain in its shadow",
 }
 
 

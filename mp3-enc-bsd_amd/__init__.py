@@ -230,7 +230,7 @@ class Batch:
             pass
 
 
-L12_KERNELS = ("k_fft12", "k12_phase", "k12_psy", "k_filter", "k12_alloc")
+L12_KERNELS = ("k_fft12", "k12_psy", "k_filter", "k12_alloc")
 L12_FRAME_SAMPLES = {1: 384, 2: 1152}
 
 
@@ -282,9 +282,9 @@ class BatchL12:
 
     def kernel_timing(self):
         """{kernel: (ms, launches)} since create (HIP events around every launch)"""
-        ms, n = (ctypes.c_double * 5)(), (ctypes.c_long * 5)()
+        ms, n = (ctypes.c_double * 4)(), (ctypes.c_long * 4)()
         self._check(self.L.mp3mi_l12_batch_kernel_timing(self.h, ms, n), "mp3mi_l12_batch_kernel_timing")
-        return {L12_KERNELS[i]: (ms[i], n[i]) for i in range(5)}
+        return {L12_KERNELS[i]: (ms[i], n[i]) for i in range(4)}
 
     def close(self):
         if self.h:

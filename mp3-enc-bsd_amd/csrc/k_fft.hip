@@ -545,13 +545,11 @@ __global__ void __launch_bounds__(64) k_cw_fix_reset(mp3mi_cw_fixlist *fix, unsi
 
 // Layers I and II (l12_dev.h): the 1024-point transform of every PASS of the psychoacoustic model for Layers I / II
 // (src/psy.c:258-270: the same Hann window, the same fft() as Layer III's long transform), one wavefront per
-// (stream, pass) task and all channels, with the same resident butterfly program.  Out: the raw bins of all 513
-// lines, (re, im) rows per (pass, channel) record -- these layers take phase and magnitude of EVERY line
-// (src/psy.c:282-292), not of 156 of them.  Passes before the stream's first sample (q < 0) are not transformed:
-// k12_phase gives them the reference's initial r = phi = 0.
+// (stream, pass) task and all channels, with the same resident butterfly program.  Out: energy, magnitude and phase of all
+// 513 lines per (pass, channel) record -- these layers take them of EVERY line (src/psy.c:282-292), not of 156.
 template <int C, int W>
 __global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict__ T, l12_geom geo,
-                                                  const int16_t *__restrict__ pcm_all, float *__restrict__ bins)
+                                                  const int16_t *__restrict__ pcm_all, float *__restrict__ erp)
 {
     __shared__ fft_lds<C, W, MP3MI_FFT_PROG_WORDS> LL;
     const int lane = wave_lane(), tid = (int) threadIdx.x;
@@ -560,6 +558,7 @@ __global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict
     const int NP = geo.np, n_task = geo.n_streams * NP;
     const long n_pitch = (long) geo.n_frames * geo.spf;
     const int lane_swz = MP3MI_FFT_SWZ(lane);
+    const bool force_exact = (geo.test_flags >> 1) & 1;
     {
         const int nw4 = T->fft_nword_l / 4;
         const uint4 *src = (const uint4 *) T->fft_prog_l;
@@ -593,65 +592,45 @@ __global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict
         }
         wave_sync();
         fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
-        // bins 0 and 512 are real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x) (src/subs.c:58, 93)
-#pragma unroll 3
-        for (int i = lane; i < L12_HBLK; i += 64) {
+        // energy, magnitude and phase of every line straight from the spectrum in LDS (src/subs.c:53-123, src/psy.c:285-286):
+        // erp[rec] = {energy, r = (float) sqrt((double) energy), phi}, rows of L12_ROW floats.  The transform is bound by
+        // the LDS pipe and leaves the vector pipe idle more than half of the time: the phases' double-precision chain runs
+        // in that shadow (as a kernel of its own it took 1.6 times the transform).  Phases in two tiers, as k_cw's (cw_bin).
+        // Bins 0 and 512 are real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x) (src/subs.c:58, 93).
+#pragma unroll 1
+        for (int k = 0; k < 9; k++) {
+            const int i = lane + 64 * k;
+            const bool on = i < L12_HBLK; // (k = 8: line 512 only)
             fft_pair<C> re, im;
-            fft_bin<C>(L.x, T->fft_rd_l[i], &re, &im);
-            if (valid && q >= 0) {
+            fft_bin<C>(L.x, T->fft_rd_l[on ? i : 0], &re, &im);
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    float *o = bins + (rec0 + c) * (2 * L12_ROW);
-                    o[i] = re.c[c];
-                    o[L12_ROW + i] = (i == 0 || i == 512) ? -0.0f : im.c[c];
+            for (int c = 0; c < C; c++) {
+                const bool real = i == 0 || i == 512;
+                const float rr = re.c[c], ii = real ? -0.0f : im.c[c];
+                float e, ph;
+                bool unsafe = force_exact;
+                if (!unsafe) cw_bin<false>(rr, ii, real, &e, &ph, &unsafe);
+                if (wave_any(unsafe && on)) cw_bin<true>(rr, ii, real, &e, &ph, &unsafe);
+                if (valid && on && q >= 0) {
+                    float *o = erp + (rec0 + c) * (3 * L12_ROW);
+                    o[i] = e;
+                    o[L12_ROW + i] = __builtin_sqrtf(e); // == (float) sqrt((double) e): 53 >= 2 * 24 + 2 bits, the double rounding is innocuous
+                    o[2 * L12_ROW + i] = ph;
                 }
             }
+        }
+        if (valid && q < 0) { // a pass before the stream's first sample: the reference's initial r = phi = 0 (src/psy.c:158-162)
+            for (int i = lane; i < L12_HBLK; i += 64)
+                for (int c = 0; c < C; c++) {
+                    float *o = erp + (rec0 + c) * (3 * L12_ROW);
+                    o[i] = 0.0f; o[L12_ROW + i] = 0.0f; o[2 * L12_ROW + i] = 0.0f;
+                }
         }
         wave_sync(); // the spectrum is dead: the next task's samples take its place
     }
 }
 
-// energy, magnitude and phase of every line of a (pass, channel) record (src/subs.c:53-123, src/psy.c:285-286), one
-// wavefront per record: erp[rec] = {energy, r = (float) sqrt((double) energy), phi}, rows of L12_ROW floats.  The phases
-// in two tiers, as k_cw's (cw_bin).  A pass before the stream's first sample has the reference's initial r = phi = 0
-// (src/psy.c:158-162; its energy is never looked at).
-__global__ void __launch_bounds__(64) k12_phase(l12_geom geo, const float *__restrict__ bins, float *__restrict__ erp)
-{
-    const int lane = wave_lane();
-    const size_t rec = blockIdx.x;
-    const int qi = (int) ((rec / (size_t) geo.channels) % (size_t) geo.np);
-    const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
-    const float *b = bins + rec * (2 * L12_ROW);
-    float *o = erp + rec * (3 * L12_ROW);
-    const int force_exact = (geo.test_flags >> 1) & 1;
-    if (q < 0) {
-        for (int i = lane; i < L12_HBLK; i += 64) { o[i] = 0.0f; o[L12_ROW + i] = 0.0f; o[2 * L12_ROW + i] = 0.0f; }
-        return;
-    }
-#pragma unroll 1
-    for (int k = 0; k < 9; k++) {
-        const int i = lane + 64 * k;
-        const bool on = i < L12_HBLK; // (k = 8: line 512 only)
-        if (!wave_any(on)) break;
-        const float re = on ? b[i] : 1.0f, im = on ? b[L12_ROW + i] : 0.0f;
-        float e, ph;
-        bool unsafe = force_exact != 0;
-        if (!unsafe) cw_bin<false>(re, im, i == 0 || i == 512, &e, &ph, &unsafe);
-        if (wave_any(unsafe)) cw_bin<true>(re, im, i == 0 || i == 512, &e, &ph, &unsafe);
-        if (on) {
-            o[i] = e;
-            o[L12_ROW + i] = __builtin_sqrtf(e); // == (float) sqrt((double) e): 53 >= 2 * 24 + 2 bits, the double rounding is innocuous
-            o[2 * L12_ROW + i] = ph;
-        }
-    }
-}
-
-void mp3mi_launch_l12_phase(const l12_geom &g, const float *bins, float *erp, hipStream_t st)
-{
-    hipLaunchKernelGGL(k12_phase, dim3((unsigned) ((size_t) g.n_streams * g.np * g.channels)), dim3(64), 0, st, g, bins, erp);
-}
-
-void mp3mi_launch_fft12(const mp3mi_tables *T, const l12_geom &g, const int16_t *pcm, float *bins, hipStream_t st)
+void mp3mi_launch_fft12(const mp3mi_tables *T, const l12_geom &g, const int16_t *pcm, float *erp, hipStream_t st)
 {
     const int n_task = g.n_streams * g.np;
     int n_cu = 256, dev = 0;
@@ -659,10 +638,10 @@ void mp3mi_launch_fft12(const mp3mi_tables *T, const l12_geom &g, const int16_t 
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     if (g.channels == 2) {
         const int W = 12, nb = (n_task + W - 1) / W;
-        hipLaunchKernelGGL((k_fft12<2, W>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, bins);
+        hipLaunchKernelGGL((k_fft12<2, W>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, erp);
     } else {
         const int W = 16, nb = (n_task + W - 1) / W;
-        hipLaunchKernelGGL((k_fft12<1, W>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, bins);
+        hipLaunchKernelGGL((k_fft12<1, W>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, erp);
     }
 }
 

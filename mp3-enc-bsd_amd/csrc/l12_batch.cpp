@@ -1,9 +1,9 @@
 // Host side of the Layer I / II batch (include/mp3mi_l12.h): set-up as the reference's driver does it
 // (src/musicin.c:528-581, src/common.c:291-347), scratch sizing, and one pipeline of kernels per chunk of frames:
 //
-//   k_fft12 -> k12_phase -> k12_psy (-> k12_snr1) ;  k_filter ;  k12_alloc
+//   k_fft12 -> k12_psy (-> k12_snr1) ;  k_filter ;  k12_alloc
 //
-// Frames are independent but for PCM history (l12_dev.h), so a chunk is just these five launches in stream order, and
+// Frames are independent but for PCM history (l12_dev.h), so a chunk is just these four launches in stream order, and
 // chunks follow each other on the batch's one HIP stream.  No CPU fallback.
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,17 +37,17 @@ struct mp3mi_l12_batch {
     std::vector<l12_stream_cfg> cfg_h;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
-    std::vector<hipEvent_t> kev; // six per chunk of the last call: around the five launches
+    std::vector<hipEvent_t> kev; // five per chunk of the last call: around the four launches
     int kev_chunks;
-    double kernel_ms[5];
-    long kernel_launches[5];
+    double kernel_ms[4];
+    long kernel_launches[4];
     bool timing_open;
     double total_ms;
     long calls;
     mp3mi_tables *T3;          // window, FFT program, filterbank tables (shared with Layer III)
     mp3mi_tables_l12 *T;
     l12_stream_cfg *cfg;
-    float *bins, *erp, *thr1, *snr;
+    float *erp, *thr1, *snr;
     double *sbs;
     l12_frame_dbg *dbg;
     int dbg_f0, dbg_nf;
@@ -79,7 +79,7 @@ struct l12_device_scope {
 
 static size_t l12_per_frame_bytes(int layer, int channels, int spf)
 {
-    const size_t rec = (size_t) (2 + 3) * L12_ROW * sizeof(float) + 32 * sizeof(float) + (layer == 1 ? L12_ROW * sizeof(float) : 0);
+    const size_t rec = (size_t) 3 * L12_ROW * sizeof(float) + 32 * sizeof(float) + (layer == 1 ? L12_ROW * sizeof(float) : 0);
     return (size_t) layer * channels * rec + (size_t) spf * 8 * channels;
 }
 
@@ -108,9 +108,9 @@ extern "C" int mp3mi_l12_batch_create(mp3mi_l12_batch **out, int layer, int n_st
     b->mode = channels == 1 ? MP3MI_MODE_MONO : MP3MI_MODE_STEREO;
     b->crc = 0; b->hdr_flags = 0; b->test_flags = 0; b->debug = 0;
     b->timing_open = false; b->total_ms = 0.0; b->calls = 0; b->kev_chunks = 0;
-    for (int i = 0; i < 5; i++) { b->kernel_ms[i] = 0.0; b->kernel_launches[i] = 0; }
+    for (int i = 0; i < 4; i++) { b->kernel_ms[i] = 0.0; b->kernel_launches[i] = 0; }
     b->ev0 = b->ev1 = 0; b->T3 = NULL; b->T = NULL; b->cfg = NULL;
-    b->bins = b->erp = b->thr1 = b->snr = NULL; b->sbs = NULL; b->dbg = NULL; b->dbg_f0 = b->dbg_nf = 0;
+    b->erp = b->thr1 = b->snr = NULL; b->sbs = NULL; b->dbg = NULL; b->dbg_f0 = b->dbg_nf = 0;
     if (hipGetDevice(&b->device) != hipSuccess) { delete b; return MP3MI_ERR_HIP; }
     b->cfg_h.resize((size_t) n_streams);
     b->max_frame_bytes = 0;
@@ -166,7 +166,6 @@ extern "C" int mp3mi_l12_batch_create(mp3mi_l12_batch **out, int layer, int n_st
         CHK(hipMemcpy(b->cfg, b->cfg_h.data(), sizeof(l12_stream_cfg) * (size_t) n_streams, hipMemcpyHostToDevice));
         const size_t np = (size_t) cf * layer + (size_t) b->lb, nrec = (size_t) n_streams * np * (size_t) channels;
         const size_t ngran = ((size_t) cf * (size_t) (b->spf / 32) + 17) / 18 + 3; // granules of 18 slots k_filter may be asked for
-        CHK(hipMalloc((void **) &b->bins, nrec * 2 * L12_ROW * sizeof(float)));
         CHK(hipMalloc((void **) &b->erp, nrec * 3 * L12_ROW * sizeof(float)));
         CHK(hipMalloc((void **) &b->snr, nrec * 32 * sizeof(float)));
         if (layer == 1) CHK(hipMalloc((void **) &b->thr1, nrec * L12_ROW * sizeof(float)));
@@ -185,7 +184,7 @@ extern "C" void mp3mi_l12_batch_destroy(mp3mi_l12_batch *b)
     {
         l12_device_scope sc(b->device);
         if (b->stream) (void) hipStreamSynchronize(b->stream);
-        (void) hipFree(b->T3); (void) hipFree(b->T); (void) hipFree(b->cfg); (void) hipFree(b->bins); (void) hipFree(b->erp);
+        (void) hipFree(b->T3); (void) hipFree(b->T); (void) hipFree(b->cfg); (void) hipFree(b->erp);
         (void) hipFree(b->thr1); (void) hipFree(b->snr); (void) hipFree(b->sbs); (void) hipFree(b->dbg);
         if (b->ev0) (void) hipEventDestroy(b->ev0);
         if (b->ev1) (void) hipEventDestroy(b->ev1);
@@ -235,8 +234,8 @@ static int l12_close_timing(mp3mi_l12_batch *b)
     CHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     b->total_ms += (double) ms;
     for (int c = 0; c < b->kev_chunks; c++)
-        for (int k = 0; k < 5; k++) {
-            CHK(hipEventElapsedTime(&ms, b->kev[(size_t) c * 6 + k], b->kev[(size_t) c * 6 + k + 1]));
+        for (int k = 0; k < 4; k++) {
+            CHK(hipEventElapsedTime(&ms, b->kev[(size_t) c * 5 + k], b->kev[(size_t) c * 5 + k + 1]));
             b->kernel_ms[k] += (double) ms;
             b->kernel_launches[k]++;
         }
@@ -256,7 +255,7 @@ extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev
     if (b->debug && !b->dbg) CHK(hipMalloc((void **) &b->dbg, sizeof(l12_frame_dbg) * (size_t) S * (size_t) b->chunk_frames));
     CHK(hipEventRecord(b->ev0, b->stream));
     {
-        const size_t want = 6 * (size_t) ((n_frames + b->chunk_frames - 1) / b->chunk_frames);
+        const size_t want = 5 * (size_t) ((n_frames + b->chunk_frames - 1) / b->chunk_frames);
         while (b->kev.size() < want) {
             hipEvent_t e;
             CHK(hipEventCreate(&e));
@@ -265,7 +264,7 @@ extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev
     }
     int chunk = 0;
     for (int f0 = 0; f0 < n_frames; f0 += b->chunk_frames, chunk++) {
-        hipEvent_t *ke = &b->kev[(size_t) chunk * 6];
+        hipEvent_t *ke = &b->kev[(size_t) chunk * 5];
         const int nf = n_frames - f0 < b->chunk_frames ? n_frames - f0 : b->chunk_frames;
         l12_geom g;
         memset(&g, 0, sizeof(g));
@@ -287,16 +286,14 @@ extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev
         fg.pcm_pitch = (long) n_frames * b->spf;
         fg.n_samples = n_samples_dev;
         CHK(hipEventRecord(ke[0], b->stream));
-        mp3mi_launch_fft12(b->T3, g, pcm_dev, b->bins, b->stream);
+        mp3mi_launch_fft12(b->T3, g, pcm_dev, b->erp, b->stream);
         CHK(hipEventRecord(ke[1], b->stream));
-        mp3mi_launch_l12_phase(g, b->bins, b->erp, b->stream);
-        CHK(hipEventRecord(ke[2], b->stream));
         mp3mi_launch_l12_psy(b->T, g, b->erp, b->thr1, b->snr, b->stream);
-        CHK(hipEventRecord(ke[3], b->stream));
+        CHK(hipEventRecord(ke[2], b->stream));
         mp3mi_launch_filter(b->T3, fg, pcm_dev, b->sbs, NULL, b->stream);
-        CHK(hipEventRecord(ke[4], b->stream));
+        CHK(hipEventRecord(ke[3], b->stream));
         mp3mi_launch_l12_alloc(b->T, g, b->cfg, b->sbs, b->snr, out_dev, out_stride, out_len_dev, b->debug ? b->dbg : NULL, b->stream);
-        CHK(hipEventRecord(ke[5], b->stream));
+        CHK(hipEventRecord(ke[4], b->stream));
         b->dbg_f0 = f0; b->dbg_nf = nf;
     }
     CHK(hipEventRecord(b->ev1, b->stream));
@@ -326,13 +323,13 @@ extern "C" int mp3mi_l12_batch_total_timing(mp3mi_l12_batch *b, double *all_kern
     return MP3MI_OK;
 }
 
-extern "C" int mp3mi_l12_batch_kernel_timing(mp3mi_l12_batch *b, double ms[5], long launches[5])
+extern "C" int mp3mi_l12_batch_kernel_timing(mp3mi_l12_batch *b, double ms[4], long launches[4])
 {
     if (!b || !ms || !launches) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
     CHK(hipStreamSynchronize(b->stream));
     { const int rc = l12_close_timing(b); if (rc != MP3MI_OK) return rc; }
-    for (int i = 0; i < 5; i++) { ms[i] = b->kernel_ms[i]; launches[i] = b->kernel_launches[i]; }
+    for (int i = 0; i < 4; i++) { ms[i] = b->kernel_ms[i]; launches[i] = b->kernel_launches[i]; }
     return MP3MI_OK;
 }
 

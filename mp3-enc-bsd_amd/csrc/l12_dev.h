@@ -6,8 +6,8 @@
  * (stream, frame) is the parallel axis everywhere and a chunk recomputes the passes just before it instead of
  * carrying state.
  *
- *   k_fft12      (k_fft.hip)  the 1024-point FFT of every pass (stream, pass q, all channels): raw bins
- *   k12_phase    (k_l12.hip)  energy, r = sqrt(energy), phi = (float) atan2 of every line      src/subs.c:53-123, src/psy.c:285-286
+ *   k_fft12      (k_fft.hip)  the 1024-point FFT of every pass (stream, pass q, all channels), and from the spectrum
+ *                             energy, r = sqrt(energy), phi = (float) atan2 of every line      src/subs.c:38-123, src/psy.c:258-286
  *   k12_psy                   unpredictability, partitions, spreading, masking, thresholds,
  *                             signal-to-mask ratio of the 32 subbands                          src/psy.c:282-386
  *   k_filter     (k_fbmdct.hip, as for Layer III) subband samples
@@ -76,8 +76,7 @@ struct l12_frame_dbg {
 };
 
 #ifdef __cplusplus
-void mp3mi_launch_fft12(const mp3mi_tables *T, const l12_geom &g, const int16_t *pcm, float *bins, hipStream_t st);
-void mp3mi_launch_l12_phase(const l12_geom &g, const float *bins, float *erp, hipStream_t st);
+void mp3mi_launch_fft12(const mp3mi_tables *T, const l12_geom &g, const int16_t *pcm, float *erp, hipStream_t st);
 void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *thr1, float *snr, hipStream_t st);
 void mp3mi_launch_l12_alloc(const mp3mi_tables_l12 *T, const l12_geom &g, const l12_stream_cfg *cfg, const double *sbs,
                             const float *snr, uint8_t *out, size_t out_stride, uint32_t *out_len, l12_frame_dbg *dbg, hipStream_t st);

@@ -18,7 +18,7 @@ def main(outdir, dest):
             k = r["Kernel_Name"].split("(")[0]
             if k.startswith("void "):
                 k = k[5:]
-            if not k.startswith("k_"):
+            if not (k.startswith("k_") or k.startswith("k12_")):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (k, r["Dispatch_Id"])
