@@ -33,6 +33,18 @@ def square(n, ch, period):
     return np.repeat(x[:, None], ch, 1).astype(np.int16).reshape(-1)
 
 
+def two_tones(n, ch, rate):
+    t = np.arange(n)
+    x = np.zeros((n, ch))
+    x[:, 0] = 32000 * np.sin(2 * np.pi * 3000 * t / rate)
+    x[:, ch - 1] = 32000 * np.sin(2 * np.pi * 5000 * t / rate)
+    return np.rint(x).astype(np.int16).reshape(-1)
+
+
+def noise(n, ch, seed):
+    return (6000 * np.random.default_rng(seed).standard_normal((n, ch))).clip(-32768, 32767).astype(np.int16).reshape(-1)
+
+
 def tones(n, ch, rate):
     t = np.arange(n)
     x = np.zeros((n, ch))
@@ -57,6 +69,12 @@ CASES = [  # name, layer, rate, kbps, mode, frames, signal
     ("l1_m48_448", 1, 48000, 448, "m", 16, "mix"),
     ("l1_j44_192_tones", 1, 44100, 192, "j", 20, "tones"),
     ("l1_s44_256_silence_noise", 1, 44100, 256, "s", 24, "silence"),
+    # coverage-guided (tools/ref_coverage_l12.py): joint stereo that does engage, with the CRC over the shared allocation
+    # (src/common.c:1301); bit estimates that run out of steps (src/encode.c:837-843, 950); unallocated subbands under -e
+    ("l2_j44_032_square_crc", 2, 44100, 32, "je", 6, "square30"),
+    ("l2_j44_064_two_tones", 2, 44100, 64, "j", 6, "two_tones"),
+    ("l2_s44_112_noise_crc", 2, 44100, 112, "se", 5, "noise"),
+    ("l1_j44_032_square_crc", 1, 44100, 32, "je", 18, "square30"),
 ]
 
 
@@ -67,7 +85,8 @@ def main():
             ch = 1 if mode[0] == "m" else 2
             n = l12_spf(layer) * frames - 101  # a ragged end: the last frame is zero-filled
             pcm = {"mix": lambda: l12_signal(n, ch, 7000 + i, rate), "silence": lambda: silence_then_noise(n, ch, i),
-                   "square": lambda: square(n, ch, 37), "tones": lambda: tones(n, ch, rate)}[kind]()
+                   "square": lambda: square(n, ch, 37), "tones": lambda: tones(n, ch, rate), "square30": lambda: square(n, ch, 30),
+                   "two_tones": lambda: two_tones(n, ch, rate), "noise": lambda: noise(n, ch, 4)}[kind]()
             mpg, dumps = ref_l12(layer, rate, kbps, mode, pcm, wd)
             assert len(dumps) == frames
             if i % 4 == 0:  # the reference's own main(): raw PCM in, same bytes out
