@@ -59,6 +59,20 @@ int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev, const int
                            uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev);
 int mp3mi_l12_batch_sync(mp3mi_l12_batch *b);
 
+/* Streaming, as mp3mi_batch_encode_next / _flush / _reset of mp3mi.h: the reference is a frame-streaming encoder
+ * (src/musicin.c:585-705), and for these layers a stream carries nothing from frame to frame but PCM history (the
+ * filterbank's taps, the FFT windows of the passes that predict the next one) -- kept in the batch.
+ *   mp3mi_l12_batch_encode_next  the NEXT n_frames frames of every stream: pcm_dev holds only these frames; out_dev /
+ *                                out_len_dev receive their bytes (whole frames: nothing stays behind).  The first call after
+ *                                create, reset, flush or a whole-file encode starts new streams.
+ *   mp3mi_l12_batch_flush        close_bit_stream_w: the file's one byte past the last frame (src/common.c:843-868); ends the streams
+ *   mp3mi_l12_batch_reset        abandons the streams in progress
+ * Concatenating the outputs of the calls and of the flush gives the bytes of mp3mi_l12_batch_encode over the whole stream. */
+int mp3mi_l12_batch_encode_next(mp3mi_l12_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev, size_t out_stride,
+                                uint32_t *out_len_dev);
+int mp3mi_l12_batch_flush(mp3mi_l12_batch *b, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev);
+int mp3mi_l12_batch_reset(mp3mi_l12_batch *b);
+
 /* Two-tier decisions (mp3mi.h, MP3MI_TEST_PHASE_EXACT | _PSY_EXACT | _CW_EXACT): force the exact tier; bytes must not change */
 int mp3mi_l12_batch_set_test_flags(mp3mi_l12_batch *b, unsigned flags);
 

@@ -261,7 +261,8 @@ MP3MI_DEVFN void fft_bin(const float *x, uint32_t rd, fft_pair<C> *re, fft_pair<
 // n_per_ch on the stream reads as zero.  t_first is wave-uniform: when the whole span lies inside the call's
 // samples -- all but its first and last granules -- the loads need no per-sample tests.
 template <int C, int N>
-MP3MI_DEVFN void fft_load_pcm(const int16_t *pcm, const int16_t *hist, long t_first, long n_per_ch, int lane, uint32_t (&smp)[N])
+MP3MI_DEVFN void fft_load_pcm(const int16_t *pcm, const int16_t *hist, long t_first, long n_per_ch, int lane, uint32_t (&smp)[N],
+                              const int hlen = MP3MI_PCM_HIST)
 {
     if (t_first >= 0 && t_first + 64 * N <= n_per_ch) {
         const int16_t *p = pcm + t_first * C;
@@ -274,8 +275,8 @@ MP3MI_DEVFN void fft_load_pcm(const int16_t *pcm, const int16_t *hist, long t_fi
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const long t = t_first + lane + 64 * k;
-            const bool in = t >= 0 && t < n_per_ch, past = hist && t < 0 && t >= -MP3MI_PCM_HIST;
-            const long th = past ? t + MP3MI_PCM_HIST : 0;
+            const bool in = t >= 0 && t < n_per_ch, past = hist && t < 0 && t >= -hlen;
+            const long th = past ? t + hlen : 0;
             if (C == 2) smp[k] = in ? ((const uint32_t *) pcm)[t] : (past ? ((const uint32_t *) hist)[th] : 0u);
             else smp[k] = in ? (uint32_t) (uint16_t) pcm[t] : (past ? (uint32_t) (uint16_t) hist[th] : 0u);
         }
@@ -571,14 +572,16 @@ __global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict
         task = valid ? task : n_task - 1;
         const int qi = task % NP, s = task / NP;
         const size_t rec0 = ((size_t) s * NP + qi) * C;
-        const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
+        const long qr = (long) geo.f0 * geo.layer - geo.lb + qi; // the pass counted from the call's first, and from the stream's
+        const long q = geo.fabs0 * geo.layer + qr;
         const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch;
         const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
-        const long t0 = (long) geo.spp * (q + 1) - geo.span; // time of savebuf[0]  (src/psy.c:258-262)
+        const long t0 = (long) geo.spp * (qr + 1) - geo.span; // time of savebuf[0], from the call's first sample  (src/psy.c:258-262)
+        const int16_t *hist = geo.hist ? geo.hist + (size_t) s * L12_PCM_HIST * (size_t) C : NULL;
         {
             float wl[16];
             uint32_t smp[16];
-            fft_load_pcm<C, 16>(pcm, NULL, t0, n_per_ch, lane, smp);
+            fft_load_pcm<C, 16>(pcm, hist, t0, n_per_ch, lane, smp, L12_PCM_HIST);
 #pragma unroll
             for (int k = 0; k < 16; k++) wl[k] = T->window[lane + 64 * k];
 #pragma unroll

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
     const int ql = (int) ((bid / (unsigned) C) % (unsigned) nq);
     const int s = (int) (bid / (unsigned) (C * nq));
     const int qi = qi0 + ql;
-    const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
+    const long q = (geo.fabs0 + geo.f0) * geo.layer - geo.lb + qi; // the pass counted from the stream's first
     if (q < 0) continue; // (Layer I, first chunk: the pass before the stream has the initial lthr, k12_snr1)
     const size_t rec = ((size_t) s * NP + qi) * C + ch;
     const float *r_n = erp + rec * (3 * L12_ROW);               // this pass: energy, r, phi
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64) k12_snr1(l12_geom geo, const float *__rest
     const int ql = (int) ((blockIdx.x / (unsigned) C) % (unsigned) nq);
     const int s = (int) (blockIdx.x / (unsigned) (C * nq));
     const int qi = geo.lb + ql;
-    const long q = (long) geo.f0 * geo.layer - geo.lb + qi;
+    const long q = (geo.fabs0 + geo.f0) * geo.layer - geo.lb + qi;
     const size_t rec = ((size_t) s * NP + qi) * C + ch;
     for (int i = lane; i < L12_HBLK; i += 64) {
         const double temp1 = (double) thr1[rec * L12_ROW + i];
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
     const long n = (long) geo.f0 + fl; // frame index in the stream
     const long n_frames_s = geo.n_samples ? ((long) geo.n_samples[s] + geo.spf - 1) / geo.spf : (long) geo.n_frames;
     if (n >= n_frames_s) {
-        if (n_frames_s == 0 && n == 0 && lane == 0) { out[(size_t) s * out_stride] = 0; out_len[s] = 1; }
+        if (n_frames_s == 0 && n == 0 && lane == 0 && geo.whole_file) { out[(size_t) s * out_stride] = 0; out_len[s] = 1; }
         return;
     }
     const l12_stream_cfg cf = cfg[s];
@@ -763,8 +763,8 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
         uint8_t *o = out + (size_t) s * out_stride + (size_t) n * (size_t) frame_bytes;
         for (int i = lane; i < frame_bytes; i += 64) o[i] = (uint8_t) (L.img[i >> 2] >> (24 - 8 * (i & 3)));
         if (n == n_frames_s - 1 && lane == 0) {
-            o[frame_bytes] = 0;
-            out_len[s] = (uint32_t) (n_frames_s * frame_bytes + 1);
+            if (geo.whole_file) o[frame_bytes] = 0;
+            out_len[s] = (uint32_t) (n_frames_s * frame_bytes + (geo.whole_file ? 1 : 0));
         }
     }
 }
@@ -775,4 +775,39 @@ void mp3mi_launch_l12_alloc(const mp3mi_tables_l12 *T, const l12_geom &g, const 
     const unsigned grid = (unsigned) ((size_t) g.n_streams * g.nf);
     if (g.layer == 1) hipLaunchKernelGGL(k12_alloc<1>, dim3(grid), dim3(64), 0, st, T, g, cfg, sbs, snr, out, out_stride, out_len, dbg);
     else hipLaunchKernelGGL(k12_alloc<2>, dim3(grid), dim3(64), 0, st, T, g, cfg, sbs, snr, out, out_stride, out_len, dbg);
+}
+
+// ---- streaming: what a stream carries from call to call is PCM history only (l12_dev.h).  The last L12_PCM_HIST samples
+// before the next call's first one -- this call's tail, preceded by the old history's when the call was shorter --
+// for the FFT windows, and the last MP3MI_PCM_HIST of them in k_filter's layout.  Out of place: in and out are two buffers.
+__global__ void __launch_bounds__(256) k12_hist_save(l12_geom geo, const int16_t *__restrict__ pcm, const int16_t *__restrict__ hist_in,
+                                                     int16_t *__restrict__ hist_out, const int16_t *__restrict__ fb_in, int16_t *__restrict__ fb_out)
+{
+    const int s = (int) blockIdx.x, C = geo.channels;
+    const long n_call = (long) geo.n_frames * geo.spf;
+    const int16_t *src = pcm + (size_t) s * (size_t) n_call * C;
+    for (int pass = 0; pass < 2; pass++) {
+        const int H = pass ? MP3MI_PCM_HIST : L12_PCM_HIST;
+        const int16_t *in = (pass ? fb_in : hist_in) + (size_t) s * H * C;
+        int16_t *outp = (pass ? fb_out : hist_out) + (size_t) s * H * C;
+        for (int i = (int) threadIdx.x; i < H * C; i += 256) {
+            const long t = (long) (i / C) + n_call - H; // time of the sample, from the call's first
+            outp[i] = t >= 0 ? src[t * C + i % C] : in[(t + H) * C + i % C];
+        }
+    }
+}
+void mp3mi_launch_l12_hist_save(const l12_geom &g, const int16_t *pcm, const int16_t *hist_in, int16_t *hist_out, const int16_t *fb_in,
+                                int16_t *fb_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k12_hist_save, dim3((unsigned) g.n_streams), dim3(256), 0, st, g, pcm, hist_in, hist_out, fb_in, fb_out);
+}
+// close_bit_stream_w: the byte under construction is written too (src/common.c:843-868) -- frames end on byte boundaries, so it is 0
+__global__ void __launch_bounds__(64) k12_flush(int n_streams, uint8_t *__restrict__ out, size_t out_stride, uint32_t *__restrict__ out_len)
+{
+    const int s = (int) (blockIdx.x * 64 + threadIdx.x);
+    if (s < n_streams) { out[(size_t) s * out_stride] = 0; out_len[s] = 1; }
+}
+void mp3mi_launch_l12_flush(int n_streams, uint8_t *out, size_t out_stride, uint32_t *out_len, hipStream_t st)
+{
+    hipLaunchKernelGGL(k12_flush, dim3((unsigned) ((n_streams + 63) / 64)), dim3(64), 0, st, n_streams, out, out_stride, out_len);
 }

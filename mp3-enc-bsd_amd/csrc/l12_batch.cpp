@@ -51,6 +51,10 @@ struct mp3mi_l12_batch {
     double *sbs;
     l12_frame_dbg *dbg;
     int dbg_f0, dbg_nf;
+    // streaming: PCM history of the streams in progress, two copies taken in turn (k12_hist_save is out of place)
+    int16_t *hist[2], *fb_hist[2];
+    int hist_cur;
+    long fabs0;              // frames every stream has been given by mp3mi_l12_batch_encode_next since the last reset
 };
 
 static int l12_have_device(void)
@@ -111,6 +115,7 @@ extern "C" int mp3mi_l12_batch_create(mp3mi_l12_batch **out, int layer, int n_st
     for (int i = 0; i < 4; i++) { b->kernel_ms[i] = 0.0; b->kernel_launches[i] = 0; }
     b->ev0 = b->ev1 = 0; b->T3 = NULL; b->T = NULL; b->cfg = NULL;
     b->erp = b->thr1 = b->snr = NULL; b->sbs = NULL; b->dbg = NULL; b->dbg_f0 = b->dbg_nf = 0;
+    b->hist[0] = b->hist[1] = b->fb_hist[0] = b->fb_hist[1] = NULL; b->hist_cur = 0; b->fabs0 = 0;
     if (hipGetDevice(&b->device) != hipSuccess) { delete b; return MP3MI_ERR_HIP; }
     b->cfg_h.resize((size_t) n_streams);
     b->max_frame_bytes = 0;
@@ -186,6 +191,7 @@ extern "C" void mp3mi_l12_batch_destroy(mp3mi_l12_batch *b)
         if (b->stream) (void) hipStreamSynchronize(b->stream);
         (void) hipFree(b->T3); (void) hipFree(b->T); (void) hipFree(b->cfg); (void) hipFree(b->erp);
         (void) hipFree(b->thr1); (void) hipFree(b->snr); (void) hipFree(b->sbs); (void) hipFree(b->dbg);
+        for (int i = 0; i < 2; i++) { (void) hipFree(b->hist[i]); (void) hipFree(b->fb_hist[i]); }
         if (b->ev0) (void) hipEventDestroy(b->ev0);
         if (b->ev1) (void) hipEventDestroy(b->ev1);
         for (hipEvent_t e : b->kev) (void) hipEventDestroy(e);
@@ -244,8 +250,8 @@ static int l12_close_timing(mp3mi_l12_batch *b)
     return MP3MI_OK;
 }
 
-extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames,
-                                      uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev)
+static int l12_encode_impl(mp3mi_l12_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames,
+                           uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev, bool whole_file)
 {
     if (!b || !pcm_dev || !out_dev || !out_len_dev || n_frames < 1 || n_frames > b->max_frames) return MP3MI_ERR_ARG;
     if (out_stride < mp3mi_l12_batch_out_stride(b, n_frames)) return MP3MI_ERR_ARG;
@@ -274,6 +280,9 @@ extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev
         g.spf = b->spf; g.spp = b->spp; g.span = b->span;
         g.actual_mode = b->mode; g.crc = b->crc; g.hdr_flags = b->hdr_flags; g.test_flags = (int) b->test_flags;
         g.n_samples = n_samples_dev;
+        g.whole_file = whole_file ? 1 : 0;
+        g.fabs0 = whole_file ? 0 : b->fabs0;
+        g.hist = (!whole_file && b->fabs0 > 0) ? b->hist[b->hist_cur] : NULL; // (nothing precedes a stream's first call: zeros)
         // the filterbank slots of the chunk: frame f's slot u is slot (spf / 32) f + u of the stream, Layer I's two slots
         // EARLIER (get_audio holds 64 samples back, src/encode.c:224-247); k_filter computes whole 18-slot granules
         const long slots = b->spf / 32, first = slots * f0 - (layer == 1 ? 2 : 0), last = slots * (f0 + nf) - 1 - (layer == 1 ? 2 : 0);
@@ -285,6 +294,8 @@ extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev
         fg.g0 = g.g0; fg.n_gran = g.n_gran;
         fg.pcm_pitch = (long) n_frames * b->spf;
         fg.n_samples = n_samples_dev;
+        fg.fabs0 = g.fabs0;
+        fg.hist = g.hist ? b->fb_hist[b->hist_cur] : NULL;
         CHK(hipEventRecord(ke[0], b->stream));
         mp3mi_launch_fft12(b->T3, g, pcm_dev, b->erp, b->stream);
         CHK(hipEventRecord(ke[1], b->stream));
@@ -296,11 +307,60 @@ extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev
         CHK(hipEventRecord(ke[4], b->stream));
         b->dbg_f0 = f0; b->dbg_nf = nf;
     }
+    if (!whole_file) { // the samples the next call will need from before its first
+        l12_geom g;
+        memset(&g, 0, sizeof(g));
+        g.n_streams = S; g.channels = C; g.n_frames = n_frames; g.spf = b->spf;
+        for (int i = 0; i < 2; i++) {
+            if (!b->hist[i]) {
+                CHK(hipMalloc((void **) &b->hist[i], sizeof(int16_t) * L12_PCM_HIST * (size_t) C * (size_t) S));
+                CHK(hipMalloc((void **) &b->fb_hist[i], sizeof(int16_t) * MP3MI_PCM_HIST * (size_t) C * (size_t) S));
+                CHK(hipMemsetAsync(b->hist[i], 0, sizeof(int16_t) * L12_PCM_HIST * (size_t) C * (size_t) S, b->stream));
+                CHK(hipMemsetAsync(b->fb_hist[i], 0, sizeof(int16_t) * MP3MI_PCM_HIST * (size_t) C * (size_t) S, b->stream));
+            }
+        }
+        if (b->fabs0 == 0) { // a stream's first call: what precedes it is silence (the reference's zero-filled buffers)
+            CHK(hipMemsetAsync(b->hist[b->hist_cur], 0, sizeof(int16_t) * L12_PCM_HIST * (size_t) C * (size_t) S, b->stream));
+            CHK(hipMemsetAsync(b->fb_hist[b->hist_cur], 0, sizeof(int16_t) * MP3MI_PCM_HIST * (size_t) C * (size_t) S, b->stream));
+        }
+        mp3mi_launch_l12_hist_save(g, pcm_dev, b->hist[b->hist_cur], b->hist[b->hist_cur ^ 1], b->fb_hist[b->hist_cur], b->fb_hist[b->hist_cur ^ 1], b->stream);
+        b->hist_cur ^= 1;
+        b->fabs0 += n_frames;
+    } else b->fabs0 = 0;
     CHK(hipEventRecord(b->ev1, b->stream));
     b->kev_chunks = chunk;
     b->timing_open = true;
     b->calls++;
     CHK(hipGetLastError());
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_l12_batch_encode(mp3mi_l12_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames,
+                                      uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev)
+{
+    return l12_encode_impl(b, pcm_dev, n_samples_dev, n_frames, out_dev, out_stride, out_len_dev, true);
+}
+
+extern "C" int mp3mi_l12_batch_encode_next(mp3mi_l12_batch *b, const int16_t *pcm_dev, int n_frames, uint8_t *out_dev, size_t out_stride,
+                                           uint32_t *out_len_dev)
+{
+    return l12_encode_impl(b, pcm_dev, NULL, n_frames, out_dev, out_stride, out_len_dev, false);
+}
+
+extern "C" int mp3mi_l12_batch_flush(mp3mi_l12_batch *b, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev)
+{
+    if (!b || !out_dev || !out_len_dev || out_stride < 1) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    mp3mi_launch_l12_flush(b->n_streams, out_dev, out_stride, out_len_dev, b->stream);
+    b->fabs0 = 0;
+    CHK(hipGetLastError());
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_l12_batch_reset(mp3mi_l12_batch *b)
+{
+    if (!b) return MP3MI_ERR_ARG;
+    b->fabs0 = 0;
     return MP3MI_OK;
 }
 

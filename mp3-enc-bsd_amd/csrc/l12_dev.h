@@ -26,6 +26,8 @@
 #define L12_HBLK 513
 #define L12_ROW 520  /* row pitch of the per-line arrays in floats (16-byte multiples) */
 #define L12_CB 63
+#define L12_PCM_HIST 1792 /* samples per channel a streaming call needs from before its first sample: the FFT window of the third
+                             pass before it (Layer I: 2 * 384 + 1024; Layer II: 576 + 1056 = 1632) */
 
 /* read-only tables, one block in device memory per batch (tables_host.cpp: mp3mi_build_tables_l12) */
 typedef struct {
@@ -60,6 +62,11 @@ struct l12_geom {
     int crc, hdr_flags;      /* error protection; bit 3 copyright, bit 2 original, bits 1-0 emphasis */
     int test_flags;          /* MP3MI_TEST_PHASE_EXACT, _PSY_EXACT, _CW_EXACT: the second tier everywhere (tests) */
     const int32_t *n_samples; /* device, [n_streams]: valid samples per channel (ragged batch) or NULL */
+    /* streaming (mp3mi_l12_batch_encode_next): the call continues streams that earlier calls began */
+    long fabs0;              /* frames of every stream encoded by earlier calls */
+    const int16_t *hist;     /* device, [n_streams][L12_PCM_HIST][channels]: the samples before the call's first (zeros at the
+                                start of a stream), or NULL */
+    int whole_file;          /* the call is the whole stream: the last frame's wavefront adds the file's last byte */
 };
 
 /* per stream, device: what depends on the stream's bitrate */
@@ -80,6 +87,9 @@ void mp3mi_launch_fft12(const mp3mi_tables *T, const l12_geom &g, const int16_t 
 void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *thr1, float *snr, hipStream_t st);
 void mp3mi_launch_l12_alloc(const mp3mi_tables_l12 *T, const l12_geom &g, const l12_stream_cfg *cfg, const double *sbs,
                             const float *snr, uint8_t *out, size_t out_stride, uint32_t *out_len, l12_frame_dbg *dbg, hipStream_t st);
+void mp3mi_launch_l12_hist_save(const l12_geom &g, const int16_t *pcm, const int16_t *hist_in, int16_t *hist_out, const int16_t *fb_in,
+                                int16_t *fb_out, hipStream_t st);
+void mp3mi_launch_l12_flush(int n_streams, uint8_t *out, size_t out_stride, uint32_t *out_len, hipStream_t st);
 extern "C" int mp3mi_build_tables_l12(mp3mi_tables_l12 *T, int rate_idx, int layer);
 #endif
 

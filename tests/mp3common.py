@@ -539,6 +539,38 @@ class L12Run:
         lens = self.mem.download(self.d_len, (self.S,), np.uint32)
         return [out[i, :lens[i]].tobytes() for i in range(self.S)]
 
+    def encode_streaming(self, pieces):
+        """the same PCM fed piece by piece (frames per call) through mp3mi_l12_batch_encode_next, then flushed; returns the
+        concatenated bytes per stream.  Whole-length streams only (ragged batches and streaming do not combine)."""
+        L = self.mp.lib
+        L.mp3mi_l12_batch_encode_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_l12_batch_flush.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        assert sum(pieces) == self.nf
+        spf = l12_spf(self.layer)
+        whole = self.mem.download(self.d_pcm, (self.S, self.row), np.int16)
+        got = [b""] * self.S
+        f0 = 0
+        for nfp in pieces:
+            n = nfp * spf * self.ch
+            piece = np.ascontiguousarray(whole[:, f0 * spf * self.ch: f0 * spf * self.ch + n])
+            d_piece = self.mem.alloc(piece.nbytes)
+            self.mem.upload(d_piece, piece)
+            rc = L.mp3mi_l12_batch_encode_next(self.b, d_piece, nfp, self.d_out, self.stride, self.d_len)
+            assert rc == 0, "mp3mi_l12_batch_encode_next -> %d" % rc
+            assert L.mp3mi_l12_batch_sync(self.b) == 0
+            out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
+            lens = self.mem.download(self.d_len, (self.S,), np.uint32)
+            for s in range(self.S):
+                got[s] += out[s, :lens[s]].tobytes()
+            f0 += nfp
+        assert L.mp3mi_l12_batch_flush(self.b, self.d_out, self.stride, self.d_len) == 0
+        assert L.mp3mi_l12_batch_sync(self.b) == 0
+        out = self.mem.download(self.d_out, (self.S, self.stride), np.uint8)
+        lens = self.mem.download(self.d_len, (self.S,), np.uint32)
+        for s in range(self.S):
+            got[s] += out[s, :lens[s]].tobytes()
+        return got
+
     def seams(self):
         """(records [S][frames of the last chunk], first frame of that chunk)"""
         d = np.zeros((self.S * self.nf,), L12_SEAM_DT)

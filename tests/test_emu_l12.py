@@ -58,3 +58,20 @@ def test_mixed_bitrates_in_one_batch(emu, orc):
         run.close()
     for i in range(4):
         assert got[i] == oracle_l12(orc, 2, 44100, kb[i], "s", pcms[i])[0], kb[i]
+
+
+@pytest.mark.parametrize("layer,rate,kbps,mode,pieces", [(2, 44100, 128, "j", [1, 3, 2]), (1, 48000, 192, "s", [1, 1, 5, 9, 2]), (2, 32000, 64, "m", [2, 1, 1, 2])])
+def test_streaming_equals_one_call(emu, orc, layer, rate, kbps, mode, pieces):
+    """the stream fed piece by piece (Layer I pieces shorter than the history a call needs) == the whole-file call == the
+    oracle; then the same batch starts new streams"""
+    ch = 1 if mode[0] == "m" else 2
+    nfr = sum(pieces)
+    pcms = [l12_signal(l12_spf(layer) * nfr, ch, 70 + i, rate) for i in range(2)]
+    want = [oracle_l12(orc, layer, rate, kbps, mode, p)[0] for p in pcms]
+    run = L12Run(emu, layer, rate, kbps, mode, pcms, scratch_mb=1)
+    try:
+        assert run.encode_streaming(pieces) == want
+        assert run.encode() == want
+        assert run.encode_streaming(pieces[::-1]) == want
+    finally:
+        run.close()

@@ -116,3 +116,20 @@ def test_full_width_batch_l12(product, oracle, layer, rate, kbps, mode, frames):
     if os.path.exists(REF_ENCODE):
         for s in sample[::8]:
             assert reference_binary_l12(pcm[s], layer, rate, ch, kbps, mode) == got[s], s
+
+
+@pytest.mark.parametrize("layer,rate,kbps,mode,pieces", [(2, 44100, 160, "j", [1, 30, 2, 17]), (1, 44100, 288, "s", [1, 2, 40, 7, 100]), (2, 32000, 64, "m", [25, 25])])
+def test_streaming_equals_one_call_gpu(product, oracle, layer, rate, kbps, mode, pieces):
+    """256 streams fed piece by piece through mp3mi_l12_batch_encode_next + flush == the whole-file call == the oracle"""
+    S, nfr = 256, sum(pieces)
+    run = L12Run(product, layer, rate, kbps, mode, n_frames=nfr, synth=(S, 77))
+    try:
+        whole = run.encode()
+        assert run.encode_streaming(pieces) == whole
+        sample = list(range(0, S, 16))
+        pcm = {s: run.pcm_of(s) for s in sample}
+    finally:
+        run.close()
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        refs = dict(zip(sample, ex.map(lambda s: oracle_l12(oracle, layer, rate, kbps, mode, pcm[s])[0], sample)))
+    assert all(whole[s] == refs[s] for s in sample)
