@@ -396,6 +396,34 @@ DM_FN void dm_sincos_fast(double x, double *sn, double *cs)
     }
 }
 
+/* Plain double-precision cosine alone, |x| < 2^10: reduction by multiples of PI (the same three parts of pi/2, taken
+ * twice) to |r| <= pi/2 and ONE even polynomial there -- the Taylor series to r^22 (the next term is below 2^-63) --, sign
+ * by the parity of the multiple.  |error| < 2^-51 absolute (tests/test_dmath_host.py).  About half the instructions of
+ * dm_sincos_fast: for callers that need no sine (k12_psy's first tier, k_l12.hip).  NOT correctly rounded. */
+DM_FN double dm_cos_fast(double x)
+{
+    const double kd = __builtin_rint(x * (0.5 * DM_2_OVER_PI)); /* multiples of pi */
+    const double k2 = kd + kd;
+    double r = dm_fma(-k2, DM_PIO2_1, x);      /* exact, as in dm_sincos_fast */
+    double z, p;
+    r = dm_fma(-k2, DM_PIO2_2, r);
+    r = dm_fma(-k2, DM_PIO2_3, r);
+    z = r * r;
+    p = 0x1.0ce396db7f853p-70;                  /*  1/22! */
+    p = dm_fma(p, z, -0x1.e542ba4020225p-62);   /* -1/20! */
+    p = dm_fma(p, z, 0x1.6827863b97d97p-53);    /*  1/18! */
+    p = dm_fma(p, z, -0x1.ae7f3e733b81fp-45);   /* -1/16! */
+    p = dm_fma(p, z, 0x1.93974a8c07c9dp-37);    /*  1/14! */
+    p = dm_fma(p, z, -0x1.1eed8eff8d898p-29);   /* -1/12! */
+    p = dm_fma(p, z, 0x1.27e4fb7789f5cp-22);    /*  1/10! */
+    p = dm_fma(p, z, -0x1.a01a01a01a01ap-16);   /* -1/8! */
+    p = dm_fma(p, z, 0x1.6c16c16c16c17p-10);    /*  1/6! */
+    p = dm_fma(p, z, -0x1.5555555555555p-5);    /* -1/4! */
+    p = dm_fma(p, z, 0.5);
+    p = dm_fma(-p, z, 1.0);
+    return dm_from_bits(dm_bits(p) ^ (long long) ((unsigned long long) ((long long) kd & 1) << 63));
+}
+
 DM_FN double dm_cos(double x)
 {
     dm_dd r, s, c;

@@ -27,9 +27,32 @@ struct psy12_lds {
     float nb[64];
 };
 
-// c[j] of src/psy.c:283-292 for one line.  FAST: sines and cosines from dm_sincos_fast (|error| < 2^-51 each); the
-// quotient is then within 2^-49 of what correctly rounded ones give (t1, t2 are off by at most (r + |r'|) 1.5 2^-51,
-// their root by sqrt 2 times that, and the divisor IS r + |r'|), and *unsafe says whether the float could differ.
+// c[j] of src/psy.c:283-292 for one line, in three tiers.
+//
+// Tier 0 (psy12_c0): |r e^(i phi) - r' e^(i phi')|^2 = r^2 + r'^2 - 2 r r' cos(phi - phi') -- ONE cosine instead of two
+// sines and two cosines.  r, r' are floats: their squares and 2 r r' are exact doubles; the cosine (dm_cos_fast, and the
+// rounding of phi - phi' where it is not exact: |phi - phi'| <= 4 pi) is within 2^-49, so x = the squared distance is
+// within (r + |r'|)^2 2^-49.5 of the exact one and cw = sqrt(x) / (r + |r'|) within 2^-50.5 / cw of the exact quotient --
+// useless for a line predicted almost perfectly (cw tiny), decisive for all others.  *undecided says whether the
+// float could differ.
+// Tier 1 (psy12_c<true>): the reference's own formula with dm_sincos_fast (|error| < 2^-51 each): the quotient within
+// 2^-49 (t1, t2 are off by at most (r + |r'|) 1.5 2^-51, their root by sqrt 2 times that, and the divisor IS r + |r'|).
+// Tier 2 (psy12_c<false>): the correctly rounded dm_sincos.
+MP3MI_DEVFN float psy12_c0(float r_new, float phi_new, float r_old, float r_oldest, float phi_old, float phi_oldest, bool *undecided)
+{
+    const float r_prime = (float) (2.0 * (double) r_old - (double) r_oldest);
+    const float phi_prime = (float) (2.0 * (double) phi_old - (double) phi_oldest);
+    const double rn = (double) r_new, rp = (double) r_prime;
+    const double cd = dm_cos_fast((double) phi_new - (double) phi_prime);
+    const double x = (rn * rn + rp * rp) - ((rn + rn) * rp) * cd;
+    const double t3 = rn + __builtin_fabs(rp);
+    double cw = 0.0;
+    if (t3 != 0.0) cw = __builtin_sqrt(x > 0.0 ? x : 0.0) / t3;
+    const bool same = r_new == r_prime && phi_new == phi_prime; // exactly 0 in the reference, and here (cos 0 == 1)
+    if (t3 != 0.0 && !same && !(cw > 0x1p-20 && l12_float_decided(cw, 0x1p-49 / cw + 0x1p-50))) *undecided = true;
+    return (float) cw;
+}
+
 template <bool FAST>
 MP3MI_DEVFN float psy12_c(float r_new, float phi_new, float r_old, float r_oldest, float phi_old, float phi_oldest, bool *unsafe)
 {
@@ -64,6 +87,7 @@ MP3MI_DEVFN float psy12_snr_band(const float *e, const float *fthr, int sb, bool
     float x;
     if (sb < 13) {
         float minthres = 60802371420160.0f, sum_energy = 0.0f;
+#pragma unroll
         for (int k = 0; k < 17; k++) {
             const float f = fthr[j + k];
             if (minthres > f) minthres = f;
@@ -72,6 +96,7 @@ MP3MI_DEVFN float psy12_snr_band(const float *e, const float *fthr, int sb, bool
         x = (float) ((double) sum_energy / ((double) minthres * 17.0));
     } else {
         float minthres = 0.0f, sum_energy = 0.0f;
+#pragma unroll
         for (int k = 0; k < 17; k++) {
             minthres = minthres + fthr[j + k];
             sum_energy = sum_energy + e[j + k];
@@ -97,7 +122,7 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
     // next one's lthr).  The wavefronts are persistent: each walks through every gridDim.x-th record.
     const int qi0 = geo.lb - (geo.layer == 1 ? 1 : 0), nq = NP - qi0;
     const unsigned n_rec = (unsigned) geo.n_streams * (unsigned) nq * (unsigned) C;
-    const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1;
+    const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1, cw_tier1 = (geo.test_flags >> 6) & 1;
     const double tmn = T->tmn[lane < L12_CB ? lane : 0];
     const float bm = T->bmaxv[lane < L12_CB ? lane : 0], rn_nl = T->rn_nl[lane < L12_CB ? lane : 0];
     const int pj0 = lane < T->npart ? T->part_first[lane] : 0, pj1 = lane < T->npart ? T->part_first[lane + 1] : 0;
@@ -115,24 +140,52 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
     const float *r_oo = erp + (rec - 2 * (size_t) C) * (3 * L12_ROW); // two before ("oldest" = the slot "new" overwrites)
     wave_sync(); // the record before is done with the LDS
 
-    // ---- unpredictability of every line, src/psy.c:282-292
+    // ---- unpredictability of every line, src/psy.c:282-292.  The seven values a line needs of the three passes are
+    // requested one step ahead of their use (a step is ~250 instructions on them: their latency hides behind it)
+    unsigned redo = 0; // bit k: line lane + 64 k needs the third tier
+    float nx[7];
+    {
+        const int i0 = lane; // (k = 0: every lane has a line)
+        nx[0] = r_n[i0]; nx[1] = r_n[L12_ROW + i0]; nx[2] = r_n[2 * L12_ROW + i0];
+        nx[3] = r_o[L12_ROW + i0]; nx[4] = r_o[2 * L12_ROW + i0];
+        nx[5] = r_oo[L12_ROW + i0]; nx[6] = r_oo[2 * L12_ROW + i0];
+    }
 #pragma unroll 1
     for (int k = 0; k < 9; k++) {
         const int i = lane + 64 * k;
         const bool on = i < L12_HBLK;
         if (!wave_any(on)) break;
-        const int ii = on ? i : 0;
-        const float en = r_n[ii], rn = r_n[L12_ROW + ii], pn = r_n[2 * L12_ROW + ii];
-        const float ro = r_o[L12_ROW + ii], po = r_o[2 * L12_ROW + ii];
-        const float roo = r_oo[L12_ROW + ii], poo = r_oo[2 * L12_ROW + ii];
-        bool unsafe = cw_exact;
-        float c = 0.0f;
-        if (!unsafe) c = psy12_c<true>(rn, pn, ro, roo, po, poo, &unsafe);
-        if (wave_any(unsafe && on)) {
-            const float cx = psy12_c<false>(rn, pn, ro, roo, po, poo, &unsafe);
-            c = unsafe ? cx : c;
+        const float en = nx[0], rn = nx[1], pn = nx[2], ro = nx[3], po = nx[4], roo = nx[5], poo = nx[6];
+        {
+            const int i2 = (i + 64 < L12_HBLK) ? i + 64 : 0;
+            nx[0] = r_n[i2]; nx[1] = r_n[L12_ROW + i2]; nx[2] = r_n[2 * L12_ROW + i2];
+            nx[3] = r_o[L12_ROW + i2]; nx[4] = r_o[2 * L12_ROW + i2];
+            nx[5] = r_oo[L12_ROW + i2]; nx[6] = r_oo[2 * L12_ROW + i2];
         }
+        bool unsafe = cw_exact, undecided = cw_exact || cw_tier1;
+        float c = 0.0f;
+        if (!undecided) c = psy12_c0(rn, pn, ro, roo, po, poo, &undecided);
+        if (!cw_exact && wave_any(undecided && on)) { // (some line of the 64 predicted too well for the one-cosine form)
+            const float c1 = psy12_c<true>(rn, pn, ro, roo, po, poo, &unsafe);
+            unsafe = unsafe && undecided;
+            c = undecided ? c1 : c;
+        }
+        if (unsafe && on) redo |= 1u << k;
         if (on) { L.e[i] = en; L.c[i] = c; }
+    }
+    // the third tier -- correctly rounded sines and cosines -- for the lines the first two could not decide, behind the
+    // loop: it is rare, and inlined into the loop its double-double arithmetic would set the loop's register budget
+    if (wave_any(redo != 0)) {
+#pragma unroll 1
+        for (int k = 0; k < 9; k++) {
+            const bool mine = (redo >> k) & 1u;
+            if (!wave_any(mine)) continue;
+            const int i = lane + 64 * k, ii = mine ? i : 0;
+            bool u = false;
+            const float cx = psy12_c<false>(r_n[L12_ROW + ii], r_n[2 * L12_ROW + ii], r_o[L12_ROW + ii], r_oo[L12_ROW + ii],
+                                            r_o[2 * L12_ROW + ii], r_oo[2 * L12_ROW + ii], &u);
+            if (mine) L.c[i] = cx;
+        }
     }
     wave_sync();
 
@@ -221,11 +274,18 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
     wave_sync();
 
     // ---- threshold of every line before pre-echo control, src/psy.c:349-353 ("temp1": the larger of two floats)
-    for (int i = lane; i < L12_HBLK; i += 64) {
-        const float t = L.nb[T->partition[i]], a = T->absthr[i];
-        const float v = (t > a) ? t : a;
-        L.thr[i] = v;
-        if (geo.layer == 1) thr1[rec * L12_ROW + i] = v;
+    {
+        const uint8_t *pt = T->partition;
+        const float *at = T->absthr;
+#if !defined(MP3MI_EMU)
+        __asm__ volatile("" : "+v"(pt), "+v"(at)); // (the tables do not depend on the record: not hoisted out of the record loop, 18 registers)
+#endif
+        for (int i = lane; i < L12_HBLK; i += 64) {
+            const float t = L.nb[pt[i]], a = at[i];
+            const float v = (t > a) ? t : a;
+            L.thr[i] = v;
+            if (geo.layer == 1) thr1[rec * L12_ROW + i] = v;
+        }
     }
     if (geo.layer == 1) continue;
     wave_sync();

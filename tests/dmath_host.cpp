@@ -12,6 +12,7 @@ void t_dm_cos(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; 
 void t_dm_atan2_fast(const double *a, const double *b, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2_fast(a[i], b[i]); }
 void t_dm_sin_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) { double c; dm_sincos_fast(x[i], &y[i], &c); } }
 void t_dm_cos_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) { double s; dm_sincos_fast(x[i], &s, &y[i]); } }
+void t_dm_cos_only_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_cos_fast(x[i]); }
 int t_dm_float_rounding_safe(double v) { return dm_float_rounding_safe(v); }
 void t_dm_atan2(const double *a, const double *b, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2(a[i], b[i]); }
 }

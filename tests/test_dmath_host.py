@@ -168,3 +168,18 @@ def test_sincos_fast_on_the_arguments_k_cw_really_has(dm):
     got = call1(dm, "sin", e)
     worst = max(abs(float(mpmath.sin(mpmath.mpf(float(v))) - mpmath.mpf(float(g)))) / max(abs(float(g)), 2.0 ** -1000) for v, g in zip(e, got))
     assert worst <= 2.0 ** -53, worst
+
+
+def test_cos_fast_alone_error_bound(dm):
+    """dm_cos_fast (the one cosine of k12_psy's first tier): |error| < 2^-51 absolute against mpmath over the arguments the
+    kernel has -- |phi - phi'| <= 4 pi --, densely around every multiple of pi / 2 (where the cosine vanishes and only an
+    ABSOLUTE bound can hold), near 0, and out to 1000"""
+    import mpmath as mp
+    mp.mp.prec = 200
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.uniform(-13, 13, 40000), (np.arange(-8, 9)[:, None] * np.pi / 2 + rng.uniform(-1e-3, 1e-3, (17, 600))).reshape(-1),
+                        rng.uniform(-1e-6, 1e-6, 500), rng.uniform(-1000, 1000, 4000), np.array([0.0, np.pi, -np.pi, 4 * np.pi])])
+    y = call1(dm, "cos_only_fast", x)
+    err = max(abs(float(mp.cos(mp.mpf(float(a))) - mp.mpf(float(b)))) for a, b in zip(x, y))
+    assert err < 2.0 ** -51, err
+    assert call1(dm, "cos_only_fast", np.array([0.0]))[0] == 1.0

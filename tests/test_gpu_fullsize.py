@@ -90,7 +90,8 @@ def test_schedule_between_the_tuned_sizes(product, oracle):
             run.close()
 
 
-def test_two_ranks_share_the_gpu():
+@pytest.mark.parametrize("layer", [3, 2])
+def test_two_ranks_share_the_gpu(layer):
     """bench.py's N > 1 path rehearsed on the one-GPU box: two ranks (gloo for the barrier and the max-over-ranks time,
     both on device 0: MP3MI_BENCH_ONE_GPU=1) each encode their own stream range and check it against the oracle; the
     line says bit_exact and names two disjoint ranges with different bytes.  A child process: this one is not replaced."""
@@ -98,8 +99,8 @@ def test_two_ranks_share_the_gpu():
     import sys
     env = dict(os.environ, MP3MI_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--streams", "1024", "--frames", "48"], env=env, capture_output=True, text=True, timeout=600)
+                        "--master-port", str(29517 + layer), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--streams", "1024", "--frames", "48", "--layer", str(layer)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
     d = json.loads(line)
