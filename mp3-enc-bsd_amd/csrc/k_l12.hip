@@ -104,6 +104,13 @@ MP3MI_DEVFN float psy12_snr_band(const float *e, const float *fthr, int sb, bool
         x = sum_energy / minthres;
     }
     const bool normal = x >= 0x1p-126f && x < __builtin_inff();
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+    if (normal) { // site: (float)(4.342944819 log x): one ulp of the logarithm
+        const double lv = dm_log((double) x), v = 4.342944819 * lv;
+        const double ulp = dm_from_bits((dm_bits(lv) & 0x7ff0000000000000LL)) * 0x1p-52;
+        ULP_CENSUS(UC_L12_SNR, !l12_float_decided(v, 4.342944819 * ulp), !l12_float_decided(v, 4.342944819 * ulp * 1048576.0));
+    }
+#endif
     if (!exact && normal) {
         const double lv = dm_log_fast((double) x), v = 4.342944819 * lv;
         const double al = __builtin_fabs(lv);
@@ -171,6 +178,19 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
             c = undecided ? c1 : c;
         }
         if (unsafe && on) redo |= 1u << k;
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        if (on) { // site: c[j] = (float)(sqrt(t1^2 + t2^2) / t3); one ulp of each sine and cosine moves the quotient by < 2^-52
+            const float r_prime = (float) (2.0 * (double) ro - (double) roo), phi_prime = (float) (2.0 * (double) po - (double) poo);
+            if (!((double) rn + __builtin_fabs((double) r_prime) == 0.0) && !(rn == r_prime && pn == phi_prime)) {
+                double s2, c2, sp, cp;
+                dm_sincos((double) pn, &s2, &c2);
+                dm_sincos((double) phi_prime, &sp, &cp);
+                const double t1 = (double) rn * c2 - (double) r_prime * cp, t2 = (double) rn * s2 - (double) r_prime * sp;
+                const double cwx = __builtin_sqrt(t1 * t1 + t2 * t2) / ((double) rn + __builtin_fabs((double) r_prime));
+                ULP_CENSUS(UC_L12_C, !l12_float_decided(cwx, 0x1p-52), !l12_float_decided(cwx, 0x1p-32));
+            }
+        }
+#endif
         if (on) { L.e[i] = en; L.c[i] = c; }
     }
     // the third tier -- correctly rounded sines and cosines -- for the lines the first two could not decide, behind the
@@ -253,7 +273,20 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
                 bc = done ? bc : bx;
             }
         }
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        if (lane < L12_CB) { // site: bc = (float)(tmn tb + nmt (1 - tb)); one ulp of the logarithm (2^-51 on [0.69, 3]) moves it by < (tmn - 5.5) 0.434 2^-51
+            const double tb = -0.434294482 * dm_log((double) cb) - 0.301029996, v = tmn * tb + nmt * (1.0 - tb);
+            const double band = __builtin_fabs(tmn - nmt) * 0.434294482 * 0x1p-51;
+            ULP_CENSUS(UC_L12_BC, !l12_float_decided(v, band), !l12_float_decided(v, band * 1048576.0));
+        }
+#endif
         bc = (bc > bm) ? bc : bm;
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        if (lane < L12_CB) { // site: (float) exp(-bc ln10/10): one ulp of the exponential
+            const double v = dm_exp((double) -bc * R_LN_TO_LOG10);
+            ULP_CENSUS(UC_L12_EXP, !l12_float_decided(v, v * 0x1p-52), !l12_float_decided(v, v * 0x1p-32));
+        }
+#endif
         {
             const double arg = (double) -bc * R_LN_TO_LOG10;
             bool done = false;
@@ -871,3 +904,5 @@ void mp3mi_launch_l12_flush(int n_streams, uint8_t *out, size_t out_stride, uint
 {
     hipLaunchKernelGGL(k12_flush, dim3((unsigned) ((n_streams + 63) / 64)), dim3(64), 0, st, n_streams, out, out_stride, out_len);
 }
+
+ULP_CENSUS_ACCESSOR(mp3mi_debug_ulp_census_l12)

@@ -211,7 +211,9 @@ typedef struct {
  * one-ulp error of every libm result involved can move the value by ("near"), calls within a band 2^20 times wider
  * ("wide": the statistics behind an estimate where "near" is too rare to be seen).  DESIGN.md section 2. */
 #if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
-enum { UC_PHASE, UC_NB, UC_PE_ATTACK, UC_PE_RESV, UC_QUANTANF, UC_SCFSI_LOG, UC_CW_STEP, UC_CW_RANGE, UC_N };
+enum { UC_PHASE, UC_NB, UC_PE_ATTACK, UC_PE_RESV, UC_QUANTANF, UC_SCFSI_LOG, UC_CW_STEP, UC_CW_RANGE,
+       UC_L12_C, UC_L12_BC, UC_L12_EXP, UC_L12_SNR, /* Layers I / II (k_l12.hip) */
+       UC_N };
 static __device__ unsigned long long g_ulp_census[UC_N][3]; /* (one copy per translation unit: no relocatable device code here) */
 /* adds this translation unit's counters to out[UC_N][3] and clears them */
 #define ULP_CENSUS_ACCESSOR(name)                                                                       \

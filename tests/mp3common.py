@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PRODUCT_SO = os.path.join(ROOT, "mp3-enc-bsd_amd", "libmp3mi.so")
+# MP3MI_LIB: a diagnostic build of the same library (tools/gpu_ulp_census*.sh), as mp3-enc-bsd_amd/__init__.py honours it
+PRODUCT_SO = os.environ.get("MP3MI_LIB") or os.path.join(ROOT, "mp3-enc-bsd_amd", "libmp3mi.so")
 EMU_SO = os.path.join(ROOT, "tests", "hipemu", "_build", "libmp3mi_emu.so")
 ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
