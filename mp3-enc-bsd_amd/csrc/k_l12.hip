@@ -379,6 +379,7 @@ __device__ static const uint8_t L12_PATTERN[5][5] = {{0, 1, 1, 2, 0}, {3, 4, 4, 
 struct alloc12_lds {
     unsigned img[L12_IMG_WORDS];
     double multiple[64];
+    double snr[18];  // the signal-to-noise ratio of a quantiser: read once per granted step, in the loop's dependent chain
     uint16_t al[32][16][4];
     int ba[2][32], sf[2][32];
     unsigned crc;
@@ -429,36 +430,37 @@ MP3MI_DEVFN int l12_scale_index(const double *mult, double m)
     }
     return lo > 0 ? lo - 1 : 0;
 }
-// a double as a 64-bit key whose unsigned order is the doubles' order (no NaN; -0 never occurs here)
+// a double as a 64-bit key whose unsigned order is the REVERSE of the doubles' order (no NaN; -0 never occurs here):
+// the smallest ratio has the largest key, and 0 -- below every key of a number -- marks a band that is not a candidate
 MP3MI_DEVFN unsigned long long l12_key(double d)
 {
     const long long b = dm_bits(d);
-    return (unsigned long long) (b ^ ((b >> 63) | (long long) 0x8000000000000000ull));
+    return ~(unsigned long long) (b ^ ((b >> 63) | (long long) 0x8000000000000000ull));
 }
-// wave minimum of 64-bit keys: DPP steps inside the rows, row broadcasts across them (lanes without a source keep their own)
-MP3MI_DEVFN unsigned long long l12_wave_min_u64(unsigned long long v)
+// wave maximum of 64-bit keys: DPP steps inside the rows, row broadcasts across them; a lane without a source reads 0,
+// the identity (bound_ctrl), so a step is two DPP moves, one 64-bit compare and two selects
+MP3MI_DEVFN unsigned long long l12_wave_max_u64(unsigned long long v)
 {
 #if defined(MP3MI_EMU)
-    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(v, m); v = o < v ? o : v; }
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(v, m); v = o > v ? o : v; }
     return v;
 #else
-    unsigned lo = (unsigned) v, hi = (unsigned) (v >> 32);
-#define L12_MIN_STEP(ctrl)                                                                                  \
+#define L12_MAX_STEP(ctrl)                                                                                  \
     {                                                                                                       \
-        const unsigned olo = (unsigned) __builtin_amdgcn_update_dpp((int) lo, (int) lo, ctrl, 0xf, 0xf, false); \
-        const unsigned ohi = (unsigned) __builtin_amdgcn_update_dpp((int) hi, (int) hi, ctrl, 0xf, 0xf, false); \
-        const bool lt = ohi < hi || (ohi == hi && olo < lo);                                                \
-        lo = lt ? olo : lo;                                                                                 \
-        hi = lt ? ohi : hi;                                                                                 \
+        const unsigned olo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) v, ctrl, 0xf, 0xf, true); \
+        const unsigned ohi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) (v >> 32), ctrl, 0xf, 0xf, true); \
+        const unsigned long long o = ((unsigned long long) ohi << 32) | olo;                                \
+        v = o > v ? o : v;                                                                                  \
     }
-    L12_MIN_STEP(0xB1)  /* quad_perm [1,0,3,2] */
-    L12_MIN_STEP(0x4E)  /* quad_perm [2,3,0,1] */
-    L12_MIN_STEP(0x141) /* row_half_mirror */
-    L12_MIN_STEP(0x140) /* row_mirror */
-    L12_MIN_STEP(0x142) /* row_bcast15 */
-    L12_MIN_STEP(0x143) /* row_bcast31 */
-#undef L12_MIN_STEP
-    return ((unsigned long long) (unsigned) __builtin_amdgcn_readlane((int) hi, 63) << 32) | (unsigned) __builtin_amdgcn_readlane((int) lo, 63);
+    L12_MAX_STEP(0xB1)  /* quad_perm [1,0,3,2] */
+    L12_MAX_STEP(0x4E)  /* quad_perm [2,3,0,1] */
+    L12_MAX_STEP(0x141) /* row_half_mirror */
+    L12_MAX_STEP(0x140) /* row_mirror */
+    L12_MAX_STEP(0x142) /* row_bcast15 */
+    L12_MAX_STEP(0x143) /* row_bcast31 */
+#undef L12_MAX_STEP
+    return ((unsigned long long) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (v >> 32), 63) << 32) |
+           (unsigned) __builtin_amdgcn_readlane((int) (unsigned) v, 63);
 #endif
 }
 MP3MI_DEVFN void l12_update_crc(unsigned data, unsigned length, unsigned *crc)
@@ -498,6 +500,7 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
 
     for (int i = lane; i < L12_IMG_WORDS; i += 64) L.img[i] = 0;
     L.multiple[lane] = T->multiple[lane];
+    if (lane < 18) L.snr[lane] = T->snr[lane];
     if (LAYER == 2)
         for (int i = lane; i < 32 * 16 * 4 / 2; i += 64) ((uint32_t *) L.al)[i] = ((const uint32_t *) T->alloc[cf.table])[i];
     wave_sync();
@@ -573,7 +576,7 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
     const int sfs = scfsi == 0 ? 3 : scfsi == 2 ? 1 : 2;                 // sfsPerScfsi, src/encode.c:825
     const int sfs_o = __shfl_xor(sfs, 1);                                // the other channel's (C == 2)
     const double smr_o = __shfl_xor(smr, 1);
-    const double *snrt = T->snr;
+    const double *snrt = L.snr;
     const int maxAlloc = LAYER == 2 ? (1 << L.al[sbc][0][1]) - 1 : 15;   // src/encode.c:838
 
     // ---- joint stereo: how many subbands stay stereo, src/encode.c:882-948
@@ -627,8 +630,8 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
 
     // ---- *_a_bit_allocation, src/encode.c:974-1172: the band with the smallest mask-to-noise ratio gets the next step,
     // the first in (subband, channel) order among equals -- lane order.  Every lane keeps its ratio as a 64-bit key
-    // whose unsigned order is the doubles' order (all ones: not a candidate) and the bits its next step would cost;
-    // one wave minimum per step, and only the winner (and, above the joint-stereo bound, its other channel) recomputes.
+    // whose unsigned order is the reverse of the doubles' order (0: not a candidate) and the bits its next step would cost;
+    // one wave maximum per step, and only the winner (and, above the joint-stereo bound, its other channel) recomputes.
     int ba = 0, used = 0, adb = cf.frame_bits;
     double mnr = snrt[0] - smr;
     {
@@ -639,6 +642,12 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
         adb -= bbal + (geo.crc ? 16 : 0) + 32;
         const int ad = adb;
         int spent = 0; // bspl + bscf + bsel
+        // Layer II keeps the table entry of the band's NEXT step in registers (one 8-byte LDS read when it wins, off the
+        // loop's dependent chain: the winner's new ratio needs only the signal-to-noise ratio of the step it just took)
+        auto entry = [&](int idx) -> uint2 { return *(const uint2 *) L.al[sbc][idx < 16 ? idx : 15]; }; // {steps | bits << 16, group | quant << 16}
+        auto bits12 = [](uint2 e) -> int { return 12 * (int) ((e.y & 0xffffu) * (e.x >> 16)); };
+        uint2 e_nxt = LAYER == 2 ? entry(1) : make_uint2(0, 0);
+        int cur12 = 0;
         // what the lane's next step costs: sample bits, and with its first step scale factor (and scfsi) bits
         auto next_cost = [&]() -> int {
             if (LAYER == 1) {
@@ -646,23 +655,22 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
                 if (sb >= jsbound) scale *= stereo;
                 return (used ? 12 : 24) + scale;
             }
-            const int nx = ba + 1 < 16 ? ba + 1 : 15;
-            int inc = 12 * (L.al[sbc][nx][2] * L.al[sbc][nx][1]);
-            if (used) return inc - 12 * (L.al[sbc][ba][2] * L.al[sbc][ba][1]);
+            int inc = bits12(e_nxt);
+            if (used) return inc - cur12;
             inc += 2 + 6 * sfs;
             if (stereo == 2 && sb >= jsbound) inc += 2 + 6 * sfs_o;
             return inc;
         };
         int need = next_cost();
-        unsigned long long key = (act && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : ~0ull;
+        unsigned long long key = (act && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : 0ull;
         for (;;) {
             unsigned long long k = key;
             if (LAYER == 1) { // src/encode.c:1012: small starts at mnr[0][0] + 1, whatever state that band is in
                 const double lim = wave_bcast_f64(mnr, 0) + 1;
-                if (!(lim > mnr)) k = ~0ull;
+                if (!(lim > mnr)) k = 0ull;
             }
-            const unsigned long long small = l12_wave_min_u64(k);
-            if (small == ~0ull) break;
+            const unsigned long long small = l12_wave_max_u64(k); // (the key of the smallest ratio)
+            if (small == 0ull) break;
             const unsigned long long tie = __ballot(k == small);
             const int win = __ffsll((long long) tie) - 1;
             const int wsb = C == 2 ? win >> 1 : win;
@@ -678,21 +686,29 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
                         mnr = -smr + snrt[ba];
                         if (ba == 14) used = 2;
                     } else {
-                        mnr = -smr + snrt[L.al[sbc][ba][3] + 1];
+                        mnr = -smr + snrt[(e_nxt.y >> 16) + 1];
+                        cur12 = bits12(e_nxt);
+                        e_nxt = entry(ba + 1);
                         if (ba >= maxAlloc) used = 2;
                     }
                 } else used = 2;
                 need = next_cost();
-                key = (used != 2 && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : ~0ull;
+                key = (used != 2 && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : 0ull;
             }
             if (C == 2 && wsb >= jsbound) { // above the joint-stereo bound the allocation applies to both channels
                 const int wba = wave_readlane_i32(ba, win), wused = wave_readlane_i32(used, win);
                 if (me_oth) {
                     ba = wba;
                     used = wused;
-                    mnr = -smr + (LAYER == 1 ? snrt[ba] : snrt[L.al[sbc][ba][3] + 1]);
+                    if (LAYER == 1) mnr = -smr + snrt[ba];
+                    else {
+                        const uint2 e_cur = entry(ba);
+                        mnr = -smr + snrt[(e_cur.y >> 16) + 1];
+                        cur12 = bits12(e_cur);
+                        e_nxt = entry(ba + 1);
+                    }
                     need = next_cost();
-                    key = (used != 2 && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : ~0ull;
+                    key = (used != 2 && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : 0ull;
                 }
             }
         }

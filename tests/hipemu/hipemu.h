@@ -25,7 +25,8 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint4 { unsigned x, y, z, w; };
-struct uint2 { unsigned x, y; };
+struct __attribute__((aligned(8))) uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 struct float2 { float x, y; };
 struct __attribute__((aligned(16))) float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
