@@ -678,6 +678,13 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
             const int wneed = wave_readlane_i32(need, win);
             const bool fits = ad >= spent + wneed;
             if (fits) spent += wneed;
+            else {
+                // The band does not get its step and is closed.  When what is left is less than ANY open band's next
+                // step, every remaining round of the reference's loop does the same -- picks a band, finds no room,
+                // closes it -- and changes nothing that is looked at afterwards (the allocation, the bits left): stop.
+                const int mn = wave_min_i32((key != 0ull && !me_win) ? need : 0x7fffffff);
+                if (ad - spent < mn) break;
+            }
             if (me_win) {
                 if (fits) {
                     ba++;
