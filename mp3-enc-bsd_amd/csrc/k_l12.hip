@@ -84,25 +84,17 @@ MP3MI_DEVFN float psy12_c(float r_new, float phi_new, float r_old, float r_oldes
 MP3MI_DEVFN float psy12_snr_band(const float *e, const float *fthr, int sb, bool exact)
 {
     const int j = 16 * sb;
-    float x;
-    if (sb < 13) {
-        float minthres = 60802371420160.0f, sum_energy = 0.0f;
+    // one walk for both forms -- the 13 lower subbands take the smallest threshold of their 17 lines, the upper ones the
+    // sum (src/psy.c:367-386) --: a wavefront that branched would walk twice
+    float minthres = 60802371420160.0f, sumthres = 0.0f, sum_energy = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 17; k++) {
-            const float f = fthr[j + k];
-            if (minthres > f) minthres = f;
-            sum_energy = sum_energy + e[j + k];
-        }
-        x = (float) ((double) sum_energy / ((double) minthres * 17.0));
-    } else {
-        float minthres = 0.0f, sum_energy = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 17; k++) {
-            minthres = minthres + fthr[j + k];
-            sum_energy = sum_energy + e[j + k];
-        }
-        x = sum_energy / minthres;
+    for (int k = 0; k < 17; k++) {
+        const float f = fthr[j + k];
+        if (minthres > f) minthres = f;
+        sumthres = sumthres + f;
+        sum_energy = sum_energy + e[j + k];
     }
+    const float x = sb < 13 ? (float) ((double) sum_energy / ((double) minthres * 17.0)) : sum_energy / sumthres;
     const bool normal = x >= 0x1p-126f && x < __builtin_inff();
 #if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
     if (normal) { // site: (float)(4.342944819 log x): one ulp of the logarithm
