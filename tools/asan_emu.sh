@@ -7,10 +7,11 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd $ROOT/tests/hipemu
 mkdir -p _asan
 FL="-O1 -g -mfma -ffp-contract=off -fPIC -std=c++17 -DMP3MI_EMU -fsanitize=address,undefined -fno-omit-frame-pointer -I. -I../../mp3-enc-bsd_amd/csrc -I../../include -Wno-unused"
-for f in k_fft k_psy k_fbmdct k_prep k_loop k_format k_debug k_dropin k_synth; do g++ $FL -x c++ -c ../../mp3-enc-bsd_amd/csrc/$f.hip -o _asan/$f.o & done
-for f in batch dropin tables_host pcm_synth_host; do g++ $FL -c ../../mp3-enc-bsd_amd/csrc/$f.cpp -o _asan/$f.o & done
+for f in k_fft k_psy k_fbmdct k_prep k_loop k_format k_debug k_dropin k_synth k_l12; do g++ $FL -x c++ -c ../../mp3-enc-bsd_amd/csrc/$f.hip -o _asan/$f.o & done
+for f in batch l12_batch dropin tables_host pcm_synth_host; do g++ $FL -c ../../mp3-enc-bsd_amd/csrc/$f.cpp -o _asan/$f.o & done
 g++ $FL -c hipemu.cpp -o _asan/hipemu.o
 wait
+(cd ../../mp3-enc-bsd_amd/csrc && ld -r -b binary -z noexecstack -o $ROOT/tests/hipemu/_asan/tables_blob.o tables_blob.bin)
 g++ -shared -fsanitize=address,undefined -o _asan/libmp3mi_emu_asan.so _asan/*.o -lm -ldl
 cat > _asan/run.py <<PY
 import sys
@@ -28,5 +29,20 @@ for S, rate, ch, kbps, nf, s0 in [(2, 44100, 2, 128, 5, 5), (2, 48000, 2, 32, 4,
     assert (out2 == out).all()
     run.close()
     print("sanitizer run ok:", rate, ch, kbps)
+# Layers I and II: whole-file (ragged, several chunks), streaming, every exact tier
+from mp3common import L12Run, l12_signal, l12_spf
+for layer, rate, kbps, mode, nfr in [(2, 44100, 128, "j", 5), (1, 32000, 96, "se", 11), (2, 48000, 56, "m", 4), (1, 44100, 448, "d", 7)]:
+    ch = 1 if mode[0] == "m" else 2
+    pcms = [l12_signal(l12_spf(layer) * nfr - 77 * i, ch, 9 + i, rate) for i in range(3)]
+    run = L12Run(mp, layer, rate, kbps, mode, pcms, scratch_mb=1)
+    a = run.encode()
+    run.set_flags(2 | 4 | 32)
+    assert run.encode() == a
+    run.close()
+    full = [l12_signal(l12_spf(layer) * nfr, ch, 9 + i, rate) for i in range(2)]
+    run = L12Run(mp, layer, rate, kbps, mode, full)
+    assert run.encode_streaming([1, nfr - 2, 1]) == run.encode()
+    run.close()
+    print("sanitizer run ok: layer", layer, rate, kbps, mode)
 PY
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 python3 _asan/run.py 2>&1 | grep -v "doesn't fully support makecontext"
