@@ -200,7 +200,11 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
 
 extern "C" void window_subband(short **buffer, double z[512], int k)
 {
-    if (!D.ready) DIE("window_subband called before L3psycho_anal fixed the sampling frequency");
+    // The reference's Layer I / II frame loops (src/musicin.c:620-704) call the filterbank without ever calling
+    // L3psycho_anal: the analysis window and the matrixing coefficients do not depend on the sampling frequency, so the
+    // hidden stream is set up with any rate's tables (a later L3psycho_anal at another rate -- another layer in the same
+    // process -- is refused)
+    if (!D.ready) ensure(0);
     HIPOK(hipMemcpyAsync(D.new32, *buffer, 32 * sizeof(int16_t), hipMemcpyHostToDevice, D.st));
     *buffer += 32; // src/encode.c:307
     mp3mi_launch_window_subband(D.T, D.ring + 512 * k, D.off[k], D.new32, D.z_d, D.st);
@@ -211,7 +215,7 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
 
 extern "C" void filter_subband(double z[512], double s[32])
 {
-    if (!D.ready) DIE("filter_subband called before L3psycho_anal fixed the sampling frequency");
+    if (!D.ready) ensure(0);
     HIPOK(hipMemcpyAsync(D.z_d, z, 512 * sizeof(double), hipMemcpyHostToDevice, D.st));
     mp3mi_launch_filter_subband(D.T, D.z_d, D.s_d, D.st);
     HIPOK(hipMemcpyAsync(s, D.s_d, 32 * sizeof(double), hipMemcpyDeviceToHost, D.st));

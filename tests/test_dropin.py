@@ -29,7 +29,8 @@ def run_cli(binary, wav, mp3, rate, kbps, mono, extra=()):
     args = [os.path.join(REF, binary), "-s", "%g" % (rate / 1000.0), "-b", str(kbps)] + list(extra)
     if mono:
         args += ["-m", "m"]
-    subprocess.run(args + [str(wav), str(mp3)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run(args + [str(wav), str(mp3)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                   cwd=os.path.dirname(str(mp3)))  # (the reference's psycho_anal writes "out.dat" where it runs)
     return open(mp3, "rb").read()
 
 
@@ -94,3 +95,42 @@ def test_baseline_config0_through_the_reference_driver(product, tmp_path):
                "frames": 383, "seconds": round(dt, 3), "frames_per_s": round(383 / dt, 1), "bit_exact": True,
                "note": "plumbing figure: every reference call is a kernel launch plus host round trips; throughput comes from the batched API"},
               open(os.path.join(out, "dropin_config0.json"), "w"), indent=1)
+
+
+
+LAYER12 = [(2, 160, ["-l", "2"]), (1, 192, ["-l", "1"]), (2, 64, ["-l", "2", "-m", "j"])]
+
+
+def without_private_bit(data, layer, kbps, rate=44100):
+    """The reference's driver never initialises info.extension (the header's private bit): `layer info` is an automatic
+    variable of main() (src/musicin.c:470) and parse_args sets every field but that one, so the bit is whatever the stack
+    held -- it differs between two LINKS of the same driver.  Masked in every frame header before two binaries are compared."""
+    fb = 4 * int(384 / (rate / 1000.0) * kbps / 32) if layer == 1 else int(1152 / (rate / 1000.0) * kbps / 8)
+    b = bytearray(data)
+    for p in range(0, len(b) - 3, fb):
+        assert b[p] == 0xff and (b[p + 1] & 0xf0) == 0xf0
+        b[p + 2] &= 0xfe
+    return bytes(b)
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "encode_dropin_emu")) and os.path.exists(os.path.join(REF, "encode"))), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("layer,kbps,extra", LAYER12)
+def test_reference_driver_layers_1_2_over_emulated_library(emu, tmp_path, layer, kbps, extra):
+    """-l 1 / -l 2 of the reference's own driver over the drop-in link: the reference's Layer I / II code with the library's
+    window_subband / filter_subband under it (the batched counterpart is include/mp3mi_l12.h)"""
+    pcm = emu.synth(1152 * 4 + 200, 2, 44100, 7, SEED)
+    write_wav(tmp_path / "a.wav", pcm, 2, 44100)
+    got = run_cli("encode_dropin_emu", tmp_path / "a.wav", tmp_path / "a.mpg", 44100, kbps, False, extra)
+    ref = run_cli("encode", tmp_path / "a.wav", tmp_path / "r.mpg", 44100, kbps, False, extra)
+    assert without_private_bit(got, layer, kbps) == without_private_bit(ref, layer, kbps)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "encode_dropin")) and os.path.exists(os.path.join(REF, "encode"))), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("layer,kbps,extra", LAYER12)
+def test_reference_driver_layers_1_2_over_hip_library(product, tmp_path, layer, kbps, extra):
+    pcm = product.synth(1152 * 20 + 200, 2, 44100, 7, SEED)
+    write_wav(tmp_path / "a.wav", pcm, 2, 44100)
+    got = run_cli("encode_dropin", tmp_path / "a.wav", tmp_path / "a.mpg", 44100, kbps, False, extra)
+    ref = run_cli("encode", tmp_path / "a.wav", tmp_path / "r.mpg", 44100, kbps, False, extra)
+    assert without_private_bit(got, layer, kbps) == without_private_bit(ref, layer, kbps)
