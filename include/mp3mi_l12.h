@@ -73,9 +73,7 @@ int mp3mi_l12_batch_encode_next(mp3mi_l12_batch *b, const int16_t *pcm_dev, int 
 int mp3mi_l12_batch_flush(mp3mi_l12_batch *b, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev);
 int mp3mi_l12_batch_reset(mp3mi_l12_batch *b);
 
-/* Tiered decisions (mp3mi.h, MP3MI_TEST_PHASE_EXACT | _PSY_EXACT | _CW_EXACT): force the exact tier; bytes must not change.
- * The unpredictability has three tiers here (k_l12.hip): MP3MI_L12_TEST_CW_TIER1 skips the first (one cosine per line). */
-enum { MP3MI_L12_TEST_CW_TIER1 = 64 };
+/* Two-tier decisions (mp3mi.h, MP3MI_TEST_PHASE_EXACT | _PSY_EXACT | _CW_EXACT): force the exact tier; bytes must not change */
 int mp3mi_l12_batch_set_test_flags(mp3mi_l12_batch *b, unsigned flags);
 
 /* Stage seams of the LAST chunk of the last call for tests (oracle/stage_dump_l12.h): enable before encoding, then

@@ -424,6 +424,37 @@ DM_FN double dm_cos_fast(double x)
     return dm_from_bits(dm_bits(p) ^ (long long) ((unsigned long long) ((long long) kd & 1) << 63));
 }
 
+/* Plain double-precision sine with a small RELATIVE error, |x| <= 8: reduction by multiples of PI (three 30-bit parts of
+ * pi/2 taken twice: exact products, pi to 2^-90) to |r| <= pi/2 and the odd Taylor series to r^23 there; sign by the parity of
+ * the multiple.  Relative error below 2^-49 (tests/test_dmath_host.py) UNLESS the argument lies within 2^-30 of a non-zero
+ * multiple of pi, where what the three parts leave out shows: then *near_multiple is set and the caller must not rely on the
+ * value.  For k12_psy's first tier (k_l12.hip), which needs sin((phi - phi') / 2) of a line that is predicted almost
+ * perfectly -- a tiny sine -- as accurately as any other.  NOT correctly rounded. */
+DM_FN double dm_sin_fast_rel(double x, int *near_multiple)
+{
+    const double kd = __builtin_rint(x * (0.5 * DM_2_OVER_PI)); /* multiples of pi */
+    const double k2 = kd + kd;
+    double r = dm_fma(-k2, DM_PIO2_1, x);      /* exact, as in dm_sincos_fast */
+    double z, q, sv;
+    r = dm_fma(-k2, DM_PIO2_2, r);
+    r = dm_fma(-k2, DM_PIO2_3, r);
+    *near_multiple = kd != 0.0 && dm_fabs(r) < 0x1p-30;
+    z = r * r;
+    q = -0x1.761b41316381ap-75;                 /* -1/23! */
+    q = dm_fma(q, z, 0x1.71b8ef6dcf572p-66);    /*  1/21! */
+    q = dm_fma(q, z, -0x1.2f49b46814157p-57);   /* -1/19! */
+    q = dm_fma(q, z, 0x1.952c77030ad4ap-49);    /*  1/17! */
+    q = dm_fma(q, z, -0x1.ae7f3e733b81fp-41);   /* -1/15! */
+    q = dm_fma(q, z, 0x1.6124613a86d09p-33);    /*  1/13! */
+    q = dm_fma(q, z, -0x1.ae64567f544e4p-26);   /* -1/11! */
+    q = dm_fma(q, z, 0x1.71de3a556c734p-19);    /*  1/9! */
+    q = dm_fma(q, z, -0x1.a01a01a01a01ap-13);   /* -1/7! */
+    q = dm_fma(q, z, 0x1.1111111111111p-7);     /*  1/5! */
+    q = dm_fma(q, z, -0x1.5555555555555p-3);    /* -1/3! */
+    sv = dm_fma(r * z, q, r);
+    return dm_from_bits(dm_bits(sv) ^ (long long) ((unsigned long long) ((long long) kd & 1) << 63));
+}
+
 DM_FN double dm_cos(double x)
 {
     dm_dd r, s, c;

@@ -27,55 +27,49 @@ struct psy12_lds {
     float nb[64];
 };
 
-// c[j] of src/psy.c:283-292 for one line, in three tiers.
+// c[j] of src/psy.c:283-292 for one line, in two tiers.
 //
-// Tier 0 (psy12_c0): |r e^(i phi) - r' e^(i phi')|^2 = r^2 + r'^2 - 2 r r' cos(phi - phi') -- ONE cosine instead of two
-// sines and two cosines.  r, r' are floats: their squares and 2 r r' are exact doubles; the cosine (dm_cos_fast, and the
-// rounding of phi - phi' where it is not exact: |phi - phi'| <= 4 pi) is within 2^-49, so x = the squared distance is
-// within (r + |r'|)^2 2^-49.5 of the exact one and cw = sqrt(x) / (r + |r'|) within 2^-50.5 / cw of the exact quotient --
-// useless for a line predicted almost perfectly (cw tiny), decisive for all others.  *undecided says whether the
-// float could differ.
-// Tier 1 (psy12_c<true>): the reference's own formula with dm_sincos_fast (|error| < 2^-51 each): the quotient within
-// 2^-49 (t1, t2 are off by at most (r + |r'|) 1.5 2^-51, their root by sqrt 2 times that, and the divisor IS r + |r'|).
-// Tier 2 (psy12_c<false>): the correctly rounded dm_sincos.
+// First tier (psy12_c0): with a = r, b = r' (floats: a - b, and 4 a b, are exact doubles) and D = phi - phi',
+//     |a e^(i phi) - b e^(i phi')|^2  =  a^2 + b^2 - 2 a b cos D  =  (a - b)^2 + 4 a b sin^2(D / 2)
+// -- ONE sine instead of the reference's two sines and two cosines, and for a b >= 0 a sum of two non-negative terms:
+// no cancellation, however well the line is predicted.  dm_sin_fast_rel is within 2^-49 RELATIVE of the sine (D / 2 is
+// exact: the subtraction is checked with its TwoSum error term, the halving is a power of two), so the squared distance
+// is within 2^-48 and cw = sqrt(x) / (a + |b|) within 2^-47 RELATIVE of the exact quotient: a float is decided unless it
+// lies that close to a rounding boundary (2^-22 of all values).  For a b < 0 (the prediction r' = 2 r_old - r_oldest went
+// negative) the second term is subtracted from (a + |b|)^2: the quotient is within 2^-51 / cw absolute -- useless only where
+// two lines of opposite sign nearly cancel.  *undecided says whether the float could differ.
+// Second tier (psy12_c_exact): the reference's own formula with the correctly rounded dm_sincos, behind the loop.
 MP3MI_DEVFN float psy12_c0(float r_new, float phi_new, float r_old, float r_oldest, float phi_old, float phi_oldest, bool *undecided)
 {
     const float r_prime = (float) (2.0 * (double) r_old - (double) r_oldest);
     const float phi_prime = (float) (2.0 * (double) phi_old - (double) phi_oldest);
-    const double rn = (double) r_new, rp = (double) r_prime;
-    const double cd = dm_cos_fast((double) phi_new - (double) phi_prime);
-    const double x = (rn * rn + rp * rp) - ((rn + rn) * rp) * cd;
-    const double t3 = rn + __builtin_fabs(rp);
+    const double a = (double) r_new, b = (double) r_prime, pn = (double) phi_new, pp = (double) phi_prime;
+    const double dl = pn - pp, bb = dl - pn, dl_err = (pn - (dl - bb)) + (-pp - bb); // TwoSum: dl + dl_err == pn - pp exactly
+    int near_multiple;
+    const double sn = dm_sin_fast_rel(0.5 * dl, &near_multiple);
+    const double d = a - b, m = (a + a) * (b + b);
+    const double x = d * d + m * (sn * sn);
+    const double t3 = a + __builtin_fabs(b);
     double cw = 0.0;
     if (t3 != 0.0) cw = __builtin_sqrt(x > 0.0 ? x : 0.0) / t3;
-    const bool same = r_new == r_prime && phi_new == phi_prime; // exactly 0 in the reference, and here (cos 0 == 1)
-    if (t3 != 0.0 && !same && !(cw > 0x1p-20 && l12_float_decided(cw, 0x1p-49 / cw + 0x1p-50))) *undecided = true;
+    const double err = m >= 0.0 ? cw * 0x1p-47 : 0x1p-51 / cw + cw * 0x1p-47;
+    if (t3 != 0.0 && !(dl_err == 0.0 && !near_multiple && (m >= 0.0 || cw > 0x1p-20) && l12_float_decided(cw, err))) *undecided = true;
     return (float) cw;
 }
 
-template <bool FAST>
-MP3MI_DEVFN float psy12_c(float r_new, float phi_new, float r_old, float r_oldest, float phi_old, float phi_oldest, bool *unsafe)
+MP3MI_DEVFN float psy12_c_exact(float r_new, float phi_new, float r_old, float r_oldest, float phi_old, float phi_oldest)
 {
     const float r_prime = (float) (2.0 * (double) r_old - (double) r_oldest);
     const float phi_prime = (float) (2.0 * (double) phi_old - (double) phi_oldest);
     const double rn = (double) r_new, rp = (double) r_prime;
     double s2, c2, sp, cp;
-    if (FAST) {
-        dm_sincos_fast((double) phi_new, &s2, &c2);
-        dm_sincos_fast((double) phi_prime, &sp, &cp);
-    } else {
-        dm_sincos((double) phi_new, &s2, &c2);
-        dm_sincos((double) phi_prime, &sp, &cp);
-    }
+    dm_sincos((double) phi_new, &s2, &c2);
+    dm_sincos((double) phi_prime, &sp, &cp);
     const double t1 = rn * c2 - rp * cp;
     const double t2 = rn * s2 - rp * sp;
     const double t3 = rn + __builtin_fabs(rp);
     double cw = 0.0;
     if (t3 != 0.0) cw = __builtin_sqrt(t1 * t1 + t2 * t2) / t3;
-    // predicted == actual bit for bit (digital silence, a stationary bin): the reference subtracts a product from
-    // itself whatever its libm returns -- exactly 0, as here
-    const bool same = r_new == r_prime && phi_new == phi_prime;
-    if (FAST && t3 != 0.0 && !same && !l12_float_decided(cw, 0x1p-49)) *unsafe = true;
     return (float) cw;
 }
 
@@ -121,7 +115,7 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
     // next one's lthr).  The wavefronts are persistent: each walks through every gridDim.x-th record.
     const int qi0 = geo.lb - (geo.layer == 1 ? 1 : 0), nq = NP - qi0;
     const unsigned n_rec = (unsigned) geo.n_streams * (unsigned) nq * (unsigned) C;
-    const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1, cw_tier1 = (geo.test_flags >> 6) & 1;
+    const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1;
     const double tmn = T->tmn[lane < L12_CB ? lane : 0];
     const float bm = T->bmaxv[lane < L12_CB ? lane : 0], rn_nl = T->rn_nl[lane < L12_CB ? lane : 0];
     const int pj0 = lane < T->npart ? T->part_first[lane] : 0, pj1 = lane < T->npart ? T->part_first[lane + 1] : 0;
@@ -141,7 +135,7 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
 
     // ---- unpredictability of every line, src/psy.c:282-292.  The seven values a line needs of the three passes are
     // requested one step ahead of their use (a step is ~250 instructions on them: their latency hides behind it)
-    unsigned redo = 0; // bit k: line lane + 64 k needs the third tier
+    unsigned redo = 0; // bit k: line lane + 64 k needs the second tier
     float nx[7];
     {
         const int i0 = lane; // (k = 0: every lane has a line)
@@ -161,15 +155,10 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
             nx[3] = r_o[L12_ROW + i2]; nx[4] = r_o[2 * L12_ROW + i2];
             nx[5] = r_oo[L12_ROW + i2]; nx[6] = r_oo[2 * L12_ROW + i2];
         }
-        bool unsafe = cw_exact, undecided = cw_exact || cw_tier1;
+        bool undecided = cw_exact;
         float c = 0.0f;
         if (!undecided) c = psy12_c0(rn, pn, ro, roo, po, poo, &undecided);
-        if (!cw_exact && wave_any(undecided && on)) { // (some line of the 64 predicted too well for the one-cosine form)
-            const float c1 = psy12_c<true>(rn, pn, ro, roo, po, poo, &unsafe);
-            unsafe = unsafe && undecided;
-            c = undecided ? c1 : c;
-        }
-        if (unsafe && on) redo |= 1u << k;
+        if (undecided && on) redo |= 1u << k;
 #if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
         if (on) { // site: c[j] = (float)(sqrt(t1^2 + t2^2) / t3); one ulp of each sine and cosine moves the quotient by < 2^-52
             const float r_prime = (float) (2.0 * (double) ro - (double) roo), phi_prime = (float) (2.0 * (double) po - (double) poo);
@@ -185,17 +174,17 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
 #endif
         if (on) { L.e[i] = en; L.c[i] = c; }
     }
-    // the third tier -- correctly rounded sines and cosines -- for the lines the first two could not decide, behind the
-    // loop: it is rare, and inlined into the loop its double-double arithmetic would set the loop's register budget
+    // the second tier -- the reference's formula with correctly rounded sines and cosines -- for the lines the first could not
+    // decide, behind the loop: it is rare, and inlined into the loop its double-double arithmetic would set the loop's
+    // register budget
     if (wave_any(redo != 0)) {
 #pragma unroll 1
         for (int k = 0; k < 9; k++) {
             const bool mine = (redo >> k) & 1u;
             if (!wave_any(mine)) continue;
             const int i = lane + 64 * k, ii = mine ? i : 0;
-            bool u = false;
-            const float cx = psy12_c<false>(r_n[L12_ROW + ii], r_n[2 * L12_ROW + ii], r_o[L12_ROW + ii], r_oo[L12_ROW + ii],
-                                            r_o[2 * L12_ROW + ii], r_oo[2 * L12_ROW + ii], &u);
+            const float cx = psy12_c_exact(r_n[L12_ROW + ii], r_n[2 * L12_ROW + ii], r_o[L12_ROW + ii], r_oo[L12_ROW + ii],
+                                           r_o[2 * L12_ROW + ii], r_oo[2 * L12_ROW + ii]);
             if (mine) L.c[i] = cx;
         }
     }

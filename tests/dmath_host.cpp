@@ -13,6 +13,7 @@ void t_dm_atan2_fast(const double *a, const double *b, double *y, size_t n) { fo
 void t_dm_sin_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) { double c; dm_sincos_fast(x[i], &y[i], &c); } }
 void t_dm_cos_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) { double s; dm_sincos_fast(x[i], &s, &y[i]); } }
 void t_dm_cos_only_fast(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_cos_fast(x[i]); }
+void t_dm_sin_fast_rel(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; i++) { int nm; y[i] = dm_sin_fast_rel(x[i], &nm); if (nm) y[i] = __builtin_nan(""); } }
 int t_dm_float_rounding_safe(double v) { return dm_float_rounding_safe(v); }
 void t_dm_atan2(const double *a, const double *b, double *y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2(a[i], b[i]); }
 }

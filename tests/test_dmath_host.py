@@ -183,3 +183,34 @@ def test_cos_fast_alone_error_bound(dm):
     err = max(abs(float(mp.cos(mp.mpf(float(a))) - mp.mpf(float(b)))) for a, b in zip(x, y))
     assert err < 2.0 ** -51, err
     assert call1(dm, "cos_only_fast", np.array([0.0]))[0] == 1.0
+
+
+def test_sin_fast_rel_error_bound(dm):
+    """dm_sin_fast_rel (the one sine of k12_psy's first tier): RELATIVE error < 2^-49 against mpmath wherever it does not
+    flag its argument -- uniformly over [-2 pi, 2 pi], for differences of floats halved (what the kernel passes), for tiny
+    arguments down to 2^-60, and near every multiple of pi down to 2^-29.5 away, inside of which it must flag"""
+    import mpmath as mp
+    mp.mp.prec = 300
+    rng = np.random.default_rng(22)
+    parts = [rng.uniform(-6.4, 6.4, 12000)]
+    for k in range(-2, 3):
+        for e in (-3, -8, -15, -22, -28, -29.5, -33):
+            parts.append(k * np.pi + rng.uniform(-1, 1, 200) * 2.0 ** e)
+    parts.append(rng.uniform(-1, 1, 600) * 2.0 ** rng.uniform(-60, -1, 600))
+    a = rng.uniform(-np.pi, np.pi, 6000).astype(np.float32).astype(np.float64)
+    b = rng.uniform(-3 * np.pi, 3 * np.pi, 6000).astype(np.float32).astype(np.float64)
+    parts.append((a - b) / 2)
+    x = np.concatenate(parts)
+    y = call1(dm, "sin_fast_rel", x)  # (NaN where the function flags its argument)
+    flagged = np.isnan(y)
+    k = np.rint(x / np.pi)
+    near = (k != 0) & (np.abs(x - k * np.pi) < 2.0 ** -31)
+    assert flagged[near].all() and not flagged[np.abs(x - k * np.pi) > 2.0 ** -29].any()
+    worst = 0.0
+    for xi, yi in zip(x[~flagged], y[~flagged]):
+        t = mp.sin(mp.mpf(float(xi)))
+        if t == 0:
+            assert yi == 0
+            continue
+        worst = max(worst, float(abs((mp.mpf(float(yi)) - t) / t)))
+    assert worst < 2.0 ** -49, worst

@@ -39,7 +39,7 @@ def test_chunks_tiers_and_ragged_streams(emu, orc, layer, rate, kbps, mode):
     nfr = 7 if layer == 2 else 17
     pcms = [l12_signal(spf * nfr - 173 * i, ch, 40 + i, rate) for i in range(3)]
     want = [oracle_l12(orc, layer, rate, kbps, mode, p)[0] for p in pcms]
-    for scratch, flags in ((0, 0), (1, 0), (0, 2 | 4 | 32), (0, 64)):
+    for scratch, flags in ((0, 0), (1, 0), (0, 2 | 4 | 32)):
         run = L12Run(emu, layer, rate, kbps, mode, pcms, scratch_mb=scratch, flags=flags)
         try:
             assert run.encode() == want, (scratch, flags)

@@ -61,7 +61,7 @@ def test_chunks_tiers_and_ragged_streams_gpu(product, oracle, layer, rate, kbps,
     nfr = 9 if layer == 2 else 25
     pcms = [l12_signal(spf * nfr - 173 * i, ch, 40 + i, rate) for i in range(5)] + [np.zeros(0, np.int16)]
     want = [oracle_l12(oracle, layer, rate, kbps, mode, p)[0] for p in pcms]
-    for scratch, flags in ((0, 0), (1, 0), (0, 2 | 4 | 32), (0, 64)):
+    for scratch, flags in ((0, 0), (1, 0), (0, 2 | 4 | 32)):
         run = L12Run(product, layer, rate, kbps, mode, pcms, n_frames=nfr, scratch_mb=scratch, flags=flags)
         try:
             assert run.encode() == want, (scratch, flags)
