@@ -105,75 +105,93 @@ MP3MI_DEVFN float psy12_snr_band(const float *e, const float *fthr, int sb, bool
     return (float) (4.342944819 * dm_log((double) x));
 }
 
-__global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restrict__ T, l12_geom geo,
+// diagnostic build: the site of c[j] (see ULP_CENSUS, mp3mi_dev.h)
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+#define L12_CENSUS_C(rn_, pn_, ro_, roo_, po_, poo_)                                                                         \
+    if (on) { /* c[j] = (float)(sqrt(t1^2 + t2^2) / t3); one ulp of each sine and cosine moves the quotient by < 2^-52 */   \
+        const float r_prime = (float) (2.0 * (double) (ro_) - (double) (roo_)), phi_prime = (float) (2.0 * (double) (po_) - (double) (poo_)); \
+        if (!((double) (rn_) + __builtin_fabs((double) r_prime) == 0.0) && !((rn_) == r_prime && (pn_) == phi_prime)) {      \
+            double s2, c2, sp, cp;                                                                                          \
+            dm_sincos((double) (pn_), &s2, &c2);                                                                            \
+            dm_sincos((double) phi_prime, &sp, &cp);                                                                        \
+            const double t1 = (double) (rn_) * c2 - (double) r_prime * cp, t2 = (double) (rn_) * s2 - (double) r_prime * sp;  \
+            const double cwx = __builtin_sqrt(t1 * t1 + t2 * t2) / ((double) (rn_) + __builtin_fabs((double) r_prime));      \
+            ULP_CENSUS(UC_L12_C, !l12_float_decided(cwx, 0x1p-52), !l12_float_decided(cwx, 0x1p-32));                       \
+        }                                                                                                                   \
+    }
+#else
+#define L12_CENSUS_C(rn_, pn_, ro_, roo_, po_, poo_)
+#endif
+#define L12_PSY_RUN 32 /* passes of one (stream, channel) a wavefront of k12_psy takes in a row */
+
+__global__ void __launch_bounds__(64, 3) k12_psy(const mp3mi_tables_l12 *__restrict__ T, l12_geom geo,
                                               const float *__restrict__ erp, float *__restrict__ thr1, float *__restrict__ snr)
 {
     __shared__ psy12_lds L;
     const int lane = wave_lane();
     const int C = geo.channels, NP = geo.np;
-    // records of this launch: the chunk's own passes, and for Layer I the one before them (its threshold is the
-    // next one's lthr).  The wavefronts are persistent: each walks through every gridDim.x-th record.
+    // Records of this launch: the chunk's own passes, and for Layer I the one before them (its threshold is the next
+    // one's lthr).  A persistent wavefront takes RUNS of consecutive passes of one (stream, channel): the magnitudes
+    // and phases of the two passes before the current one -- what the prediction of a line is made of -- stay in
+    // registers from pass to pass (lane l: lines l + 64 k), so a record costs three rows of memory reads, not seven
+    // (plus four per run to start it).  The kernel waits for these rows more than for anything else.
     const int qi0 = geo.lb - (geo.layer == 1 ? 1 : 0), nq = NP - qi0;
-    const unsigned n_rec = (unsigned) geo.n_streams * (unsigned) nq * (unsigned) C;
+    const int n_run = (nq + L12_PSY_RUN - 1) / L12_PSY_RUN;
+    const unsigned n_item = (unsigned) geo.n_streams * (unsigned) n_run * (unsigned) C;
     const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1;
     const double tmn = T->tmn[lane < L12_CB ? lane : 0];
     const float bm = T->bmaxv[lane < L12_CB ? lane : 0], rn_nl = T->rn_nl[lane < L12_CB ? lane : 0];
     const int pj0 = lane < T->npart ? T->part_first[lane] : 0, pj1 = lane < T->npart ? T->part_first[lane + 1] : 0;
 #pragma unroll 1
-    for (unsigned bid = blockIdx.x; bid < n_rec; bid += gridDim.x) {
+    for (unsigned bid = blockIdx.x; bid < n_item; bid += gridDim.x) {
     const int ch = (int) (bid % (unsigned) C);
-    const int ql = (int) ((bid / (unsigned) C) % (unsigned) nq);
-    const int s = (int) (bid / (unsigned) (C * nq));
-    const int qi = qi0 + ql;
-    const long q = (geo.fabs0 + geo.f0) * geo.layer - geo.lb + qi; // the pass counted from the stream's first
-    if (q < 0) continue; // (Layer I, first chunk: the pass before the stream has the initial lthr, k12_snr1)
-    const size_t rec = ((size_t) s * NP + qi) * C + ch;
-    const float *r_n = erp + rec * (3 * L12_ROW);               // this pass: energy, r, phi
-    const float *r_o = erp + (rec - (size_t) C) * (3 * L12_ROW);     // the pass before ("old")
-    const float *r_oo = erp + (rec - 2 * (size_t) C) * (3 * L12_ROW); // two before ("oldest" = the slot "new" overwrites)
-    wave_sync(); // the record before is done with the LDS
-
-    // ---- unpredictability of every line, src/psy.c:282-292.  The seven values a line needs of the three passes are
-    // requested one step ahead of their use (a step is ~250 instructions on them: their latency hides behind it)
-    unsigned redo = 0; // bit k: line lane + 64 k needs the second tier
-    float nx[7];
+    const int run = (int) ((bid / (unsigned) C) % (unsigned) n_run);
+    const int s = (int) (bid / (unsigned) (C * n_run));
+    const int qa = qi0 + run * L12_PSY_RUN, qb = qa + L12_PSY_RUN < NP ? qa + L12_PSY_RUN : NP;
+    float h_ro[9], h_po[9], h_roo[9], h_poo[9]; // r, phi of the pass before ("old") and of the one before that ("oldest")
     {
-        const int i0 = lane; // (k = 0: every lane has a line)
-        nx[0] = r_n[i0]; nx[1] = r_n[L12_ROW + i0]; nx[2] = r_n[2 * L12_ROW + i0];
-        nx[3] = r_o[L12_ROW + i0]; nx[4] = r_o[2 * L12_ROW + i0];
-        nx[5] = r_oo[L12_ROW + i0]; nx[6] = r_oo[2 * L12_ROW + i0];
+        const float *r_o = erp + (((size_t) s * NP + qa - 1) * C + ch) * (3 * L12_ROW);
+        const float *r_oo = erp + (((size_t) s * NP + qa - 2) * C + ch) * (3 * L12_ROW);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int ii = lane + 64 * k < L12_HBLK ? lane + 64 * k : 0;
+            h_ro[k] = r_o[L12_ROW + ii]; h_po[k] = r_o[2 * L12_ROW + ii];
+            h_roo[k] = r_oo[L12_ROW + ii]; h_poo[k] = r_oo[2 * L12_ROW + ii];
+        }
     }
 #pragma unroll 1
-    for (int k = 0; k < 9; k++) {
-        const int i = lane + 64 * k;
-        const bool on = i < L12_HBLK;
-        if (!wave_any(on)) break;
-        const float en = nx[0], rn = nx[1], pn = nx[2], ro = nx[3], po = nx[4], roo = nx[5], poo = nx[6];
-        {
-            const int i2 = (i + 64 < L12_HBLK) ? i + 64 : 0;
-            nx[0] = r_n[i2]; nx[1] = r_n[L12_ROW + i2]; nx[2] = r_n[2 * L12_ROW + i2];
-            nx[3] = r_o[L12_ROW + i2]; nx[4] = r_o[2 * L12_ROW + i2];
-            nx[5] = r_oo[L12_ROW + i2]; nx[6] = r_oo[2 * L12_ROW + i2];
+    for (int qi = qa; qi < qb; qi++) {
+    const long q = (geo.fabs0 + geo.f0) * geo.layer - geo.lb + qi; // the pass counted from the stream's first
+    const size_t rec = ((size_t) s * NP + qi) * C + ch;
+    const float *r_n = erp + rec * (3 * L12_ROW);               // this pass: energy, r, phi
+    const float *r_o = erp + (rec - (size_t) C) * (3 * L12_ROW);     // (the second tier reads the passes before from memory)
+    const float *r_oo = erp + (rec - 2 * (size_t) C) * (3 * L12_ROW);
+    wave_sync(); // the record before is done with the LDS
+
+    // ---- unpredictability of every line, src/psy.c:282-292
+    unsigned redo = 0; // bit k: line lane + 64 k needs the second tier
+    {
+        float en[9], rn[9], pn[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { // (all 27 loads in flight together)
+            const int ii = lane + 64 * k < L12_HBLK ? lane + 64 * k : 0;
+            en[k] = r_n[ii]; rn[k] = r_n[L12_ROW + ii]; pn[k] = r_n[2 * L12_ROW + ii];
         }
-        bool undecided = cw_exact;
-        float c = 0.0f;
-        if (!undecided) c = psy12_c0(rn, pn, ro, roo, po, poo, &undecided);
-        if (undecided && on) redo |= 1u << k;
-#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
-        if (on) { // site: c[j] = (float)(sqrt(t1^2 + t2^2) / t3); one ulp of each sine and cosine moves the quotient by < 2^-52
-            const float r_prime = (float) (2.0 * (double) ro - (double) roo), phi_prime = (float) (2.0 * (double) po - (double) poo);
-            if (!((double) rn + __builtin_fabs((double) r_prime) == 0.0) && !(rn == r_prime && pn == phi_prime)) {
-                double s2, c2, sp, cp;
-                dm_sincos((double) pn, &s2, &c2);
-                dm_sincos((double) phi_prime, &sp, &cp);
-                const double t1 = (double) rn * c2 - (double) r_prime * cp, t2 = (double) rn * s2 - (double) r_prime * sp;
-                const double cwx = __builtin_sqrt(t1 * t1 + t2 * t2) / ((double) rn + __builtin_fabs((double) r_prime));
-                ULP_CENSUS(UC_L12_C, !l12_float_decided(cwx, 0x1p-52), !l12_float_decided(cwx, 0x1p-32));
-            }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int i = lane + 64 * k;
+            const bool on = i < L12_HBLK;
+            bool undecided = cw_exact;
+            float c = 0.0f;
+            if (!undecided) c = psy12_c0(rn[k], pn[k], h_ro[k], h_roo[k], h_po[k], h_poo[k], &undecided);
+            if (undecided && on) redo |= 1u << k;
+            L12_CENSUS_C(rn[k], pn[k], h_ro[k], h_roo[k], h_po[k], h_poo[k]);
+            if (on) { L.e[i] = en[k]; L.c[i] = c; }
+            h_roo[k] = h_ro[k]; h_poo[k] = h_po[k]; // the next pass's "oldest" and "old"
+            h_ro[k] = rn[k]; h_po[k] = pn[k];
         }
-#endif
-        if (on) { L.e[i] = en; L.c[i] = c; }
     }
+    if (q < 0) continue; // (Layer I, first chunk: the pass before the stream has the initial lthr, k12_snr1; its r = phi = 0 are history all the same)
     // the second tier -- the reference's formula with correctly rounded sines and cosines -- for the lines the first could not
     // decide, behind the loop: it is rare, and inlined into the loop its double-double arithmetic would set the loop's
     // register budget
@@ -305,6 +323,7 @@ __global__ void __launch_bounds__(64, 4) k12_psy(const mp3mi_tables_l12 *__restr
     wave_sync();
     if (lane < 32) snr[rec * 32 + lane] = psy12_snr_band(L.e, L.thr, lane, psy_exact);
     }
+    }
 }
 
 // Layer I: the threshold of a line is limited by 32 x the threshold of the pass before and floored at 0.00316 x its
@@ -337,15 +356,15 @@ __global__ void __launch_bounds__(64) k12_snr1(l12_geom geo, const float *__rest
 void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *thr1, float *snr, hipStream_t st)
 {
     const int nq = g.np - g.lb + (g.layer == 1 ? 1 : 0);
-    const size_t n_rec = (size_t) g.n_streams * nq * g.channels;
-    static int n_wave = 0; // resident wavefronts: 16 per CU at the kernel's 128 registers
+    const size_t n_item = (size_t) g.n_streams * ((nq + L12_PSY_RUN - 1) / L12_PSY_RUN) * g.channels;
+    static int n_wave = 0; // resident wavefronts: 12 per CU at the kernel's 168 registers
     if (!n_wave) {
         int dev = 0;
         hipDeviceProp_t prop;
-        n_wave = 256 * 16;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_wave = prop.multiProcessorCount * 16;
+        n_wave = 256 * 12;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_wave = prop.multiProcessorCount * 12;
     }
-    hipLaunchKernelGGL(k12_psy, dim3((unsigned) (n_rec < (size_t) n_wave ? n_rec : (size_t) n_wave)), dim3(64), 0, st, T, g, erp, thr1, snr);
+    hipLaunchKernelGGL(k12_psy, dim3((unsigned) (n_item < (size_t) n_wave ? n_item : (size_t) n_wave)), dim3(64), 0, st, T, g, erp, thr1, snr);
     if (g.layer == 1)
         hipLaunchKernelGGL(k12_snr1, dim3((unsigned) ((size_t) g.n_streams * (g.np - g.lb) * g.channels)), dim3(64), 0, st, g, erp, thr1, snr);
 }
