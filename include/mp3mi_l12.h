@@ -7,7 +7,7 @@
  *   get_audio                         src/encode.c:187-269              the caller's PCM rows, read on the device
  *   window_subband / filter_subband   src/encode.c:287-409              k_filter (shared with Layer III)
  *   I_/II_scale_factor_calc, I_/II_combine_LR, II_transmission_pattern  src/encode.c:469-691          k12_alloc
- *   psycho_anal                       src/psy.c:36-421                  k_fft12, k12_psy (k12_snr1)
+ *   psycho_anal                       src/psy.c:36-421                  k_fft12, k12_psy
  *   I_/II_main_bit_allocation         src/encode.c:782-1172             k12_alloc
  *   I_/II_CRC_calc, encode_info, encode_CRC, *_encode_bit_alloc, *_encode_scale,
  *   *_subband_quantization, *_sample_encoding, put1bit                  src/common.c:1251-1327, src/encode.c:418-437, 695-748, 1174-1430   k12_alloc
@@ -89,7 +89,7 @@ long mp3mi_l12_batch_debug_fetch(mp3mi_l12_batch *b, void *host_dst, size_t cap,
 
 /* milliseconds inside the kernels of all encode calls since create (HIP events on the batch's stream), and the calls */
 int mp3mi_l12_batch_total_timing(mp3mi_l12_batch *b, double *all_kernels_ms, long *calls);
-/* the same per kernel, HIP events around every launch: [0] k_fft12, [1] k12_psy (Layer I: + k12_snr1), [2] k_filter,
+/* the same per kernel, HIP events around every launch: [0] k_fft12, [1] k12_psy, [2] k_filter,
  * [3] k12_alloc -- milliseconds and launches since create */
 int mp3mi_l12_batch_kernel_timing(mp3mi_l12_batch *b, double ms[4], long launches[4]);
 

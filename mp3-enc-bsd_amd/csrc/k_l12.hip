@@ -2,8 +2,7 @@
 //
 //   k12_psy    one wavefront per (stream, pass, channel) record: the unpredictability of all 513 lines, the partition
 //              sums, spreading, tonality, masking threshold per line and -- Layer II -- the signal-to-mask ratio of
-//              the 32 subbands (src/psy.c:282-386).  Layer I's threshold also looks at the pass before (pre-echo
-//              control, src/psy.c:355-359): k12_psy stores the per-line thresholds and k12_snr1 finishes.
+//              the 32 subbands (src/psy.c:282-386), by runs of consecutive passes of one (stream, channel).
 //   k12_alloc  one wavefront per (stream, frame), a lane per (subband, channel): scale factors, transmission pattern,
 //              joint-stereo bound, the greedy bit allocation, CRC, quantisation, and the frame's bits assembled in LDS
 //              (src/encode.c:512-1416, src/common.c:1251-1327).
@@ -23,6 +22,7 @@ MP3MI_DEVFN bool l12_float_decided(double v, double err) { return (float) (v - e
 
 struct psy12_lds {
     float e[L12_ROW], c[L12_ROW], thr[L12_ROW];
+    float thr_prev[L12_ROW]; // Layer I: the thresholds of the pass before, before pre-echo control ("lthr" / 32, src/psy.c:355-361)
     float2 g2[64]; // grouped_e, grouped_c of partition k
     float nb[64];
 };
@@ -125,17 +125,17 @@ MP3MI_DEVFN float psy12_snr_band(const float *e, const float *fthr, int sb, bool
 #define L12_PSY_RUN 32 /* passes of one (stream, channel) a wavefront of k12_psy takes in a row */
 
 __global__ void __launch_bounds__(64, 3) k12_psy(const mp3mi_tables_l12 *__restrict__ T, l12_geom geo,
-                                              const float *__restrict__ erp, float *__restrict__ thr1, float *__restrict__ snr)
+                                              const float *__restrict__ erp, float *__restrict__ snr)
 {
     __shared__ psy12_lds L;
     const int lane = wave_lane();
     const int C = geo.channels, NP = geo.np;
-    // Records of this launch: the chunk's own passes, and for Layer I the one before them (its threshold is the next
-    // one's lthr).  A persistent wavefront takes RUNS of consecutive passes of one (stream, channel): the magnitudes
+    // Records of this launch: the chunk's own passes.  A persistent wavefront takes RUNS of consecutive passes of one (stream, channel): the magnitudes
     // and phases of the two passes before the current one -- what the prediction of a line is made of -- stay in
     // registers from pass to pass (lane l: lines l + 64 k), so a record costs three rows of memory reads, not seven
-    // (plus four per run to start it).  The kernel waits for these rows more than for anything else.
-    const int qi0 = geo.lb - (geo.layer == 1 ? 1 : 0), nq = NP - qi0;
+    // (plus four per run to start it).  Layer I's pre-echo control looks at the thresholds of the pass before: a run starts
+    // one pass early there (its thresholds stay in LDS for the next pass; nothing of it is written).
+    const int qi0 = geo.lb, nq = NP - qi0, warm = geo.layer == 1 ? 1 : 0;
     const int n_run = (nq + L12_PSY_RUN - 1) / L12_PSY_RUN;
     const unsigned n_item = (unsigned) geo.n_streams * (unsigned) n_run * (unsigned) C;
     const bool cw_exact = (geo.test_flags >> 5) & 1, psy_exact = (geo.test_flags >> 2) & 1;
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(64, 3) k12_psy(const mp3mi_tables_l12 *__restr
     const int ch = (int) (bid % (unsigned) C);
     const int run = (int) ((bid / (unsigned) C) % (unsigned) n_run);
     const int s = (int) (bid / (unsigned) (C * n_run));
-    const int qa = qi0 + run * L12_PSY_RUN, qb = qa + L12_PSY_RUN < NP ? qa + L12_PSY_RUN : NP;
+    const int qa = qi0 + run * L12_PSY_RUN - warm, qb = qa + warm + L12_PSY_RUN < NP ? qa + warm + L12_PSY_RUN : NP;
     float h_ro[9], h_po[9], h_roo[9], h_poo[9]; // r, phi of the pass before ("old") and of the one before that ("oldest")
     {
         const float *r_o = erp + (((size_t) s * NP + qa - 1) * C + ch) * (3 * L12_ROW);
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(64, 3) k12_psy(const mp3mi_tables_l12 *__restr
             h_ro[k] = rn[k]; h_po[k] = pn[k];
         }
     }
-    if (q < 0) continue; // (Layer I, first chunk: the pass before the stream has the initial lthr, k12_snr1; its r = phi = 0 are history all the same)
+    if (q < 0) continue; // (Layer I's warm-up pass of a stream's first run lies before the stream: the initial lthr stands in for it, below; its r = phi = 0 are history all the same)
     // the second tier -- the reference's formula with correctly rounded sines and cosines -- for the lines the first could not
     // decide, behind the loop: it is rare, and inlined into the loop its double-double arithmetic would set the loop's
     // register budget
@@ -315,47 +315,29 @@ __global__ void __launch_bounds__(64, 3) k12_psy(const mp3mi_tables_l12 *__restr
         for (int i = lane; i < L12_HBLK; i += 64) {
             const float t = L.nb[pt[i]], a = at[i];
             const float v = (t > a) ? t : a;
-            L.thr[i] = v;
-            if (geo.layer == 1) thr1[rec * L12_ROW + i] = v;
+            if (geo.layer == 1) {
+                // pre-echo control, src/psy.c:355-361: limited by 32 x the threshold of the pass before (lthr starts at
+                // 60802371420160.0, :161-162), floored at 0.00316 x its own value
+                const double temp1 = (double) v;
+                const float lthr = q >= 1 ? (float) (32.0 * (double) L.thr_prev[i]) : 60802371420160.0f;
+                float f = (temp1 < (double) lthr) ? v : lthr;
+                const double temp2 = temp1 * 0.00316;
+                f = (temp2 > (double) f) ? (float) temp2 : f;
+                L.thr[i] = f;
+                L.thr_prev[i] = v;
+            } else L.thr[i] = v;
         }
     }
-    if (geo.layer == 1) continue;
+    if (qi < qa + warm) continue; // (Layer I's warm-up pass: its thresholds were all that was wanted)
     wave_sync();
     if (lane < 32) snr[rec * 32 + lane] = psy12_snr_band(L.e, L.thr, lane, psy_exact);
     }
     }
 }
 
-// Layer I: the threshold of a line is limited by 32 x the threshold of the pass before and floored at 0.00316 x its
-// own value (pre-echo control, src/psy.c:355-361; lthr starts at 60802371420160.0, :161-162)
-__global__ void __launch_bounds__(64) k12_snr1(l12_geom geo, const float *__restrict__ erp, const float *__restrict__ thr1,
-                                               float *__restrict__ snr)
+void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *snr, hipStream_t st)
 {
-    __shared__ psy12_lds L;
-    const int lane = wave_lane();
-    const int C = geo.channels, NP = geo.np, nq = NP - geo.lb;
-    const int ch = (int) (blockIdx.x % (unsigned) C);
-    const int ql = (int) ((blockIdx.x / (unsigned) C) % (unsigned) nq);
-    const int s = (int) (blockIdx.x / (unsigned) (C * nq));
-    const int qi = geo.lb + ql;
-    const long q = (geo.fabs0 + geo.f0) * geo.layer - geo.lb + qi;
-    const size_t rec = ((size_t) s * NP + qi) * C + ch;
-    for (int i = lane; i < L12_HBLK; i += 64) {
-        const double temp1 = (double) thr1[rec * L12_ROW + i];
-        const float lthr = q >= 1 ? (float) (32.0 * (double) thr1[(rec - (size_t) C) * L12_ROW + i]) : 60802371420160.0f;
-        float f = (temp1 < (double) lthr) ? (float) temp1 : lthr;
-        const double temp2 = temp1 * 0.00316;
-        f = (temp2 > (double) f) ? (float) temp2 : f;
-        L.thr[i] = f;
-        L.e[i] = erp[rec * (3 * L12_ROW) + i];
-    }
-    wave_sync();
-    if (lane < 32) snr[rec * 32 + lane] = psy12_snr_band(L.e, L.thr, lane, (geo.test_flags >> 2) & 1);
-}
-
-void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *thr1, float *snr, hipStream_t st)
-{
-    const int nq = g.np - g.lb + (g.layer == 1 ? 1 : 0);
+    const int nq = g.np - g.lb;
     const size_t n_item = (size_t) g.n_streams * ((nq + L12_PSY_RUN - 1) / L12_PSY_RUN) * g.channels;
     static int n_wave = 0; // resident wavefronts: 12 per CU at the kernel's 168 registers
     if (!n_wave) {
@@ -364,9 +346,7 @@ void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const fl
         n_wave = 256 * 12;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_wave = prop.multiProcessorCount * 12;
     }
-    hipLaunchKernelGGL(k12_psy, dim3((unsigned) (n_item < (size_t) n_wave ? n_item : (size_t) n_wave)), dim3(64), 0, st, T, g, erp, thr1, snr);
-    if (g.layer == 1)
-        hipLaunchKernelGGL(k12_snr1, dim3((unsigned) ((size_t) g.n_streams * (g.np - g.lb) * g.channels)), dim3(64), 0, st, g, erp, thr1, snr);
+    hipLaunchKernelGGL(k12_psy, dim3((unsigned) (n_item < (size_t) n_wave ? n_item : (size_t) n_wave)), dim3(64), 0, st, T, g, erp, snr);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

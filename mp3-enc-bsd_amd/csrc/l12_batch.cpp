@@ -1,7 +1,7 @@
 // Host side of the Layer I / II batch (include/mp3mi_l12.h): set-up as the reference's driver does it
 // (src/musicin.c:528-581, src/common.c:291-347), scratch sizing, and one pipeline of kernels per chunk of frames:
 //
-//   k_fft12 -> k12_psy (-> k12_snr1) ;  k_filter ;  k12_alloc
+//   k_fft12 -> k12_psy ;  k_filter ;  k12_alloc
 //
 // Frames are independent but for PCM history (l12_dev.h), so a chunk is just these four launches in stream order, and
 // chunks follow each other on the batch's one HIP stream.  No CPU fallback.
@@ -47,7 +47,7 @@ struct mp3mi_l12_batch {
     mp3mi_tables *T3;          // window, FFT program, filterbank tables (shared with Layer III)
     mp3mi_tables_l12 *T;
     l12_stream_cfg *cfg;
-    float *erp, *thr1, *snr;
+    float *erp, *snr;
     double *sbs;
     l12_frame_dbg *dbg;
     int dbg_f0, dbg_nf;
@@ -83,7 +83,7 @@ struct l12_device_scope {
 
 static size_t l12_per_frame_bytes(int layer, int channels, int spf)
 {
-    const size_t rec = (size_t) 3 * L12_ROW * sizeof(float) + 32 * sizeof(float) + (layer == 1 ? L12_ROW * sizeof(float) : 0);
+    const size_t rec = (size_t) 3 * L12_ROW * sizeof(float) + 32 * sizeof(float);
     return (size_t) layer * channels * rec + (size_t) spf * 8 * channels;
 }
 
@@ -114,7 +114,7 @@ extern "C" int mp3mi_l12_batch_create(mp3mi_l12_batch **out, int layer, int n_st
     b->timing_open = false; b->total_ms = 0.0; b->calls = 0; b->kev_chunks = 0;
     for (int i = 0; i < 4; i++) { b->kernel_ms[i] = 0.0; b->kernel_launches[i] = 0; }
     b->ev0 = b->ev1 = 0; b->T3 = NULL; b->T = NULL; b->cfg = NULL;
-    b->erp = b->thr1 = b->snr = NULL; b->sbs = NULL; b->dbg = NULL; b->dbg_f0 = b->dbg_nf = 0;
+    b->erp = b->snr = NULL; b->sbs = NULL; b->dbg = NULL; b->dbg_f0 = b->dbg_nf = 0;
     b->hist[0] = b->hist[1] = b->fb_hist[0] = b->fb_hist[1] = NULL; b->hist_cur = 0; b->fabs0 = 0;
     if (hipGetDevice(&b->device) != hipSuccess) { delete b; return MP3MI_ERR_HIP; }
     b->cfg_h.resize((size_t) n_streams);
@@ -173,7 +173,6 @@ extern "C" int mp3mi_l12_batch_create(mp3mi_l12_batch **out, int layer, int n_st
         const size_t ngran = ((size_t) cf * (size_t) (b->spf / 32) + 17) / 18 + 3; // granules of 18 slots k_filter may be asked for
         CHK(hipMalloc((void **) &b->erp, nrec * 3 * L12_ROW * sizeof(float)));
         CHK(hipMalloc((void **) &b->snr, nrec * 32 * sizeof(float)));
-        if (layer == 1) CHK(hipMalloc((void **) &b->thr1, nrec * L12_ROW * sizeof(float)));
         CHK(hipMalloc((void **) &b->sbs, (size_t) n_streams * ngran * (size_t) channels * 576 * sizeof(double)));
         return MP3MI_OK;
     };
@@ -190,7 +189,7 @@ extern "C" void mp3mi_l12_batch_destroy(mp3mi_l12_batch *b)
         l12_device_scope sc(b->device);
         if (b->stream) (void) hipStreamSynchronize(b->stream);
         (void) hipFree(b->T3); (void) hipFree(b->T); (void) hipFree(b->cfg); (void) hipFree(b->erp);
-        (void) hipFree(b->thr1); (void) hipFree(b->snr); (void) hipFree(b->sbs); (void) hipFree(b->dbg);
+        (void) hipFree(b->snr); (void) hipFree(b->sbs); (void) hipFree(b->dbg);
         for (int i = 0; i < 2; i++) { (void) hipFree(b->hist[i]); (void) hipFree(b->fb_hist[i]); }
         if (b->ev0) (void) hipEventDestroy(b->ev0);
         if (b->ev1) (void) hipEventDestroy(b->ev1);
@@ -299,7 +298,7 @@ static int l12_encode_impl(mp3mi_l12_batch *b, const int16_t *pcm_dev, const int
         CHK(hipEventRecord(ke[0], b->stream));
         mp3mi_launch_fft12(b->T3, g, pcm_dev, b->erp, b->stream);
         CHK(hipEventRecord(ke[1], b->stream));
-        mp3mi_launch_l12_psy(b->T, g, b->erp, b->thr1, b->snr, b->stream);
+        mp3mi_launch_l12_psy(b->T, g, b->erp, b->snr, b->stream);
         CHK(hipEventRecord(ke[2], b->stream));
         mp3mi_launch_filter(b->T3, fg, pcm_dev, b->sbs, NULL, b->stream);
         CHK(hipEventRecord(ke[3], b->stream));

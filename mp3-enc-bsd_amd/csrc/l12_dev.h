@@ -84,7 +84,7 @@ struct l12_frame_dbg {
 
 #ifdef __cplusplus
 void mp3mi_launch_fft12(const mp3mi_tables *T, const l12_geom &g, const int16_t *pcm, float *erp, hipStream_t st);
-void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *thr1, float *snr, hipStream_t st);
+void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const float *erp, float *snr, hipStream_t st);
 void mp3mi_launch_l12_alloc(const mp3mi_tables_l12 *T, const l12_geom &g, const l12_stream_cfg *cfg, const double *sbs,
                             const float *snr, uint8_t *out, size_t out_stride, uint32_t *out_len, l12_frame_dbg *dbg, hipStream_t st);
 void mp3mi_launch_l12_hist_save(const l12_geom &g, const int16_t *pcm, const int16_t *hist_in, int16_t *hist_out, const int16_t *fb_in,
