@@ -609,9 +609,17 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
     }
 
     // ---- *_a_bit_allocation, src/encode.c:974-1172: the band with the smallest mask-to-noise ratio gets the next step,
-    // the first in (subband, channel) order among equals -- lane order.  Every lane keeps its ratio as a 64-bit key
-    // whose unsigned order is the reverse of the doubles' order (0: not a candidate) and the bits its next step would cost;
-    // one wave maximum per step, and only the winner (and, above the joint-stereo bound, its other channel) recomputes.
+    // the first in (subband, channel) order among equals -- lane order -- until a step does not fit; then that band is
+    // closed and the others go on.  Every lane keeps its ratio as a 64-bit key whose unsigned order is the reverse of the
+    // doubles' order (0: not a candidate), what its next step would cost, and the key it would have after that step.
+    //
+    // Steps are granted in ROUNDS where they can be: a band's ratio only rises with its steps, so every current key above
+    // T = the largest key any band would have AFTER its next step belongs to a step that the reference takes before all
+    // others (every other step -- a band's later one, or a current one at or below T -- comes after them); if the steps
+    // of that set fit together, each of them fits when its turn comes, and they are granted at once.  (T is taken from
+    // the keys' upper halves, rounded up: a smaller set, never a wrong one.)  Where the set does not fit -- the end
+    // game -- or the bands are coupled (above the joint-stereo bound the allocation applies to both channels), the
+    // reference's one-band-at-a-time order is followed literally: one wave maximum per step.
     int ba = 0, used = 0, adb = cf.frame_bits;
     double mnr = snrt[0] - smr;
     {
@@ -621,33 +629,66 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
         else bbal = wave_sum_i32(code ? (int) L.al[sbc][0][1] : 0);
         adb -= bbal + (geo.crc ? 16 : 0) + 32;
         const int ad = adb;
+        const bool coupled = C == 2 && jsbound < (LAYER == 1 ? 32 : sblimit);
         int spent = 0; // bspl + bscf + bsel
-        // Layer II keeps the table entry of the band's NEXT step in registers (one 8-byte LDS read when it wins, off the
-        // loop's dependent chain: the winner's new ratio needs only the signal-to-noise ratio of the step it just took)
         auto entry = [&](int idx) -> uint2 { return *(const uint2 *) L.al[sbc][idx < 16 ? idx : 15]; }; // {steps | bits << 16, group | quant << 16}
         auto bits12 = [](uint2 e) -> int { return 12 * (int) ((e.y & 0xffffu) * (e.x >> 16)); };
-        uint2 e_nxt = LAYER == 2 ? entry(1) : make_uint2(0, 0);
-        int cur12 = 0;
-        // what the lane's next step costs: sample bits, and with its first step scale factor (and scfsi) bits
-        auto next_cost = [&]() -> int {
+        auto keyof = [&](double m, bool open) -> unsigned long long { return (open && (LAYER == 1 || 999999.0 > m)) ? l12_key(m) : 0ull; };
+        // the band's NEXT step: its cost (sample bits, and with the first step scale factor and scfsi bits), the ratio
+        // after it, and whether it is the band's last (then the band is closed: src/encode.c:1041, 1147)
+        int cur12 = 0, need = 0;
+        double mnr_nxt = 0.0;
+        bool last_nxt = false;
+        auto look_ahead = [&]() {
             if (LAYER == 1) {
                 int scale = used ? 0 : 6;
                 if (sb >= jsbound) scale *= stereo;
-                return (used ? 12 : 24) + scale;
+                need = (used ? 12 : 24) + scale;
+                mnr_nxt = -smr + snrt[ba + 1 < 17 ? ba + 1 : 17];
+                last_nxt = ba + 1 == 14;
+            } else {
+                const uint2 e = entry(ba + 1);
+                need = bits12(e);
+                if (used) need -= cur12;
+                else {
+                    need += 2 + 6 * sfs;
+                    if (stereo == 2 && sb >= jsbound) need += 2 + 6 * sfs_o;
+                }
+                mnr_nxt = -smr + snrt[(e.y >> 16) + 1];
+                last_nxt = ba + 1 >= maxAlloc;
             }
-            int inc = bits12(e_nxt);
-            if (used) return inc - cur12;
-            inc += 2 + 6 * sfs;
-            if (stereo == 2 && sb >= jsbound) inc += 2 + 6 * sfs_o;
-            return inc;
         };
-        int need = next_cost();
-        unsigned long long key = (act && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : 0ull;
+        auto take_step = [&]() { // the band gets its next step
+            ba++;
+            used = last_nxt ? 2 : 1;
+            mnr = mnr_nxt;
+            if (LAYER == 2) cur12 = bits12(entry(ba));
+        };
+        look_ahead();
+        unsigned long long key = keyof(mnr, act), nkey = keyof(mnr_nxt, act && !last_nxt);
         for (;;) {
             unsigned long long k = key;
             if (LAYER == 1) { // src/encode.c:1012: small starts at mnr[0][0] + 1, whatever state that band is in
                 const double lim = wave_bcast_f64(mnr, 0) + 1;
                 if (!(lim > mnr)) k = 0ull;
+            }
+            if (!coupled) { // a round
+                if (!__ballot(k != 0ull)) break;
+                const unsigned hi = wave_max_u32(k != 0ull ? (unsigned) (nkey >> 32) : 0u); // (keys of numbers are far below all ones)
+                const bool in = k > (((unsigned long long) hi << 32) | 0xffffffffull);
+                if (__ballot(in)) {
+                    const int cost = wave_sum_i32(in ? need : 0);
+                    if (ad >= spent + cost) {
+                        spent += cost;
+                        if (in) {
+                            take_step();
+                            if (used != 2) look_ahead();
+                            key = keyof(mnr, used != 2);
+                            nkey = keyof(mnr_nxt, used != 2 && !last_nxt);
+                        }
+                        continue;
+                    }
+                }
             }
             const unsigned long long small = l12_wave_max_u64(k); // (the key of the smallest ratio)
             if (small == 0ull) break;
@@ -666,21 +707,11 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
                 if (ad - spent < mn) break;
             }
             if (me_win) {
-                if (fits) {
-                    ba++;
-                    used = 1;
-                    if (LAYER == 1) {
-                        mnr = -smr + snrt[ba];
-                        if (ba == 14) used = 2;
-                    } else {
-                        mnr = -smr + snrt[(e_nxt.y >> 16) + 1];
-                        cur12 = bits12(e_nxt);
-                        e_nxt = entry(ba + 1);
-                        if (ba >= maxAlloc) used = 2;
-                    }
-                } else used = 2;
-                need = next_cost();
-                key = (used != 2 && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : 0ull;
+                if (fits) take_step();
+                else used = 2;
+                if (used != 2) look_ahead();
+                key = keyof(mnr, used != 2);
+                nkey = keyof(mnr_nxt, used != 2 && !last_nxt);
             }
             if (C == 2 && wsb >= jsbound) { // above the joint-stereo bound the allocation applies to both channels
                 const int wba = wave_readlane_i32(ba, win), wused = wave_readlane_i32(used, win);
@@ -692,10 +723,10 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
                         const uint2 e_cur = entry(ba);
                         mnr = -smr + snrt[(e_cur.y >> 16) + 1];
                         cur12 = bits12(e_cur);
-                        e_nxt = entry(ba + 1);
                     }
-                    need = next_cost();
-                    key = (used != 2 && (LAYER == 1 || 999999.0 > mnr)) ? l12_key(mnr) : 0ull;
+                    if (used != 2) look_ahead();
+                    key = keyof(mnr, used != 2);
+                    nkey = keyof(mnr_nxt, used != 2 && !last_nxt);
                 }
             }
         }

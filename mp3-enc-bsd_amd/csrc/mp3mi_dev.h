@@ -349,6 +349,20 @@ MP3MI_DEVFN void wave_reduce_i32(int (&v)[NSUM + NMAX])
     for (int k = 0; k < NSUM + NMAX; k++) v[k] = __builtin_amdgcn_readlane(v[k], 63);
 #endif
 }
+/* wave maximum of unsigned values: DPP steps with the maximum folded into the move (a lane without a source reads 0) */
+MP3MI_DEVFN unsigned wave_max_u32(unsigned v)
+{
+#if defined(MP3MI_EMU)
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+#else
+    const int ident = 0;
+#define MP3MI_UMAX_STEP(ctrl) { const unsigned o = (unsigned) MP3MI_DPP((int) v, ctrl, 0xf); v = o > v ? o : v; }
+    MP3MI_UMAX_STEP(0xB1) MP3MI_UMAX_STEP(0x4E) MP3MI_UMAX_STEP(0x141) MP3MI_UMAX_STEP(0x140) MP3MI_UMAX_STEP(0x142) MP3MI_UMAX_STEP(0x143)
+#undef MP3MI_UMAX_STEP
+    return (unsigned) __builtin_amdgcn_readlane((int) v, 63);
+#endif
+}
 MP3MI_DEVFN int wave_min_i32(int v)
 {
     for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o < v ? o : v; }
