@@ -473,7 +473,14 @@ __global__ void __launch_bounds__(64) k12_alloc(const mp3mi_tables_l12 *__restri
         return;
     }
     const l12_stream_cfg cf = cfg[s];
-    const int sblimit = cf.sblimit, frame_bytes = cf.frame_bits / 8;
+    const int sblimit = cf.sblimit;
+    // Two-channel Layer I at 32 kbps and 44.1 / 48 kHz: header and allocation fields alone (32 + 256 bits, + 16 with -e) are
+    // more than the frame's 256 bits.  The reference's budget goes negative, nothing is allocated, no padding is written --
+    // and the frame it has written is LONGER than its slot; the next one follows it directly (src/encode.c:997-998,
+    // src/musicin.c:657).  Reproduced: such a stream's frames are 36 (38) bytes apart.  (Joint stereo lowers its bound
+    // until the fields fit, src/encode.c:907-918; Layer II's smallest frame holds its fields at every rate.)
+    const int fields = LAYER == 1 && geo.actual_mode != 1 ? 32 + (geo.crc ? 16 : 0) + 128 * stereo : 0;
+    const int frame_bytes = (cf.frame_bits > fields ? cf.frame_bits : fields) / 8;
     const int sb = C == 2 ? lane >> 1 : lane, ch = C == 2 ? lane & 1 : 0;
     const bool act = sb < sblimit && lane < 32 * C; // a (subband, channel) the layer codes
     const int sbc = sb < 32 ? sb : 31;

@@ -227,7 +227,10 @@ extern "C" int mp3mi_l12_batch_set_test_flags(mp3mi_l12_batch *b, unsigned flags
 extern "C" size_t mp3mi_l12_batch_out_stride(const mp3mi_l12_batch *b, int n_frames)
 {
     if (!b || n_frames < 0) return 0;
-    return ((size_t) n_frames * (size_t) b->max_frame_bytes + 1 + 255) / 256 * 256;
+    // (two-channel Layer I below its fields' size: the reference's frames outgrow their slots, k_l12.hip)
+    size_t fb = (size_t) b->max_frame_bytes;
+    if (b->layer == 1 && b->channels == 2 && fb < 38) fb = 38;
+    return ((size_t) n_frames * fb + 1 + 255) / 256 * 256;
 }
 extern "C" void mp3mi_l12_batch_debug_enable(mp3mi_l12_batch *b, int on) { if (b) b->debug = on != 0; }
 

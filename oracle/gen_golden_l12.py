@@ -75,6 +75,10 @@ CASES = [  # name, layer, rate, kbps, mode, frames, signal
     ("l2_j44_064_two_tones", 2, 44100, 64, "j", 6, "two_tones"),
     ("l2_s44_112_noise_crc", 2, 44100, 112, "se", 5, "noise"),
     ("l1_j44_032_square_crc", 1, 44100, 32, "je", 18, "square30"),
+    # the reference's frames outgrow their slots: two-channel Layer I at 32 kbps, 44.1 / 48 kHz -- the header and the
+    # allocation fields alone exceed the frame's 256 bits (found by tools/matrix_parity_l12.py on the device)
+    ("l1_s44_032_fields_exceed_frame", 1, 44100, 32, "s", 12, "mix"),
+    ("l1_d48_032_crc_fields_exceed_frame", 1, 48000, 32, "de", 12, "tones"),
 ]
 
 

@@ -18,7 +18,8 @@ def orc():
 
 
 @pytest.mark.parametrize("name", ["l2_j44_064", "l2_j48_096_crc", "l2_m44_032", "l2_s44_128_silence_noise", "l1_j32_096_crc",
-                                  "l1_s44_256_silence_noise", "l1_m48_448", "l2_j44_032_square_crc", "l1_j44_032_square_crc"])
+                                  "l1_s44_256_silence_noise", "l1_m48_448", "l2_j44_032_square_crc", "l1_j44_032_square_crc", "l1_s44_032_fields_exceed_frame",
+                                  "l1_d48_032_crc_fields_exceed_frame"])
 def test_emulated_kernels_reproduce_golden_vectors(emu, name):
     meta, pcm, mpg, dumps = golden_l12.load(name)
     run = L12Run(emu, meta["layer"], meta["rate"], meta["kbps"], meta["mode"], [pcm], seams=True)

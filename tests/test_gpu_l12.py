@@ -32,12 +32,14 @@ def test_gpu_reproduces_reference_golden_l12(product, name):
 
 
 def test_matrix_sample_against_the_oracle(product, oracle):
-    """60 cells of layer x rate x mode (with -e) x bitrate, 6 streams of different lengths each"""
+    """84 cells of layer x rate x mode (with -e) x bitrate, 6 streams of different lengths each: a random 60, and every
+    two-channel cell at the layers' lowest bitrate (tools/matrix_parity_l12.py runs all 504: profiles/*_parity_matrix_l12_*)"""
     cells = [(layer, rate, mode, kbps) for layer in (1, 2) for rate in (44100, 48000, 32000)
              for mode in ("s", "m", "j", "d", "se", "je") for kbps in L12_BITRATES[layer]]
+    lowest = [c for c in cells if c[3] == 32 and c[2] != "m"]
     random.Random(4).shuffle(cells)
     bad = []
-    for layer, rate, mode, kbps in cells[:60]:
+    for layer, rate, mode, kbps in cells[:60] + lowest:
         ch = 1 if mode[0] == "m" else 2
         spf = l12_spf(layer)
         nfr = 6 if layer == 2 else 15
