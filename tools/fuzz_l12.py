@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="")
+    ap.add_argument("--streaming", action="store_true", help="half of the cases through mp3mi_l12_batch_encode_next in random pieces")
     a = ap.parse_args()
     rnd = random.Random(a.seed)
     mp, orc = Mp3mi(), Oracle()
@@ -49,9 +50,18 @@ def main():
             else:
                 p = l12_signal(n, ch, case * 17 + i, rate)
             pcms.append(p)
+        streaming = a.streaming and rnd.random() < 0.5
+        if streaming:  # whole-length streams fed in random pieces (ragged batches and streaming do not combine)
+            lens = [spf * nfr] * S
+            pcms = [l12_signal(spf * nfr, ch, case * 17 + i, rate) for i in range(S)]
+            pieces, left = [], nfr
+            while left:
+                p = rnd.randint(1, left)
+                pieces.append(p)
+                left -= p
         run = L12Run(mp, layer, rate, kb[0] if same else kb, mode, pcms, n_frames=nfr, scratch_mb=rnd.choice((0, 1)))
         try:
-            got = run.encode()
+            got = run.encode_streaming(pieces) if streaming else run.encode()
         finally:
             run.close()
         with ThreadPoolExecutor(max_workers=16) as ex:
