@@ -33,12 +33,16 @@ struct psy12_lds {
 //     |a e^(i phi) - b e^(i phi')|^2  =  a^2 + b^2 - 2 a b cos D  =  (a - b)^2 + 4 a b sin^2(D / 2)
 // -- ONE sine instead of the reference's two sines and two cosines, and for a b >= 0 a sum of two non-negative terms:
 // no cancellation, however well the line is predicted.  dm_sin_fast_rel is within 2^-49 RELATIVE of the sine (D / 2 is
-// exact: the subtraction is checked with its TwoSum error term, the halving is a power of two), so the squared distance
-// is within 2^-48 and cw = sqrt(x) / (a + |b|) within 2^-47 RELATIVE of the exact quotient: a float is decided unless it
-// lies that close to a rounding boundary (2^-22 of all values).  For a b < 0 (the prediction r' = 2 r_old - r_oldest went
-// negative) the second term is subtracted from (a + |b|)^2: the quotient is within 2^-51 / cw absolute -- useless only where
-// two lines of opposite sign nearly cancel.  *undecided says whether the float could differ.
-// Second tier (psy12_c_exact): the reference's own formula with the correctly rounded dm_sincos, behind the loop.
+// exact: the subtraction is checked with its TwoSum error term, the halving is a power of two), so cw = sqrt(x) / (a + |b|)
+// is within 2^-48 RELATIVE of the mathematical quotient (for a b < 0, where the second term is subtracted from
+// (a + |b|)^2, within 2^-51 / cw absolute).  The REFERENCE's double arithmetic is not that close to it: each of
+// t1 = r cos phi - r' cos phi', t2 = ... carries (r + |r'|) 2^-52 of rounding (two products, a libm that may be off by
+// an ulp, the difference), their root sqrt 2 times that, and the divisor is r + |r'|: its quotient lies within 2^-51.5 +
+// 3 2^-53 cw of the mathematical one.  So the float is decided unless it lies within 2^-50 + 2^-47 cw (+ 2^-51 / cw) of a
+// rounding boundary: 2^-15 of the lines at cw = 2^-10 -- and every line predicted better than 2^-25, whose float
+// the reference's own rounding noise decides.  *undecided says whether the float could differ.
+// Second tier (psy12_c_exact): the reference's formula operation by operation with the correctly rounded dm_sincos,
+// behind the loop.
 MP3MI_DEVFN float psy12_c0(float r_new, float phi_new, float r_old, float r_oldest, float phi_old, float phi_oldest, bool *undecided)
 {
     const float r_prime = (float) (2.0 * (double) r_old - (double) r_oldest);
@@ -52,7 +56,7 @@ MP3MI_DEVFN float psy12_c0(float r_new, float phi_new, float r_old, float r_olde
     const double t3 = a + __builtin_fabs(b);
     double cw = 0.0;
     if (t3 != 0.0) cw = __builtin_sqrt(x > 0.0 ? x : 0.0) / t3;
-    const double err = m >= 0.0 ? cw * 0x1p-47 : 0x1p-51 / cw + cw * 0x1p-47;
+    const double err = 0x1p-50 + cw * 0x1p-47 + (m >= 0.0 ? 0.0 : 0x1p-51 / cw);
     if (t3 != 0.0 && !(dl_err == 0.0 && !near_multiple && (m >= 0.0 || cw > 0x1p-20) && l12_float_decided(cw, err))) *undecided = true;
     return (float) cw;
 }
