@@ -187,7 +187,8 @@ int mp3mi_encode_host_ex(int n_streams, int rate_hz, int channels, const int *kb
  * compare them with oracle/stage_dump.h).  what: 0 = psychoacoustic records (mp3mi_psy_out),
  * 1 = xr (f64[576] per granule-channel), 2 = quantised values (int16[576]), 3 = side info
  * (mp3mi_frame_side per frame), 4 = raw subband samples (f64[576], enabled by
- * mp3mi_batch_debug_enable).  Returns the number of bytes written, or a negative error. */
+ * mp3mi_batch_debug_enable), 5 = the loop's stateless head (csrc/mp3mi_dev.h: mp3mi_loop_prep, 472 bytes per
+ * granule-channel).  Returns the number of bytes written, or a negative error. */
 long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst, size_t cap);
 void mp3mi_batch_debug_enable(mp3mi_batch *b, int on);
 
@@ -200,7 +201,8 @@ enum {
     MP3MI_TEST_PHASE_EXACT = 2,  /* phases: correctly rounded atan2 (k_cw) */
     MP3MI_TEST_PSY_EXACT = 4,    /* masking threshold: dm_log / dm_exp (k_psy) */
     MP3MI_TEST_QUANT_EXACT = 8,  /* quantiser: every line against the (i - 0.4054)^(4/3) table (k_loop) */
-    MP3MI_TEST_PREP_EXACT = 16,  /* quantanf_init: correctly rounded logs (k_prep) */
+    MP3MI_TEST_PREP_EXACT = 16,  /* the loop's stateless head by k_prep for every record, the reference's walk with correctly
+                                    rounded logs, instead of k_mdct's tail */
     MP3MI_TEST_CW_EXACT = 32,    /* unpredictability: correctly rounded sines and cosines for every record (k_cw) */
     MP3MI_TEST_ALL_EXACT = 63
 };
@@ -223,6 +225,8 @@ int mp3mi_debug_fastmath_bounds(double out[3]);
  * the unpredictability (k_part's check); *n_records receives their number.  Call after
  * mp3mi_batch_sync. */
 int mp3mi_batch_debug_cw_fixups(mp3mi_batch *b, int *n_listed, int *n_records);
+/* likewise: the records of the last item whose loop-prep values k_mdct's tail could not decide (k_prep recomputed them) */
+int mp3mi_batch_debug_prep_fixups(mp3mi_batch *b, int *n_listed);
 
 /* Library / device identification string for logs. */
 const char *mp3mi_version(void);

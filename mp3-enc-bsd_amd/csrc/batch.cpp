@@ -78,7 +78,8 @@ struct mp3mi_batch {
     mp3mi_cw_fixlist *cw_fix; // the (granule, channel) records whose unpredictability needs its second tier (k_part)
     float *part_cb;
     mp3mi_psy_out *psy[2];
-    mp3mi_prep_block *prep[2];
+    mp3mi_loop_prep *prep[2];
+    mp3mi_prep_fixlist *prep_fix; // the records k_mdct's tail could not decide (k_prep works through the list); front stream only
     void *psy_state, *loop_state;
     int16_t *ix;
     mp3mi_frame_side *side;
@@ -305,10 +306,12 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     CHK(hipMalloc((void **) &b->cw_mid, ngc * 50 * sizeof(double)));
     CHK(hipMalloc((void **) &b->cw_fix, mp3mi_cw_fixlist_bytes(ngc)));
     CHK(hipMemset(b->cw_fix, 0, sizeof(mp3mi_cw_fixlist)));
+    CHK(hipMalloc((void **) &b->prep_fix, mp3mi_prep_fixlist_bytes(ngc)));
+    CHK(hipMemset(b->prep_fix, 0, sizeof(mp3mi_prep_fixlist)));
     for (int i = 0; i < 2; i++) {
         CHK(hipMalloc((void **) &b->xr[i], ngc * 576 * sizeof(double)));
         CHK(hipMalloc((void **) &b->psy[i], ngc * sizeof(mp3mi_psy_out)));
-        CHK(hipMalloc((void **) &b->prep[i], ((ngc + 63) / 64) * sizeof(mp3mi_prep_block)));
+        CHK(hipMalloc((void **) &b->prep[i], ngc * sizeof(mp3mi_loop_prep)));
     }
     CHK(hipMalloc((void **) &b->sbs, (ngc + (size_t) n_streams * channels) * 576 * sizeof(double)));
     CHK(hipMalloc((void **) &b->ix, ngc * 576 * sizeof(int16_t)));
@@ -392,7 +395,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     if (b->stream) hipStreamSynchronize(b->stream);
     if (b->lstream) hipStreamSynchronize(b->lstream);
     void *bufs[] = {b->T, b->bits_per_frame, b->bitrate_index, b->energy_l, b->energy_s, b->hist6, b->fft_bins, b->cw_mid, b->cw_fix,
-                    b->part_eb, b->part_cb, b->xr[0], b->xr[1], b->psy[0], b->psy[1], b->prep[0], b->prep[1], b->sbs, b->ix, b->side,
+                    b->part_eb, b->part_cb, b->xr[0], b->xr[1], b->psy[0], b->psy[1], b->prep[0], b->prep[1], b->prep_fix, b->sbs, b->ix, b->side,
                     b->psy_state, b->loop_state, b->pcm_hist, b->out_base, b->carry, b->carry_len, b->gate_count, b->place_order, b->place_cost, b->place_zero, b->sb_dbg, b->voided, b->status_dev};
     for (void *p : bufs)
         if (p) hipFree(p);
@@ -678,9 +681,13 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         mp3mi_launch_filter(b->T, g, pcm_dev + v.s0 * pcm_pitch, b->sbs + v.s0 * (size_t) (g.n_gran + 1) * (size_t) C * 576,
                             b->debug ? b->sb_dbg + r * 576 : NULL, b->stream);
         CHK(hipGetLastError());
-        mp3mi_launch_mdct(b->T, g, b->psy[v.slot] + r, b->sbs + v.s0 * (size_t) (g.n_gran + 1) * (size_t) C * 576, b->xr[v.slot] + r * 576, b->stream);
+        // k_mdct's tail also computes the loop's stateless head and lists the records it could not decide; k_prep works
+        // through the list (MP3MI_TEST_PREP_EXACT: through every record, the reference's way)
+        CHK(hipMemsetAsync(&b->prep_fix->count, 0, sizeof(unsigned), b->stream));
+        mp3mi_launch_mdct(b->T, g, b->psy[v.slot] + r, b->sbs + v.s0 * (size_t) (g.n_gran + 1) * (size_t) C * 576, b->xr[v.slot] + r * 576,
+                          b->prep[v.slot] + r, b->prep_fix, b->stream);
         CHK(hipGetLastError());
-        mp3mi_launch_prep(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r / 64, b->prep_exact, b->stream);
+        mp3mi_launch_prep(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r, b->prep_exact ? NULL : b->prep_fix, b->prep_exact, b->stream);
         CHK(hipGetLastError());
         if (k + 1 < n_items) {
             const item_view nv = view(k + 1);
@@ -708,7 +715,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
                 place.n_simd = b->n_simd;
             }
             if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
-            mp3mi_launch_loop(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r / 64, b->bits_per_frame + v.s0,
+            mp3mi_launch_loop(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r, b->bits_per_frame + v.s0,
                               (char *) b->loop_state + v.s0 * loop_state_bytes, b->ix + r * 576, b->side + v.s0 * (size_t) g.nf,
                               b->gate_count, place, b->lstream);
             CHK(hipGetLastError());
@@ -806,6 +813,17 @@ extern "C" int mp3mi_batch_debug_cw_fixups(mp3mi_batch *b, int *n_listed, int *n
     return MP3MI_OK;
 }
 
+extern "C" int mp3mi_batch_debug_prep_fixups(mp3mi_batch *b, int *n_listed)
+{
+    if (!b || !n_listed) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    mp3mi_prep_fixlist h;
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return MP3MI_ERR_HIP;
+    CHK(hipMemcpy(&h, b->prep_fix, sizeof(h), hipMemcpyDeviceToHost));
+    *n_listed = (int) h.count;
+    return MP3MI_OK;
+}
+
 extern "C" int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_kernels_ms, int *launches)
 {
     if (!b || !b->have_done || b->call_no == 0) return MP3MI_ERR_ARG; // nothing has been encoded yet
@@ -841,6 +859,7 @@ extern "C" long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst
     case 2: src = b->ix; n = ngc * 576 * sizeof(int16_t); break;
     case 3: src = b->side; n = (size_t) b->n_streams * (size_t) b->last_nf * sizeof(mp3mi_frame_side); break;
     case 4: src = b->sb_dbg; n = ngc * 576 * sizeof(double); break;
+    case 5: src = b->prep[b->last_slot]; n = ngc * sizeof(mp3mi_loop_prep); break;
     default: return MP3MI_ERR_ARG;
     }
     if (!src || n > cap) return MP3MI_ERR_ARG;

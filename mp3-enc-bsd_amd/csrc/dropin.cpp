@@ -67,7 +67,7 @@ struct DropIn {
     int32_t *bt_d = nullptr;
     // loop
     mp3mi_psy_out *psy4 = nullptr;
-    mp3mi_prep_block *prep4 = nullptr;
+    mp3mi_loop_prep *prep4 = nullptr;
     int16_t *ix_d = nullptr;
     mp3mi_frame_side *side_d = nullptr;
     void *loop_state = nullptr;
@@ -120,7 +120,7 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.xr_d, 4 * 576 * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.bt_d, 4 * sizeof(int32_t)));
     HIPOK(hipMalloc((void **) &D.psy4, 4 * sizeof(mp3mi_psy_out)));
-    HIPOK(hipMalloc((void **) &D.prep4, sizeof(mp3mi_prep_block)));
+    HIPOK(hipMalloc((void **) &D.prep4, 4 * sizeof(mp3mi_loop_prep)));
     HIPOK(hipMalloc((void **) &D.ix_d, 4 * 576 * sizeof(int16_t)));
     HIPOK(hipMalloc((void **) &D.side_d, sizeof(mp3mi_frame_side)));
     HIPOK(hipMalloc((void **) &D.loop_state, mp3mi_loop_state_size()));
@@ -276,7 +276,7 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
     HIPOK(hipMemcpyAsync(D.bits_d, &bpf, sizeof(bpf), hipMemcpyHostToDevice, D.st));
     mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1, 0, 1);
     g.crc = crc;
-    mp3mi_launch_prep(D.T, g, D.xr_d, D.psy4, D.prep4, 0, D.st);
+    mp3mi_launch_prep(D.T, g, D.xr_d, D.psy4, D.prep4, NULL, 0, D.st); // (the caller's spectrum: every record, the reference's walk)
     mp3mi_launch_loop(D.T, g, D.xr_d, D.psy4, D.prep4, D.bits_d, D.loop_state, D.ix_d, D.side_d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
     static int16_t ix[4][576];
     mp3mi_frame_side sd;

@@ -12,6 +12,7 @@
 //
 // Arithmetic and its ordering: fbmdct_dev.h.
 #include "fbmdct_dev.h"
+#include "dmath.h"
 
 // k_filter: one LANE per slot.  A slot's 32 subband samples are a function of 512 PCM samples, and every operand
 // of that function but the PCM itself is the same for all slots: the 512 window taps and the 31 x 32 matrixing
@@ -272,9 +273,173 @@ MP3MI_DEVFN void mdct_other_reg(const double *prev, const double *cur, double *p
     }
 }
 
+// ---- the stateless head of the iteration loop, computed here while the granule's spectrum is in LDS (k_prep.hip has
+//      the reference's walk and the error analysis; this is its parallel form) ----
+// calc_xmin (src/loop.c:1085-1118) hands the band energies on as DOUBLES that k_loop compares with noise sums: they are
+// summed in the reference's order, every band a chain of its own in a lane of its own (21 long bands, or 12 short
+// bands with three windows each; the longest is 102 lines).  Everything else only reaches the loop through an INTEGER:
+//   * quantanf_init (src/loop.c:369-402): nint(8 ln sfm) from the total energy -- a 576-term chain in the reference --
+//     and the sum of 576 logs.  Here: the lanes' partial sums of the squares added by a butterfly (non-negative terms:
+//     any order is within 576 ulp / 2 = 6.4e-14 relative of any other), the product of the mantissas and the sum of the
+//     exponents instead of the logs (k_prep.hip), and ln sfm = S / 576 - ln(tot / 576) without the reference's exp:
+//     v is within 1e-9 of the reference's, and decided unless it lies within 2e-9 max(1, |v|) of a rounding boundary;
+//   * calc_scfsi's (int)(log(x) / log 2) of the total and the band energies and thresholds (src/loop.c:631-667): the
+//     exponent field of x, unless x lies within 2^-30 of a power of two (where the reference's quotient of two rounded
+//     logarithms decides; an exact power of two is such a case).
+// A record with anything undecided is LISTED: k_prep recomputes it the reference's way (probability ~1e-7; all
+// records under MP3MI_TEST_PREP_EXACT).
+MP3MI_DEVFN int mdct_ilog2_fast(double v, bool &amb)
+{
+    if (v == 0.0) return 0;
+    const long long b = dm_bits(v);
+    const int ef = (int) ((b >> 52) & 0x7ff);
+    const unsigned long long fr = (unsigned long long) b & 0x000fffffffffffffull;
+    if (b < 0 || ef == 0 || ef == 0x7ff || fr < (1ull << 22) || fr > 0x000fffffffffffffull - (1ull << 22)) {
+        amb = true;
+        return 0;
+    }
+    const int e = ef - 1023; // log2 v lies strictly between e and e + 1: the cast truncates towards zero
+    return e >= 0 ? e : e + 1;
+}
+
+#if !defined(MP3MI_EMU)
+template <int CTRL> MP3MI_DEVFN double mdct_dpp_f64(double v)
+{
+    const long long b = dm_bits(v);
+    const int lo = (int) b, hi = (int) (b >> 32);
+    const unsigned l2 = (unsigned) __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false), h2 = (unsigned) __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return dm_from_bits((long long) (((unsigned long long) h2 << 32) | l2));
+}
+#endif
+#if defined(MP3MI_EMU)
+#define MDCT_LDS_PTR(type) type *
+#else
+#define MDCT_LDS_PTR(type) type __attribute__((address_space(3))) * // (ds_read, not a flat load through a generic pointer)
+#endif
+// (a function of its own, not inlined: inside k_mdct's loop its presence alone took the kernel from 186 to 222 registers --
+// past the 192 that fit beside k_loop)
+__device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, MDCT_LDS_PTR(const double) X, bool wr, int bt, bool any_long, bool any_short, int WL, int WS,
+                                                         const mp3mi_psy_out *po, mp3mi_loop_prep *out, mp3mi_prep_fixlist *fix, unsigned rec)
+{
+    const int band = wave_lane() & 31, h = wave_lane() >> 5;
+    // the band-energy chain of this lane: first line and lines, long and short
+    int ch_l0 = 0, ch_ln = 0, ch_s0 = 0, ch_sn = 0;
+    if (band < 21) { ch_l0 = T->sfb_l[band]; ch_ln = T->sfb_l[band + 1] - ch_l0; }
+    if (band < 12) { ch_s0 = 3 * T->sfb_s[band]; ch_sn = T->sfb_s[band + 1] - T->sfb_s[band]; }
+    const bool shortb = bt == 2;
+    // the psychoacoustic ratios of this lane's band, asked for now and used at the end
+    const double *rp = shortb ? &po->ratio_s[band < 12 ? band : 0][0] : &po->ratio_l[band < 21 ? band : 0];
+    const double r0 = rp[0], r1 = shortb ? rp[1] : 0.0, r2 = shortb ? rp[2] : 0.0;
+    bool amb = false;
+    double tot = 0.0, amax = 0.0, prod = 1.0;
+    int esum = 0;
+#pragma unroll
+    for (int m = 0; m < 18; m++) { // this lane's 18 lines
+        const double x = X[band * 18 + m], sq = x * x, ax = __builtin_fabs(x);
+        tot = tot + sq;
+        amax = ax > amax ? ax : amax;
+        const long long sb = dm_bits(sq);
+        const int ef = (int) (sb >> 52);
+        if (x != 0.0 && ef == 0) amb = true; // xr^2 below the normal range: the reference's log sees it
+        prod = prod * (ef != 0 ? dm_from_bits((sb & 0x000fffffffffffffLL) | 0x3ff0000000000000LL) : 1.0);
+        esum += ef != 0 ? ef - 1023 : 0;
+    }
+    // butterflies within the half (commutative steps: every lane ends with the same values)
+#if defined(MP3MI_EMU)
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        tot = tot + __shfl_xor(tot, d);
+        const double oa = __shfl_xor(amax, d);
+        amax = oa > amax ? oa : amax;
+        prod = prod * __shfl_xor(prod, d);
+        esum += __shfl_xor(esum, d);
+    }
+#else
+#define MDCT_TAIL_STEP(CTRL)                                                  \
+    {                                                                         \
+        tot = tot + mdct_dpp_f64<CTRL>(tot);                                  \
+        const double oa = mdct_dpp_f64<CTRL>(amax);                           \
+        amax = oa > amax ? oa : amax;                                         \
+        prod = prod * mdct_dpp_f64<CTRL>(prod);                               \
+        esum += __builtin_amdgcn_update_dpp(esum, esum, CTRL, 0xf, 0xf, false); \
+    }
+    MDCT_TAIL_STEP(0xB1)  // quad_perm [1, 0, 3, 2]
+    MDCT_TAIL_STEP(0x4E)  // quad_perm [2, 3, 0, 1]
+    MDCT_TAIL_STEP(0x141) // row_half_mirror
+    MDCT_TAIL_STEP(0x140) // row_mirror: the sixteen lanes of a row agree
+#undef MDCT_TAIL_STEP
+#endif
+    { // and the two rows of the half
+        tot = tot + __shfl_xor(tot, 16);
+        const double oa = __shfl_xor(amax, 16);
+        amax = oa > amax ? oa : amax;
+        prod = prod * __shfl_xor(prod, 16);
+        esum += __shfl_xor(esum, 16);
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (any_long) {
+        const int n_l = shortb ? 0 : ch_ln;
+#pragma unroll 8
+        for (int i = 0; i < WL; i++) { // (every lane loads: an idle one line 0, and adds a zero)
+            const bool on = i < n_l;
+            const double v = X[on ? ch_l0 + i : 0], x = on ? v : 0.0;
+            a0 = a0 + x * x;
+        }
+    }
+    if (any_short) {
+        const int n_s = shortb ? ch_sn : 0;
+#pragma unroll 4
+        for (int i = 0; i < WS; i++) {
+            const bool on = i < n_s;
+            MDCT_LDS_PTR(const double) p = X + (on ? ch_s0 + 3 * i : 0);
+            const double v0 = p[0], v1 = p[1], v2 = p[2];
+            const double x0 = on ? v0 : 0.0, x1 = on ? v1 : 0.0, x2 = on ? v2 : 0.0;
+            a0 = a0 + x0 * x0;
+            a1 = a1 + x1 * x1;
+            a2 = a2 + x2 * x2;
+        }
+    }
+    if (!shortb) {
+        if (band < 21) {
+            const double xmin = r0 * a0 / (double) ch_ln;
+            const int se = mdct_ilog2_fast(a0, amb), sx = mdct_ilog2_fast(xmin, amb);
+            if (wr) { out->xmin[band] = xmin; out->sc_en[band] = se; out->sc_xm[band] = sx; }
+        }
+    } else if (band < 12) {
+        const double cnt = (double) ch_sn;
+        if (wr) {
+            out->xmin[band * 3 + 0] = r0 * a0 / cnt;
+            out->xmin[band * 3 + 1] = r1 * a1 / cnt;
+            out->xmin[band * 3 + 2] = r2 * a2 / cnt;
+        }
+    }
+    int tp = 0;
+    if (tot != 0.0) {
+        const double A = ((double) esum * 0x1.62e42fefa39efp-1 + dm_log_fast(prod)) / 576.0, B = tot / 576.0;
+        if (__builtin_fabs(A) < 700.0 && B > 0x1p-1000 && B < 0x1p1000) { // (the reference's exp and quotient stay normal)
+            const double v = 8.0 * (A - dm_log_fast(B));
+            tp = (v < 0) ? (int) (v - 0.5) : (int) (v + 0.5);
+            if (tp < -100) tp = -100;
+            const double av = __builtin_fabs(v), fr = av - __builtin_floor(av);
+            if (!(__builtin_fabs(fr - 0.5) > 2e-9 * (av > 1.0 ? av : 1.0))) amb = true;
+        } else
+            amb = true;
+    }
+    const int en_tot = mdct_ilog2_fast(tot, amb);
+    if (band == 0 && wr) {
+        out->q0 = tp - 70;
+        out->sc_en_tot = en_tot;
+        out->sc_xrmax = (int) amax;
+        out->nonzero = (amax != 0.0) ? 1 : 0;
+    }
+    const unsigned long long am = __ballot(amb);
+    if (band == 0 && wr && ((am >> (32 * h)) & 0xffffffffull) != 0) fix->list[atomicAdd(&fix->count, 1u)] = rec;
+}
+
 __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ sbs, const mp3mi_psy_out *__restrict__ psy,
-                                                double *__restrict__ xr_out)
+                                                double *__restrict__ xr_out, mp3mi_loop_prep *__restrict__ prep,
+                                                mp3mi_prep_fixlist *__restrict__ fix)
 {
     __shared__ mdct_out_lds L;
     const int lane = wave_lane(), band = lane & 31, h = lane >> 5;
@@ -295,6 +460,12 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
     double *prev = &L.prev[0][lane];
 #pragma unroll
     for (int k = 0; k < 18; k++) prev[64 * k] = blk[32 * k]; // the run's first "previous granule"
+    // the longest band-energy chains, long and short (lane & 31 = scalefactor band)
+    int WL = 0, WS = 0;
+    if (prep) {
+        WL = wave_max_i32(band < 21 ? T->sfb_l[band + 1] - T->sfb_l[band] : 0);
+        WS = wave_max_i32(band < 12 ? T->sfb_s[band + 1] - T->sfb_s[band] : 0);
+    }
     for (int kk = 0; kk < n; kk++) {
         // (this granule's samples are read where they are used, once, and parked in LDS for the next granule)
         const double *cur = blk + (size_t) (kk + 1) * pitch;
@@ -340,6 +511,11 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
             }
         }
         __syncthreads();
+        // ---- the loop's stateless head for these two granules (see above); BEFORE the spectrum's stores: a function
+        //      begins by waiting for every memory operation in flight ----
+        if (prep)
+            mdct_prep_tail(T, (MDCT_LDS_PTR(const double)) &L.x[h][0], h == 0 || two, bt, bt0 != 2 || bt1 != 2, bt0 == 2 || bt1 == 2, WL, WS,
+                           &psy[rec0 + (size_t) kk * C], &prep[rec0 + (size_t) kk * C], fix, (unsigned) (rec0 + (size_t) kk * C));
         // element lane + 64 j of the two [band][18] blocks: j < 9 the lower track's, then the upper one's
         double *out_lo = xr_out + (rec_lo + (size_t) kk * C) * 576, *out_hi = xr_out + (rec_hi + (size_t) kk * C) * 576;
         const double *flat = &L.x[0][0];
@@ -360,7 +536,9 @@ void mp3mi_launch_filter(const mp3mi_tables *T, const mp3mi_geom &g, const int16
     hipLaunchKernelGGL(k_filter, dim3((unsigned) (g.n_streams * g.channels * (((g.n_gran + 1) * 18 + FILT_SLOTS - 1) / FILT_SLOTS))), dim3(64), 0, st, T, g, pcm, sbs, sb_dbg);
 }
 
-void mp3mi_launch_mdct(const mp3mi_tables *T, const mp3mi_geom &g, const mp3mi_psy_out *psy, const double *sbs, double *xr, hipStream_t st)
+void mp3mi_launch_mdct(const mp3mi_tables *T, const mp3mi_geom &g, const mp3mi_psy_out *psy, const double *sbs, double *xr,
+                       mp3mi_loop_prep *prep, mp3mi_prep_fixlist *fix, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_mdct, dim3((unsigned) (((g.n_streams * g.channels + 1) / 2) * ((g.n_gran + MDCT_RUN - 1) / MDCT_RUN))), dim3(64), 0, st, T, g, sbs, psy, xr);
+    hipLaunchKernelGGL(k_mdct, dim3((unsigned) (((g.n_streams * g.channels + 1) / 2) * ((g.n_gran + MDCT_RUN - 1) / MDCT_RUN))), dim3(64), 0, st, T, g, sbs, psy, xr,
+                       prep, fix);
 }

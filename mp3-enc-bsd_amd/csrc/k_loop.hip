@@ -10,7 +10,7 @@
 // registers between passes is |xr|^(3/4) of the lane's nine lines and the per-band state.
 //
 // The stateless head of the loop (calc_xmin, quantanf_init, the values calc_scfsi stores) comes
-// from k_prep.  Band noise -- only ever compared with the allowed distortion -- is summed in
+// from k_mdct's tail (k_fbmdct.hip; k_prep.hip).  Band noise -- only ever compared with the allowed distortion -- is summed in
 // ~10-line parts by all lanes, with the reference's sequential order as the fallback when a band
 // lands within 1e-12 of its threshold.  Integer work is order-free.
 //
@@ -689,7 +689,7 @@ void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st)
 template <bool QUEUE>
 MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geom &geo,
                              const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
-                             const mp3mi_prep_block *__restrict__ prep,
+                             const mp3mi_loop_prep *__restrict__ prep,
                              const int32_t *__restrict__ bits_per_frame,
                              mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
                              mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
@@ -758,25 +758,24 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 }
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
-                //      were computed by k_prep; only the stateful decision of calc_scfsi happens here ----
+                //      were computed by k_mdct's tail (k_prep); only the stateful decision of calc_scfsi happens here ----
                 PROF(0);
-                const mp3mi_prep_block *pp = &prep[rec >> 6]; // records come in blocks of 64, field by field
-                const int ps = (int) (rec & 63);
+                const mp3mi_loop_prep *pp = &prep[rec];
                 // per-band state (allowed distortion, scalefactors): L.band_*
                 if (lane < 36) {
-                    L.band_xmin[lane] = lane < nband ? pp->xmin[lane][ps] : 0.0;
+                    L.band_xmin[lane] = lane < nband ? pp->xmin[lane] : 0.0;
                     L.band_sf[lane] = 0;
                     L.band_sfsave[lane] = 0;
                 }
                 if (lane == 0) {
-                    L.st.sc_xrmax[gr][ch] = pp->sc_xrmax[ps];
-                    L.st.sc_en_tot[gr][ch] = pp->sc_en_tot[ps];
+                    L.st.sc_xrmax[gr][ch] = pp->sc_xrmax;
+                    L.st.sc_en_tot[gr][ch] = pp->sc_en_tot;
                 }
                 if (!shortb && lane < 21) {
-                    L.st.sc_en[gr][ch][lane] = pp->sc_en[lane][ps];
-                    L.st.sc_xm[gr][ch][lane] = pp->sc_xm[lane][ps];
+                    L.st.sc_en[gr][ch][lane] = pp->sc_en[lane];
+                    L.st.sc_xm[gr][ch][lane] = pp->sc_xm[lane];
                 }
-                const int nonzero = pp->nonzero[ps];
+                const int nonzero = pp->nonzero;
                 int scfsi_m = 0; // this granule's scfsi bits (wave-uniform): what the search asks for between passes
                 wave_sync();
                 if (gr == 1) {
@@ -841,7 +840,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 wave_sync();
 
                 if (nonzero) {
-                    g.q = pp->q0[ps]; // quantanf_init (src/loop.c:369-402), from k_prep
+                    g.q = pp->q0; // quantanf_init (src/loop.c:369-402), from k_prep
 
                     // ---- outer_loop (src/loop.c:415-558) ----
                     int iteration = 0, bits = 0, over, status, save_preflag, save_compress;
@@ -1165,7 +1164,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
 }
 
 #define LOOP_KERNEL_ARGS const mp3mi_tables *__restrict__ T, mp3mi_geom geo, const double *__restrict__ xr_all,                     \
-                         const mp3mi_psy_out *__restrict__ psy, const mp3mi_prep_block *__restrict__ prep,                      \
+                         const mp3mi_psy_out *__restrict__ psy, const mp3mi_loop_prep *__restrict__ prep,                      \
                          const int32_t *__restrict__ bits_per_frame, mp3mi_loop_state *__restrict__ state,                     \
                          int16_t *__restrict__ ix_out, mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count, \
                          mp3mi_loop_place place
@@ -1261,7 +1260,7 @@ int mp3mi_loop_waves(int n_streams)
 }
 
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
-                       const mp3mi_prep_block *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
+                       const mp3mi_loop_prep *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
                        mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place, hipStream_t st)
 {
     const int want = (g.n_streams + LOOP_W - 1) / LOOP_W, wg_cap = loop_wg_cap();

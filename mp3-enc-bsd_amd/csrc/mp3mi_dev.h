@@ -163,21 +163,15 @@ typedef struct {
 } mp3mi_psy_out;
 
 /* Stateless per-(granule, channel) inputs of the iteration loop, computed for all granules in
- * parallel by k_prep so that the serial kernel starts from them: allowed distortion
- * (calc_xmin, src/loop.c:1085), the integer log-energies calc_scfsi stores (src/loop.c:631-667)
- * and the start value of the quantiser step (quantanf_init, src/loop.c:369). */
+ * parallel (k_mdct's tail; k_prep for the records it lists) so that the serial kernel starts from them: allowed
+ * distortion (calc_xmin, src/loop.c:1085), the integer log-energies calc_scfsi stores (src/loop.c:631-667)
+ * and the start value of the quantiser step (quantanf_init, src/loop.c:369).  One 472-byte record per (granule,
+ * channel), record-major: k_mdct's lanes write a record's fields side by side and k_loop's wavefront reads them so. */
 typedef struct {
     double xmin[36];                 /* long: [sfb], sfb < 21; short: [sfb*3 + window], sfb < 12 */
     int32_t sc_en[21], sc_xm[21];    /* written for non-short granules only */
     int32_t sc_en_tot, sc_xrmax, q0, nonzero;
 } mp3mi_loop_prep;
-/* In memory the records come in blocks of 64, field by field: k_prep's 64 lanes are 64 consecutive records
- * and store one field of all of them as one contiguous line (record r = slot r % 64 of block r / 64). */
-typedef struct {
-    double xmin[36][64];
-    int32_t sc_en[21][64], sc_xm[21][64];
-    int32_t sc_en_tot[64], sc_xrmax[64], q0[64], nonzero[64];
-} mp3mi_prep_block;
 
 /* Side information of one (granule, channel) as the iteration loop leaves it
  * (subset of gr_info, src/l3side.h:60-87, that the formatter needs). */

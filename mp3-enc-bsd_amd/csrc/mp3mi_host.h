@@ -75,10 +75,20 @@ void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *e
                       const float *energy_s, double *cw_mid, float *hist6, const float *bins, mp3mi_cw_fixlist *fix,
                       void *psy_state, double *eb_all, float *cb_all, mp3mi_psy_out *out, hipStream_t st, int which = 3);
 void mp3mi_launch_filter(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, double *sbs, double *sb_dbg, hipStream_t st);
-void mp3mi_launch_mdct(const mp3mi_tables *T, const mp3mi_geom &g, const mp3mi_psy_out *psy, const double *sbs, double *xr, hipStream_t st);
+/* records whose loop-prep values k_mdct's tail could not decide (k_fbmdct.hip): k_prep works through the list;
+ * device memory, mp3mi_prep_fixlist_bytes(records) */
+struct mp3mi_prep_fixlist {
+    unsigned count, pad[3];
+    unsigned list[1]; /* one entry per record of a launch at most */
+};
+static inline size_t mp3mi_prep_fixlist_bytes(size_t n_rec) { return sizeof(mp3mi_prep_fixlist) + n_rec * sizeof(unsigned); }
+/* prep / fix NULL: the spectrum only (fix->count is zeroed by the caller, on the same stream) */
+void mp3mi_launch_mdct(const mp3mi_tables *T, const mp3mi_geom &g, const mp3mi_psy_out *psy, const double *sbs, double *xr,
+                       mp3mi_loop_prep *prep, mp3mi_prep_fixlist *fix, hipStream_t st);
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g); /* subband samples between k_filter and k_mdct */
+/* fix != NULL: the records it lists (a fixed small grid walks the list); NULL: every record of the launch */
 void mp3mi_launch_prep(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
-                       const mp3mi_psy_out *psy, mp3mi_prep_block *prep, int force_exact, hipStream_t st);
+                       const mp3mi_psy_out *psy, mp3mi_loop_prep *prep, const mp3mi_prep_fixlist *fix, int force_exact, hipStream_t st);
 /* stream placement of k_loop (k_loop.hip: loop_place_stream); all pointers NULL = stream == blockIdx */
 #define MP3MI_PLACE_KEYS 8192
 struct mp3mi_loop_place {
@@ -92,7 +102,7 @@ struct mp3mi_loop_place {
 };
 void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st);
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr,
-                       const mp3mi_psy_out *psy, const mp3mi_prep_block *prep, const int32_t *bits_per_frame,
+                       const mp3mi_psy_out *psy, const mp3mi_loop_prep *prep, const int32_t *bits_per_frame,
                        void *loop_state, int16_t *ix, mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place,
                        hipStream_t st);
 /* bounded wait (one wavefront) until k_loop's start census reaches `target` -- see k_loop.hip */

@@ -30,6 +30,8 @@ GI = {n: i for i, n in enumerate([
 
 # mp3-enc-bsd_amd/csrc/mp3mi_dev.h
 PSY_DT = np.dtype([("pe", "<f8"), ("ratio_l", "<f8", (21,)), ("ratio_s", "<f8", (12, 3)), ("block_type", "<i4"), ("pad", "<i4")])
+PREP_DT = np.dtype([("xmin", "<f8", (36,)), ("sc_en", "<i4", (21,)), ("sc_xm", "<i4", (21,)), ("sc_en_tot", "<i4"), ("sc_xrmax", "<i4"),
+                    ("q0", "<i4"), ("nonzero", "<i4")])  # mp3mi_loop_prep, csrc/mp3mi_dev.h
 GRSIDE_DT = np.dtype([
     ("part2_3_length", "<i4"), ("big_values", "<i4"), ("count1", "<i4"), ("global_gain", "<i4"),
     ("scalefac_compress", "<i4"), ("window_switching_flag", "<i4"), ("block_type", "<i4"),
@@ -144,6 +146,7 @@ class Mp3mi:
         L.mp3mi_batch_flush.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_batch_reset.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_debug_cw_fixups.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.mp3mi_batch_debug_prep_fixups.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         L.mp3mi_batch_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_error_protection.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mp3mi_batch_set_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -312,6 +315,19 @@ class BatchRun:
         rc = self.mp.lib.mp3mi_batch_stream_status(self.b, st.ctypes.data)
         assert rc >= 0, "mp3mi_batch_stream_status -> %d" % rc
         return st
+
+    def fetch(self, what, dtype):
+        """mp3mi_batch_debug_fetch of the last call (one chunk): records [S, 2 * n_frames, channels] of dtype"""
+        a = np.zeros((self.S, 2 * self.nf, self.ch), dtype)
+        n = self.mp.lib.mp3mi_batch_debug_fetch(self.b, what, a.ctypes.data, a.nbytes)
+        assert n == a.nbytes, (n, a.nbytes)
+        return a
+
+    def prep_fixups(self):
+        """records of the last item that k_mdct's tail listed for k_prep"""
+        a = ctypes.c_int()
+        assert self.mp.lib.mp3mi_batch_debug_prep_fixups(self.b, ctypes.byref(a)) == 0
+        return a.value
 
     def cw_fixups(self):
         """(records listed for the second tier of the unpredictability, records) of the last call's last chunk"""

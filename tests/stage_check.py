@@ -3,10 +3,10 @@ import ctypes
 
 import numpy as np
 
-from mp3common import GI, PSY_DT, SIDE_DT
+from mp3common import GI, PREP_DT, PSY_DT, SIDE_DT
 
 
-def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames, mode=None, expect_abort=False):
+def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames, mode=None, expect_abort=False, flags=0):
     """pcm: int16 [S, n_frames*1152*channels]; mode: None or the driver's option string as oracle/ref_harness.c
     takes it (the -m letter s / d / m, then e / c / o for -e / -c / -o).  Returns (bytes per stream, stages dict);
     with expect_abort (inputs the reference dies on) mp3mi_batch_sync must say so and the stages dict carries the
@@ -26,6 +26,7 @@ def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames, mode=None, e
             assert L.mp3mi_batch_set_error_protection(b, 1 if "e" in mode[1:] else 0) == 0
             assert L.mp3mi_batch_set_header(b, 1 if "c" in mode[1:] else 0, 1 if "o" in mode[1:] else 0, 0) == 0
         L.mp3mi_batch_debug_enable(b, 1)
+        assert L.mp3mi_batch_set_test_flags(b, flags) == 0
         stride = L.mp3mi_batch_out_stride(b, n_frames)
         is_emu = b"emulator" in L.mp3mi_version()
         if is_emu:
@@ -62,7 +63,8 @@ def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames, mode=None, e
         st["ix"] = np.zeros((S, G, channels, 576), np.int16)
         st["side"] = np.zeros((S, n_frames), SIDE_DT)
         st["sb"] = np.zeros((S, G, channels, 18, 32))
-        for what, key in ((0, "psy"), (1, "xr"), (2, "ix"), (3, "side"), (4, "sb")):
+        st["prep"] = np.zeros((S, G, channels), PREP_DT)
+        for what, key in ((0, "psy"), (1, "xr"), (2, "ix"), (3, "side"), (4, "sb"), (5, "prep")):
             n = L.mp3mi_batch_debug_fetch(b, what, st[key].ctypes.data, st[key].nbytes)
             assert n == st[key].nbytes, (key, n, st[key].nbytes)
         st["status"] = np.zeros(S, np.int32)
@@ -114,3 +116,21 @@ def compare_stages(st, s, dumps, channels, frames=None):
         chk(w, "resvDrain", st["side"][s, f]["resvDrain"], d["resvDrain"])
         chk(w, "scfsi", st["side"][s, f]["scfsi"][:channels], d["scfsi"][:channels])
     return bad
+
+
+def compare_prep_records(a, b, psy):
+    """The loop's stateless head (mp3mi_loop_prep) of two runs, field by field and bit for bit, over the fields a
+    record of its block type defines: long blocks xmin[0..20], sc_en, sc_xm; short blocks xmin[0..35]; all the
+    four scalars.  Returns the number of records compared."""
+    assert a.shape == b.shape == psy.shape
+    short = psy["block_type"] == 2
+    for name in ("q0", "sc_en_tot", "sc_xrmax", "nonzero"):
+        bad = np.argwhere(a[name] != b[name])
+        assert bad.size == 0, (name, bad[:4], a[name][tuple(bad[0])], b[name][tuple(bad[0])])
+    xa, xb = a["xmin"].view(np.uint64), b["xmin"].view(np.uint64)
+    bad = np.argwhere((xa != xb) & (short[..., None] | (np.arange(36) < 21)))
+    assert bad.size == 0, ("xmin", bad[:4])
+    for name in ("sc_en", "sc_xm"):
+        bad = np.argwhere((a[name] != b[name]) & ~short[..., None])
+        assert bad.size == 0, (name, bad[:4])
+    return int(a.size)

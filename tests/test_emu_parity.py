@@ -144,6 +144,22 @@ def test_prep_exact_tier_matches_fast_tier(emu, oracle, monkeypatch):
         assert fast[s] == ref and exact[s] == ref
 
 
+@pytest.mark.parametrize("rate,ch", [(44100, 2), (48000, 1), (32000, 2)])
+def test_loop_prep_of_mdct_tail_equals_k_prep(emu, rate, ch):
+    """The loop's stateless head comes from k_mdct's tail (band energies in the reference's order, the integers from
+    order-free sums with a margin) and from k_prep -- the reference's 576-line walk -- only for the records the tail
+    lists.  Both paths over every record: the records must agree bit for bit, long and short blocks."""
+    from stage_check import run_batch_with_stages, compare_prep_records
+    nf = 6
+    pcm = np.stack([emu.synth(nf * 1152, ch, rate, 90 + s) for s in range(2)])  # (bursts: short blocks)
+    pcm[1, : pcm.shape[1] // 3] = 0  # digital silence: records without energy
+    got, st = run_batch_with_stages(emu, pcm, rate, ch, 128, nf)
+    got_k, st_k = run_batch_with_stages(emu, pcm, rate, ch, 128, nf, flags=16)  # MP3MI_TEST_PREP_EXACT
+    assert got == got_k
+    assert (st["psy"]["block_type"] == 2).any() and (st["psy"]["block_type"] == 0).any()
+    assert compare_prep_records(st["prep"], st_k["prep"], st["psy"]) == 2 * 2 * nf * ch
+
+
 def test_noise_exact_tier_matches_partial_sums(emu, oracle, monkeypatch):
     """k_loop decides `noise > xmin` from partial sums spread over the lanes and takes the reference's
     sequential order only when a band lands within 1e-12 of its threshold; forcing the sequential

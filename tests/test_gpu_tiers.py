@@ -6,7 +6,8 @@ import ctypes
 import numpy as np
 import pytest
 
-from mp3common import BatchRun
+from mp3common import BatchRun, PREP_DT, PSY_DT
+from stage_check import compare_prep_records
 
 pytestmark = pytest.mark.gpu
 
@@ -44,5 +45,26 @@ def test_every_exact_tier_gives_identical_bytes(product, oracle, rate, ch, kbps,
         for s in sorted(set(np.linspace(0, S - 1, 24).astype(int).tolist())):  # and they are the oracle's bytes
             ref, _ = oracle.encode(run.pcm_of(s), rate, kbps, ch)
             assert base[s, :base_len[s]].tobytes() == ref, "stream %d differs from the oracle" % s
+    finally:
+        run.close()
+
+
+@pytest.mark.parametrize("rate,ch,kbps,S,nf,stream0", [(44100, 2, 128, 4096, 24, 0), (48000, 2, 320, 1024, 20, 5000), (32000, 1, 64, 2048, 20, 9000)])
+def test_loop_prep_of_mdct_tail_equals_k_prep(product, rate, ch, kbps, S, nf, stream0):
+    """The loop's stateless head (allowed distortion, calc_scfsi's integers, the first quantiser step) comes from
+    k_mdct's tail -- band energies in the reference's order, the integers from order-free sums with a margin -- and
+    from k_prep, the reference's 576-line walk, only for the records the tail lists.  Both over EVERY record of a
+    full-chip batch: the records agree bit for bit, and the tail lists next to nothing."""
+    run = BatchRun(product, S, rate, ch, kbps, nf, stream0=stream0)
+    try:
+        run.encode(0)
+        listed = run.prep_fixups()
+        tail, psy = run.fetch(5, PREP_DT), run.fetch(0, PSY_DT)
+        run.encode(FLAGS["prep"])
+        walk = run.fetch(5, PREP_DT)
+        n = compare_prep_records(tail, walk, psy)
+        short = int((psy["block_type"] == 2).sum())
+        print("%d records (%d short blocks) agree; %d listed for k_prep" % (n, short, listed))
+        assert n == S * 2 * nf * ch and short > 0 and listed < n // 1000
     finally:
         run.close()
