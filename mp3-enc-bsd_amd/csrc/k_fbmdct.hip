@@ -175,7 +175,8 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
 // conflict).  A granule's samples come from memory ONCE, as "cur", and are parked here on the way for their second use
 // as the next granule's "prev" -- until round 3 they were read from memory twice (65 GB of the step's reads instead of
 // 36), because 36 more doubles do not fit the registers beside the transform.
-struct mdct_out_lds { double x[2][576]; double prev[18][64]; };
+struct mdct_out_lds { double x[2][576]; double zero[8]; double prev[18][64]; }; // (zero: what an idle chain step of the tail adds)
+#define MDCT_ZERO (2 * 576) /* index of zero[0] from x[0][0] */
 
 // ordered signed sum of windowed inputs: ops[i] = index | 0x80 (subtract / negate)   (src/mdct.c:205-508)
 template <int N> MP3MI_DEVFN double mdct_group_reg(const double (&fin)[36], const uint8_t *ops)
@@ -333,17 +334,22 @@ __device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, 
     bool amb = false;
     double tot = 0.0, amax = 0.0, prod = 1.0;
     int esum = 0;
+    int nzero = 0;
 #pragma unroll
     for (int m = 0; m < 18; m++) { // this lane's 18 lines
         const double x = X[band * 18 + m], sq = x * x, ax = __builtin_fabs(x);
         tot = tot + sq;
-        amax = ax > amax ? ax : amax;
+        amax = __builtin_fmax(amax, ax);
+        // sq = m 2^e: the product takes m, the sum e.  A zero line has the mantissa 1 and is counted (its exponent
+        // field adds nothing); xr != 0 whose square falls below the normal range is the reference's log's business
         const long long sb = dm_bits(sq);
         const int ef = (int) (sb >> 52);
-        if (x != 0.0 && ef == 0) amb = true; // xr^2 below the normal range: the reference's log sees it
-        prod = prod * (ef != 0 ? dm_from_bits((sb & 0x000fffffffffffffLL) | 0x3ff0000000000000LL) : 1.0);
-        esum += ef != 0 ? ef - 1023 : 0;
+        amb |= (ef == 0) & (x != 0.0);
+        prod = prod * dm_from_bits((sb & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+        esum += ef;
+        nzero += ef == 0;
     }
+    esum -= 1023 * (18 - nzero);
     // butterflies within the half (commutative steps: every lane ends with the same values)
 #if defined(MP3MI_EMU)
 #pragma unroll
@@ -376,27 +382,37 @@ __device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, 
         prod = prod * __shfl_xor(prod, 16);
         esum += __shfl_xor(esum, 16);
     }
+    // the chains, eight lines at a time: the loads first, all in flight together.  An idle lane -- and a lane past its
+    // band's end -- reads the zeros behind the spectrum (MDCT_ZERO) and adds them
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    MDCT_LDS_PTR(const double) Z = X + (MDCT_ZERO - 576 * h);
     if (any_long) {
         const int n_l = shortb ? 0 : ch_ln;
-#pragma unroll 8
-        for (int i = 0; i < WL; i++) { // (every lane loads: an idle one line 0, and adds a zero)
-            const bool on = i < n_l;
-            const double v = X[on ? ch_l0 + i : 0], x = on ? v : 0.0;
-            a0 = a0 + x * x;
+        for (int i0 = 0; i0 < WL; i0 += 8) {
+            MDCT_LDS_PTR(const double) blk = X + ch_l0 + i0;
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (i0 + j < n_l ? blk : Z)[j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) a0 = a0 + v[j] * v[j];
         }
     }
     if (any_short) {
         const int n_s = shortb ? ch_sn : 0;
-#pragma unroll 4
-        for (int i = 0; i < WS; i++) {
-            const bool on = i < n_s;
-            MDCT_LDS_PTR(const double) p = X + (on ? ch_s0 + 3 * i : 0);
-            const double v0 = p[0], v1 = p[1], v2 = p[2];
-            const double x0 = on ? v0 : 0.0, x1 = on ? v1 : 0.0, x2 = on ? v2 : 0.0;
-            a0 = a0 + x0 * x0;
-            a1 = a1 + x1 * x1;
-            a2 = a2 + x2 * x2;
+        for (int i0 = 0; i0 < WS; i0 += 2) {
+            MDCT_LDS_PTR(const double) blk = X + ch_s0 + 3 * i0;
+            double v[6];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                MDCT_LDS_PTR(const double) p = i0 + j < n_s ? blk : Z;
+                v[3 * j] = p[3 * j]; v[3 * j + 1] = p[3 * j + 1]; v[3 * j + 2] = p[3 * j + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                a0 = a0 + v[3 * j] * v[3 * j];
+                a1 = a1 + v[3 * j + 1] * v[3 * j + 1];
+                a2 = a2 + v[3 * j + 2] * v[3 * j + 2];
+            }
         }
     }
     if (!shortb) {
@@ -415,7 +431,8 @@ __device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, 
     }
     int tp = 0;
     if (tot != 0.0) {
-        const double A = ((double) esum * 0x1.62e42fefa39efp-1 + dm_log_fast(prod)) / 576.0, B = tot / 576.0;
+        // (times 1 / 576 rounded, not divided: one more ulp in a value that is compared with a margin of 2e-9)
+        const double A = ((double) esum * 0x1.62e42fefa39efp-1 + dm_log_fast(prod)) * 0x1.c71c71c71c71cp-10, B = tot * 0x1.c71c71c71c71cp-10;
         if (__builtin_fabs(A) < 700.0 && B > 0x1p-1000 && B < 0x1p1000) { // (the reference's exp and quotient stay normal)
             const double v = 8.0 * (A - dm_log_fast(B));
             tp = (v < 0) ? (int) (v - 0.5) : (int) (v + 0.5);
@@ -460,6 +477,7 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
     double *prev = &L.prev[0][lane];
 #pragma unroll
     for (int k = 0; k < 18; k++) prev[64 * k] = blk[32 * k]; // the run's first "previous granule"
+    if (lane < 8) L.zero[lane] = 0.0;
     // the longest band-energy chains, long and short (lane & 31 = scalefactor band)
     int WL = 0, WS = 0;
     if (prep) {
