@@ -1,7 +1,7 @@
 // Host side of the batched encoder: owns the device buffers, cuts the frames of a call into
 // chunks that fit the scratch budget, and enqueues the kernels of every chunk on TWO HIP streams:
 //
-//   front stream (low priority):  k_fft | k_cw k_part k_psy k_filter k_mdct k_prep   of chunk c+1
+//   front stream (low priority):  k_fft | k_cw k_part k_psy k_filter k_mdct (k_prep: the records k_mdct lists)   of chunk c+1
 //   loop  stream (high priority): k_loop k_format                                   of chunk c
 //
 // k_loop keeps one wavefront per stream resident for a whole chunk (four per SIMD) and leaves room for
@@ -65,7 +65,7 @@ struct mp3mi_batch {
     mp3mi_batch_options opt; // as given at create time (defaults resolved where a field says "-1 default")
     unsigned *voided;        // device counter: streams whose file a call voided (the reference dies on them), since the last sync
     int32_t *status_dev;     // [S]: scratch of mp3mi_batch_stream_status
-    int prep_exact;          // MP3MI_TEST_PREP_EXACT: k_prep skips its fast first tier (tests)
+    int prep_exact;          // MP3MI_TEST_PREP_EXACT: k_prep over every record, its second tier only, instead of k_mdct's tail (tests)
     int test_flags;          // mp3mi_geom::test_flags
     int hdr_flags;           // copyright << 3 | original << 2 | emphasis (src/l3bitstream.c:330-334)
     int hdr_mode;            // header mode field: 0 stereo, 2 dual channel, 3 mono (src/common.h:233-236)
@@ -242,7 +242,7 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
         CHK(hipStreamCreateWithPriority(&b->lstream, hipStreamDefault, greatest));
     }
     {   // parts: as few as hold the batch with at most mp3mi_loop_resident() streams each, equal in size (a multiple of
-        // 64: the prep records come in blocks); options.loop_part_streams overrides (tests); options.loop_queue: one
+        // 64); options.loop_part_streams overrides (tests); options.loop_queue: one
         // part whatever the size, k_loop in its queue form
         const int resident = mp3mi_loop_resident();
         int np = (n_streams + resident - 1) / resident;
@@ -265,7 +265,7 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     b->last_slot = 0;
     b->overlap_calls = opt.call_overlap != 0;
     b->slot_base = 0;
-    b->test_flags = (int) (opt.test_flags & 15u) | ((opt.test_flags & MP3MI_TEST_CW_EXACT) ? 16 : 0);
+    b->test_flags = (int) (opt.test_flags & 15u) | ((opt.test_flags & MP3MI_TEST_CW_EXACT) ? 16 : 0) | ((opt.test_flags & MP3MI_TEST_PREP_LIST) ? 32 : 0);
     b->prep_exact = (opt.test_flags & MP3MI_TEST_PREP_EXACT) ? 1 : 0;
     b->hdr_flags = 0;
     b->hdr_mode = (channels == 1) ? 3 : 0;
@@ -359,7 +359,7 @@ extern "C" int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_
     if (opt_in) {
         if (opt_in->struct_size != sizeof(opt)) return MP3MI_ERR_ARG; // another version of the header
         opt = *opt_in;
-        if ((opt.test_flags & ~(unsigned) MP3MI_TEST_ALL_EXACT) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||
+        if ((opt.test_flags & ~(unsigned) (MP3MI_TEST_ALL_EXACT | MP3MI_TEST_PREP_LIST)) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||
             (opt.loop_part_streams % 64) != 0 || opt.psy_beside > 2)
             return MP3MI_ERR_ARG;
     }
@@ -423,8 +423,8 @@ extern "C" void mp3mi_batch_debug_enable(mp3mi_batch *b, int on) { b->debug = on
 
 extern "C" int mp3mi_batch_set_test_flags(mp3mi_batch *b, unsigned flags)
 {
-    if (!b || (flags & ~(unsigned) MP3MI_TEST_ALL_EXACT)) return MP3MI_ERR_ARG;
-    b->test_flags = (int) (flags & 15u) | ((flags & MP3MI_TEST_CW_EXACT) ? 16 : 0);
+    if (!b || (flags & ~(unsigned) (MP3MI_TEST_ALL_EXACT | MP3MI_TEST_PREP_LIST))) return MP3MI_ERR_ARG;
+    b->test_flags = (int) (flags & 15u) | ((flags & MP3MI_TEST_CW_EXACT) ? 16 : 0) | ((flags & MP3MI_TEST_PREP_LIST) ? 32 : 0);
     b->prep_exact = (flags & MP3MI_TEST_PREP_EXACT) ? 1 : 0;
     return MP3MI_OK;
 }

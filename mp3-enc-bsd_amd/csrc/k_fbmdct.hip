@@ -319,7 +319,7 @@ template <int CTRL> MP3MI_DEVFN double mdct_dpp_f64(double v)
 #endif
 // (a function of its own, not inlined: inside k_mdct's loop its presence alone took the kernel from 186 to 222 registers --
 // past the 192 that fit beside k_loop)
-__device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, MDCT_LDS_PTR(const double) X, bool wr, int bt, bool any_long, bool any_short, int WL, int WS,
+__device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, MDCT_LDS_PTR(const double) X, bool wr, int bt, bool any_long, bool any_short, int WL, int WS, bool spoil,
                                                          const mp3mi_psy_out *po, mp3mi_loop_prep *out, mp3mi_prep_fixlist *fix, unsigned rec)
 {
     const int band = wave_lane() & 31, h = wave_lane() >> 5;
@@ -328,6 +328,7 @@ __device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, 
     if (band < 21) { ch_l0 = T->sfb_l[band]; ch_ln = T->sfb_l[band + 1] - ch_l0; }
     if (band < 12) { ch_s0 = 3 * T->sfb_s[band]; ch_sn = T->sfb_s[band + 1] - T->sfb_s[band]; }
     const bool shortb = bt == 2;
+    const bool spoiled = spoil && rec % 3 == 0; // MP3MI_TEST_PREP_LIST: this record goes through the list, and what is written here must not survive
     // the psychoacoustic ratios of this lane's band, asked for now and used at the end
     const double *rp = shortb ? &po->ratio_s[band < 12 ? band : 0][0] : &po->ratio_l[band < 21 ? band : 0];
     const double r0 = rp[0], r1 = shortb ? rp[1] : 0.0, r2 = shortb ? rp[2] : 0.0;
@@ -419,12 +420,12 @@ __device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, 
         if (band < 21) {
             const double xmin = r0 * a0 / (double) ch_ln;
             const int se = mdct_ilog2_fast(a0, amb), sx = mdct_ilog2_fast(xmin, amb);
-            if (wr) { out->xmin[band] = xmin; out->sc_en[band] = se; out->sc_xm[band] = sx; }
+            if (wr) { out->xmin[band] = spoiled ? 0.0 : xmin; out->sc_en[band] = se; out->sc_xm[band] = sx; }
         }
     } else if (band < 12) {
         const double cnt = (double) ch_sn;
         if (wr) {
-            out->xmin[band * 3 + 0] = r0 * a0 / cnt;
+            out->xmin[band * 3 + 0] = spoiled ? 0.0 : r0 * a0 / cnt;
             out->xmin[band * 3 + 1] = r1 * a1 / cnt;
             out->xmin[band * 3 + 2] = r2 * a2 / cnt;
         }
@@ -443,6 +444,10 @@ __device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, 
             amb = true;
     }
     const int en_tot = mdct_ilog2_fast(tot, amb);
+    if (spoiled) {
+        amb = true;
+        tp = 170;
+    }
     if (band == 0 && wr) {
         out->q0 = tp - 70;
         out->sc_en_tot = en_tot;
@@ -532,7 +537,7 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
         // ---- the loop's stateless head for these two granules (see above); BEFORE the spectrum's stores: a function
         //      begins by waiting for every memory operation in flight ----
         if (prep)
-            mdct_prep_tail(T, (MDCT_LDS_PTR(const double)) &L.x[h][0], h == 0 || two, bt, bt0 != 2 || bt1 != 2, bt0 == 2 || bt1 == 2, WL, WS,
+            mdct_prep_tail(T, (MDCT_LDS_PTR(const double)) &L.x[h][0], h == 0 || two, bt, bt0 != 2 || bt1 != 2, bt0 == 2 || bt1 == 2, WL, WS, (geo.test_flags & 32) != 0,
                            &psy[rec0 + (size_t) kk * C], &prep[rec0 + (size_t) kk * C], fix, (unsigned) (rec0 + (size_t) kk * C));
         // element lane + 64 j of the two [band][18] blocks: j < 9 the lower track's, then the upper one's
         double *out_lo = xr_out + (rec_lo + (size_t) kk * C) * 576, *out_hi = xr_out + (rec_hi + (size_t) kk * C) * 576;

@@ -208,3 +208,16 @@ def test_quant_exact_tier_matches_estimate(emu, oracle):
             assert [out[s, :lens[s]].tobytes() for s in range(2)] == ref, "flags %d" % flags
     finally:
         run.close()
+
+
+def test_records_listed_by_the_mdct_tail_are_redone_by_k_prep(emu, oracle):
+    """The tail lists a record it cannot decide (probability ~1e-7: no input of the corpus does it) and k_prep works
+    through the list.  MP3MI_TEST_PREP_LIST makes the tail list every third record and spoil what it wrote for it:
+    the bytes are the oracle's only if the list path delivers."""
+    from stage_check import run_batch_with_stages, compare_prep_records
+    nf, rate, ch = 6, 44100, 2
+    pcm = np.stack([emu.synth(nf * 1152, ch, rate, 90 + s) for s in range(2)])
+    got, st = run_batch_with_stages(emu, pcm, rate, ch, 128, nf)
+    got_l, st_l = run_batch_with_stages(emu, pcm, rate, ch, 128, nf, flags=64)
+    assert got_l == got == [oracle.encode(pcm[s], rate, 128, ch)[0] for s in range(2)]
+    compare_prep_records(st["prep"], st_l["prep"], st["psy"])

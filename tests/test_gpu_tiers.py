@@ -68,3 +68,19 @@ def test_loop_prep_of_mdct_tail_equals_k_prep(product, rate, ch, kbps, S, nf, st
         assert n == S * 2 * nf * ch and short > 0 and listed < n // 1000
     finally:
         run.close()
+
+
+def test_records_listed_by_the_mdct_tail_are_redone_by_k_prep(product):
+    """MP3MI_TEST_PREP_LIST: the tail lists every third record and spoils what it wrote for it; k_prep's walk through
+    the list must restore every one of them (a third of 393 216 records), bit for bit."""
+    run = BatchRun(product, 4096, 44100, 2, 128, 24)
+    try:
+        base, base_len = run.encode(0)
+        tail, psy = run.fetch(5, PREP_DT), run.fetch(0, PSY_DT)
+        out, lens = run.encode(64)
+        listed = run.prep_fixups()
+        assert listed == (tail.size + 2) // 3, listed
+        assert np.array_equal(lens, base_len) and np.array_equal(out, base)
+        compare_prep_records(tail, run.fetch(5, PREP_DT), psy)
+    finally:
+        run.close()
