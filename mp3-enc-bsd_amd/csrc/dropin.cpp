@@ -1,6 +1,7 @@
 // The reference's per-frame Layer III call surface (include/mp3mi_dropin.h) over the HIP
 // kernels: one hidden default stream, n_streams = 1.  Host code only marshals caller-owned
-// arrays to and from the device and reproduces the caller-visible side effects of each
+// arrays to and from the device -- through host-mapped buffers that the kernels read and write in place (a call is
+// its launches and ONE wait; a few kilobytes per call cross the bus either way) -- and reproduces the caller-visible side effects of each
 // function (savebuf shift, buffer pointer advance, in-place sign flips, back pointer); every
 // number that ends up in the bitstream is computed by the kernels.
 //
@@ -16,8 +17,8 @@
 
 size_t mp3mi_psy_state_size(void);
 size_t mp3mi_loop_state_size(void);
-void mp3mi_launch_window_subband(const mp3mi_tables *T, double *ring, int off, const int16_t *new32, double *z, hipStream_t st);
 void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double *s, hipStream_t st);
+void mp3mi_launch_window_filter(const mp3mi_tables *T, double *ring, int off, const mp3mi_dropin_samples &in, double *zs, hipStream_t st);
 void mp3mi_launch_mdct_sub(const mp3mi_tables *T, double *sb, const int32_t *bt, double *xr, int stereo, int mode_gr, hipStream_t st);
 
 #define DIE(...)                                   \
@@ -45,36 +46,51 @@ struct loop_state_host {
     int32_t ref_abort;
 };
 
+// a buffer that crosses the boundary: host-mapped, h for the host code, d for the kernels
+template <typename T> struct io_buf {
+    T *h = nullptr, *d = nullptr;
+    void alloc(size_t bytes)
+    {
+        HIPOK(hipHostMalloc((void **) &h, bytes, hipHostMallocMapped));
+        HIPOK(hipHostGetDevicePointer((void **) &d, h, 0));
+        memset(h, 0, bytes);
+    }
+};
+
 struct DropIn {
     bool ready = false;
     int rate_idx = -1;
     hipStream_t st = 0;
     mp3mi_tables *T = nullptr;
     // psy
-    int16_t *pcm_d = nullptr;
+    io_buf<int16_t> pcm;
     float *el = nullptr, *es = nullptr, *h6 = nullptr, *bins = nullptr, *part_cb = nullptr;
     double *part_eb = nullptr;
     double *cw = nullptr;
     mp3mi_cw_fixlist *cw_fix = nullptr;
     void *psy_state = nullptr;
-    mp3mi_psy_out *psy1 = nullptr;
+    io_buf<mp3mi_psy_out> psy1;
     // filterbank
     double *ring = nullptr, *z_d = nullptr, *s_d = nullptr;
-    int16_t *new32 = nullptr;
     int off[2] = {0, 0};
+    // window_subband computes the filter_subband that follows it in the same launch: z[512] and s[32] arrive in a
+    // host-mapped buffer, and filter_subband hands s out when the z it is given is still the one it got (compared)
+    double *zs_h = nullptr, *zs_d = nullptr;
+    double last_z[512], last_s[32];
+    bool have_s = false;
     // mdct
-    double *sb_d = nullptr, *xr_d = nullptr;
-    int32_t *bt_d = nullptr;
+    io_buf<double> sb, xr;
+    io_buf<int32_t> bt;
     // loop
-    mp3mi_psy_out *psy4 = nullptr;
+    io_buf<mp3mi_psy_out> psy4;
     mp3mi_loop_prep *prep4 = nullptr;
-    int16_t *ix_d = nullptr;
-    mp3mi_frame_side *side_d = nullptr;
-    void *loop_state = nullptr;
-    int32_t *bits_d = nullptr, *bri_d = nullptr;
+    io_buf<int16_t> ix;
+    io_buf<mp3mi_frame_side> side;
+    io_buf<loop_state_host> loop_state;
+    io_buf<int32_t> bits, bri;
     bool loop_first = true;
     // format
-    uint8_t *win_d = nullptr;
+    io_buf<uint8_t> win; // the formatter's byte window: k_format places the frames, emit() reads them in place
     uint32_t *len_d = nullptr;
     size_t win_bytes = 0;
     long frames_done = 0, abs_emitted = 0, m_end = 0;
@@ -99,7 +115,7 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.T, sizeof(mp3mi_tables)));
     HIPOK(hipMemcpy(D.T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
     free(Th);
-    HIPOK(hipMalloc((void **) &D.pcm_d, 2304 * sizeof(int16_t)));
+    D.pcm.alloc(2304 * sizeof(int16_t));
     HIPOK(hipMalloc((void **) &D.el, MP3MI_HBLK_P * sizeof(float)));
     HIPOK(hipMalloc((void **) &D.part_eb, MP3MI_PART_P * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.part_cb, MP3MI_PART_P * sizeof(float)));
@@ -110,25 +126,25 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.cw_fix, mp3mi_cw_fixlist_bytes(4)));
     HIPOK(hipMalloc((void **) &D.psy_state, 2 * mp3mi_psy_state_size()));
     HIPOK(hipMemset(D.psy_state, 0, 2 * mp3mi_psy_state_size()));
-    HIPOK(hipMalloc((void **) &D.psy1, sizeof(mp3mi_psy_out)));
+    D.psy1.alloc(sizeof(mp3mi_psy_out));
     HIPOK(hipMalloc((void **) &D.ring, 2 * 512 * sizeof(double)));
     HIPOK(hipMemset(D.ring, 0, 2 * 512 * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.z_d, 512 * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.s_d, 32 * sizeof(double)));
-    HIPOK(hipMalloc((void **) &D.new32, 32 * sizeof(int16_t)));
-    HIPOK(hipMalloc((void **) &D.sb_d, sizeof(L3SBS)));
-    HIPOK(hipMalloc((void **) &D.xr_d, 4 * 576 * sizeof(double)));
-    HIPOK(hipMalloc((void **) &D.bt_d, 4 * sizeof(int32_t)));
-    HIPOK(hipMalloc((void **) &D.psy4, 4 * sizeof(mp3mi_psy_out)));
+    HIPOK(hipHostMalloc((void **) &D.zs_h, (512 + 32) * sizeof(double), hipHostMallocMapped));
+    HIPOK(hipHostGetDevicePointer((void **) &D.zs_d, D.zs_h, 0));
+    D.sb.alloc(sizeof(L3SBS));
+    D.xr.alloc(4 * 576 * sizeof(double));
+    D.bt.alloc(4 * sizeof(int32_t));
+    D.psy4.alloc(4 * sizeof(mp3mi_psy_out));
     HIPOK(hipMalloc((void **) &D.prep4, 4 * sizeof(mp3mi_loop_prep)));
-    HIPOK(hipMalloc((void **) &D.ix_d, 4 * 576 * sizeof(int16_t)));
-    HIPOK(hipMalloc((void **) &D.side_d, sizeof(mp3mi_frame_side)));
-    HIPOK(hipMalloc((void **) &D.loop_state, mp3mi_loop_state_size()));
-    HIPOK(hipMemset(D.loop_state, 0, mp3mi_loop_state_size()));
-    HIPOK(hipMalloc((void **) &D.bits_d, sizeof(int32_t)));
-    HIPOK(hipMalloc((void **) &D.bri_d, sizeof(int32_t)));
-    HIPOK(hipMalloc((void **) &D.len_d, sizeof(uint32_t)));
+    D.ix.alloc(4 * 576 * sizeof(int16_t));
+    D.side.alloc(sizeof(mp3mi_frame_side));
     if (sizeof(loop_state_host) != mp3mi_loop_state_size()) DIE("internal: loop state layout mismatch");
+    D.loop_state.alloc(sizeof(loop_state_host));
+    D.bits.alloc(sizeof(int32_t));
+    D.bri.alloc(sizeof(int32_t));
+    HIPOK(hipMalloc((void **) &D.len_d, sizeof(uint32_t)));
     D.rate_idx = rate_idx;
     D.ready = true;
 }
@@ -156,11 +172,9 @@ void emit(long upto, long base)
 {
     if (upto <= D.abs_emitted) return;
     const size_t n = (size_t) (upto - D.abs_emitted);
-    uint8_t *tmp = (uint8_t *) malloc(n);
     if (D.abs_emitted - base < 0 || (size_t) (upto - base) > D.win_bytes) DIE("internal: formatter window too small");
-    HIPOK(hipMemcpy(tmp, D.win_d + (D.abs_emitted - base), n, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; i++) D.putbits(D.bs, tmp[i], 8);
-    free(tmp);
+    const uint8_t *src = D.win.h + (D.abs_emitted - base); // (the stream was waited for by the caller)
+    for (size_t i = 0; i < n; i++) D.putbits(D.bs, src[i], 8);
     D.abs_emitted = upto;
 }
 
@@ -178,18 +192,15 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
     memcpy(savebuf + 768, buffer, 576 * sizeof(short));
     // present the 1344-sample window to k_fft as granule 2 of a mono pseudo-stream: its window
     // starts at sample 576*2 - 768 = 384
-    static int16_t host_pcm[2304];
-    memset(host_pcm, 0, sizeof(host_pcm));
-    memcpy(host_pcm + 384, savebuf, 1344 * sizeof(int16_t));
-    HIPOK(hipMemcpyAsync(D.pcm_d, host_pcm, sizeof(host_pcm), hipMemcpyHostToDevice, D.st));
+    memset(D.pcm.h, 0, 2304 * sizeof(int16_t));
+    memcpy(D.pcm.h + 384, savebuf, 1344 * sizeof(int16_t));
     mp3mi_geom g = mp3mi_make_geom(1, 1, D.rate_idx, 2, 1, 1);
     g.g0 = 2;
     g.n_gran = 1;
-    mp3mi_launch_fft(D.T, g, D.pcm_d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
-    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.part_eb, D.part_cb, D.psy1, D.st);
-    mp3mi_psy_out o;
-    HIPOK(hipMemcpyAsync(&o, D.psy1, sizeof(o), hipMemcpyDeviceToHost, D.st));
+    mp3mi_launch_fft(D.T, g, D.pcm.d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
+    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.part_eb, D.part_cb, D.psy1.d, D.st);
     HIPOK(hipStreamSynchronize(D.st));
+    const mp3mi_psy_out &o = *D.psy1.h;
     memcpy(ratio_d, o.ratio_l, sizeof(o.ratio_l));
     memcpy(ratio_ds, o.ratio_s, sizeof(o.ratio_s));
     *pe = o.pe;
@@ -205,17 +216,25 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
     // hidden stream is set up with any rate's tables (a later L3psycho_anal at another rate -- another layer in the same
     // process -- is refused)
     if (!D.ready) ensure(0);
-    HIPOK(hipMemcpyAsync(D.new32, *buffer, 32 * sizeof(int16_t), hipMemcpyHostToDevice, D.st));
+    mp3mi_dropin_samples in;
+    memcpy(in.v, *buffer, sizeof(in.v));
     *buffer += 32; // src/encode.c:307
-    mp3mi_launch_window_subband(D.T, D.ring + 512 * k, D.off[k], D.new32, D.z_d, D.st);
-    HIPOK(hipMemcpyAsync(z, D.z_d, 512 * sizeof(double), hipMemcpyDeviceToHost, D.st));
+    mp3mi_launch_window_filter(D.T, D.ring + 512 * k, D.off[k], in, D.zs_d, D.st);
     HIPOK(hipStreamSynchronize(D.st));
+    memcpy(z, D.zs_h, 512 * sizeof(double));
+    memcpy(D.last_z, D.zs_h, 512 * sizeof(double));
+    memcpy(D.last_s, D.zs_h + 512, 32 * sizeof(double));
+    D.have_s = true;
     D.off[k] = (D.off[k] + 480) & 511; // src/encode.c:313-314
 }
 
 extern "C" void filter_subband(double z[512], double s[32])
 {
     if (!D.ready) ensure(0);
+    if (D.have_s && memcmp(z, D.last_z, sizeof(D.last_z)) == 0) { // the z that window_subband just returned: its s is here already
+        memcpy(s, D.last_s, sizeof(D.last_s));
+        return;
+    }
     HIPOK(hipMemcpyAsync(D.z_d, z, 512 * sizeof(double), hipMemcpyHostToDevice, D.st));
     mp3mi_launch_filter_subband(D.T, D.z_d, D.s_d, D.st);
     HIPOK(hipMemcpyAsync(s, D.s_d, 32 * sizeof(double), hipMemcpyDeviceToHost, D.st));
@@ -229,15 +248,13 @@ extern "C" void mdct_sub(L3SBS *sb_sample, double (*mdct_freq)[2][576], int ster
     int32_t bt[4] = {0, 0, 0, 0};
     for (int gr = 0; gr < 2; gr++)
         for (int ch = 0; ch < stereo; ch++) bt[gr * 2 + ch] = (int32_t) l3_side->gr[gr].ch[ch].tt.block_type;
-    HIPOK(hipMemcpyAsync(D.sb_d, sb_sample, sizeof(L3SBS), hipMemcpyHostToDevice, D.st));
-    HIPOK(hipMemcpyAsync(D.bt_d, bt, sizeof(bt), hipMemcpyHostToDevice, D.st));
-    mp3mi_launch_mdct_sub(D.T, D.sb_d, D.bt_d, D.xr_d, stereo, mode_gr, D.st);
-    HIPOK(hipMemcpyAsync(sb_sample, D.sb_d, sizeof(L3SBS), hipMemcpyDeviceToHost, D.st));
-    static double xr[2][2][576];
-    HIPOK(hipMemcpyAsync(xr, D.xr_d, sizeof(xr), hipMemcpyDeviceToHost, D.st));
+    memcpy(D.sb.h, sb_sample, sizeof(L3SBS));
+    memcpy(D.bt.h, bt, sizeof(bt));
+    mp3mi_launch_mdct_sub(D.T, D.sb.d, D.bt.d, D.xr.d, stereo, mode_gr, D.st);
     HIPOK(hipStreamSynchronize(D.st));
+    memcpy(sb_sample, D.sb.h, sizeof(L3SBS));
     for (int gr = 0; gr < 2; gr++)
-        for (int ch = 0; ch < stereo; ch++) memcpy(mdct_freq[gr][ch], xr[gr][ch], sizeof(xr[0][0]));
+        for (int ch = 0; ch < stereo; ch++) memcpy(mdct_freq[gr][ch], D.xr.h + ((size_t) gr * 2 + ch) * 576, 576 * sizeof(double));
 }
 
 extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy_ratio *ratio, III_side_info_t *l3_side,
@@ -258,9 +275,9 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
         D.loop_first = false;
     }
     // records in the batch layout [gr][ch] for one stream, one frame
-    static mp3mi_psy_out rec[4];
-    static double xr[4][576];
-    memset(rec, 0, sizeof(rec));
+    mp3mi_psy_out *rec = D.psy4.h;
+    double (*xr)[576] = (double (*)[576]) D.xr.h;
+    memset(rec, 0, 4 * sizeof(mp3mi_psy_out));
     for (int gr = 0; gr < 2; gr++)
         for (int ch = 0; ch < C; ch++) {
             mp3mi_psy_out *r = &rec[gr * C + ch];
@@ -270,21 +287,15 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
             r->block_type = (int32_t) l3_side->gr[gr].ch[ch].tt.block_type;
             memcpy(xr[gr * C + ch], xr_org[gr][ch], sizeof(xr[0]));
         }
-    const int32_t bpf = bitsPerFrame;
-    HIPOK(hipMemcpyAsync(D.psy4, rec, sizeof(rec), hipMemcpyHostToDevice, D.st));
-    HIPOK(hipMemcpyAsync(D.xr_d, xr, sizeof(xr), hipMemcpyHostToDevice, D.st));
-    HIPOK(hipMemcpyAsync(D.bits_d, &bpf, sizeof(bpf), hipMemcpyHostToDevice, D.st));
+    *D.bits.h = bitsPerFrame;
     mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1, 0, 1);
     g.crc = crc;
-    mp3mi_launch_prep(D.T, g, D.xr_d, D.psy4, D.prep4, NULL, 0, D.st); // (the caller's spectrum: every record, the reference's walk)
-    mp3mi_launch_loop(D.T, g, D.xr_d, D.psy4, D.prep4, D.bits_d, D.loop_state, D.ix_d, D.side_d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
-    static int16_t ix[4][576];
-    mp3mi_frame_side sd;
-    loop_state_host ls;
-    HIPOK(hipMemcpyAsync(ix, D.ix_d, sizeof(ix), hipMemcpyDeviceToHost, D.st));
-    HIPOK(hipMemcpyAsync(&sd, D.side_d, sizeof(sd), hipMemcpyDeviceToHost, D.st));
-    HIPOK(hipMemcpyAsync(&ls, D.loop_state, sizeof(ls), hipMemcpyDeviceToHost, D.st));
+    mp3mi_launch_prep(D.T, g, D.xr.d, D.psy4.d, D.prep4, NULL, 0, D.st); // (the caller's spectrum: every record, the reference's walk)
+    mp3mi_launch_loop(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.bits.d, D.loop_state.d, D.ix.d, D.side.d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
     HIPOK(hipStreamSynchronize(D.st));
+    const int16_t (*ix)[576] = (const int16_t (*)[576]) D.ix.h;
+    const mp3mi_frame_side &sd = *D.side.h;
+    const loop_state_host &ls = *D.loop_state.h;
     // inputs the reference dies on: so does this call, with the reference's own words (its assert() prints the
     // expression and abort()s)
     if ((ls.ref_abort & 255) == MP3MI_DEV_ABORT_GLOBAL_GAIN) DIE("iteration_loop: Assertion `cod_info->global_gain < 256' failed (src/loop.c:358)");
@@ -347,16 +358,15 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
         D.frame_bytes = frame_bytes;
         D.si_bytes = si_bytes;
         D.win_bytes = (size_t) (WIN_FRAMES + 1) * frame_bytes;
-        if (D.win_d) HIPOK(hipFree(D.win_d));
-        HIPOK(hipMalloc((void **) &D.win_d, D.win_bytes));
-        HIPOK(hipMemset(D.win_d, 0, D.win_bytes));
+        if (D.win.h) HIPOK(hipHostFree(D.win.h));
+        D.win.alloc(D.win_bytes);
         D.abs_emitted = 0;
         D.m_end = 0;
     } else if (frame_bytes != D.frame_bytes)
         DIE("III_format_bitstream: frame length changed (padding is never used by the reference driver)");
     // signs of the spectrum go onto the quantised values, in place (src/l3bitstream.c:115-125)
-    static int16_t ix[4][576];
-    static mp3mi_frame_side sd;
+    int16_t (*ix)[576] = (int16_t (*)[576]) D.ix.h;
+    mp3mi_frame_side &sd = *D.side.h;
     memset(&sd, 0, sizeof(sd));
     for (int gr = 0; gr < 2; gr++)
         for (int ch = 0; ch < C; ch++) {
@@ -385,26 +395,18 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
     // slide the byte window so that this frame sits at index widx
     const long n = D.frames_done;
     const int widx = (int) (n < WIN_FRAMES ? n : WIN_FRAMES);
-    if (n > WIN_FRAMES) {
-        uint8_t *tmp = NULL;
-        HIPOK(hipMalloc((void **) &tmp, D.win_bytes));
-        HIPOK(hipMemsetAsync(tmp, 0, D.win_bytes, D.st));
-        HIPOK(hipMemcpyAsync(tmp, D.win_d + frame_bytes, D.win_bytes - (size_t) frame_bytes, hipMemcpyDeviceToDevice, D.st));
-        HIPOK(hipStreamSynchronize(D.st));
-        HIPOK(hipFree(D.win_d));
-        D.win_d = tmp;
+    if (n > WIN_FRAMES) { // (the window is host memory that the device writes: moved here, between two launches)
+        memmove(D.win.h, D.win.h + frame_bytes, D.win_bytes - (size_t) frame_bytes);
+        memset(D.win.h + D.win_bytes - (size_t) frame_bytes, 0, (size_t) frame_bytes);
     }
     const long base = (n - widx) * (long) frame_bytes;
-    const int32_t bpf = bitsPerFrame, bri = info->bitrate_index;
-    HIPOK(hipMemcpyAsync(D.ix_d, ix, sizeof(ix), hipMemcpyHostToDevice, D.st));
-    HIPOK(hipMemcpyAsync(D.side_d, &sd, sizeof(sd), hipMemcpyHostToDevice, D.st));
-    HIPOK(hipMemcpyAsync(D.bits_d, &bpf, sizeof(bpf), hipMemcpyHostToDevice, D.st));
-    HIPOK(hipMemcpyAsync(D.bri_d, &bri, sizeof(bri), hipMemcpyHostToDevice, D.st));
+    *D.bits.h = bitsPerFrame;
+    *D.bri.h = info->bitrate_index;
     mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1 << 30, widx, 1);
     g.hdr_mode = info->mode;
     g.crc = crc;
     g.hdr_flags = ((info->mode_ext & 3) << 4) | ((info->copyright & 1) << 3) | ((info->original & 1) << 2) | (info->emphasis & 3);
-    mp3mi_launch_format(D.T, g, D.ix_d, D.side_d, D.bits_d, D.bri_d, D.win_d, D.win_bytes, D.len_d, NULL, 0, NULL, D.st);
+    mp3mi_launch_format(D.T, g, D.ix.d, D.side.d, D.bits.d, D.bri.d, D.win.d, D.win_bytes, D.len_d, NULL, 0, NULL, D.st);
     HIPOK(hipStreamSynchronize(D.st));
     // bytes that are final now = everything up to the end of this frame's main data
     long bits = sd.resvDrain;

@@ -5,17 +5,6 @@
 // k_format directly with n_streams = 1 (dropin.cpp).
 #include "fbmdct_dev.h"
 
-// src/encode.c:287-316: ring[ch] is the 512-entry history x[k][], off the running offset
-__global__ void __launch_bounds__(64) k_window_subband(const mp3mi_tables *__restrict__ T, double *__restrict__ ring,
-                                                       int off, const int16_t *__restrict__ new32,
-                                                       double *__restrict__ z)
-{
-    const int lane = wave_lane();
-    if (lane < 32) ring[(31 - lane + off) & 511] = (double) new32[lane] * (1.0 / 32768.0);
-    __syncthreads();
-    for (int i = lane; i < 512; i += 64) z[i] = ring[(i + off) & 511] * T->enwindow[i];
-}
-
 // src/encode.c:361-409
 __global__ void __launch_bounds__(64) k_filter_subband(const mp3mi_tables *__restrict__ T, const double *__restrict__ z,
                                                        double *__restrict__ s)
@@ -30,6 +19,35 @@ __global__ void __launch_bounds__(64) k_filter_subband(const mp3mi_tables *__res
         double frow[31];
         for (int j = 0; j < 31; j++) frow[j] = T->filt[lane][j];
         s[lane] = fbm_matrix(y, frow);
+    }
+}
+
+// window_subband (src/encode.c:287-316: ring[ch] is the 512-entry history x[k][], off the running offset) and the
+// filter_subband that the reference's frame loops call right after it (src/musicin.c:640-642, 676-678, 722-724) in ONE launch: the 32 new samples arrive as a kernel argument, z[512] and s[32] go to zs -- a
+// host-mapped buffer -- so that the call is one launch and one wait instead of three copies, two launches and two waits.
+// filter_subband's arithmetic is that of the kernel above, operation by operation.
+__global__ void __launch_bounds__(64) k_window_filter(const mp3mi_tables *__restrict__ T, double *__restrict__ ring, int off,
+                                                      mp3mi_dropin_samples in, double *__restrict__ zs)
+{
+    __shared__ double zl[512];
+    __shared__ double y[64];
+    const int lane = wave_lane();
+    if (lane < 32) ring[(31 - lane + off) & 511] = (double) in.v[lane] * (1.0 / 32768.0);
+    __syncthreads();
+    for (int i = lane; i < 512; i += 64) {
+        const double v = ring[(i + off) & 511] * T->enwindow[i];
+        zl[i] = v;
+        zs[i] = v;
+    }
+    __syncthreads();
+    double acc = zl[lane];
+    for (int k = 1; k < 8; k++) acc = acc + zl[lane + 64 * k];
+    y[lane] = acc;
+    __syncthreads();
+    if (lane < 32) {
+        double frow[31];
+        for (int j = 0; j < 31; j++) frow[j] = T->filt[lane][j];
+        zs[512 + lane] = fbm_matrix(y, frow);
     }
 }
 
@@ -58,9 +76,9 @@ __global__ void __launch_bounds__(64) k_mdct_sub(const mp3mi_tables *__restrict_
     for (int i = lane; i < 576; i += 64) sbc[i] = sbc[mode_gr * 576 + i];
 }
 
-void mp3mi_launch_window_subband(const mp3mi_tables *T, double *ring, int off, const int16_t *new32, double *z, hipStream_t st)
+void mp3mi_launch_window_filter(const mp3mi_tables *T, double *ring, int off, const mp3mi_dropin_samples &in, double *zs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_window_subband, dim3(1), dim3(64), 0, st, T, ring, off, new32, z);
+    hipLaunchKernelGGL(k_window_filter, dim3(1), dim3(64), 0, st, T, ring, off, in, zs);
 }
 
 void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double *s, hipStream_t st)

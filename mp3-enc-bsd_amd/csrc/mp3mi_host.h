@@ -74,6 +74,8 @@ void mp3mi_launch_cw_fix(const mp3mi_geom &g, const float *bins, double *cw_mid,
 void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l,
                       const float *energy_s, double *cw_mid, float *hist6, const float *bins, mp3mi_cw_fixlist *fix,
                       void *psy_state, double *eb_all, float *cb_all, mp3mi_psy_out *out, hipStream_t st, int which = 3);
+/* the 32 new samples of a window_subband call, as a kernel argument (k_dropin.hip) */
+struct mp3mi_dropin_samples { int16_t v[32]; };
 void mp3mi_launch_filter(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, double *sbs, double *sb_dbg, hipStream_t st);
 /* records whose loop-prep values k_mdct's tail could not decide (k_fbmdct.hip): k_prep works through the list;
  * device memory, mp3mi_prep_fixlist_bytes(records) */

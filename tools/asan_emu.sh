@@ -27,6 +27,8 @@ for S, rate, ch, kbps, nf, s0 in [(2, 44100, 2, 128, 5, 5), (2, 48000, 2, 32, 4,
     assert all(got[s] == out[s, :lens[s]].tobytes() for s in range(S))
     out2, _ = run.encode(63)
     assert (out2 == out).all()
+    out3, _ = run.encode(64)  # the records k_mdct's tail lists, through k_prep
+    assert (out3 == out).all()
     run.close()
     print("sanitizer run ok:", rate, ch, kbps)
 # Layers I and II: whole-file (ragged, several chunks), streaming, every exact tier
