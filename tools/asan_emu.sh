@@ -48,3 +48,23 @@ for layer, rate, kbps, mode, nfr in [(2, 44100, 128, "j", 5), (1, 32000, 96, "se
     print("sanitizer run ok: layer", layer, rate, kbps, mode)
 PY
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 python3 _asan/run.py 2>&1 | grep -v "doesn't fully support makecontext"
+# The drop-in surface (dropin.cpp: host-mapped buffers, the filterbank's result cache): the reference's unchanged driver objects
+# (oracle/_ref/obj, where the reference was compiled) linked against the sanitized library, twelve frames, bytes compared
+# with the reference binary's.
+if [ -f $ROOT/oracle/_ref/obj/musicin.o ] && [ -x $ROOT/oracle/_ref/encode ]; then
+  (cd $ROOT/oracle && gcc -rdynamic -o $ROOT/tests/hipemu/_asan/encode_dropin_asan $(for f in musicin common ieeefloat portableio psy subs tables tonal; do echo _ref/obj/$f.o; done) \
+      _ref/obj/encode_nofb.o $ROOT/tests/hipemu/_asan/libmp3mi_emu_asan.so -lm -lstdc++ 2>/dev/null)
+  T=$(mktemp -d)
+  python3 - $ROOT $T <<'PY'
+import sys
+sys.path.insert(0, sys.argv[1] + "/tests")
+from mp3common import Mp3mi, SEED
+from test_dropin import write_wav
+write_wav(sys.argv[2] + "/a.wav", Mp3mi(emu=True).synth(1152 * 12, 2, 44100, 0, SEED), 2, 44100)
+PY
+  (cd $T && LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 \
+      $ROOT/tests/hipemu/_asan/encode_dropin_asan -s 44.1 -b 128 a.wav a.mp3 > drop.log 2>&1; $ROOT/oracle/_ref/encode -s 44.1 -b 128 a.wav r.mp3 > /dev/null 2>&1
+   if grep -q "ERROR: AddressSanitizer\|runtime error" drop.log; then grep -m5 "ERROR\|runtime error" drop.log; exit 1; fi
+   cmp a.mp3 r.mp3 && echo "sanitizer run ok: drop-in driver, 12 frames, bytes identical to the reference binary's")
+  rm -rf $T
+fi
