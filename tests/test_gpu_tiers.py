@@ -84,3 +84,15 @@ def test_records_listed_by_the_mdct_tail_are_redone_by_k_prep(product):
         compare_prep_records(tail, run.fetch(5, PREP_DT), psy)
     finally:
         run.close()
+
+
+def test_listed_records_in_a_batch_that_goes_through_k_loop_in_parts(product):
+    """The list of undecided records is one per batch and the items of a larger batch (two parts of 4096 streams,
+    two chunks) use it in turn: with every third record listed and spoiled, the bytes stay what they are."""
+    run = BatchRun(product, 8192, 44100, 2, 128, 12, options=product.options(chunk_frames=6))
+    try:
+        base, base_len = run.encode(0)
+        out, lens = run.encode(64)
+        assert np.array_equal(lens, base_len) and np.array_equal(out, base)
+    finally:
+        run.close()
