@@ -116,6 +116,24 @@ def current_profile(source_hash, streams, frames):
     return d, None
 
 
+def current_profile_l12(layer, source_hash, streams, frames):
+    """The same for `--layer N`: profiles/CURRENT_LAYER<N> names a profile of tools/gpu_l12_profile.sh."""
+    ptr = os.path.join(ROOT, "profiles", "CURRENT_LAYER%d" % layer)
+    if not os.path.exists(ptr):
+        return None, "no profiles/CURRENT_LAYER%d" % layer
+    name = open(ptr).read().strip()
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception as e:
+        return None, "profiles/%s unreadable: %s" % (name, e)
+    if d.get("source_hash") != source_hash:
+        return None, "profiles/%s was taken on sources %s, this library is %s: counters not quoted" % (name, d.get("source_hash"), source_hash)
+    if d.get("streams") != streams or d.get("frames") != frames:
+        return None, "profiles/%s is of %s x %s, this run of %d x %d" % (name, d.get("streams"), d.get("frames"), streams, frames)
+    d["file"] = name
+    return d, None
+
+
 def issue_roofline(k, streams, kernel_s_per_launch):
     """The bound the kernel actually runs against: VALU issue.  From the SQ counter passes of the profile (per-wave
     quad-cycles, MI355X_MICROARCH.md):
@@ -291,6 +309,16 @@ def main_l12(args, mp3, dev, cdev, rank, world, distributed):
         avg_launch_s = dom_ms / 1e3 / max(dom_n, 1)
         frames_per_launch = S * nf * args.steps / max(dom_n, 1)
         achieved = alg * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # HBM bytes of the dominant kernel per launch, from the committed counter profile of this build (if there is one)
+        prof, prof_why = current_profile_l12(layer, mp3.lib().mp3mi_source_hash().decode(), S, nf)
+        traffic = pipeline = None
+        if prof is not None:
+            pk = [v for k, v in prof["kernels"].items() if k.split("<")[0] == dom]
+            if pk and "hbm_read_GB_per_step" in pk[0]:
+                traffic = int((pk[0]["hbm_read_GB_per_step"] + pk[0]["hbm_write_GB_per_step"]) * 1e9 / max(pk[0].get("launches_per_step", 1), 1))
+            own = [v for k, v in prof["kernels"].items() if k.split("<")[0] in kt]
+            hbm = sum(v.get("hbm_read_GB_per_step", 0) + v.get("hbm_write_GB_per_step", 0) for v in own) * 1e9
+            pipeline = {"alg_bytes_per_step": alg * S * nf, "hbm_bytes_per_step": int(hbm), "ratio": round(hbm / (alg * S * nf), 2)}
         result = {
             "metric": "Layer %s stereo 44.1 kHz frames/s @%d kbps (bit-exact), MI355X" % ("I" if layer == 1 else "II", kbps),
             "value": round(S * nf * args.steps * world / dt, 1) if parity_ok else None, "unit": "frames/s", "n_gpus": world,
@@ -303,7 +331,10 @@ def main_l12(args, mp3, dev, cdev, rank, world, distributed):
                        "pcm": "mp3mi_synth_pcm_device, seed 0x%08x, streams rank*S .." % SEED,
                        "parallelism": "streams sharded across GPUs, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE), the step's bytes of the kernel over its launches",
+                         "traffic_source": ("profiles/" + prof["file"]) if prof is not None else None, "traffic_unavailable_because": prof_why,
+                         "pipeline": pipeline,
                          "algorithmic_bytes_per_frame": alg, "kernel_ms_per_launch": round(avg_launch_s * 1e3, 3),
                          "launches_per_step": dom_n // max(args.steps, 1),
                          "limited_by": "instruction issue and latency of the frame kernels, not HBM (kernels: what bounds each)",
