@@ -4,6 +4,8 @@
 #   2. rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, one step: HBM bytes per kernel)
 #   3. three SQ counter passes of one step          (instruction mix, wait shares)
 # -- merged into gpurun_out/<tag>/profile_layer<N>.json with the library's source hash.  The program goes directly after `--`.
+# Copy the result to profiles/<tag>_profile_layer<N>_<S>x<F>.json and name it in profiles/CURRENT_LAYER<N>: bench.py --layer N quotes
+# its counters while the library's source hash is the profile's.
 # Usage: tools/gpu_l12_profile.sh <tag> <layer>
 tag=$1; layer=$2
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
