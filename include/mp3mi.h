@@ -15,6 +15,20 @@
  * Every function fails loudly (non-zero return / abort with a message for the void drop-in
  * symbols, like the reference's exit()/abort()) when no gfx950 device is usable: there is no
  * CPU fallback in this library.
+ *
+ * Threads ("one thread or process per device"):
+ *   - A batch object (mp3mi_batch, mp3mi_l12_batch) belongs to ONE thread at a time: calls on the same object must not
+ *     overlap; the caller serialises them (any thread may make the next call once the previous one has returned --
+ *     every entry point selects the batch's own device for its duration and restores the caller's).
+ *   - DIFFERENT batch objects are independent: they may be created, used and destroyed concurrently from different
+ *     threads, on the same device or on different ones.  A batch owns its HIP streams, events and device buffers;
+ *     the only library-wide state is the construction of the constant tables, which the library serialises itself
+ *     (csrc/tables_host.cpp).  Two batches on one device share its compute units: correct, each at a part of
+ *     the rate (tests/test_threads.py: two threads, two batches, one device, interleaved calls, both bit-exact).
+ *   - mp3mi_encode_host / mp3mi_encode_host_ex / mp3mi_encode_host_async create a batch of their own per call: reentrant.
+ *   - The drop-in symbols (section 2 above) keep the reference's contract: ONE stream per process, one caller at a
+ *     time -- the reference's own functions hold their state in function statics (src/l3psy.c:130-160, src/loop.c:240).
+ *   - The mp3mi_debug_* accessors of diagnostic builds read device-global counters: single-threaded use only.
  */
 #ifndef MP3MI_H
 #define MP3MI_H
@@ -57,9 +71,11 @@ typedef struct mp3mi_batch_options {
                                  1 = one launch whose wavefronts take streams in turn */
     int32_t loop_part_streams; /* streams per part (multiple of 64); 0 = the resident wavefronts of the device */
     int32_t y_after_loop;     /* the filterbank / MDCT / prep kernels of a chunk wait for the loop kernel before it: -1 default (only with loop_queue), 0, 1 */
-    int32_t psy_beside;       /* what of the psychoacoustic stage runs beside a loop kernel: -1 default (by the number of parts),
-                                 0 nothing, 1 k_cw + k_part + k_psy, 2 k_psy only */
+    int32_t psy_beside;       /* what of the psychoacoustic stage runs beside a loop kernel: -1 default (k_cw + k_part + k_psy beside a
+                                 resident loop kernel, nothing beside the queue form), 0 nothing, 1 k_cw + k_part + k_psy, 2 k_psy only */
 } mp3mi_batch_options;
+/* mp3mi_batch_create_ex returns MP3MI_ERR_ARG for a value outside the ranges named above (the three-state fields take
+ * -1, 0, 1; psy_beside -1 .. 2; loop_queue 0, 1; loop_part_streams a multiple of 64; unknown test flags). */
 void mp3mi_batch_options_default(mp3mi_batch_options *opt);
 /* The same, then overridden by the MP3MI_* environment variables that tools/ and tests/ use (MP3MI_SCRATCH_MB,
  * MP3MI_CHUNK_FRAMES, MP3MI_{NOISE,PHASE,PSY,QUANT,PREP,CW}_EXACT, MP3MI_CALL_OVERLAP, MP3MI_NO_GATE, MP3MI_NO_PLACE,
@@ -102,10 +118,12 @@ int mp3mi_batch_sync(mp3mi_batch *b);
  *                                   when the last main data ends exactly on a slot boundary with headers still queued
  * The reference's process ends there and leaves no usable file.  A batch cannot end for one stream: the stream's status
  * records the first such event, its out_len becomes 0 for that call and every later one, the other streams are not
- * affected, and mp3mi_batch_sync returns MP3MI_ERR_REFERENCE_ABORT once.  (The drop-in symbols abort() with the
- * reference's message, as the reference does.)
+ * affected, and mp3mi_batch_sync returns MP3MI_ERR_REFERENCE_ABORT once -- the first sync after the call in which the
+ * event happened (whole-file and streaming calls alike; the final flush reports what it finds itself), while the
+ * status is there to be read.  (The drop-in symbols abort() with the reference's message, as the reference does.)
  * mp3mi_batch_stream_status waits for the work issued so far and copies the status of every stream of the most recent
- * streams (since the last reset / whole-file call) to status_host[n_streams]: 0, or code | frame << 8 where frame is the
+ * streams (since the last reset / whole-file call; after mp3mi_batch_flush: of the streams it ended, until the next
+ * encode starts new ones) to status_host[n_streams]: 0, or code | frame << 8 where frame is the
  * index of the frame it happened in (the number of frames for the final flush).  Returns the number of streams with a
  * non-zero status, or a negative MP3MI_ERR_*. */
 enum { MP3MI_STREAM_OK = 0, MP3MI_STREAM_ABORT_GLOBAL_GAIN = 1, MP3MI_STREAM_ABORT_HUFF_BITS = 2, MP3MI_STREAM_ABORT_FLUSH_SLOT = 3 };

@@ -65,6 +65,7 @@ struct mp3mi_batch {
     mp3mi_batch_options opt; // as given at create time (defaults resolved where a field says "-1 default")
     unsigned *voided;        // device counter: streams whose file a call voided (the reference dies on them), since the last sync
     int32_t *status_dev;     // [S]: scratch of mp3mi_batch_stream_status
+    bool status_kept;        // status_dev holds the status of the streams the last flush ended (their state is reset)
     int prep_exact;          // MP3MI_TEST_PREP_EXACT: k_prep over every record, its second tier only, instead of k_mdct's tail (tests)
     int test_flags;          // mp3mi_geom::test_flags
     int hdr_flags;           // copyright << 3 | original << 2 | emphasis (src/l3bitstream.c:330-334)
@@ -359,8 +360,10 @@ extern "C" int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_
     if (opt_in) {
         if (opt_in->struct_size != sizeof(opt)) return MP3MI_ERR_ARG; // another version of the header
         opt = *opt_in;
+        auto tri = [](int v) { return v >= -1 && v <= 1; }; // -1 default, 0 off, 1 on
         if ((opt.test_flags & ~(unsigned) (MP3MI_TEST_ALL_EXACT | MP3MI_TEST_PREP_LIST)) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||
-            (opt.loop_part_streams % 64) != 0 || opt.psy_beside > 2)
+            (opt.loop_part_streams % 64) != 0 || opt.psy_beside < -1 || opt.psy_beside > 2 || !tri(opt.call_overlap) || !tri(opt.gate) ||
+            !tri(opt.placement) || !tri(opt.y_after_loop) || (opt.loop_queue != 0 && opt.loop_queue != 1))
             return MP3MI_ERR_ARG;
     }
     // argument errors first: they are the caller's, whatever the machine
@@ -532,6 +535,11 @@ extern "C" int mp3mi_batch_flush(mp3mi_batch *b, uint8_t *out_dev, size_t out_st
     mp3mi_launch_stream_tail(g, 1, (int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->bits_per_frame, out_dev, out_stride,
                              b->out_base, b->carry, b->carry_len, out_len_dev, b->voided, b->lstream); // behind the last call's k_format
     CHK(hipGetLastError());
+    // the streams' status words go with the state the reset clears: keep what mp3mi_batch_stream_status is asked for
+    // after the flush (until the next encode starts new streams)
+    mp3mi_launch_status_gather(b->n_streams, (const int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->status_dev, b->lstream);
+    CHK(hipGetLastError());
+    b->status_kept = true;
     CHK(hipEventRecord(b->ev_done, b->lstream));
     b->have_done = true;
     return reset_impl(b); // the streams are over: the next encode_next starts new ones
@@ -569,6 +577,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     }
     const long fabs0 = b->frames_done;
     b->fresh = false;
+    b->status_kept = false;
     if (b->place_cost) CHK(hipMemsetAsync(b->place_cost, 0, sizeof(int) * (size_t) S, b->lstream)); // first chunk: order = identity
     CHK(hipMemsetAsync(out_dev, 0, out_stride * (size_t) S, b->lstream)); // (behind the formatter of the call before: it may be the same buffer)
     if (!whole_file && fabs0 > 0) { // the bytes earlier calls formatted but could not deliver lead the rows
@@ -791,9 +800,12 @@ extern "C" int mp3mi_batch_stream_status(mp3mi_batch *b, int32_t *status_host)
 {
     if (!b || !status_host) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
-    // (the state of the most recent streams: a whole-file call leaves it behind, the next call's reset clears it)
-    mp3mi_launch_status_gather(b->n_streams, (const int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->status_dev, b->lstream);
-    CHK(hipGetLastError());
+    // (the state of the most recent streams: a whole-file call leaves it behind, the next call's reset clears it; a
+    // flush gathers it before its reset)
+    if (!b->status_kept) {
+        mp3mi_launch_status_gather(b->n_streams, (const int32_t *) b->loop_state, (int) (mp3mi_loop_state_size() / 4), b->status_dev, b->lstream);
+        CHK(hipGetLastError());
+    }
     CHK(hipStreamSynchronize(b->stream));
     CHK(hipStreamSynchronize(b->lstream));
     CHK(hipMemcpy(status_host, b->status_dev, sizeof(int32_t) * (size_t) b->n_streams, hipMemcpyDeviceToHost));
@@ -891,8 +903,11 @@ static int encode_host_impl(int n_streams, int rate_hz, int channels, const int 
         rc = n_samples ? mp3mi_batch_encode_ragged(b, pcm_d, ns_d, n_frames, out_d, out_stride, len_d)
                        : mp3mi_batch_encode(b, pcm_d, n_frames, out_d, out_stride, len_d);
         if (rc == MP3MI_OK) rc = mp3mi_batch_sync(b);
-        if (rc == MP3MI_OK && (hipMemcpy(out, out_d, out_stride * n_streams, hipMemcpyDeviceToHost) != hipSuccess ||
-                               hipMemcpy(out_len, len_d, sizeof(uint32_t) * n_streams, hipMemcpyDeviceToHost) != hipSuccess))
+        // MP3MI_ERR_REFERENCE_ABORT means "done, and some stream is an input the reference dies on": that stream's out_len is
+        // 0 and every other stream's output is valid (mp3mi.h), so the results are delivered and the code is kept
+        if ((rc == MP3MI_OK || rc == MP3MI_ERR_REFERENCE_ABORT) &&
+            (hipMemcpy(out, out_d, out_stride * n_streams, hipMemcpyDeviceToHost) != hipSuccess ||
+             hipMemcpy(out_len, len_d, sizeof(uint32_t) * n_streams, hipMemcpyDeviceToHost) != hipSuccess))
             rc = MP3MI_ERR_HIP;
     }
     if (pcm_d) hipFree(pcm_d);

@@ -665,13 +665,7 @@ void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t 
     // W: as many wavefronts as fit the 160 KB of LDS next to the shared program; one workgroup per CU (that
     // is all the LDS allows), each working through its share of the batches
     const int n_task = g.n_streams * g.n_gran;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = mp3mi_current_cu_count();
     if (!(which & 1)) {
     } else if (g.channels == 2) {
         const int W = 12, WS = 15, nb = (n_task + W - 1) / W, nbs = (n_task + WS - 1) / WS;

@@ -358,8 +358,14 @@ __global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, i
         const int keep = (int) (end - fin); // <= 511 bytes of open slots plus the headers in between
         for (int i = lane; i < keep && i < MP3MI_CARRY_BYTES; i += 64) cr[i] = row[fin - base + i];
         if (lane == 0) {
-            // (a stream the reference died on delivers nothing more; mp3mi_batch_stream_status says why)
-            out_len[s] = loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)] ? 0u : (uint32_t) (fin - base);
+            // (a stream the reference died on delivers nothing more; mp3mi_batch_stream_status says why.  The sync after
+            // the call in which it happened reports it -- once: MP3MI_DEV_ABORT_REPORTED marks the word)
+            int32_t *st = &loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)];
+            if (*st != 0 && !(*st & MP3MI_DEV_ABORT_REPORTED)) {
+                *st |= MP3MI_DEV_ABORT_REPORTED;
+                if (voided) atomicAdd(voided, 1u);
+            }
+            out_len[s] = *st ? 0u : (uint32_t) (fin - base);
             carry_len[s] = keep < MP3MI_CARRY_BYTES ? keep : MP3MI_CARRY_BYTES;
             out_base[s] = fin;
         }
@@ -374,7 +380,10 @@ __global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, i
         if (lane == 0) {
             int32_t *st = &loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)];
             if (*st == 0 && fmt_flush_dies(n_done, m_end, slot)) *st = MP3MI_DEV_ABORT_FLUSH_SLOT | (int32_t) (n_done << 8);
-            if (*st != 0 && voided) atomicAdd(voided, 1u);
+            if (*st != 0 && !(*st & MP3MI_DEV_ABORT_REPORTED)) { // (an earlier call of the stream may have reported it already)
+                *st |= MP3MI_DEV_ABORT_REPORTED;
+                if (voided) atomicAdd(voided, 1u);
+            }
             out_len[s] = *st ? 0u : (uint32_t) (n > 0 ? n : 0);
             carry_len[s] = 0;
             out_base[s] = total;
@@ -385,7 +394,7 @@ __global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, i
 __global__ void __launch_bounds__(256) k_status_gather(int n_streams, const int32_t *__restrict__ loop_state, int loop_state_words, int32_t *__restrict__ status)
 {
     const int s = (int) (blockIdx.x * 256 + threadIdx.x);
-    if (s < n_streams) status[s] = loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)];
+    if (s < n_streams) status[s] = loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)] & ~MP3MI_DEV_ABORT_REPORTED;
 }
 
 void mp3mi_launch_status_gather(int n_streams, const int32_t *loop_state, int loop_state_words, int32_t *status, hipStream_t st)

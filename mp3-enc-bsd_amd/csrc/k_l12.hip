@@ -343,13 +343,7 @@ void mp3mi_launch_l12_psy(const mp3mi_tables_l12 *T, const l12_geom &g, const fl
 {
     const int nq = g.np - g.lb;
     const size_t n_item = (size_t) g.n_streams * ((nq + L12_PSY_RUN - 1) / L12_PSY_RUN) * g.channels;
-    static int n_wave = 0; // resident wavefronts: 12 per CU at the kernel's 168 registers
-    if (!n_wave) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_wave = 256 * 12;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_wave = prop.multiProcessorCount * 12;
-    }
+    const int n_wave = mp3mi_current_cu_count() * 12; // resident wavefronts: 12 per CU at the kernel's 168 registers
     hipLaunchKernelGGL(k12_psy, dim3((unsigned) (n_item < (size_t) n_wave ? n_item : (size_t) n_wave)), dim3(64), 0, st, T, g, erp, snr);
 }
 

@@ -63,6 +63,13 @@ struct loop_lds {
     // themselves go straight to memory
     int p23[2][2];      // part2_3_length (ResvFrameEnd adds the stuffing bits, src/reservoir.c:190-224)
     int preflag0[2];    // granule 0's preflag (src/loop.c:1172-1176)
+    // Region maxima without a walk over the values (loop_count_bits).  A quantised value is a monotone function of
+    // |xr| and a band is only ever scaled as a whole (pre-emphasis, amplification: rounding is monotone), so the line
+    // that holds a band's largest |xr| holds its largest quantised value in EVERY pass of the granule: found once per
+    // granule (loop_band_argmax), read once per pass by the band's lane.  Long, start and stop blocks: bands 0..20
+    // and "band 21", the lines above the last scalefactor band.
+    unsigned long long band_key[22]; // the band's largest |xr| as its bit pattern (non-negative doubles order as integers)
+    struct { int line, se; } band_ls[22]; // a line that holds it; the band's first line | end << 16
 };
 
 // The reference DIES on some inputs (an assert fails: tests/golden/coverage_notes.json, "reference_aborts").  A batch cannot
@@ -160,6 +167,29 @@ MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
     return loop_estimate(y34max, LOOP_FAST_EXP2F(-0.1875f * (float) q)) < 0.999f;
 }
 
+// Per granule (not short blocks): band_ls[b].line = a line of band b whose |xr| is the band's largest.  Every lane offers
+// its nine lines to their bands (an LDS maximum of the 64-bit patterns: lanes of one band serialise, once per granule),
+// then every line that equals its band's maximum writes its index -- equal values, equal quantised values: any winner will do.
+// (The spectrum is read back from LDS, a line at a time: held in registers across this it would not fit the kernel's 80.)
+MP3MI_DEVFN void loop_band_argmax(const mp3mi_tables *T, loop_lds &L, int lane)
+{
+    const unsigned long long bandpack = T->lane_bands[0][lane];
+    if (lane < 22) L.band_key[lane] = 0ull;
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int b = (int) ((bandpack >> (6 * j)) & 63ull);
+        atomicMax(&L.band_key[b], (unsigned long long) __builtin_bit_cast(long long, __builtin_fabs(L.xr[lane + 64 * j])));
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int b = (int) ((bandpack >> (6 * j)) & 63ull);
+        if (L.band_key[b] == (unsigned long long) __builtin_bit_cast(long long, __builtin_fabs(L.xr[lane + 64 * j]))) L.band_ls[b].line = lane + 64 * j;
+    }
+    wave_sync();
+}
+
 // What a pass needs to know about the quantised values besides the values themselves (which go to L.ix): the run
 // lengths of calc_runlen for long blocks, the two region maxima of short blocks.  Taken while every value is still
 // in a register, so that the nine values of a lane are never alive across the counting.
@@ -194,9 +224,8 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
         // estimate f of x^(3/4) + 0.4054 (>= 0.4054); from 2047.5 on the answer is the table's last entry
         float f = loop_estimate(y34[j], cq);
         f = __builtin_fminf(f, 2047.5f);
-        const float fl = __builtin_floorf(f);
-        p[j] = (int) fl;
-        const float d = __builtin_fabsf((f - fl) - 0.5f);
+        p[j] = (int) f; // f >= 0.4054: the conversion truncates = floor
+        const float d = __builtin_fabsf(LOOP_FRACTF(f) - 0.5f); // f - floor(f), exact
         gmax = __builtin_fmaxf(gmax, __builtin_fmaf(3.5e-6f, f, d));
     }
     if (force_exact || wave_any(gmax > guard)) {
@@ -204,7 +233,7 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
 #pragma unroll
         for (int j = 0; j < 9; j++) {
             const float f = __builtin_fminf(loop_estimate(y34[j], cq), 2047.5f);
-            const float d = __builtin_fabsf((f - __builtin_floorf(f)) - 0.5f);
+            const float d = __builtin_fabsf(LOOP_FRACTF(f) - 0.5f);
             if (force_exact || __builtin_fmaf(3.5e-6f, f, d) > guard) {
                 const double x = __builtin_fabs(L.xr[lane + 64 * j]) * ostep;
                 int pp = p[j];
@@ -226,6 +255,7 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
             L.ix[i] = (int16_t) p[j];
         }
     } else {
+#if defined(LOOP_RUNLEN_BALLOT) // (until round 4: nine pairs of lane masks and scalar bit scans, ~95 scalar instructions per pass)
 #pragma unroll
         for (int j = 0; j < 9; j++) {
             const unsigned long long nz = __ballot(p[j] != 0), big = __ballot(p[j] > 1);
@@ -233,6 +263,24 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
             qi.n_big = big ? 64 * j + 64 - __clzll((long long) big) : qi.n_big;
             L.ix[lane + 64 * j] = (int16_t) p[j];
         }
+#else
+        // min(p, 2) of the lane's nine lines as 2-bit fields of one word, slot j in bits 2j, 2j + 1: its highest set bit
+        // names the lane's last non-zero line, the highest set ODD bit its last line above 1; line + 1 = 64 slot + lane
+        // + 1 is the lane's key (an empty word gives slot -1: a key <= 0), and two wave maxima in lock-step are the run
+        // lengths.  All vector work: a scalar instruction costs this kernel more than a vector one.
+        unsigned w = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const unsigned c = (unsigned) (p[j] < 2 ? p[j] : 2);
+            w |= c << (2 * j);
+            L.ix[lane + 64 * j] = (int16_t) p[j];
+        }
+        const int t_nz = 31 - __clz((int) w), t_big = 31 - __clz((int) (w & 0x2AAAAu)); // -1 for an empty word
+        int kv[2] = {((t_nz >> 1) << 6) + lane + 1, ((t_big >> 1) << 6) + lane + 1};
+        wave_reduce_i32<0, 2>(kv); // (an empty lane's key is lane - 63 <= 0, and lane 63's is exactly 0: the maxima are >= 0)
+        qi.n_nz = kv[0];
+        qi.n_big = kv[1];
+#endif
     }
     wave_sync();
     return qi;
@@ -308,6 +356,33 @@ MP3MI_DEVFN int loop_pick(int da, int s0, int s1, int s2, int *sum)
     } else {
         if (c1 && s1 <= best) { choice = c1; best = s1; }
         if (c2 && s2 <= best) { choice = c2; best = s2; }
+    }
+    *sum = best;
+    return choice;
+}
+
+// The same decision on values that live in ONE LANE of vector registers (the sums as the reduction leaves them): the
+// descriptor is taken into a vector register too, so that every instruction of the decision is a vector one.
+// s01 = candidate 0's sum | candidate 1's << 16.  NC3: some region of the pass has a third candidate.
+template <bool NC3>
+MP3MI_DEVFN int loop_pick_v(int da, int s01, int s2, int *sum)
+{
+    int dav = da;
+#if !defined(MP3MI_EMU)
+    asm volatile("" : "+v"(dav));
+#endif
+    const int c0 = dav & 31, c1 = (dav >> 5) & 31;
+    const int s0 = s01 & 0xffff, s1 = (int) ((unsigned) s01 >> 16);
+    // the linbits pair compares with '<' (s1 + 1 <= s0), the others with '<='; no second candidate: never
+    const int t1 = c1 ? s1 + (c0 >= 15 ? 1 : 0) : 0x7fffffff;
+    const bool take1 = t1 <= s0;
+    int best = take1 ? s1 : s0, choice = take1 ? c1 : c0;
+    if (NC3) {
+        const int c2 = (dav >> 10) & 31;
+        const int t2 = c2 ? s2 : 0x7fffffff;
+        const bool take2 = t2 <= best;
+        best = take2 ? s2 : best;
+        choice = take2 ? c2 : choice;
     }
     *sum = best;
     return choice;
@@ -473,9 +548,13 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     // consecutive lines (32 pairs: one word each) per step straight out of L.ix, so a line is visited once,
     // by the region it belongs to, with that region's wave-uniform descriptor; lines from slot nslot on are
     // zero.  (Written out per region: arrays indexed by the region would live in scratch memory.)
+#if defined(LOOP_REGION_MAX_WALK)
     const int nzend = 64 * nslot;
+#endif
     auto region_max = [&](int lo, int hi) {
+#if defined(LOOP_REGION_MAX_WALK)
         hi = hi < nzend ? hi : nzend; // both even
+#endif
         int m = 0;
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
         for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // pair index of lane 0
@@ -490,8 +569,48 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         return m; // this lane's part
     };
     // the three region maxima and the count1 region's two bit sums: four reductions in lock-step
+#if defined(LOOP_REGION_MAX_WALK) // (until round 4: always by a walk over the regions' values)
     int red[4] = {c1part, region_max(0, a1), region_max(a1, a2), region_max(a2, e2)};
     wave_reduce_i32<1, 3>(red);
+#else
+    // Without window switching and with big values, a1 and a2 are edges of scalefactor bands (subdivide), so a region is a
+    // run of whole bands -- plus, at e2 = 2 big_values, possibly the head of one more.  Lane b < 22 reads the value of
+    // its band's arg-max line (loop_band_argmax): the band's maximum.  The head of the last band: a band maximum >= 2
+    // sits below n_big <= e2, i.e. inside region 2, and then the whole band's maximum IS the head's; a maximum of 0 is
+    // exact as well; only when region 2 comes out at 1 could the 1 lie past e2, and then -- as with window switching or
+    // stale addresses (big_values == 0), where region ends need not be band edges -- the regions are walked.
+    int red[4];
+    bool walk = true;
+    if (g.wsf == 0 && e2 != 0) {
+        int pb = 0, bs = 0x7fff, be = 0x7fff;
+        if (lane < 22) {
+            pb = L.ix[L.band_ls[lane].line];
+            const int se = L.band_ls[lane].se;
+            bs = se & 0xffff;
+            be = se >> 16;
+        }
+        red[0] = c1part;
+        red[1] = be <= a1 ? pb : 0;
+        red[2] = (bs >= a1 && be <= a2) ? pb : 0;
+        red[3] = (bs >= a2 && bs < e2) ? pb : 0;
+        wave_reduce_i32<1, 3>(red);
+        walk = a2 < e2 && red[3] <= 1;
+    }
+    if (walk) {
+        red[0] = c1part; red[1] = region_max(0, a1); red[2] = region_max(a1, a2); red[3] = region_max(a2, e2);
+        wave_reduce_i32<1, 3>(red);
+    }
+#if defined(MP3MI_EMU) // the test build checks every pass against the walk
+    else {
+        int mw[3] = {region_max(0, a1), region_max(a1, a2), region_max(a2, e2)};
+        wave_reduce_i32<0, 3>(mw);
+        if (mw[0] != red[1] || mw[1] != red[2] || mw[2] != red[3]) {
+            fprintf(stderr, "k_loop: band maxima %d %d %d differ from the walk's %d %d %d (a1 %d a2 %d e2 %d)\n", red[1], red[2], red[3], mw[0], mw[1], mw[2], a1, a2, e2);
+            abort();
+        }
+    }
+#endif
+#endif
     CBPROF(2); // region maxima + reduction
     {
         const int sum0 = red[0] & 0xffff, sum1 = (red[0] >> 16) & 0xffff; // table A vs table B (src/loop.c:1531-1580)
@@ -519,6 +638,42 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     CBPROF(3); // descriptors + region walks
     const bool third = (((da[0] | da[1] | da[2]) >> 10) & 31) != 0; // (descriptors of empty regions are zero)
     int s2v[3] = {0, 0, 0};
+#if !defined(LOOP_PICK_SCALAR)
+    // The sums stay where the reduction leaves them -- lane 63 of a vector register -- and new_choose_table's decision
+    // is taken THERE, by vector instructions on values no other lane holds; four lane reads bring back the bit count and
+    // the three tables.  As scalar code (until round 4: LOOP_PICK_SCALAR) the decision cost ~20 scalar instructions per
+    // region, and a scalar instruction costs this kernel more than a vector one.  An empty
+    // region's descriptor and sums are zero: table 0, no bits, as src/loop.c:1771-1777 leaves it.
+    {
+        int tot, ts[3];
+        if (third) { // five reductions in lock-step
+            int fs[5] = {s01p[0], s01p[1], s01p[2], s2p[0] | (s2p[1] << 16), s2p[2]};
+            wave_reduce_keep_i32<5, 0>(fs);
+            const int s2k[3] = {fs[3] & 0xffff, (int) ((unsigned) fs[3] >> 16), fs[4]};
+            tot = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                int best;
+                ts[r] = loop_pick_v<true>(da[r], fs[r], s2k[r], &best);
+                tot += best;
+            }
+        } else {
+            wave_reduce_keep_i32<3, 0>(s01p);
+            tot = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                int best;
+                ts[r] = loop_pick_v<false>(da[r], s01p[r], 0, &best);
+                tot += best;
+            }
+        }
+        bits += wave_readlane_i32(tot, 63);
+#pragma unroll
+        for (int r = 0; r < 3; r++) g.table_select[r] = wave_readlane_i32(ts[r], 63);
+    }
+    CBPROF(4); // cost reductions + picks
+    return bits;
+#endif
     if (third) { // five reductions in lock-step
         int fs[5] = {s01p[0], s01p[1], s01p[2], s2p[0] | (s2p[1] << 16), s2p[2]};
         wave_reduce_i32<5, 0>(fs);
@@ -717,6 +872,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];
     if (lane < 8) L.ix[576 + lane] = 0;
     if (lane == 0) L.xr[576] = 0.0;
+    if (lane < 22) L.band_ls[lane].se = T->sfb_l[lane] | (T->sfb_l[lane + 1] << 16);
     wave_sync();
     int ref_abort = __builtin_amdgcn_readfirstlane(L.st.ref_abort); // (sticky: the first event of the stream stands)
 
@@ -748,6 +904,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 g.address3 = L.st.addr[gr][ch][2];
                 const int nband = shortb ? 36 : 21;   // band lanes
                 float y34[9], y34max;
+#if defined(LOOP_REGION_MAX_WALK)
                 {
                     double xr[9];
 #pragma unroll
@@ -756,6 +913,21 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
 #pragma unroll
                     for (int j = 0; j < 9; j++) L.xr[lane + 64 * j] = xr[j];
                 }
+#else
+                // spectrum -> LDS; the bands' arg-max lines from there, while nothing else of the granule is in registers
+                // yet (the powers are taken from a second read: nine LDS loads per granule for ~20 registers at this point)
+#pragma unroll
+                for (int j = 0; j < 9; j++) L.xr[lane + 64 * j] = xr_all[rec * 576 + lane + 64 * j];
+                wave_sync();
+                if (!shortb) loop_band_argmax(T, L, wave_lane_here());
+                {
+                    const int ln = wave_lane_here();
+                    double xr[9];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) xr[j] = L.xr[ln + 64 * j];
+                    y34max = loop_power34(xr, y34);
+                }
+#endif
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
                 //      were computed by k_mdct's tail (k_prep); only the stateful decision of calc_scfsi happens here ----
@@ -1236,18 +1408,7 @@ size_t mp3mi_loop_state_size(void) { return sizeof(mp3mi_loop_state); }
 
 // workgroups that are resident together: four of LOOP_W = 4 wavefronts per CU (four wavefronts per SIMD: what stays
 // resident beside the feed-forward kernels, batch.cpp)
-static int loop_wg_cap(void)
-{
-    static int wg_cap = 0;
-    if (!wg_cap) {
-        int dev = 0;
-        const int per_cu = 4;
-        hipDeviceProp_t prop;
-        wg_cap = 256 * per_cu;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) wg_cap = prop.multiProcessorCount * per_cu;
-    }
-    return wg_cap;
-}
+static int loop_wg_cap(void) { return mp3mi_current_cu_count() * 4; }
 
 // streams one launch of k_loop holds resident, a wavefront each
 int mp3mi_loop_resident(void) { return loop_wg_cap() * LOOP_W; }

@@ -142,7 +142,10 @@ extern "C" int mp3mi_l12_batch_create(mp3mi_l12_batch **out, int layer, int n_st
         if (c.frame_bits / 8 > b->max_frame_bytes) b->max_frame_bytes = c.frame_bits / 8;
     }
     const size_t budget = (size_t) (scratch_mb ? scratch_mb : 32768u) << 20;
-    long cf = (long) (budget / (l12_per_frame_bytes(layer, channels, b->spf) * (size_t) n_streams));
+    // per stream the chunk's buffers also hold the lb warm-up passes and three extra filterbank granules, whatever its length
+    const size_t per_stream_fixed = (size_t) b->lb * channels * ((size_t) 3 * L12_ROW * sizeof(float) + 32 * sizeof(float)) + (size_t) 4 * channels * 576 * sizeof(double);
+    const size_t per_stream_budget = budget / (size_t) n_streams;
+    long cf = per_stream_budget > per_stream_fixed ? (long) ((per_stream_budget - per_stream_fixed) / l12_per_frame_bytes(layer, channels, b->spf)) : 1;
     if (cf < 1) cf = 1;
     if (cf > max_frames) cf = max_frames;
     b->chunk_frames = (int) cf;
@@ -270,10 +273,13 @@ static int l12_encode_impl(mp3mi_l12_batch *b, const int16_t *pcm_dev, const int
             b->kev.push_back(e);
         }
     }
+    // equal chunks (as batch.cpp cuts a Layer III call): a short remainder -- 191 + 191 + 1 frames of the 383-frame bench call --
+    // costs four full launches over all streams and recomputes the warm-up passes for one frame
+    const int nchunks = (n_frames + b->chunk_frames - 1) / b->chunk_frames, cfr = (n_frames + nchunks - 1) / nchunks;
     int chunk = 0;
-    for (int f0 = 0; f0 < n_frames; f0 += b->chunk_frames, chunk++) {
+    for (int f0 = 0; f0 < n_frames; f0 += cfr, chunk++) {
         hipEvent_t *ke = &b->kev[(size_t) chunk * 5];
-        const int nf = n_frames - f0 < b->chunk_frames ? n_frames - f0 : b->chunk_frames;
+        const int nf = n_frames - f0 < cfr ? n_frames - f0 : cfr;
         l12_geom g;
         memset(&g, 0, sizeof(g));
         g.n_streams = S; g.channels = C; g.layer = layer; g.rate_idx = b->rate_idx;

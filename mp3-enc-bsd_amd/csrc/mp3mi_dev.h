@@ -70,6 +70,7 @@ static inline int mp3mi_fft_swz_rt(int p)
 #define MP3MI_DEV_ABORT_GLOBAL_GAIN 1 /* assert( cod_info->global_gain < 256 ), src/loop.c:358 */
 #define MP3MI_DEV_ABORT_HUFF_BITS 2   /* assert( max_bits >= 0 ), src/loop.c:579 */
 #define MP3MI_DEV_ABORT_FLUSH_SLOT 3  /* assert( l ), src/formatBitstream.c:390, from BF_FlushBitstream's remainder call */
+#define MP3MI_DEV_ABORT_REPORTED 0x40000000 /* set in the status word once a streaming call has counted the stream in `voided` (k_format.hip) */
 
 /* Data movement the reference's FFT ends with; folded into the read-out tables fft_rd_* (tables_host.cpp) */
 enum {
@@ -194,7 +195,9 @@ typedef struct {
 #if defined(MP3MI_EMU)
 #define LOOP_FAST_SQRTF(x) __builtin_sqrtf(x)
 #define LOOP_FAST_EXP2F(x) __builtin_exp2f(x)
+#define LOOP_FRACTF(x) ((x) - __builtin_floorf(x)) /* exact for the quantiser's 0.4 <= x < 2048 */
 #else
+#define LOOP_FRACTF(x) __builtin_amdgcn_fractf(x)  /* v_fract_f32: x - floor(x), exact there */
 #define LOOP_FAST_SQRTF(x) __builtin_amdgcn_sqrtf(x)
 #define LOOP_FAST_EXP2F(x) __builtin_amdgcn_exp2f(x) /* |x| < 80 here: no denormal range to care for */
 #endif
@@ -341,6 +344,29 @@ MP3MI_DEVFN void wave_reduce_i32(int (&v)[NSUM + NMAX])
 #undef MP3MI_RSTEP
 #pragma unroll
     for (int k = 0; k < NSUM + NMAX; k++) v[k] = __builtin_amdgcn_readlane(v[k], 63);
+#endif
+}
+/* The same, but the results stay in LANE 63 of the vector registers (what the other lanes hold is unspecified): for a
+ * caller that goes on computing with them there and reads back only its final values (k_loop's table choice). */
+template <int NSUM, int NMAX>
+MP3MI_DEVFN void wave_reduce_keep_i32(int (&v)[NSUM + NMAX])
+{
+#if defined(MP3MI_EMU)
+    wave_reduce_i32<NSUM, NMAX>(v);
+#else
+    const int ident = 0;
+#define MP3MI_RSTEP(ctrl, rmask)                                                                   \
+    _Pragma("unroll") for (int k = 0; k < NSUM + NMAX; k++) {                                      \
+        const int o = MP3MI_DPP(v[k], ctrl, rmask);                                                \
+        v[k] = (k < NSUM) ? v[k] + o : (o > v[k] ? o : v[k]);                                      \
+    }
+    MP3MI_RSTEP(0xB1, 0xf)
+    MP3MI_RSTEP(0x4E, 0xf)
+    MP3MI_RSTEP(0x141, 0xf)
+    MP3MI_RSTEP(0x140, 0xf)
+    MP3MI_RSTEP(0x142, 0xf)
+    MP3MI_RSTEP(0x143, 0xf)
+#undef MP3MI_RSTEP
 #endif
 }
 /* wave maximum of unsigned values: DPP steps with the maximum folded into the move (a lane without a source reads 0) */

@@ -128,6 +128,14 @@ void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16
                          const mp3mi_frame_side *side, const int32_t *bits_per_frame,
                          const int32_t *bitrate_index, uint8_t *out, size_t out_stride,
                          uint32_t *out_len, int32_t *loop_state, int loop_state_words, unsigned *voided, hipStream_t st);
+/* Compute units of the CURRENT device (launch geometry of the persistent kernels).  Asked per call: batches of
+   several devices may be driven from one process, by several threads (mp3mi.h, "Threads") -- no cached static. */
+static inline int mp3mi_current_cu_count(void)
+{
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+}
 #endif
 
 #endif

@@ -19,6 +19,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 #include "mp3mi_host.h"
 #include "mp3mi_tables_gen.h"
@@ -71,21 +72,24 @@ static void tb_put(uint32_t id, int rate, const void *src, size_t bytes)
 #else
 /* product: copy out of the linked blob */
 extern "C" const unsigned char _binary_tables_blob_bin_start[], _binary_tables_blob_bin_end[];
+/* Threads: table builds are serialised (g_tables_mutex, taken by the three entry points at the end of this file), so
+ * the statics here and in the generator code below have one user at a time; the blob's checksum is verified once per
+ * process (std::call_once). */
 static int tb_failed = 0; /* some entry was missing or the blob is damaged: build_tables_unpinned reports it */
 static int tb_get(uint32_t id, int rate, void *dst, size_t bytes)
 {
     const unsigned char *b = _binary_tables_blob_bin_start;
     const size_t total = (size_t) (_binary_tables_blob_bin_end - _binary_tables_blob_bin_start);
-    static int checked = 0; /* 0 not yet, 1 good, -1 bad */
-    if (!checked) {
+    static std::once_flag checked_once;
+    static int checked = -1; /* 1 good, -1 bad */
+    std::call_once(checked_once, [&]() {
         uint64_t h = 0;
-        checked = -1;
         if (total > sizeof(tb_header) + 8 && !memcmp(b, "MP3MITB1", 8)) {
             memcpy(&h, b + total - 8, 8);
             if (h == tb_fnv(b, total - 8)) checked = 1;
         }
         if (checked < 0) fprintf(stderr, "mp3mi: the linked table blob (csrc/tables_blob.bin) is damaged\n");
-    }
+    });
     if (checked < 0) { tb_failed = 1; return -1; }
     tb_header hd;
     memcpy(&hd, b, sizeof(hd));
@@ -922,9 +926,12 @@ static void table_hashes(const mp3mi_tables *T, uint64_t *out)
 
 /* hashes of the table members for rate_idx as THIS host builds them (no comparison with the pins); names[i]
  * receives the member names.  Returns the number of members, or a negative error. */
+static std::mutex g_tables_mutex; /* one table build at a time (batches may be created from several threads: mp3mi.h) */
+
 extern "C" int mp3mi_tables_digest(int rate_idx, uint64_t *hashes, const char **names, int cap)
 {
     if (rate_idx < 0 || rate_idx > 2 || !hashes || cap < MP3MI_N_TABLE_MEMBERS) return -1;
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
     mp3mi_tables *T = (mp3mi_tables *) calloc(1, sizeof(mp3mi_tables));
     if (!T) return -1;
     const int rc = build_tables_unpinned(T, rate_idx);
@@ -938,6 +945,7 @@ extern "C" int mp3mi_tables_digest(int rate_idx, uint64_t *hashes, const char **
 
 extern "C" int mp3mi_build_tables(mp3mi_tables *T, int rate_idx)
 {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
     const int rc = build_tables_unpinned(T, rate_idx);
     if (rc == -7) return -8; /* the blob lacks an entry or is damaged: reported as MP3MI_ERR_TABLES */
     if (rc != 0) return rc;
@@ -1075,6 +1083,7 @@ static int build_tables_l12_unpinned(mp3mi_tables_l12 *T, int ri, int layer, flo
 
 extern "C" int mp3mi_build_tables_l12(mp3mi_tables_l12 *T, int rate_idx, int layer)
 {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
     static float s[L12_CB][L12_CB];
     const int rc = build_tables_l12_unpinned(T, rate_idx, layer, s);
     if (rc == -7) return -8;

@@ -88,6 +88,7 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
     return __shfl(v, l < 0 ? (int) (threadIdx.x & 63) : l, width);
 }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; } // fibers run one at a time
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; if (v > o) *p = v; return o; }
 #define __ATOMIC_RELEASE_EMU 0
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
@@ -126,7 +127,7 @@ static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 double hipemu_now();
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0}; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emu_event{0}; return hipSuccess; }
-enum { hipDeviceAttributeCanUseStreamWaitValue = 1, hipMallocSignalMemory = 2, hipStreamWaitValueGte = 0 };
+enum { hipDeviceAttributeCanUseStreamWaitValue = 1, hipMallocSignalMemory = 2, hipStreamWaitValueGte = 0, hipDeviceAttributeMultiprocessorCount = 3 };
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 1; return hipSuccess; }

@@ -109,3 +109,7 @@ def test_two_ranks_share_the_gpu(layer):
     assert [x["rank"] for x in ranks] == [0, 1]
     assert ranks[0]["first_stream"] + ranks[0]["streams"] <= ranks[1]["first_stream"]  # disjoint stream ranges
     assert ranks[0]["sample_digest"] != ranks[1]["sample_digest"]
+    # the CPU baseline is part of the line at every N (rank 0 times it after the timed region), and the roofline object
+    # names the bound the kernel runs against beside its HBM figure
+    assert d["cpu_baseline"] is not None and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["roofline"]["bound"] == "valu-issue" and d["roofline"]["unit"] == "GB/s" and 0 < d["roofline"]["frac"] < 1
