@@ -366,6 +366,10 @@ def main():
                     help="3: the Layer III path (BASELINE.json's metric, the default); 1 / 2: the Layer I / II path of SURVEY 8(f) row 4")
     ap.add_argument("--streams", type=int, default=0, help="override: streams per GPU")
     ap.add_argument("--frames", type=int, default=0, help="override: frames per stream")
+    ap.add_argument("--host-io", action="store_true",
+                    help="after the resident measurement (which stays `value`), time the same K steps through "
+                         "mp3mi_batch_encode_host_async -- PCM in page-locked host memory, file bytes back to it, both crossing PCIe "
+                         "chunk by chunk beside the kernels -- and add an `end_to_end` object to the line (SURVEY 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the timed CPU baseline (profiling passes); a small oracle parity check remains")
     args = ap.parse_args()
@@ -435,6 +439,47 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # End to end with PCIe (--host-io): the same K steps with the PCM in page-locked host memory and the bytes delivered to it.
+    end_to_end = None
+    if args.host_io:
+        h_pcm = wl.pcm.cpu().pin_memory()
+        h_out = torch.empty(wl.out.shape, dtype=torch.uint8).pin_memory()
+        h_len = torch.empty(S, dtype=torch.int32).pin_memory()
+        for _ in range(max(args.warmup, 1)):
+            wl.batch.encode_host_async(h_pcm, nf, h_out, h_len)
+            wl.batch.sync()
+        barrier()
+        st0 = wl.batch.host_io_stats()
+        th0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.batch.encode_host_async(h_pcm, nf, h_out, h_len)  # back to back: call n + 1's PCM goes up beside call n's last kernels
+        wl.batch.sync()
+        barrier()
+        dth = time.perf_counter() - th0
+        st1 = wl.batch.host_io_stats()
+        if distributed:
+            tmax = torch.tensor([dth], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dth = float(tmax.item())
+        same = bool(torch.equal(h_len, wl.out_len.cpu())) and all(
+            torch.equal(h_out[i, : int(h_len[i])], wl.out[i, : int(h_len[i])].cpu()) for i in range(0, S, max(1, S // 256)))
+        up_b, dn_b = st1["h2d_bytes"] - st0["h2d_bytes"], st1["d2h_bytes"] - st0["d2h_bytes"]
+        up_ms, dn_ms = st1["h2d_ms"] - st0["h2d_ms"], st1["d2h_ms"] - st0["d2h_ms"]
+        copy_ms_per_step = (up_ms + dn_ms) / args.steps
+        extra_ms = max(0.0, (dth - dt) / args.steps * 1e3)
+        end_to_end = {"frames_per_s": round(S * nf * args.steps * world / dth, 1), "ms_per_step": round(dth / args.steps * 1e3, 3),
+                      "ratio_to_resident": round(dt / dth, 4),
+                      "h2d_GBs": round(up_b / up_ms / 1e6, 2) if up_ms > 0 else None, "d2h_GBs": round(dn_b / dn_ms / 1e6, 2) if dn_ms > 0 else None,
+                      "h2d_GB_per_step": round(up_b / args.steps / 1e9, 3), "d2h_GB_per_step": round(dn_b / args.steps / 1e9, 3),
+                      "copy_ms_per_step": round(copy_ms_per_step, 2),
+                      "overlap": round(1.0 - min(1.0, extra_ms / copy_ms_per_step), 4) if copy_ms_per_step > 0 else None,
+                      "bytes_equal_resident_path": same,
+                      "how": "mp3mi_batch_encode_host_async on page-locked buffers: the PCM goes up as a 2-D copy per chunk on a copy stream of its "
+                             "own (the chunk's first kernel waits for it), the call's bytes come down in one copy behind its last formatter, beside "
+                             "the next call's kernels; GB/s = bytes / summed copy durations (HIP events on the copy streams); overlap = share of the "
+                             "copy time that did not lengthen the step"}
+        del h_pcm, h_out, h_len
+
     # parity spot check on the exact device bytes of THIS rank (every rank checks its own streams; the CPU baseline is
     # timed on rank 0 -- at every N, AFTER the timed region: the other ranks do their small check and wait at the
     # parity vote below -- so that every bench line carries it)
@@ -448,6 +493,8 @@ def main():
     got = [out_h[k, : len_h[k]].tobytes() for k in range(len(idx))]
     fps, refs = cpu_baseline(pcm_sample, rate, kb_sample, C, cores)
     bad = [int(idx[k]) for k in range(len(idx)) if got[k] != refs[k]]
+    if end_to_end is not None and not end_to_end["bytes_equal_resident_path"]:
+        bad.append(-1)  # the host path delivered other bytes than the device path: a parity failure like any other
     cpu = None
     if timed_baseline:
         cpu = {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
@@ -527,6 +574,7 @@ def main():
                          "limited_by": "instruction issue of the dominant kernel, not HBM (issue: share of the SIMDs' VALU issue capacity in use; kernels: what bounds each)",
                          "issue": issue, "pipeline": pipeline, "kernels": kernels, "source_hash": src_hash},
             "cpu_baseline": cpu,
+            "end_to_end": end_to_end,
             "ranks": ranks,
             "parity_spot_check": {"streams_per_rank": len(idx), "bit_exact": parity_ok, "mismatching_streams_rank0": bad,
                                   "witness": "oracle/liboracle.so" + (" + oracle/_ref/encode" if cpu and cpu["kind"] == "reference" else "")},

@@ -73,13 +73,16 @@ typedef struct mp3mi_batch_options {
     int32_t y_after_loop;     /* the filterbank / MDCT / prep kernels of a chunk wait for the loop kernel before it: -1 default (only with loop_queue), 0, 1 */
     int32_t psy_beside;       /* what of the psychoacoustic stage runs beside a loop kernel: -1 default (k_cw + k_part + k_psy beside a
                                  resident loop kernel, nothing beside the queue form), 0 nothing, 1 k_cw + k_part + k_psy, 2 k_psy only */
+    int32_t dropin_lookahead; /* the drop-in symbols' look-ahead (mp3mi_dropin.h): -1 default = 1 both, 0 none, 2 the filterbank's only,
+                                 3 L3psycho_anal's only.  Not a property of a batch: the hidden default stream of the drop-in symbols
+                                 reads it through mp3mi_batch_options_from_env (MP3MI_DROPIN_LOOKAHEAD) */
 } mp3mi_batch_options;
 /* mp3mi_batch_create_ex returns MP3MI_ERR_ARG for a value outside the ranges named above (the three-state fields take
- * -1, 0, 1; psy_beside -1 .. 2; loop_queue 0, 1; loop_part_streams a multiple of 64; unknown test flags). */
+ * -1, 0, 1; psy_beside -1 .. 2; dropin_lookahead -1 .. 3; loop_queue 0, 1; loop_part_streams a multiple of 64; unknown test flags). */
 void mp3mi_batch_options_default(mp3mi_batch_options *opt);
 /* The same, then overridden by the MP3MI_* environment variables that tools/ and tests/ use (MP3MI_SCRATCH_MB,
  * MP3MI_CHUNK_FRAMES, MP3MI_{NOISE,PHASE,PSY,QUANT,PREP,CW}_EXACT, MP3MI_CALL_OVERLAP, MP3MI_NO_GATE, MP3MI_NO_PLACE,
- * MP3MI_LOOP_PARTS, MP3MI_LOOP_PART_STREAMS, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE).  This is the ONLY place the library
+ * MP3MI_LOOP_PARTS, MP3MI_LOOP_PART_STREAMS, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE, MP3MI_DROPIN_LOOKAHEAD).  This is the ONLY place the library
  * reads its environment: mp3mi_batch_create calls it once; mp3mi_batch_create_ex never does. */
 void mp3mi_batch_options_from_env(mp3mi_batch_options *opt);
 
@@ -189,7 +192,33 @@ int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, float *all_ke
 int mp3mi_batch_total_timing(mp3mi_batch *b, double *loop_kernel_ms, double *all_kernels_ms,
                              long *loop_kernel_launches, long *calls);
 
-/* Host-buffer convenience wrapper (tests, smoke): copies PCM up, encodes, copies results back.
+/* Host buffers in, host buffers out, OVERLAPPED with the encode -- what the reference's driver does frame by frame with
+ * get_audio / read_samples and fwrite (/root/reference/src/encode.c:123-269, src/common.c:843-868), for a whole batch:
+ * the call's PCM crosses PCIe chunk by chunk on a copy stream while the chunks before it are encoded, and the call's
+ * file bytes come back in one copy behind its last formatter; with calls issued back to back the next call's PCM goes up
+ * and this call's bytes come down beside the next call's kernels (two calls may be in flight; the batch keeps two
+ * device copies of PCM and output).  out_stride = mp3mi_batch_out_stride(b, max_frames) makes the download one plain copy.
+ *   pcm_host: [n_streams][n_frames*1152][channels]; out_host: [n_streams][out_stride], out_stride >= n_frames * the largest
+ *   frame size + 1; out_len_host: [n_streams].  A whole-file call like mp3mi_batch_encode: every stream starts afresh.
+ * Asynchronous: returns once everything is enqueued; the buffers must stay valid -- and the results are there -- when
+ * mp3mi_batch_sync returns (which reports MP3MI_ERR_REFERENCE_ABORT as for device calls).  Page-locked buffers
+ * (mp3mi_host_alloc, hipHostMalloc, hipHostRegister) move at the full PCIe rate beside the kernels; pageable memory
+ * works, but the runtime stages it and the call blocks while it does.  bench.py --host-io measures this path. */
+int mp3mi_batch_encode_host_async(mp3mi_batch *b, const int16_t *pcm_host, int n_frames, uint8_t *out_host, size_t out_stride,
+                                  uint32_t *out_len_host);
+/* Bytes moved and time spent inside the copies (HIP events on the two copy streams) over all host-buffer calls since the
+ * batch was created; waits for the calls issued so far. */
+typedef struct mp3mi_host_io_stats {
+    double h2d_bytes, d2h_bytes; /* PCM up, file bytes down */
+    double h2d_ms, d2h_ms;       /* summed durations of the copies */
+    long calls;
+} mp3mi_host_io_stats;
+int mp3mi_batch_host_io_stats(mp3mi_batch *b, mp3mi_host_io_stats *st);
+/* page-locked host memory for the call above, for callers that do not link HIP themselves; NULL on failure */
+void *mp3mi_host_alloc(size_t bytes);
+void mp3mi_host_free(void *p);
+
+/* Host-buffer convenience wrapper (tests, smoke): a batch of its own per call, mp3mi_batch_encode_host_async, sync.
  * pcm: [n_streams][n_frames*1152*channels]; out: [n_streams][out_stride]; out_len: [n_streams]. */
 int mp3mi_encode_host(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all,
                       const int16_t *pcm, int n_frames, uint8_t *out, size_t out_stride,

@@ -152,6 +152,21 @@ void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int l3_enc[2][2
  * the stream and resets the formatter. */
 void III_FlushBitstream(void);
 
+/* LOOK-AHEAD.  Served one call at a time, a frame of the reference's loop costs 79 waits for the device.  The library
+ * therefore reads ahead -- only in memory the caller has already handed over:
+ *   - window_subband / filter_subband: the four L3psycho_anal calls of a frame were given &buffer[ch][0] and
+ *     &buffer[ch][576] (src/musicin.c:754-758); when a channel's first window_subband of the frame starts at that same
+ *     &buffer[ch][0], the 36 slots of both channels are computed in one launch and handed out call by call, while every
+ *     call's pointer is where the previous one left it and its 32 samples are still what was read;
+ *   - L3psycho_anal: when a channel's two calls of the frame BEFORE were given p and p + 576 and the first call of this
+ *     frame is given the same p, both granules are analysed in one launch; the second call is served from it if its
+ *     pointer, its samples and the delay line are what was read.
+ * A caller that moves or rewrites its buffers in between gets the call-by-call service (the channel's state is put back
+ * to where the calls served so far left it): tests/test_dropin.py, oracle/dropin_probe.c -- bit-exact either way.  7 waits
+ * per frame instead of 79 under the reference's driver.  MP3MI_DROPIN_LOOKAHEAD = 0 none, 2 / 3 one of the two
+ * (mp3mi_batch_options_from_env).  mp3mi_dropin_waits: waits for the device so far (tests, tools). */
+long mp3mi_dropin_waits(void);
+
 #ifdef __cplusplus
 }
 #endif

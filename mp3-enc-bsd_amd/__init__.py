@@ -35,7 +35,7 @@ class BatchOptions(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("scratch_mb", ctypes.c_uint32), ("chunk_frames", ctypes.c_int32),
                 ("test_flags", ctypes.c_uint32), ("call_overlap", ctypes.c_int32), ("gate", ctypes.c_int32),
                 ("placement", ctypes.c_int32), ("loop_queue", ctypes.c_int32), ("loop_part_streams", ctypes.c_int32),
-                ("y_after_loop", ctypes.c_int32), ("psy_beside", ctypes.c_int32)]
+                ("y_after_loop", ctypes.c_int32), ("psy_beside", ctypes.c_int32), ("dropin_lookahead", ctypes.c_int32)]
 
 
 def default_options(**kw):
@@ -76,6 +76,11 @@ def lib():
         L.mp3mi_batch_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_batch_sync.argtypes = [ctypes.c_void_p]
+        L.mp3mi_batch_encode_host_async.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_host_io_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.mp3mi_host_alloc.argtypes = [ctypes.c_size_t]
+        L.mp3mi_host_alloc.restype = ctypes.c_void_p
+        L.mp3mi_host_free.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
         L.mp3mi_batch_total_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -160,6 +165,21 @@ class Batch:
     def _check(self, rc, what):
         if rc != 0:
             raise Mp3miError("%s failed with %d" % (what, rc))
+
+    def encode_host_async(self, pcm, n_frames, out, out_len):
+        """Host tensors in and out (pinned: torch's pin_memory), PCM up and file bytes down chunk by chunk beside the
+        kernels (mp3mi_batch_encode_host_async); the results are there after sync()."""
+        assert not pcm.is_cuda and not out.is_cuda and not out_len.is_cuda and pcm.is_contiguous() and out.is_contiguous()
+        self._check(self.L.mp3mi_batch_encode_host_async(self.h, pcm.data_ptr(), n_frames, out.data_ptr(), out.shape[1], out_len.data_ptr()),
+                    "mp3mi_batch_encode_host_async")
+
+    def host_io_stats(self):
+        """{h2d_bytes, d2h_bytes, h2d_ms, d2h_ms, calls} over the host-buffer calls so far (waits for them)"""
+        class S(ctypes.Structure):
+            _fields_ = [("h2d_bytes", ctypes.c_double), ("d2h_bytes", ctypes.c_double), ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("calls", ctypes.c_long)]
+        st = S()
+        self._check(self.L.mp3mi_batch_host_io_stats(self.h, ctypes.byref(st)), "mp3mi_batch_host_io_stats")
+        return {k: getattr(st, k) for k, _ in S._fields_}
 
     def encode_next(self, pcm, n_frames, out, out_len):
         """Streaming: the NEXT n_frames frames of every stream (pcm holds only these); out / out_len receive the file

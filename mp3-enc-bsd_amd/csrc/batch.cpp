@@ -92,6 +92,27 @@ struct mp3mi_batch {
     uint8_t *carry;          // [S][MP3MI_CARRY_BYTES]: file bytes formatted but not final yet
     int32_t *carry_len;      // [S]
     int debug, last_nf;
+    // Host-buffer calls (mp3mi_batch_encode_host_async): the call's PCM goes up and its file bytes come down chunk by
+    // chunk on two copy streams of their own, beside the kernels; two calls may be in flight, so the device copies of
+    // PCM and output exist twice (slot = call number & 1).  Created with the first such call.
+    struct host_io {
+        bool ready;
+        hipStream_t h2d, d2h;
+        int16_t *pcm[2];          // [S][max_frames * 1152][C]
+        uint8_t *out[2];          // [S][out_stride]
+        uint32_t *len[2];         // [S]
+        size_t out_stride;
+        hipEvent_t pcm_free[2], out_free[2]; // the slot's PCM has been read by its last kernel / its output by its last copy
+        bool pcm_used[2], out_used[2];
+        std::vector<hipEvent_t> ev_fmt[2];   // per chunk: the chunk's formatter is done
+        std::vector<hipEvent_t> t_up[2], t_dn[2]; // per chunk two events around the copy (the second is what consumers wait for)
+        int n_chunks[2];
+        double bytes_up[2], bytes_dn[2];
+        bool pending[2];
+        unsigned call_no;
+        double tot_up_bytes, tot_dn_bytes, tot_up_ms, tot_dn_ms;
+        long tot_calls;
+    } hio;
     // HIP-event timing of the calls: two sets taken in turn, so that a call can be issued while the one before still
     // runs; a set is read out (harvested) when its turn comes again -- which also keeps the host at most two calls
     // ahead of the device -- or when the timing is asked for
@@ -159,7 +180,7 @@ extern "C" void mp3mi_batch_options_default(mp3mi_batch_options *o)
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->struct_size = (uint32_t) sizeof(*o);
-    o->call_overlap = o->gate = o->placement = o->y_after_loop = o->psy_beside = -1;
+    o->call_overlap = o->gate = o->placement = o->y_after_loop = o->psy_beside = o->dropin_lookahead = -1;
 }
 
 // The one place the library reads its environment (mp3mi.h): the knobs of tools/ and tests/.
@@ -184,6 +205,7 @@ extern "C" void mp3mi_batch_options_from_env(mp3mi_batch_options *o)
     if ((e = getenv("MP3MI_LOOP_PART_STREAMS")) && atoi(e) >= 64) o->loop_part_streams = atoi(e) / 64 * 64;
     if ((e = getenv("MP3MI_Y_AFTER_LOOP"))) o->y_after_loop = atoi(e) != 0;
     if ((e = getenv("MP3MI_PSY_BESIDE"))) o->psy_beside = atoi(e) == 2 ? 2 : (atoi(e) ? 1 : 0);
+    if ((e = getenv("MP3MI_DROPIN_LOOKAHEAD")) && atoi(e) >= 0 && atoi(e) <= 3) o->dropin_lookahead = atoi(e);
 }
 
 // Fills *b step by step; on any failure the caller destroys the partially built object (every pointer and handle
@@ -362,7 +384,7 @@ extern "C" int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_
         opt = *opt_in;
         auto tri = [](int v) { return v >= -1 && v <= 1; }; // -1 default, 0 off, 1 on
         if ((opt.test_flags & ~(unsigned) (MP3MI_TEST_ALL_EXACT | MP3MI_TEST_PREP_LIST)) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||
-            (opt.loop_part_streams % 64) != 0 || opt.psy_beside < -1 || opt.psy_beside > 2 || !tri(opt.call_overlap) || !tri(opt.gate) ||
+            (opt.loop_part_streams % 64) != 0 || opt.psy_beside < -1 || opt.psy_beside > 2 || opt.dropin_lookahead < -1 || opt.dropin_lookahead > 3 || !tri(opt.call_overlap) || !tri(opt.gate) ||
             !tri(opt.placement) || !tri(opt.y_after_loop) || (opt.loop_queue != 0 && opt.loop_queue != 1))
             return MP3MI_ERR_ARG;
     }
@@ -409,6 +431,21 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
         if (e) hipEventDestroy(e);
     for (int k = 0; k < 2; k++)
         for (size_t i = 0; i < b->ts[k].loop_ev.size(); i++) hipEventDestroy(b->ts[k].loop_ev[i]);
+    if (b->hio.ready) {
+        hipStreamSynchronize(b->hio.h2d);
+        hipStreamSynchronize(b->hio.d2h);
+        for (int i = 0; i < 2; i++) {
+            if (b->hio.pcm[i]) hipFree(b->hio.pcm[i]);
+            if (b->hio.out[i]) hipFree(b->hio.out[i]);
+            if (b->hio.len[i]) hipFree(b->hio.len[i]);
+            if (b->hio.pcm_free[i]) hipEventDestroy(b->hio.pcm_free[i]);
+            if (b->hio.out_free[i]) hipEventDestroy(b->hio.out_free[i]);
+            for (std::vector<hipEvent_t> *v : {&b->hio.ev_fmt[i], &b->hio.t_up[i], &b->hio.t_dn[i]})
+                for (hipEvent_t e : *v) hipEventDestroy(e);
+        }
+        if (b->hio.h2d) hipStreamDestroy(b->hio.h2d);
+        if (b->hio.d2h) hipStreamDestroy(b->hio.d2h);
+    }
     if (b->stream) hipStreamDestroy(b->stream);
     if (b->lstream) hipStreamDestroy(b->lstream);
     delete b;
@@ -457,8 +494,15 @@ extern "C" int mp3mi_batch_set_error_protection(mp3mi_batch *b, int on)
     return MP3MI_OK;
 }
 
+struct host_call { // a call on host buffers (mp3mi_batch_encode_host_async): where the PCM comes from and the results go
+    const int16_t *pcm;
+    uint8_t *out;
+    size_t out_stride;
+    uint32_t *out_len;
+    int slot;
+};
 static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames, uint8_t *out_dev,
-                       size_t out_stride, uint32_t *out_len_dev, bool whole_file);
+                       size_t out_stride, uint32_t *out_len_dev, bool whole_file, const host_call *hc = NULL);
 
 // reads a timing set out (waits for its call to finish)
 static int harvest_timing(mp3mi_batch *b, int k)
@@ -546,7 +590,7 @@ extern "C" int mp3mi_batch_flush(mp3mi_batch *b, uint8_t *out_dev, size_t out_st
 }
 
 static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_samples_dev, int n_frames, uint8_t *out_dev,
-                       size_t out_stride, uint32_t *out_len_dev, bool whole_file)
+                       size_t out_stride, uint32_t *out_len_dev, bool whole_file, const host_call *hc)
 {
     if (!b || !pcm_dev || !out_dev || !out_len_dev || n_frames <= 0 || n_frames > b->max_frames) return MP3MI_ERR_ARG;
     if (out_stride < (size_t) n_frames * (size_t) b->max_frame_bytes + 1 + (whole_file ? 0 : MP3MI_CARRY_BYTES)) return MP3MI_ERR_ARG;
@@ -579,6 +623,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     b->fresh = false;
     b->status_kept = false;
     if (b->place_cost) CHK(hipMemsetAsync(b->place_cost, 0, sizeof(int) * (size_t) S, b->lstream)); // first chunk: order = identity
+    if (hc && b->hio.out_used[hc->slot]) CHK(hipStreamWaitEvent(b->lstream, b->hio.out_free[hc->slot], 0)); // the call two before this one copied out of it
     CHK(hipMemsetAsync(out_dev, 0, out_stride * (size_t) S, b->lstream)); // (behind the formatter of the call before: it may be the same buffer)
     if (!whole_file && fabs0 > 0) { // the bytes earlier calls formatted but could not deliver lead the rows
         mp3mi_launch_carry_in(S, b->carry, b->carry_len, out_dev, out_stride, b->lstream);
@@ -643,11 +688,37 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         return v;
     };
     const size_t pcm_pitch = (size_t) n_frames * 1152 * (size_t) C; // int16 per stream in the caller's buffer
+    if (hc) {
+        // The whole call's PCM, chunk by chunk, in order on the upload stream: a 2-D copy per chunk (every stream's samples of
+        // the chunk's frames; the layout on the device is the caller's).  The chunk's first kernel waits for its copy, so chunk
+        // c + 1 crosses PCIe while chunk c is encoded -- and, with calls issued back to back, the next call's first chunk
+        // while this call's last one is.
+        mp3mi_batch::host_io &H = b->hio;
+        const int sl = hc->slot;
+        if (H.pcm_used[sl]) CHK(hipStreamWaitEvent(H.h2d, H.pcm_free[sl], 0)); // (the kernels of the call two before this one)
+        while ((int) H.t_up[sl].size() < 2 * nchunks) {
+            hipEvent_t e;
+            for (std::vector<hipEvent_t> *v : {&H.t_up[sl], &H.t_dn[sl]}) { CHK(hipEventCreate(&e)); v->push_back(e); }
+            if (H.t_up[sl].size() % 2 == 0) { CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); H.ev_fmt[sl].push_back(e); }
+        }
+        H.n_chunks[sl] = nchunks;
+        H.bytes_up[sl] = H.bytes_dn[sl] = 0.0;
+        for (int c = 0; c < nchunks; c++) {
+            const int f0 = c * cfr, nf = (n_frames - f0 < cfr) ? n_frames - f0 : cfr;
+            const size_t off = (size_t) f0 * 1152 * (size_t) C, width = (size_t) nf * 1152 * (size_t) C * sizeof(int16_t);
+            CHK(hipEventRecord(H.t_up[sl][2 * c], H.h2d));
+            CHK(hipMemcpy2DAsync(H.pcm[sl] + off, pcm_pitch * sizeof(int16_t), hc->pcm + off, pcm_pitch * sizeof(int16_t), width, (size_t) S,
+                                 hipMemcpyHostToDevice, H.h2d));
+            CHK(hipEventRecord(H.t_up[sl][2 * c + 1], H.h2d));
+            H.bytes_up[sl] += (double) width * S;
+        }
+    }
     const size_t psy_state_bytes = mp3mi_psy_state_size() * (size_t) C, loop_state_bytes = mp3mi_loop_state_size();
     // which: 1 the FFTs, 2 k_cw, 4 the partition sums (k_part), 8 k_psy
     auto stage_x = [&](int k, int which) -> int {
         const item_view v = view(k);
         const size_t r = v.rec0;
+        if (hc && (which & 1) && k % P == 0) CHK(hipStreamWaitEvent(b->stream, b->hio.t_up[hc->slot][2 * (k / P) + 1], 0)); // the chunk's PCM is up
         if (which & 3) {
             mp3mi_launch_fft(b->T, v.g, pcm_dev + v.s0 * pcm_pitch, b->energy_l + r * MP3MI_HBLK_P, b->energy_s + r * 3 * MP3MI_HBLK_S,
                              b->fft_bins + r * MP3MI_FFT_BINS, b->cw_mid + r * 50, b->hist6 + r * 12, b->stream, which & 3);
@@ -737,6 +808,28 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
                             out_dev + v.s0 * out_stride, out_stride, out_len_dev + v.s0, (int32_t *) ((char *) b->loop_state + v.s0 * loop_state_bytes),
                             (int) (loop_state_bytes / 4), b->voided, b->lstream);
         CHK(hipGetLastError());
+        if (hc && k == n_items - 1) {
+            // The call's file bytes, behind its last formatter, as ONE copy: rows of the caller's stride when that is the device
+            // buffer's (mp3mi_batch_out_stride(b, max_frames): a plain copy, which the DMA engines take), a 2-D copy
+            // otherwise.  (A window of columns per chunk -- the bytes that became final with it -- was measured first: the
+            // runtime runs such rectangles as copy KERNELS, 11 ms each beside the encoder's own, and the step lost 56 ms;
+            // profiles/r04_experiments.txt.  With calls issued back to back this copy runs beside the next call's kernels.)
+            mp3mi_batch::host_io &H = b->hio;
+            const int sl = hc->slot;
+            const size_t row = hc->out_stride < out_stride ? hc->out_stride : out_stride;
+            CHK(hipEventRecord(H.ev_fmt[sl][0], b->lstream));
+            CHK(hipStreamWaitEvent(H.d2h, H.ev_fmt[sl][0], 0));
+            CHK(hipEventRecord(H.t_dn[sl][0], H.d2h));
+            if (hc->out_stride == out_stride)
+                CHK(hipMemcpyAsync(hc->out, out_dev, out_stride * (size_t) S, hipMemcpyDeviceToHost, H.d2h));
+            else
+                CHK(hipMemcpy2DAsync(hc->out, hc->out_stride, out_dev, out_stride, row, (size_t) S, hipMemcpyDeviceToHost, H.d2h));
+            CHK(hipMemcpyAsync(hc->out_len, out_len_dev, sizeof(uint32_t) * (size_t) S, hipMemcpyDeviceToHost, H.d2h));
+            CHK(hipEventRecord(H.t_dn[sl][1], H.d2h));
+            H.bytes_dn[sl] += (double) row * S;
+            CHK(hipEventRecord(H.out_free[sl], H.d2h));
+            H.out_used[sl] = true;
+        }
         b->last_nf = g.nf;
         b->last_slot = v.slot;
     }
@@ -768,6 +861,11 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipEventRecord(b->ev_hist, b->stream));
         CHK(hipStreamWaitEvent(b->lstream, b->ev_hist, 0)); // ev_done below then covers both streams
     }
+    if (hc) { // (lstream has just joined the front stream: every kernel that reads the slot's PCM is ahead of this)
+        CHK(hipEventRecord(b->hio.pcm_free[hc->slot], b->lstream));
+        b->hio.pcm_used[hc->slot] = true;
+        b->hio.pending[hc->slot] = true;
+    }
     b->slot_base = (b->slot_base + nchunks) & 1;
     b->frames_done = whole_file ? 0 : fabs0 + n_frames; // a whole-file call leaves finished streams behind
     CHK(hipEventRecord(ts.ev1, b->lstream));
@@ -785,6 +883,10 @@ extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
     ON_DEVICE(b);
     CHK(hipStreamSynchronize(b->stream));
     CHK(hipStreamSynchronize(b->lstream));
+    if (b->hio.ready) { // host-buffer calls: the results are in the caller's memory when this returns
+        CHK(hipStreamSynchronize(b->hio.h2d));
+        CHK(hipStreamSynchronize(b->hio.d2h));
+    }
     CHK(hipGetLastError());
     // streams whose file was voided since the last sync: the reference dies on those inputs (mp3mi.h)
     unsigned voided = 0;
@@ -881,6 +983,87 @@ extern "C" long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst
     return (long) n;
 }
 
+// ---- host buffers in, host buffers out, overlapped with the encode ("end-to-end with PCIe") ----
+// What the reference's driver does per frame with get_audio / read_samples (src/encode.c:123-269) and fwrite: here the
+// PCM of a whole call crosses PCIe chunk by chunk on a copy stream while the chunks before it are encoded, and the
+// file bytes come back behind each chunk's formatter (encode_impl).
+static int host_io_harvest(mp3mi_batch *b, int sl)
+{
+    mp3mi_batch::host_io &H = b->hio;
+    if (!H.pending[sl]) return MP3MI_OK;
+    const int n = H.n_chunks[sl];
+    CHK(hipEventSynchronize(H.t_dn[sl][1]));
+    CHK(hipEventSynchronize(H.t_up[sl][2 * n - 1]));
+    float ms = 0;
+    for (int c = 0; c < n; c++) {
+        CHK(hipEventElapsedTime(&ms, H.t_up[sl][2 * c], H.t_up[sl][2 * c + 1]));
+        H.tot_up_ms += ms;
+    }
+    CHK(hipEventElapsedTime(&ms, H.t_dn[sl][0], H.t_dn[sl][1]));
+    H.tot_dn_ms += ms;
+    H.tot_up_bytes += H.bytes_up[sl];
+    H.tot_dn_bytes += H.bytes_dn[sl];
+    H.tot_calls++;
+    H.pending[sl] = false;
+    return MP3MI_OK;
+}
+
+static int host_io_init(mp3mi_batch *b)
+{
+    mp3mi_batch::host_io &H = b->hio;
+    if (H.ready) return MP3MI_OK;
+    const size_t S = (size_t) b->n_streams;
+    H.out_stride = mp3mi_batch_out_stride(b, b->max_frames);
+    CHK(hipStreamCreateWithFlags(&H.h2d, hipStreamNonBlocking));
+    CHK(hipStreamCreateWithFlags(&H.d2h, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        CHK(hipMalloc((void **) &H.pcm[i], S * (size_t) b->max_frames * 1152 * (size_t) b->channels * sizeof(int16_t)));
+        CHK(hipMalloc((void **) &H.out[i], S * H.out_stride));
+        CHK(hipMalloc((void **) &H.len[i], S * sizeof(uint32_t)));
+        CHK(hipEventCreateWithFlags(&H.pcm_free[i], hipEventDisableTiming));
+        CHK(hipEventCreateWithFlags(&H.out_free[i], hipEventDisableTiming));
+    }
+    H.ready = true;
+    return MP3MI_OK;
+}
+
+extern "C" int mp3mi_batch_encode_host_async(mp3mi_batch *b, const int16_t *pcm_host, int n_frames, uint8_t *out_host, size_t out_stride,
+                                             uint32_t *out_len_host)
+{
+    if (!b || !pcm_host || !out_host || !out_len_host || n_frames <= 0 || n_frames > b->max_frames) return MP3MI_ERR_ARG;
+    if (out_stride < (size_t) n_frames * (size_t) b->max_frame_bytes + 1) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    if (host_io_init(b) != MP3MI_OK) return MP3MI_ERR_HIP;
+    mp3mi_batch::host_io &H = b->hio;
+    const int sl = (int) (H.call_no & 1);
+    if (host_io_harvest(b, sl) != MP3MI_OK) return MP3MI_ERR_HIP; // (waits for the call two before this one: at most two in flight)
+    const host_call hc = {pcm_host, out_host, out_stride, out_len_host, sl};
+    H.call_no++;
+    return encode_impl(b, H.pcm[sl], NULL, n_frames, H.out[sl], H.out_stride, H.len[sl], true, &hc);
+}
+
+extern "C" int mp3mi_batch_host_io_stats(mp3mi_batch *b, mp3mi_host_io_stats *st)
+{
+    if (!b || !st) return MP3MI_ERR_ARG;
+    ON_DEVICE(b);
+    memset(st, 0, sizeof(*st));
+    if (!b->hio.ready) return MP3MI_OK;
+    if (host_io_harvest(b, 0) != MP3MI_OK || host_io_harvest(b, 1) != MP3MI_OK) return MP3MI_ERR_HIP;
+    st->calls = b->hio.tot_calls;
+    st->h2d_bytes = b->hio.tot_up_bytes; st->d2h_bytes = b->hio.tot_dn_bytes;
+    st->h2d_ms = b->hio.tot_up_ms; st->d2h_ms = b->hio.tot_dn_ms;
+    return MP3MI_OK;
+}
+
+// page-locked host memory for the calls above (a caller that does not link HIP itself)
+extern "C" void *mp3mi_host_alloc(size_t bytes)
+{
+    void *p = NULL;
+    if (!have_device() || hipHostMalloc(&p, bytes, 0) != hipSuccess) return NULL;
+    return p;
+}
+extern "C" void mp3mi_host_free(void *p) { if (p) (void) hipHostFree(p); }
+
 static int encode_host_impl(int n_streams, int rate_hz, int channels, const int *kbps, int kbps_all, const int16_t *pcm,
                             const int32_t *n_samples, int n_frames, int hdr, uint8_t *out, size_t out_stride, uint32_t *out_len)
 {
@@ -893,6 +1076,12 @@ static int encode_host_impl(int n_streams, int rate_hz, int channels, const int 
     uint8_t *out_d = NULL;
     uint32_t *len_d = NULL;
     int32_t *ns_d = NULL;
+    if (rc == MP3MI_OK && !n_samples) { // whole streams: the overlapped host path (pageable buffers here: staged by the runtime)
+        rc = mp3mi_batch_encode_host_async(b, pcm, n_frames, out, out_stride, out_len);
+        if (rc == MP3MI_OK) rc = mp3mi_batch_sync(b); // (MP3MI_ERR_REFERENCE_ABORT: done, the outputs are delivered -- mp3mi.h)
+        mp3mi_batch_destroy(b);
+        return rc;
+    }
     if (rc == MP3MI_OK) rc = MP3MI_ERR_HIP;
     if (rc == MP3MI_ERR_HIP && hipMalloc((void **) &pcm_d, pcm_bytes) == hipSuccess &&
         hipMalloc((void **) &out_d, out_stride * n_streams) == hipSuccess &&

@@ -20,6 +20,9 @@ size_t mp3mi_loop_state_size(void);
 void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double *s, hipStream_t st);
 void mp3mi_launch_window_filter(const mp3mi_tables *T, double *ring, int off, const mp3mi_dropin_samples &in, double *zs, hipStream_t st);
 void mp3mi_launch_mdct_sub(const mp3mi_tables *T, double *sb, const int32_t *bt, double *xr, int stereo, int mode_gr, hipStream_t st);
+void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
+                                      double *zs, hipStream_t st);
+void mp3mi_launch_ring_advance(double *ring, int off0, const int16_t *smp, int n_done, hipStream_t st);
 
 #define DIE(...)                                   \
     do {                                           \
@@ -78,6 +81,41 @@ struct DropIn {
     double *zs_h = nullptr, *zs_d = nullptr;
     double last_z[512], last_s[32];
     bool have_s = false;
+    // LOOK-AHEAD (round 4).  The reference's Layer III frame loop (src/musicin.c:751-769) calls L3psycho_anal four times and
+    // window_subband / filter_subband 72 times per frame -- 76 launches with a wait each when every call is served on its own.
+    // Both work on memory the caller has ALREADY handed over:
+    //   * window_subband: the four L3psycho_anal calls of a frame were given &buffer[ch][0] and &buffer[ch][576]; when a
+    //     channel's first window_subband of the frame starts at that same &buffer[ch][0], the frame's 36 slots of BOTH
+    //     channels are computed in one launch and handed out call by call -- as long as every call's pointer is where the
+    //     previous one left it and its 32 samples still are what was read ahead.  Anything else (a caller that moves or
+    //     rewrites its buffer between calls, the Layer I / II loops, which never call L3psycho_anal) is served call by
+    //     call as before, from a ring that is first brought to where the handed-out slots left it.
+    //   * L3psycho_anal: when a channel's two calls of the LAST frame were given p and p + 576 and this frame's first one
+    //     is given the same p again, both granules are analysed in one launch; the second call is served from it if its
+    //     pointer, its 576 samples and the delay line are what was read ahead, otherwise the channel's state is put back
+    //     (a device copy taken before the launch) and granule 0 is analysed again alone.
+    // MP3MI_DROPIN_LOOKAHEAD=0 turns both off.
+    bool lookahead = true, lookahead_psy = true; // (MP3MI_DROPIN_LOOKAHEAD: 0 neither, 1 both, 2 the filterbank's only, 3 L3psycho_anal's only)
+    struct win_ahead {
+        bool valid = false;
+        const short *p0 = nullptr; // where the channel's slot 0 was read
+        int next = 0;              // slots handed out
+    } wa[2];
+    io_buf<int16_t> wa_smp;        // [2][1152]: the samples read ahead
+    io_buf<double> wa_zs;          // [2][36][544]: z and s of every slot
+    const short *psy_ptr[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // this frame's L3psycho_anal buffers, [ch][gr]
+    int psy_seen[2] = {0, 0};      // bit gr: seen since the channel's last window look-ahead
+    const short *psy_prev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // the frame before
+    struct psy_ahead {
+        bool valid = false;
+        const short *p1 = nullptr; // where granule 1's samples were read
+        short smp1[576];           // ... and what they were
+        short save_after[1344];    // the delay line as the first call left it
+        mp3mi_psy_out out1;        // granule 1's result (the other channel's launch reuses the result buffer)
+    } pa[2];
+    io_buf<mp3mi_psy_out> psy2;    // the two granules' results
+    void *psy_snap = nullptr;      // [2] psychoacoustic state before a two-granule launch
+    long n_launch_waits = 0;       // (statistics: waits for the device, mp3mi_dropin_waits)
     // mdct
     io_buf<double> sb, xr;
     io_buf<int32_t> bt;
@@ -116,13 +154,13 @@ void ensure(int rate_idx)
     HIPOK(hipMemcpy(D.T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
     free(Th);
     D.pcm.alloc(2304 * sizeof(int16_t));
-    HIPOK(hipMalloc((void **) &D.el, MP3MI_HBLK_P * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.part_eb, MP3MI_PART_P * sizeof(double)));
-    HIPOK(hipMalloc((void **) &D.part_cb, MP3MI_PART_P * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.es, 3 * MP3MI_HBLK_S * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.h6, 12 * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.bins, MP3MI_FFT_BINS * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.cw, 50 * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.el, 2 * MP3MI_HBLK_P * sizeof(float))); // (two records: a channel's two granules in one launch)
+    HIPOK(hipMalloc((void **) &D.part_eb, 2 * MP3MI_PART_P * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.part_cb, 2 * MP3MI_PART_P * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.es, 2 * 3 * MP3MI_HBLK_S * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.h6, 2 * 12 * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.bins, 2 * MP3MI_FFT_BINS * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.cw, 2 * 50 * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.cw_fix, mp3mi_cw_fixlist_bytes(4)));
     HIPOK(hipMalloc((void **) &D.psy_state, 2 * mp3mi_psy_state_size()));
     HIPOK(hipMemset(D.psy_state, 0, 2 * mp3mi_psy_state_size()));
@@ -133,6 +171,17 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.s_d, 32 * sizeof(double)));
     HIPOK(hipHostMalloc((void **) &D.zs_h, (512 + 32) * sizeof(double), hipHostMallocMapped));
     HIPOK(hipHostGetDevicePointer((void **) &D.zs_d, D.zs_h, 0));
+    D.wa_smp.alloc(2 * 1152 * sizeof(int16_t));
+    D.wa_zs.alloc((size_t) 2 * 36 * 544 * sizeof(double));
+    D.psy2.alloc(2 * sizeof(mp3mi_psy_out));
+    HIPOK(hipMalloc(&D.psy_snap, 2 * mp3mi_psy_state_size()));
+    {
+        mp3mi_batch_options o; // (the one place the library reads its environment: batch.cpp)
+        mp3mi_batch_options_from_env(&o);
+        const int v = o.dropin_lookahead < 0 ? 1 : o.dropin_lookahead;
+        D.lookahead = v == 1 || v == 2;
+        D.lookahead_psy = v == 1 || v == 3;
+    }
     D.sb.alloc(sizeof(L3SBS));
     D.xr.alloc(4 * 576 * sizeof(double));
     D.bt.alloc(4 * sizeof(int32_t));
@@ -180,16 +229,11 @@ void emit(long upto, long base)
 
 } // namespace
 
-extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int chn, int lay, float snr32[32],
-                              double sfreq, double ratio_d[21], double ratio_ds[12][3], double *pe,
-                              gr_info *cod_info)
+static void psy_wait() { HIPOK(hipStreamSynchronize(D.st)); D.n_launch_waits++; }
+
+// one granule of one channel, the reference's way: the delay line as the caller holds it (already shifted)
+static void psy_one_granule(const short *savebuf, int chn, mp3mi_psy_out *dst_d)
 {
-    (void) snr32;
-    if (lay != 3) DIE("L3psycho_anal: layer %d is not served by this library", lay);
-    ensure(rate_index_of(sfreq));
-    // delay line: drop the oldest 576 samples, append the new ones (src/l3psy.c:477-481)
-    memmove(savebuf, savebuf + 576, 768 * sizeof(short));
-    memcpy(savebuf + 768, buffer, 576 * sizeof(short));
     // present the 1344-sample window to k_fft as granule 2 of a mono pseudo-stream: its window
     // starts at sample 576*2 - 768 = 384
     memset(D.pcm.h, 0, 2304 * sizeof(int16_t));
@@ -198,15 +242,102 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
     g.g0 = 2;
     g.n_gran = 1;
     mp3mi_launch_fft(D.T, g, D.pcm.d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
-    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.part_eb, D.part_cb, D.psy1.d, D.st);
-    HIPOK(hipStreamSynchronize(D.st));
-    const mp3mi_psy_out &o = *D.psy1.h;
+    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.part_eb, D.part_cb, dst_d, D.st);
+}
+
+static void psy_hand_out(const mp3mi_psy_out &o, double ratio_d[21], double ratio_ds[12][3], double *pe, gr_info *cod_info)
+{
     memcpy(ratio_d, o.ratio_l, sizeof(o.ratio_l));
     memcpy(ratio_ds, o.ratio_s, sizeof(o.ratio_s));
     *pe = o.pe;
     cod_info->block_type = (unsigned) o.block_type;
     cod_info->window_switching_flag = (o.block_type == 0) ? 0 : 1;
     cod_info->mixed_block_flag = 0;
+}
+
+extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int chn, int lay, float snr32[32],
+                              double sfreq, double ratio_d[21], double ratio_ds[12][3], double *pe,
+                              gr_info *cod_info)
+{
+    (void) snr32;
+    if (lay != 3) DIE("L3psycho_anal: layer %d is not served by this library", lay);
+    if (chn < 0 || chn > 1) DIE("L3psycho_anal: channel %d", chn);
+    ensure(rate_index_of(sfreq));
+    DropIn::psy_ahead &A = D.pa[chn];
+    if (A.valid) { // the channel's second granule was analysed with its first one: is this the call that was foreseen?
+        A.valid = false;
+        const bool same = buffer == A.p1 && memcmp(buffer, A.smp1, sizeof(A.smp1)) == 0 && memcmp(savebuf, A.save_after, sizeof(A.save_after)) == 0;
+        // delay line: drop the oldest 576 samples, append the new ones (src/l3psy.c:477-481)
+        memmove(savebuf, savebuf + 576, 768 * sizeof(short));
+        memcpy(savebuf + 768, buffer, 576 * sizeof(short));
+        D.psy_ptr[chn][1] = buffer;
+        D.psy_seen[chn] |= 2;
+        if (same) {
+            psy_hand_out(A.out1, ratio_d, ratio_ds, pe, cod_info);
+            return;
+        }
+        // not what was read ahead: the state goes back to before the pair, granule 0 is analysed again alone (from the
+        // delay line as the first call left it), then this call on its own
+        const size_t ss = mp3mi_psy_state_size();
+        HIPOK(hipMemcpyAsync((char *) D.psy_state + (size_t) chn * ss, (char *) D.psy_snap + (size_t) chn * ss, ss, hipMemcpyDeviceToDevice, D.st));
+        psy_one_granule(A.save_after, chn, D.psy1.d);
+        psy_wait(); // (D.pcm is host memory the kernels read: the next launch's samples may only be written now)
+        psy_one_granule(savebuf, chn, D.psy1.d);
+        psy_wait();
+        psy_hand_out(*D.psy1.h, ratio_d, ratio_ds, pe, cod_info);
+        return;
+    }
+    // a channel's first call of a frame (or any call when nothing was foreseen)
+    memmove(savebuf, savebuf + 576, 768 * sizeof(short));
+    memcpy(savebuf + 768, buffer, 576 * sizeof(short));
+    const bool first_of_frame = !(D.psy_seen[chn] & 1) || (D.psy_seen[chn] & 2);
+    if (first_of_frame) {
+        D.psy_prev[chn][0] = D.psy_ptr[chn][0]; D.psy_prev[chn][1] = D.psy_ptr[chn][1];
+        D.psy_ptr[chn][0] = buffer; D.psy_ptr[chn][1] = nullptr;
+        D.psy_seen[chn] = 1;
+    } else { // the second granule of a frame whose first one was served alone
+        D.psy_ptr[chn][1] = buffer;
+        D.psy_seen[chn] |= 2;
+    }
+    // both granules at once: the caller gave p and p + 576 last frame and gives the same p now -- [p, p + 1152) is memory
+    // it has handed over before
+    if (D.lookahead_psy && first_of_frame && D.psy_prev[chn][0] == buffer && D.psy_prev[chn][1] == buffer + 576) {
+        const size_t ss = mp3mi_psy_state_size();
+        HIPOK(hipMemcpyAsync((char *) D.psy_snap + (size_t) chn * ss, (char *) D.psy_state + (size_t) chn * ss, ss, hipMemcpyDeviceToDevice, D.st));
+        // the pseudo-stream: granule 2's window is [384, 1728) = the delay line now, granule 3's [960, 2304) = the same
+        // shifted by the next 576 samples
+        memset(D.pcm.h, 0, 384 * sizeof(int16_t));
+        memcpy(D.pcm.h + 384, savebuf, 1344 * sizeof(int16_t));
+        memcpy(D.pcm.h + 1728, buffer + 576, 576 * sizeof(int16_t));
+        mp3mi_geom g = mp3mi_make_geom(1, 1, D.rate_idx, 2, 1, 1);
+        g.g0 = 2;
+        g.n_gran = 2;
+        mp3mi_launch_fft(D.T, g, D.pcm.d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
+        mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, (char *) D.psy_state + (size_t) chn * ss, D.part_eb, D.part_cb, D.psy2.d, D.st);
+        psy_wait();
+        A.valid = true;
+        A.p1 = buffer + 576;
+        memcpy(A.smp1, buffer + 576, sizeof(A.smp1));
+        memcpy(A.save_after, savebuf, sizeof(A.save_after));
+        A.out1 = D.psy2.h[1];
+        psy_hand_out(D.psy2.h[0], ratio_d, ratio_ds, pe, cod_info);
+        return;
+    }
+    psy_one_granule(savebuf, chn, D.psy1.d);
+    psy_wait();
+    psy_hand_out(*D.psy1.h, ratio_d, ratio_ds, pe, cod_info);
+}
+
+// the ring of channel k is brought to where the slots handed out so far left it; the look-ahead of the channel ends
+static void window_ahead_close(int k)
+{
+    DropIn::win_ahead &W = D.wa[k];
+    if (!W.valid) return;
+    if (W.next > 0) {
+        mp3mi_launch_ring_advance(D.ring + 512 * k, D.off[k], D.wa_smp.d + 1152 * k, W.next, D.st); // (in order before whatever is launched next)
+        D.off[k] = (D.off[k] - 32 * W.next) & 511; // 480 = -32 mod 512 per slot (src/encode.c:313-314)
+    }
+    W.valid = false;
 }
 
 extern "C" void window_subband(short **buffer, double z[512], int k)
@@ -216,17 +347,57 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
     // hidden stream is set up with any rate's tables (a later L3psycho_anal at another rate -- another layer in the same
     // process -- is refused)
     if (!D.ready) ensure(0);
+    if (k < 0 || k > 1) DIE("window_subband: channel %d", k);
+    DropIn::win_ahead &W = D.wa[k];
+    if (W.valid) { // is this the call that was foreseen: the pointer where the last one left it, the samples unchanged?
+        if (*buffer == W.p0 + 32 * W.next && memcmp(*buffer, D.wa_smp.h + 1152 * k + 32 * W.next, 32 * sizeof(int16_t)) == 0) {
+            const double *zs = D.wa_zs.h + ((size_t) k * 36 + W.next) * 544;
+            *buffer += 32; // src/encode.c:307
+            memcpy(z, zs, 512 * sizeof(double));
+            memcpy(D.last_z, zs, 512 * sizeof(double));
+            memcpy(D.last_s, zs + 512, 32 * sizeof(double));
+            D.have_s = true;
+            if (++W.next == 36) window_ahead_close(k);
+            return;
+        }
+        window_ahead_close(k); // no: from here on call by call
+    }
+    // the frame's first slot of this channel, at the very buffer both of the channel's L3psycho_anal calls were given?
+    if (D.lookahead && D.psy_seen[k] == 3 && *buffer == D.psy_ptr[k][0] && D.psy_ptr[k][1] == D.psy_ptr[k][0] + 576) {
+        // ... then [*buffer, *buffer + 1152) has been handed over, and so has the other channel's if its calls were seen:
+        // both channels' 36 slots in one launch
+        const int other = k ^ 1;
+        const bool both = D.psy_seen[other] == 3 && D.psy_ptr[other][1] == D.psy_ptr[other][0] + 576 && !D.wa[other].valid;
+        const int first = both ? 0 : k, n_ch = both ? 2 : 1;
+        for (int c = first; c < first + n_ch; c++) {
+            memcpy(D.wa_smp.h + 1152 * c, D.psy_ptr[c][0], 1152 * sizeof(int16_t));
+            D.wa[c].valid = true;
+            D.wa[c].p0 = D.psy_ptr[c][0];
+            D.wa[c].next = 0;
+            D.psy_seen[c] = 0; // (the next frame's calls have to be seen again)
+        }
+        mp3mi_launch_window_filter_frame(D.T, D.ring + 512 * first, D.off[first], D.off[first + n_ch - 1], D.wa_smp.d + 1152 * first, n_ch, 36,
+                                         D.wa_zs.d + (size_t) first * 36 * 544, D.st);
+        HIPOK(hipStreamSynchronize(D.st));
+        D.n_launch_waits++;
+        window_subband(buffer, z, k); // handed out from what was just computed
+        return;
+    }
     mp3mi_dropin_samples in;
     memcpy(in.v, *buffer, sizeof(in.v));
     *buffer += 32; // src/encode.c:307
     mp3mi_launch_window_filter(D.T, D.ring + 512 * k, D.off[k], in, D.zs_d, D.st);
     HIPOK(hipStreamSynchronize(D.st));
+    D.n_launch_waits++;
     memcpy(z, D.zs_h, 512 * sizeof(double));
     memcpy(D.last_z, D.zs_h, 512 * sizeof(double));
     memcpy(D.last_s, D.zs_h + 512, 32 * sizeof(double));
     D.have_s = true;
     D.off[k] = (D.off[k] + 480) & 511; // src/encode.c:313-314
 }
+
+// (statistics for tests and tools: waits for the device since the process started)
+extern "C" long mp3mi_dropin_waits(void) { return D.n_launch_waits; }
 
 extern "C" void filter_subband(double z[512], double s[32])
 {

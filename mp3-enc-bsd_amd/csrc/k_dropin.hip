@@ -51,6 +51,62 @@ __global__ void __launch_bounds__(64) k_window_filter(const mp3mi_tables *__rest
     }
 }
 
+// A whole FRAME of window_subband + filter_subband calls of up to two channels in one launch (dropin.cpp: look-ahead).
+// Workgroup (ch, i) computes slot i of channel ch: its 512-sample window holds the frame's samples 32 (i - m) + j at
+// z index 32 m + 31 - j (m < 16, j < 32) -- what the reference's ring holds after it has taken in slots 0..i
+// (src/encode.c:287-316) --; samples before the frame are read out of the ring as it stood at the frame's start (ring,
+// off0: neither is written here), where sample 32 q + j (q < 0) sits at (31 - j + off0 - 32 q) & 511.  z[512] and s[32]
+// go to zs[ch][i][544].  The arithmetic per slot is k_window_filter's, operation by operation.
+__global__ void __launch_bounds__(64) k_window_filter_frame(const mp3mi_tables *__restrict__ T, const double *__restrict__ ring_all,
+                                                            int off0_a, int off0_b, const int16_t *__restrict__ samples, int n_slots,
+                                                            double *__restrict__ zs)
+{
+    __shared__ double zl[512];
+    __shared__ double y[64];
+    const int lane = wave_lane(), ch = (int) blockIdx.x / n_slots, i = (int) blockIdx.x % n_slots;
+    const double *ring = ring_all + 512 * ch;
+    const int16_t *smp = samples + (size_t) ch * 32 * n_slots;
+    const int off0 = ch ? off0_b : off0_a;
+    double *out = zs + ((size_t) ch * n_slots + i) * 544;
+    for (int t = lane; t < 512; t += 64) {
+        const int m = t >> 5, j = 31 - (t & 31), q = i - m;
+        const double x = q >= 0 ? (double) smp[32 * q + j] * (1.0 / 32768.0) : ring[(31 - j + off0 - 32 * q) & 511];
+        const double v = x * T->enwindow[t];
+        zl[t] = v;
+        out[t] = v;
+    }
+    __syncthreads();
+    double acc = zl[lane];
+    for (int k = 1; k < 8; k++) acc = acc + zl[lane + 64 * k];
+    y[lane] = acc;
+    __syncthreads();
+    if (lane < 32) {
+        double frow[31];
+        for (int j = 0; j < 31; j++) frow[j] = T->filt[lane][j];
+        out[512 + lane] = fbm_matrix(y, frow);
+    }
+}
+
+// The ring after n_done slots of such a frame have been handed out: what n_done calls of window_subband would have left
+// (only the last sixteen slots' samples survive in it).
+__global__ void __launch_bounds__(64) k_ring_advance(double *__restrict__ ring, int off0, const int16_t *__restrict__ smp, int n_done)
+{
+    const int lane = wave_lane();
+    for (int q = n_done > 16 ? n_done - 16 : 0; q < n_done; q++)
+        if (lane < 32) ring[(31 - lane + off0 - 32 * q) & 511] = (double) smp[32 * q + lane] * (1.0 / 32768.0);
+}
+
+void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
+                                      double *zs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_window_filter_frame, dim3((unsigned) (n_ch * n_slots)), dim3(64), 0, st, T, ring, off0_a, off0_b, samples, n_slots, zs);
+}
+
+void mp3mi_launch_ring_advance(double *ring, int off0, const int16_t *smp, int n_done, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ring_advance, dim3(1), dim3(64), 0, st, ring, off0, smp, n_done);
+}
+
 // src/mdct.c:25-103: sb is the caller's L3SBS [2][3][18][32]; bt[gr][ch]; xr [gr][ch][576]
 __global__ void __launch_bounds__(64) k_mdct_sub(const mp3mi_tables *__restrict__ T, double *__restrict__ sb,
                                                  const int32_t *__restrict__ bt, double *__restrict__ xr, int mode_gr)

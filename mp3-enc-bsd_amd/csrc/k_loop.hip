@@ -63,13 +63,6 @@ struct loop_lds {
     // themselves go straight to memory
     int p23[2][2];      // part2_3_length (ResvFrameEnd adds the stuffing bits, src/reservoir.c:190-224)
     int preflag0[2];    // granule 0's preflag (src/loop.c:1172-1176)
-    // Region maxima without a walk over the values (loop_count_bits).  A quantised value is a monotone function of
-    // |xr| and a band is only ever scaled as a whole (pre-emphasis, amplification: rounding is monotone), so the line
-    // that holds a band's largest |xr| holds its largest quantised value in EVERY pass of the granule: found once per
-    // granule (loop_band_argmax), read once per pass by the band's lane.  Long, start and stop blocks: bands 0..20
-    // and "band 21", the lines above the last scalefactor band.
-    unsigned long long band_key[22]; // the band's largest |xr| as its bit pattern (non-negative doubles order as integers)
-    struct { int line, se; } band_ls[22]; // a line that holds it; the band's first line | end << 16
 };
 
 // The reference DIES on some inputs (an assert fails: tests/golden/coverage_notes.json, "reference_aborts").  A batch cannot
@@ -165,29 +158,6 @@ MP3MI_DEVFN float loop_estimate(float y34, float cq) { return __builtin_fmaf(y34
 MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
 {
     return loop_estimate(y34max, LOOP_FAST_EXP2F(-0.1875f * (float) q)) < 0.999f;
-}
-
-// Per granule (not short blocks): band_ls[b].line = a line of band b whose |xr| is the band's largest.  Every lane offers
-// its nine lines to their bands (an LDS maximum of the 64-bit patterns: lanes of one band serialise, once per granule),
-// then every line that equals its band's maximum writes its index -- equal values, equal quantised values: any winner will do.
-// (The spectrum is read back from LDS, a line at a time: held in registers across this it would not fit the kernel's 80.)
-MP3MI_DEVFN void loop_band_argmax(const mp3mi_tables *T, loop_lds &L, int lane)
-{
-    const unsigned long long bandpack = T->lane_bands[0][lane];
-    if (lane < 22) L.band_key[lane] = 0ull;
-    wave_sync();
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const int b = (int) ((bandpack >> (6 * j)) & 63ull);
-        atomicMax(&L.band_key[b], (unsigned long long) __builtin_bit_cast(long long, __builtin_fabs(L.xr[lane + 64 * j])));
-    }
-    wave_sync();
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const int b = (int) ((bandpack >> (6 * j)) & 63ull);
-        if (L.band_key[b] == (unsigned long long) __builtin_bit_cast(long long, __builtin_fabs(L.xr[lane + 64 * j]))) L.band_ls[b].line = lane + 64 * j;
-    }
-    wave_sync();
 }
 
 // What a pass needs to know about the quantised values besides the values themselves (which go to L.ix): the run
@@ -548,13 +518,9 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     // consecutive lines (32 pairs: one word each) per step straight out of L.ix, so a line is visited once,
     // by the region it belongs to, with that region's wave-uniform descriptor; lines from slot nslot on are
     // zero.  (Written out per region: arrays indexed by the region would live in scratch memory.)
-#if defined(LOOP_REGION_MAX_WALK)
     const int nzend = 64 * nslot;
-#endif
     auto region_max = [&](int lo, int hi) {
-#if defined(LOOP_REGION_MAX_WALK)
         hi = hi < nzend ? hi : nzend; // both even
-#endif
         int m = 0;
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
         for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // pair index of lane 0
@@ -569,48 +535,8 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         return m; // this lane's part
     };
     // the three region maxima and the count1 region's two bit sums: four reductions in lock-step
-#if defined(LOOP_REGION_MAX_WALK) // (until round 4: always by a walk over the regions' values)
     int red[4] = {c1part, region_max(0, a1), region_max(a1, a2), region_max(a2, e2)};
     wave_reduce_i32<1, 3>(red);
-#else
-    // Without window switching and with big values, a1 and a2 are edges of scalefactor bands (subdivide), so a region is a
-    // run of whole bands -- plus, at e2 = 2 big_values, possibly the head of one more.  Lane b < 22 reads the value of
-    // its band's arg-max line (loop_band_argmax): the band's maximum.  The head of the last band: a band maximum >= 2
-    // sits below n_big <= e2, i.e. inside region 2, and then the whole band's maximum IS the head's; a maximum of 0 is
-    // exact as well; only when region 2 comes out at 1 could the 1 lie past e2, and then -- as with window switching or
-    // stale addresses (big_values == 0), where region ends need not be band edges -- the regions are walked.
-    int red[4];
-    bool walk = true;
-    if (g.wsf == 0 && e2 != 0) {
-        int pb = 0, bs = 0x7fff, be = 0x7fff;
-        if (lane < 22) {
-            pb = L.ix[L.band_ls[lane].line];
-            const int se = L.band_ls[lane].se;
-            bs = se & 0xffff;
-            be = se >> 16;
-        }
-        red[0] = c1part;
-        red[1] = be <= a1 ? pb : 0;
-        red[2] = (bs >= a1 && be <= a2) ? pb : 0;
-        red[3] = (bs >= a2 && bs < e2) ? pb : 0;
-        wave_reduce_i32<1, 3>(red);
-        walk = a2 < e2 && red[3] <= 1;
-    }
-    if (walk) {
-        red[0] = c1part; red[1] = region_max(0, a1); red[2] = region_max(a1, a2); red[3] = region_max(a2, e2);
-        wave_reduce_i32<1, 3>(red);
-    }
-#if defined(MP3MI_EMU) // the test build checks every pass against the walk
-    else {
-        int mw[3] = {region_max(0, a1), region_max(a1, a2), region_max(a2, e2)};
-        wave_reduce_i32<0, 3>(mw);
-        if (mw[0] != red[1] || mw[1] != red[2] || mw[2] != red[3]) {
-            fprintf(stderr, "k_loop: band maxima %d %d %d differ from the walk's %d %d %d (a1 %d a2 %d e2 %d)\n", red[1], red[2], red[3], mw[0], mw[1], mw[2], a1, a2, e2);
-            abort();
-        }
-    }
-#endif
-#endif
     CBPROF(2); // region maxima + reduction
     {
         const int sum0 = red[0] & 0xffff, sum1 = (red[0] >> 16) & 0xffff; // table A vs table B (src/loop.c:1531-1580)
@@ -872,7 +798,6 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
     for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];
     if (lane < 8) L.ix[576 + lane] = 0;
     if (lane == 0) L.xr[576] = 0.0;
-    if (lane < 22) L.band_ls[lane].se = T->sfb_l[lane] | (T->sfb_l[lane + 1] << 16);
     wave_sync();
     int ref_abort = __builtin_amdgcn_readfirstlane(L.st.ref_abort); // (sticky: the first event of the stream stands)
 
@@ -904,7 +829,6 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 g.address3 = L.st.addr[gr][ch][2];
                 const int nband = shortb ? 36 : 21;   // band lanes
                 float y34[9], y34max;
-#if defined(LOOP_REGION_MAX_WALK)
                 {
                     double xr[9];
 #pragma unroll
@@ -913,21 +837,6 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
 #pragma unroll
                     for (int j = 0; j < 9; j++) L.xr[lane + 64 * j] = xr[j];
                 }
-#else
-                // spectrum -> LDS; the bands' arg-max lines from there, while nothing else of the granule is in registers
-                // yet (the powers are taken from a second read: nine LDS loads per granule for ~20 registers at this point)
-#pragma unroll
-                for (int j = 0; j < 9; j++) L.xr[lane + 64 * j] = xr_all[rec * 576 + lane + 64 * j];
-                wave_sync();
-                if (!shortb) loop_band_argmax(T, L, wave_lane_here());
-                {
-                    const int ln = wave_lane_here();
-                    double xr[9];
-#pragma unroll
-                    for (int j = 0; j < 9; j++) xr[j] = L.xr[ln + 64 * j];
-                    y34max = loop_power34(xr, y34);
-                }
-#endif
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
                 //      were computed by k_mdct's tail (k_prep); only the stateful decision of calc_scfsi happens here ----

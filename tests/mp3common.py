@@ -96,7 +96,7 @@ class BatchOptions(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("scratch_mb", ctypes.c_uint32), ("chunk_frames", ctypes.c_int32),
                 ("test_flags", ctypes.c_uint32), ("call_overlap", ctypes.c_int32), ("gate", ctypes.c_int32),
                 ("placement", ctypes.c_int32), ("loop_queue", ctypes.c_int32), ("loop_part_streams", ctypes.c_int32),
-                ("y_after_loop", ctypes.c_int32), ("psy_beside", ctypes.c_int32)]
+                ("y_after_loop", ctypes.c_int32), ("psy_beside", ctypes.c_int32), ("dropin_lookahead", ctypes.c_int32)]
 
 
 class Mp3mi:
@@ -143,6 +143,11 @@ class Mp3mi:
         L.mp3mi_synth_pcm_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_debug_fastmath_bounds.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_encode_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_encode_host_async.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.mp3mi_batch_host_io_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.mp3mi_host_alloc.argtypes = [ctypes.c_size_t]
+        L.mp3mi_host_alloc.restype = ctypes.c_void_p
+        L.mp3mi_host_free.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_flush.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_batch_reset.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_debug_cw_fixups.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]

@@ -139,3 +139,39 @@ def test_reference_driver_layers_1_2_over_hip_library(product, tmp_path, layer, 
     got = run_cli("encode_dropin", tmp_path / "a.wav", tmp_path / "a.mpg", 44100, kbps, False, extra)
     ref = run_cli("encode", tmp_path / "a.wav", tmp_path / "r.mpg", 44100, kbps, False, extra)
     assert without_private_bit(got, layer, kbps) == without_private_bit(ref, layer, kbps)
+
+
+def run_probe(binary, dump, frames, lookahead=None):
+    env = dict(os.environ)
+    if lookahead is not None:
+        env["MP3MI_DROPIN_LOOKAHEAD"] = str(lookahead)
+    r = subprocess.run([os.path.join(REF, binary), str(dump), str(frames)], check=True, capture_output=True, text=True, env=env, cwd=os.path.dirname(str(dump)))
+    waits = [int(x.split()[1]) for x in r.stdout.splitlines() if x.startswith("waits")]
+    return open(dump, "rb").read(), (waits[0] if waits else None)
+
+
+def probe_case(binary, tmp_path, frames=11):
+    """oracle/dropin_probe.c: a caller that rewrites samples the look-ahead has read, moves its pointer back in the middle of a
+    frame and changes buffers between frames -- every value the library returns equals what the reference's own functions
+    return to the same caller, with the look-ahead on, off and half on; and the look-ahead did save waits where the caller
+    behaved, and did fall back where it did not"""
+    ref, _ = run_probe("dropin_probe_ref", tmp_path / "ref.bin", frames)
+    waits = {}
+    for mode in (0, 1, 2, 3):
+        got, waits[mode] = run_probe(binary, tmp_path / ("m%d.bin" % mode), frames, lookahead=mode)
+        assert got == ref, "look-ahead mode %d: the library's values differ from the reference's" % mode
+    assert waits[0] == frames * (4 + 72)  # every call on its own
+    # with both: 2 + 1 waits per well-behaved frame; the misbehaving frames fall back to call-by-call service part of the way
+    assert frames * 3 < waits[1] < waits[0] // 2, waits
+    assert waits[1] < waits[2] < waits[0] and waits[1] < waits[3] < waits[0], waits
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "dropin_probe_emu")) and os.path.exists(os.path.join(REF, "dropin_probe_ref"))), reason="oracle/_ref/dropin_probe* not built")
+def test_lookahead_survives_a_caller_that_breaks_its_assumptions_emulated(tmp_path):
+    probe_case("dropin_probe_emu", tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "dropin_probe")) and os.path.exists(os.path.join(REF, "dropin_probe_ref"))), reason="oracle/_ref/dropin_probe* not built")
+def test_lookahead_survives_a_caller_that_breaks_its_assumptions_gpu(tmp_path):
+    probe_case("dropin_probe", tmp_path)
