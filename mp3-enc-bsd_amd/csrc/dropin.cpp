@@ -22,7 +22,10 @@ void mp3mi_launch_window_filter(const mp3mi_tables *T, double *ring, int off, co
 void mp3mi_launch_mdct_sub(const mp3mi_tables *T, double *sb, const int32_t *bt, double *xr, int stereo, int mode_gr, hipStream_t st);
 void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
                                       double *zs, hipStream_t st);
-void mp3mi_launch_ring_advance(double *ring, int off0, const int16_t *smp, int n_done, hipStream_t st);
+void mp3mi_launch_part_wave(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l, const double *cw_mid, const float *hist6,
+                            const void *psy_state, double *eb_all, float *cb_all, hipStream_t st);
+void mp3mi_launch_prep_tail(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy, mp3mi_loop_prep *prep,
+                            mp3mi_prep_fixlist *fix, hipStream_t st);
 
 #define DIE(...)                                   \
     do {                                           \
@@ -74,7 +77,9 @@ struct DropIn {
     void *psy_state = nullptr;
     io_buf<mp3mi_psy_out> psy1;
     // filterbank
-    double *ring = nullptr, *z_d = nullptr, *s_d = nullptr;
+    io_buf<double> ring; // [2][512]: the filterbank's sample history, host-mapped: the kernels of the call-by-call service
+                         // write it, and so does the host when it closes a look-ahead (window_ahead_close)
+    double *z_d = nullptr, *s_d = nullptr;
     int off[2] = {0, 0};
     // window_subband computes the filter_subband that follows it in the same launch: z[512] and s[32] arrive in a
     // host-mapped buffer, and filter_subband hands s out when the z it is given is still the one it got (compared)
@@ -122,6 +127,7 @@ struct DropIn {
     // loop
     io_buf<mp3mi_psy_out> psy4;
     mp3mi_loop_prep *prep4 = nullptr;
+    mp3mi_prep_fixlist *prep_fix = nullptr;
     io_buf<int16_t> ix;
     io_buf<mp3mi_frame_side> side;
     io_buf<loop_state_host> loop_state;
@@ -165,8 +171,7 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.psy_state, 2 * mp3mi_psy_state_size()));
     HIPOK(hipMemset(D.psy_state, 0, 2 * mp3mi_psy_state_size()));
     D.psy1.alloc(sizeof(mp3mi_psy_out));
-    HIPOK(hipMalloc((void **) &D.ring, 2 * 512 * sizeof(double)));
-    HIPOK(hipMemset(D.ring, 0, 2 * 512 * sizeof(double)));
+    D.ring.alloc(2 * 512 * sizeof(double));
     HIPOK(hipMalloc((void **) &D.z_d, 512 * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.s_d, 32 * sizeof(double)));
     HIPOK(hipHostMalloc((void **) &D.zs_h, (512 + 32) * sizeof(double), hipHostMallocMapped));
@@ -187,6 +192,7 @@ void ensure(int rate_idx)
     D.bt.alloc(4 * sizeof(int32_t));
     D.psy4.alloc(4 * sizeof(mp3mi_psy_out));
     HIPOK(hipMalloc((void **) &D.prep4, 4 * sizeof(mp3mi_loop_prep)));
+    HIPOK(hipMalloc((void **) &D.prep_fix, mp3mi_prep_fixlist_bytes(4)));
     D.ix.alloc(4 * 576 * sizeof(int16_t));
     D.side.alloc(sizeof(mp3mi_frame_side));
     if (sizeof(loop_state_host) != mp3mi_loop_state_size()) DIE("internal: loop state layout mismatch");
@@ -231,6 +237,19 @@ void emit(long upto, long base)
 
 static void psy_wait() { HIPOK(hipStreamSynchronize(D.st)); D.n_launch_waits++; }
 
+// the kernels behind one L3psycho_anal launch (g: one or two granules of a mono pseudo-stream).  The unpredictability comes
+// from the correctly rounded sines throughout (k_cw's second tier: MP3MI_TEST_CW_EXACT) and the partition sums from
+// k_part_wave, a lane per partition: with a record or two per launch, k_part's lane per RECORD and its two runs around the
+// list of doubtful records cost 4 x 64 us per frame.
+static void psy_launch(mp3mi_geom g, int chn, mp3mi_psy_out *dst_d)
+{
+    void *state = (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size();
+    g.test_flags |= 16; // k_cw: second tier for every record
+    mp3mi_launch_fft(D.T, g, D.pcm.d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
+    mp3mi_launch_part_wave(D.T, g, D.el, D.cw, D.h6, state, D.part_eb, D.part_cb, D.st);
+    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, state, D.part_eb, D.part_cb, dst_d, D.st, 2);
+}
+
 // one granule of one channel, the reference's way: the delay line as the caller holds it (already shifted)
 static void psy_one_granule(const short *savebuf, int chn, mp3mi_psy_out *dst_d)
 {
@@ -241,8 +260,7 @@ static void psy_one_granule(const short *savebuf, int chn, mp3mi_psy_out *dst_d)
     mp3mi_geom g = mp3mi_make_geom(1, 1, D.rate_idx, 2, 1, 1);
     g.g0 = 2;
     g.n_gran = 1;
-    mp3mi_launch_fft(D.T, g, D.pcm.d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
-    mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, (char *) D.psy_state + (size_t) chn * mp3mi_psy_state_size(), D.part_eb, D.part_cb, dst_d, D.st);
+    psy_launch(g, chn, dst_d);
 }
 
 static void psy_hand_out(const mp3mi_psy_out &o, double ratio_d[21], double ratio_ds[12][3], double *pe, gr_info *cod_info)
@@ -312,8 +330,7 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
         mp3mi_geom g = mp3mi_make_geom(1, 1, D.rate_idx, 2, 1, 1);
         g.g0 = 2;
         g.n_gran = 2;
-        mp3mi_launch_fft(D.T, g, D.pcm.d, D.el, D.es, D.bins, D.cw, D.h6, D.st);
-        mp3mi_launch_psy(D.T, g, D.el, D.es, D.cw, D.h6, D.bins, D.cw_fix, (char *) D.psy_state + (size_t) chn * ss, D.part_eb, D.part_cb, D.psy2.d, D.st);
+        psy_launch(g, chn, D.psy2.d);
         psy_wait();
         A.valid = true;
         A.p1 = buffer + 576;
@@ -334,7 +351,13 @@ static void window_ahead_close(int k)
     DropIn::win_ahead &W = D.wa[k];
     if (!W.valid) return;
     if (W.next > 0) {
-        mp3mi_launch_ring_advance(D.ring + 512 * k, D.off[k], D.wa_smp.d + 1152 * k, W.next, D.st); // (in order before whatever is launched next)
+        // what W.next calls of window_subband would have left in the ring (src/encode.c:306-312; only the last sixteen
+        // slots' samples survive): written by the host -- nothing is in flight on the stream: every launch is waited for --
+        // where round 4's first version launched a kernel for it (14 us, twice a frame)
+        double *ring = D.ring.h + 512 * k;
+        const int16_t *smp = D.wa_smp.h + 1152 * k;
+        for (int q = W.next > 16 ? W.next - 16 : 0; q < W.next; q++)
+            for (int j = 0; j < 32; j++) ring[(31 - j + D.off[k] - 32 * q) & 511] = (double) smp[32 * q + j] * (1.0 / 32768.0);
         D.off[k] = (D.off[k] - 32 * W.next) & 511; // 480 = -32 mod 512 per slot (src/encode.c:313-314)
     }
     W.valid = false;
@@ -376,7 +399,7 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
             D.wa[c].next = 0;
             D.psy_seen[c] = 0; // (the next frame's calls have to be seen again)
         }
-        mp3mi_launch_window_filter_frame(D.T, D.ring + 512 * first, D.off[first], D.off[first + n_ch - 1], D.wa_smp.d + 1152 * first, n_ch, 36,
+        mp3mi_launch_window_filter_frame(D.T, D.ring.d + 512 * first, D.off[first], D.off[first + n_ch - 1], D.wa_smp.d + 1152 * first, n_ch, 36,
                                          D.wa_zs.d + (size_t) first * 36 * 544, D.st);
         HIPOK(hipStreamSynchronize(D.st));
         D.n_launch_waits++;
@@ -386,7 +409,7 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
     mp3mi_dropin_samples in;
     memcpy(in.v, *buffer, sizeof(in.v));
     *buffer += 32; // src/encode.c:307
-    mp3mi_launch_window_filter(D.T, D.ring + 512 * k, D.off[k], in, D.zs_d, D.st);
+    mp3mi_launch_window_filter(D.T, D.ring.d + 512 * k, D.off[k], in, D.zs_d, D.st);
     HIPOK(hipStreamSynchronize(D.st));
     D.n_launch_waits++;
     memcpy(z, D.zs_h, 512 * sizeof(double));
@@ -461,7 +484,11 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
     *D.bits.h = bitsPerFrame;
     mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1, 0, 1);
     g.crc = crc;
-    mp3mi_launch_prep(D.T, g, D.xr.d, D.psy4.d, D.prep4, NULL, 0, D.st); // (the caller's spectrum: every record, the reference's walk)
+    // the loop's stateless head of the caller's spectrum: k_mdct's tail as a kernel of its own, then the reference's walk for
+    // the records it lists as undecided (k_prep.hip; none, practically)
+    HIPOK(hipMemsetAsync(&D.prep_fix->count, 0, sizeof(unsigned), D.st));
+    mp3mi_launch_prep_tail(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.prep_fix, D.st);
+    mp3mi_launch_prep(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.prep_fix, 0, D.st);
     mp3mi_launch_loop(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.bits.d, D.loop_state.d, D.ix.d, D.side.d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
     HIPOK(hipStreamSynchronize(D.st));
     const int16_t (*ix)[576] = (const int16_t (*)[576]) D.ix.h;

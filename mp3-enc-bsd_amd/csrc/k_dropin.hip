@@ -87,24 +87,10 @@ __global__ void __launch_bounds__(64) k_window_filter_frame(const mp3mi_tables *
     }
 }
 
-// The ring after n_done slots of such a frame have been handed out: what n_done calls of window_subband would have left
-// (only the last sixteen slots' samples survive in it).
-__global__ void __launch_bounds__(64) k_ring_advance(double *__restrict__ ring, int off0, const int16_t *__restrict__ smp, int n_done)
-{
-    const int lane = wave_lane();
-    for (int q = n_done > 16 ? n_done - 16 : 0; q < n_done; q++)
-        if (lane < 32) ring[(31 - lane + off0 - 32 * q) & 511] = (double) smp[32 * q + lane] * (1.0 / 32768.0);
-}
-
 void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
                                       double *zs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_window_filter_frame, dim3((unsigned) (n_ch * n_slots)), dim3(64), 0, st, T, ring, off0_a, off0_b, samples, n_slots, zs);
-}
-
-void mp3mi_launch_ring_advance(double *ring, int off0, const int16_t *smp, int n_done, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_ring_advance, dim3(1), dim3(64), 0, st, ring, off0, smp, n_done);
 }
 
 // src/mdct.c:25-103: sb is the caller's L3SBS [2][3][18][32]; bt[gr][ch]; xr [gr][ch][576]

@@ -552,6 +552,42 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
     }
 }
 
+// The loop's stateless head for a spectrum that does not come out of k_mdct: the drop-in iteration_loop, whose xr is the
+// CALLER's (dropin.cpp).  A wavefront per two records: their 576 lines go to LDS in k_mdct's layout and mdct_prep_tail does
+// what it does behind a transform -- the band chains in the reference's order, the integers with their margins, the
+// undecided records on the list for k_prep.  (Until round 4 the drop-in sent every record through k_prep's 576-step walk
+// with a correctly rounded logarithm per line, one LANE per record: 153 us per frame.)
+__global__ void __launch_bounds__(64) k_prep_tail(const mp3mi_tables *__restrict__ T, mp3mi_geom geo, const double *__restrict__ xr,
+                                                  const mp3mi_psy_out *__restrict__ psy, mp3mi_loop_prep *__restrict__ prep,
+                                                  mp3mi_prep_fixlist *__restrict__ fix)
+{
+    __shared__ mdct_out_lds L;
+    const int lane = wave_lane(), band = lane & 31, h = lane >> 5;
+    const size_t n_rec = (size_t) geo.n_streams * (size_t) geo.n_gran * (size_t) geo.channels;
+    const size_t r0 = 2 * (size_t) blockIdx.x, r1 = r0 + 1 < n_rec ? r0 + 1 : r0;
+    const bool two = r0 + 1 < n_rec;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        L.x[0][lane + 64 * j] = xr[r0 * 576 + lane + 64 * j];
+        L.x[1][lane + 64 * j] = xr[r1 * 576 + lane + 64 * j];
+    }
+    if (lane < 8) L.zero[lane] = 0.0;
+    const int bt0 = psy[r0].block_type, bt1 = psy[r1].block_type;
+    const int WL = wave_max_i32(band < 21 ? T->sfb_l[band + 1] - T->sfb_l[band] : 0);
+    const int WS = wave_max_i32(band < 12 ? T->sfb_s[band + 1] - T->sfb_s[band] : 0);
+    __syncthreads();
+    const size_t rec = h ? r1 : r0;
+    mdct_prep_tail(T, (MDCT_LDS_PTR(const double)) &L.x[h][0], h == 0 || two, h ? bt1 : bt0, bt0 != 2 || bt1 != 2, bt0 == 2 || bt1 == 2, WL, WS, false,
+                   &psy[rec], &prep[rec], fix, (unsigned) rec);
+}
+
+void mp3mi_launch_prep_tail(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy, mp3mi_loop_prep *prep,
+                            mp3mi_prep_fixlist *fix, hipStream_t st)
+{
+    const size_t n_rec = (size_t) g.n_streams * (size_t) g.n_gran * (size_t) g.channels;
+    hipLaunchKernelGGL(k_prep_tail, dim3((unsigned) ((n_rec + 1) / 2)), dim3(64), 0, st, T, g, xr, psy, prep, fix);
+}
+
 size_t mp3mi_sbs_bytes(const mp3mi_geom &g) { return (size_t) g.n_streams * (size_t) (g.n_gran + 1) * (size_t) g.channels * 576 * sizeof(double); }
 
 void mp3mi_launch_filter(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *pcm, double *sbs, double *sb_dbg, hipStream_t st)

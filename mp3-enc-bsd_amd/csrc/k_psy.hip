@@ -46,6 +46,12 @@ struct part_walk {
     double eb, eb0;
     float cb, cb0;
     int b, pend; // open partition and the line after its last (wave-uniform)
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+    // census site UC_CW_REACH: the open partition's sum as it would stand had every float of a "near" step come out one
+    // float ulp lower / higher -- does the difference survive to the value that leaves the kernel?
+    float cb_lo, cb_hi;
+    int near_steps;
+#endif
 };
 
 // A closed partition's 64 values (one per lane = record) wait in an LDS tile; every eight partitions the tile
@@ -117,12 +123,34 @@ MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, i
             // by at most one ulp each: c_w moves by < 5e-16 -- 1.6e-16 through t1, t2, the root and the quotient, plus a
             // few flipped roundings on the way --, d by < 5e-16 e + an ulp of d = (4.5 e / d + 1) ulps; 4.5 e + 2 d is counted)
             ULP_CENSUS(UC_CW_STEP, !CHECK && range && !((double) dist * d > 4.5 * e + 2.0 * d), !CHECK && range && !((double) dist * d > (4.5 * e + 2.0 * d) * 1048576.0));
+            // ... and if it did: the shadow sums take this step's float one ulp down / up (every near step of the partition,
+            // both directions at once: the worst case), and the partition's close compares what comes of it
+            if (!CHECK) {
+                float lo = (float) ((double) W.cb_lo + cw * e), hi = (float) ((double) W.cb_hi + cw * e);
+                if (range && !((double) dist * d > 4.5 * e + 2.0 * d)) {
+                    lo = __builtin_bit_cast(float, __builtin_bit_cast(int, lo) - (lo > 0.0f ? 1 : 0));
+                    hi = __builtin_bit_cast(float, __builtin_bit_cast(int, hi) + 1);
+                    W.near_steps++;
+                }
+                W.cb_lo = lo; W.cb_hi = hi;
+            }
             // (sums below the floats' normal range -- a line-0 energy of next to nothing -- are counted apart: the grid there
             // is absolute, 2^-149, and a relative 1e-16 does not reach a midpoint; k_part sends them to the second tier all the same)
             if (!CHECK && !range) ULP_CENSUS(UC_CW_RANGE, 0, 0);
         }
 #endif
         W.cb = (float) d;
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        if (!(dm_bits(cw) != (long long) 0x8000000000000000ull && cw != 0.4 && e != 0.0 && Lt.rec[wave_lane_here()] != PART_NO_REC) || CHECK) { // steps outside the census: the shadows follow the sum
+            W.cb_lo = (float) ((double) W.cb_lo + cw * e);
+            W.cb_hi = (float) ((double) W.cb_hi + cw * e);
+        }
+        if (j + 1 == W.pend) { // the partition closes: did a one-ulp difference at its near steps reach the sum that goes on?
+            if (!CHECK && W.near_steps > 0 && Lt.rec[wave_lane_here()] != PART_NO_REC) ULP_CENSUS(UC_CW_REACH, W.cb_lo != W.cb || W.cb_hi != W.cb, 0);
+            W.cb_lo = W.cb_hi = 0.0f;
+            W.near_steps = 0;
+        }
+#endif
         while (W.b < MP3MI_CBANDS && j + 1 == W.pend) { // closes this partition and any empty ones after it
             if (W.b == 0) { W.eb0 = W.eb; W.cb0 = W.cb; }
             else {
@@ -177,6 +205,10 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
 
     part_walk W;
     W.eb = W.eb0 = 0.0; W.cb = W.cb0 = 0.0f;
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+    W.cb_lo = W.cb_hi = 0.0f;
+    W.near_steps = 0;
+#endif
     W.b = 0; W.pend = T->part_l_start[1];
     while (W.b < MP3MI_CBANDS && W.pend == 0) { W.b++; W.pend = W.b < MP3MI_CBANDS ? T->part_l_start[W.b + 1] : -1; } // (never: partition 0 has lines)
 
@@ -246,6 +278,67 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
         const unsigned i = atomicAdd(&fix->count, 1u);
         if (i < fix->cap) fix->list[i] = (unsigned) rec;
     }
+}
+
+// k_part for a HANDFUL of records (the drop-in L3psycho_anal: one or two per launch): a wavefront per record, a LANE PER
+// PARTITION -- the partitions' sums are independent chains of at most a few dozen lines, where k_part's lane walks all
+// 513 lines of its record (64 us per launch when the wavefront has two records to show for it).  The same sums in the
+// same order: eb in double, cb rounded to float at every step (src/l3psy.c:565-578); lines beyond the table's coverage
+// go on top of partition 0's (lane 0 walks on).  cw_mid must hold SECOND-tier values (k_cw with MP3MI_TEST_CW_EXACT):
+// nothing is checked here, nothing is listed.
+__global__ void __launch_bounds__(64) k_part_wave(const mp3mi_tables *__restrict__ T, mp3mi_geom geo, const float *__restrict__ energy_l,
+                                                  const double *__restrict__ cw_mid, const float *__restrict__ hist6,
+                                                  const mp3mi_psy_state *__restrict__ state, double *__restrict__ eb_all, float *__restrict__ cb_all)
+{
+    const int lane = wave_lane();
+    const int C = geo.channels, G = geo.n_gran;
+    const size_t rec = blockIdx.x;
+    const int ch = (int) (rec % C), gl = (int) ((rec / C) % G);
+    const size_t s = rec / ((size_t) C * G);
+    const mp3mi_psy_state *st = &state[s * C + ch];
+    const float *er = energy_l + rec * MP3MI_HBLK_P;
+    const double *cwr = cw_mid + rec * 50;
+    if (lane >= MP3MI_CBANDS) return;
+    int j0 = T->part_l_start[lane], j1 = T->part_l_start[lane + 1];
+    if (j1 > T->part_l_covered) j1 = T->part_l_covered;
+    double eb = 0.0;
+    float cb = 0.0f;
+    for (int pass = 0; pass < 2; pass++) { // (lane 0: its own lines, then the uncovered ones)
+        for (int j = j0; j < j1; j++) {
+            double cw;
+            if (j < 6) { // unpredictability from this granule's r / phi and the two granules before it (src/l3psy.c:496-512): as k_part
+                const float rn = hist6[rec * 12 + j], pn = hist6[rec * 12 + 6 + j];
+                const float r1 = gl >= 1 ? hist6[(rec - C) * 12 + j] : st->r1[j], p1 = gl >= 1 ? hist6[(rec - C) * 12 + 6 + j] : st->p1[j];
+                const float r2 = gl >= 2 ? hist6[(rec - 2 * C) * 12 + j] : (gl == 1 ? st->r1[j] : st->r2[j]);
+                const float p2 = gl >= 2 ? hist6[(rec - 2 * C) * 12 + 6 + j] : (gl == 1 ? st->p1[j] : st->p2[j]);
+                const double r_prime = 2.0 * (double) r1 - (double) r2;
+                const double phi_prime = 2.0 * (double) p1 - (double) p2;
+                double sn, cn, sp, cp;
+                dm_sincos((double) pn, &sn, &cn);
+                dm_sincos(phi_prime, &sp, &cp);
+                const double t1 = (double) rn * cn - r_prime * cp;
+                const double t2 = (double) rn * sn - r_prime * sp;
+                const double t3 = (double) rn + __builtin_fabs(r_prime);
+                cw = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
+                if ((double) rn == r_prime && (double) pn == phi_prime) cw = -0.0;
+            } else
+                cw = j < 206 ? cwr[(j - 6) >> 2] : 0.4;
+            const double e = (double) er[j];
+            eb = eb + e;
+            cb = (float) ((double) cb + cw * e);
+        }
+        if (lane != 0) break;
+        j0 = T->part_l_covered; j1 = MP3MI_HBLK;
+    }
+    eb_all[rec * MP3MI_PART_P + lane] = eb;
+    cb_all[rec * MP3MI_PART_P + lane] = cb;
+}
+
+void mp3mi_launch_part_wave(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l, const double *cw_mid, const float *hist6,
+                            const void *psy_state, double *eb_all, float *cb_all, hipStream_t st)
+{
+    const size_t n_rec = (size_t) g.n_streams * (size_t) g.n_gran * (size_t) g.channels;
+    hipLaunchKernelGGL(k_part_wave, dim3((unsigned) n_rec), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all);
 }
 
 // The kernel is a chain of dependent steps per granule (k_part's sums in, spreading, threshold, entropy, ratios out),

@@ -72,7 +72,12 @@ def main():
             sites.append({"site": name, "calls": calls, "near": near, "wide": wide, "near_estimate": round(est_near, 3),
                           "near_per_million_frames": round(est_near / frames * 1e6, 3)})
             print("config %d  %-72s calls %13d  near %6d  wide %9d  (near ~ %.2f)" % (cid, name, calls, near, wide, est_near))
+        # site 12 (UC_CW_REACH): of the partitions that hold a near step of the c_w site, how many end in another float when
+        # every near step's float is moved one ulp down / up (both at once: the worst case)?
+        reach_parts, reach_hits = int(buf[3 * 12]), int(buf[3 * 12 + 1])
+        print("config %d  %-72s partitions with a near step %d, of which the sum that leaves k_part changes: %d" % (cid, "c_w: does a one-ulp float survive its partition?", reach_parts, reach_hits))
         row = {"config": cid, "workload": cfg["name"], "frames": frames, "sites": sites,
+               "cw_near_steps_partitions": reach_parts, "cw_near_steps_partitions_whose_sum_changes": reach_hits,
                "p_frame_differs_from_any_libm_within_one_ulp": adversarial / frames,
                "p_frame_differs_from_glibc_2_35_estimate": expected / frames}
         print("config %d: %d frames; per frame: <= %.2e against any libm within one ulp, ~ %.1e against glibc 2.35" % (
