@@ -162,7 +162,7 @@ void III_FlushBitstream(void);
  *     frame is given the same p, both granules are analysed in one launch; the second call is served from it if its
  *     pointer, its samples and the delay line are what was read.
  * A caller that moves or rewrites its buffers in between gets the call-by-call service (the channel's state is put back
- * to where the calls served so far left it): tests/test_dropin.py, oracle/dropin_probe.c -- bit-exact either way.  7 waits
+ * to where the calls served so far left it): tests/test_dropin.py, oracle/dropin_probe.c -- bit-exact either way.  6 waits
  * per frame instead of 79 under the reference's driver.  MP3MI_DROPIN_LOOKAHEAD = 0 none, 2 / 3 one of the two
  * (mp3mi_batch_options_from_env).  mp3mi_dropin_waits: waits for the device so far (tests, tools). */
 long mp3mi_dropin_waits(void);

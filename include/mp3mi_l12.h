@@ -20,6 +20,7 @@
  * padded (src/musicin.c:566-581 drops the fraction before looking at it).
  *
  * No CPU fallback: every entry point returns MP3MI_ERR_NO_DEVICE when HIP has no device.  Error codes: mp3mi.h.
+ * Threads: as for mp3mi_batch (mp3mi.h, "Threads"): one thread at a time per mp3mi_l12_batch, different batches independent.
  */
 #ifndef MP3MI_L12_H
 #define MP3MI_L12_H

@@ -322,7 +322,12 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     CHK(hipMemcpy(b->bitrate_index, b->bitrate_index_h.data(), sizeof(int32_t) * n_streams, hipMemcpyHostToDevice));
     CHK(hipMalloc((void **) &b->energy_l, ngc * MP3MI_HBLK_P * sizeof(float)));
     CHK(hipMalloc((void **) &b->part_eb, ngc * MP3MI_PART_P * sizeof(double)));
+#if defined(MP3MI_ULP_CENSUS) // (diagnostic build: two shadow copies behind the sums, mp3mi_geom::census_cb_stride)
+    CHK(hipMalloc((void **) &b->part_cb, 3 * ngc * MP3MI_PART_P * sizeof(float)));
+    CHK(hipMemset(b->part_cb, 0, 3 * ngc * MP3MI_PART_P * sizeof(float)));
+#else
     CHK(hipMalloc((void **) &b->part_cb, ngc * MP3MI_PART_P * sizeof(float)));
+#endif
     CHK(hipMalloc((void **) &b->energy_s, ngc * 3 * MP3MI_HBLK_S * sizeof(float)));
     CHK(hipMalloc((void **) &b->hist6, ngc * 12 * sizeof(float)));
     CHK(hipMalloc((void **) &b->fft_bins, ngc * MP3MI_FFT_BINS * sizeof(float)));
@@ -681,6 +686,9 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         g.hist = b->pcm_hist + v.s0 * MP3MI_PCM_HIST * (size_t) C;
         g.out_base = whole_file ? NULL : b->out_base + v.s0;
         g.whole_file = whole_file ? 1 : 0;
+#if defined(MP3MI_ULP_CENSUS)
+        g.census_cb_stride = (size_t) S * 2 * (size_t) b->chunk_frames * (size_t) C * MP3MI_PART_P;
+#endif
         v.g = g;
         v.slot = (c + b->slot_base) & 1;
         v.ev = v.slot * P + part;

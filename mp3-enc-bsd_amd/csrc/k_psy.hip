@@ -25,6 +25,9 @@ typedef struct {
 struct psy_lds {
     double eb[MP3MI_CBANDS], thr[MP3MI_CBANDS], pev[MP3MI_CBANDS];
     float cb[MP3MI_CBANDS];
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+    float cb_lo[MP3MI_CBANDS], cb_hi[MP3MI_CBANDS]; // k_part's shadow sums (census site UC_CW_NB)
+#endif
     double ebs[MP3MI_CBANDS_S], thrs[MP3MI_CBANDS_S];
     double held_l[21], held_s[36];
     double pe;
@@ -53,6 +56,13 @@ struct part_walk {
     int near_steps;
 #endif
 };
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+#define PART_CENSUS_ARG , size_t cstride
+#define PART_CENSUS_PASS , geo.census_cb_stride
+#else
+#define PART_CENSUS_ARG
+#define PART_CENSUS_PASS
+#endif
 
 // A closed partition's 64 values (one per lane = record) wait in an LDS tile; every eight partitions the tile
 // goes out transposed, 64 contiguous bytes of eb (32 of cb) per record, instead of one 8-byte store per lane
@@ -103,7 +113,7 @@ MP3MI_DEVFN bool part_cw_safe(double d, double e)
 // CHECK: cw is a first-tier value; *amb is set when a float rounding could depend on its last bits.
 template <bool CHECK>
 MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, int j, float ef, double cw,
-                           double *__restrict__ eb_all, float *__restrict__ cb_all, bool *amb)
+                           double *__restrict__ eb_all, float *__restrict__ cb_all, bool *amb PART_CENSUS_ARG)
 {
     const double e = (double) ef;
     if (j < T->part_l_covered) {
@@ -147,6 +157,15 @@ MP3MI_DEVFN void part_line(const mp3mi_tables *T, part_walk &W, part_tile &Lt, i
         }
         if (j + 1 == W.pend) { // the partition closes: did a one-ulp difference at its near steps reach the sum that goes on?
             if (!CHECK && W.near_steps > 0 && Lt.rec[wave_lane_here()] != PART_NO_REC) ULP_CENSUS(UC_CW_REACH, W.cb_lo != W.cb || W.cb_hi != W.cb, 0);
+            // ... and the shadow sums go on to k_psy (census site UC_CW_NB: do they reach a threshold?).  Partition 0 also takes
+            // the lines beyond the table's coverage (a constant c_w: the same addend for all three): its shadows keep the
+            // DIFFERENCE to the sum as it stands here, k_psy adds it to the final value
+            const unsigned rr = Lt.rec[wave_lane_here()];
+            if (cstride && rr != PART_NO_REC && W.b < MP3MI_CBANDS) {
+                cb_all[cstride + (size_t) rr * MP3MI_PART_P + W.b] = W.cb_lo; // (a first-tier step moves the shadows like the sum)
+                cb_all[2 * cstride + (size_t) rr * MP3MI_PART_P + W.b] = W.cb_hi;
+                if (W.b == 0) cb_all[(size_t) rr * MP3MI_PART_P + MP3MI_CBANDS] = W.cb; // (the row's one free slot: partition 0's sum at its close)
+            }
             W.cb_lo = W.cb_hi = 0.0f;
             W.near_steps = 0;
         }
@@ -229,7 +248,7 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
         const double t3 = (double) rn + __builtin_fabs(r_prime);
         double cw = (t3 != 0.0) ? __builtin_sqrt(t1 * t1 + t2 * t2) / t3 : 0.0;
         if ((double) rn == r_prime && (double) pn == phi_prime) cw = -0.0; // an exact zero in the reference too (k_fft.hip, cw_record)
-        part_line<false>(T, W, Lt, j, er[j], cw, eb_all, cb_all, &amb); // (correctly rounded sines: nothing to check)
+        part_line<false>(T, W, Lt, j, er[j], cw, eb_all, cb_all, &amb PART_CENSUS_PASS); // (correctly rounded sines: nothing to check)
     }
     // lines 6..511 in blocks of 32 = one 128-byte line of the energy row; the unpredictability of lines
     // 6+4n..9+4n is cw_mid[n] (src/l3psy.c:531-549), from line 206 on the constant 0.4 (src/l3psy.c:555-556).
@@ -259,11 +278,11 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
             const int jj = 32 * k + l;
             if (jj < 6) continue; // done above (only in block 0; wave-uniform)
             const int q = ((l - 6) >> 2) + 2; // arithmetic shift: l < 6 never reaches here with k == 0
-            if (jj < 206 && check) part_line<true>(T, W, Lt, jj, ev[l], cwv[q], eb_all, cb_all, &amb);
-            else part_line<false>(T, W, Lt, jj, ev[l], jj < 206 ? cwv[q] : 0.4, eb_all, cb_all, &amb);
+            if (jj < 206 && check) part_line<true>(T, W, Lt, jj, ev[l], cwv[q], eb_all, cb_all, &amb PART_CENSUS_PASS);
+            else part_line<false>(T, W, Lt, jj, ev[l], jj < 206 ? cwv[q] : 0.4, eb_all, cb_all, &amb PART_CENSUS_PASS);
         }
     }
-    part_line<false>(T, W, Lt, 512, er[512], 0.4, eb_all, cb_all, &amb);
+    part_line<false>(T, W, Lt, 512, er[512], 0.4, eb_all, cb_all, &amb PART_CENSUS_PASS);
     for (int b = W.b < 1 ? 1 : W.b; b < MP3MI_CBANDS; b++) { // partitions without lines
         Lt.eb[b & 7][lane] = 0.0;
         Lt.cb[b & 7][lane] = 0.0f;
@@ -412,6 +431,18 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
             const float rn = hist6[rec * 12 + lane], pn = hist6[rec * 12 + 6 + lane];
             r2 = r1; p2 = p1; r1 = rn; p1 = pn;
         }
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        if (b < MP3MI_CBANDS) { // the shadows of this granule's sums (k_part wrote them on the second-tier run only for listed records: the others carry the sum itself)
+            const size_t cs = geo.census_cb_stride;
+            float lo = cb_all[cs + rec * MP3MI_PART_P + b], hi = cb_all[2 * cs + rec * MP3MI_PART_P + b];
+            if (b == 0) { // partition 0: the shadows stopped at its close, the uncovered lines came on top (see k_part)
+                const float at_close = cb_all[rec * MP3MI_PART_P + MP3MI_CBANDS], fin = cb_all[rec * MP3MI_PART_P];
+                lo = fin + (lo - at_close); hi = fin + (hi - at_close);
+            }
+            L.cb_lo[b] = cs ? lo : cb_all[rec * MP3MI_PART_P + b];
+            L.cb_hi[b] = cs ? hi : cb_all[rec * MP3MI_PART_P + b];
+        }
+#endif
         if (b < MP3MI_CBANDS) {
             L.eb[b] = eb_next;
             L.cb[b] = cb_next;
@@ -426,6 +457,12 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
         // spreading (src/l3psy.c:586-605, 1062-1084)
         float ecb = 0.0f;
         double ctb = 0.0;
+#if defined(MP3MI_ULP_CENSUS) && !defined(MP3MI_EMU)
+        double ctb_lo = 0.0, ctb_hi = 0.0;
+#define PSY_CENSUS_SPREAD(sv, k) { ctb_lo = ctb_lo + (sv) * (double) L.cb_lo[k]; ctb_hi = ctb_hi + (sv) * (double) L.cb_hi[k]; }
+#else
+#define PSY_CENSUS_SPREAD(sv, k)
+#endif
         if (SPARSE) { // every lane takes PSY_S3_W steps; a step past the row's end adds nothing (table build checks the width)
 #pragma unroll
             for (int i = 0; i < PSY_S3_W; i++) {
@@ -434,6 +471,7 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
                     const double sv = s3rows[i][lane];
                     ecb = (float) ((double) ecb + sv * L.eb[k]);
                     ctb = ctb + sv * (double) L.cb[k];
+                    PSY_CENSUS_SPREAD(sv, k)
                 }
             }
         } else if (b < MP3MI_CBANDS) {
@@ -447,6 +485,7 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
                     if (svv[u] != 1.0) { // src/l3psy.c:596-603: entries that are exactly 1 are skipped at these rates
                         ecb = (float) ((double) ecb + svv[u] * L.eb[k0 + u]);
                         ctb = ctb + svv[u] * (double) L.cb[k0 + u];
+                        PSY_CENSUS_SPREAD(svv[u], k0 + u)
                     }
                 }
             }
@@ -491,6 +530,24 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
             const double prx = ((double) ecb * norm_l) * dm_exp(-snr * R_LN_TO_LOG10);
             const long long dd = dm_float_midpoint_distance_ulps(prx);
             ULP_CENSUS(UC_NB, dd <= 20, dd <= (20LL << 20));
+            // site UC_CW_NB: this partition's threshold with k_part's shadow sums in the spreading -- every float of a near
+            // step of the c_w site one ulp lower, and one ulp higher -- : calls = thresholds a shadow reaches at all (the
+            // spread unpredictability differs), near = thresholds that come out as another float
+            if (ctb_lo != ctb || ctb_hi != ctb) {
+                bool differs = false;
+                for (int w = 0; w < 2; w++) {
+                    double c2 = (w ? ctb_hi : ctb_lo) / (double) ecb;
+                    if (c2 < 0.01) c2 = 0.01;
+                    c2 = dm_log(c2);
+                    double t2 = -0.299 - 0.43 * c2;
+                    t2 = (0.0 > t2) ? 0.0 : t2;
+                    t2 = (1.0 < t2) ? 1.0 : t2;
+                    double s2 = 29.0 * t2 + 6.0 * (1.0 - t2);
+                    s2 = (minval > s2) ? minval : s2;
+                    differs |= (float) (((double) ecb * norm_l) * dm_exp(-s2 * R_LN_TO_LOG10)) != (float) prx;
+                }
+                ULP_CENSUS(UC_CW_NB, differs, 0);
+            }
         }
 #endif
         if (b < MP3MI_CBANDS) {

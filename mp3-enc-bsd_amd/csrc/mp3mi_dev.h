@@ -211,6 +211,7 @@ typedef struct {
 enum { UC_PHASE, UC_NB, UC_PE_ATTACK, UC_PE_RESV, UC_QUANTANF, UC_SCFSI_LOG, UC_CW_STEP, UC_CW_RANGE,
        UC_L12_C, UC_L12_BC, UC_L12_EXP, UC_L12_SNR, /* Layers I / II (k_l12.hip) */
        UC_CW_REACH, /* k_part: partitions with a near step of UC_CW_STEP (calls), those whose sum changes when the steps' floats move by one ulp (near) */
+       UC_CW_NB,    /* k_psy: thresholds nb whose spread unpredictability such a changed sum reaches (calls), those that come out as another float (near) */
        UC_N };
 static __device__ unsigned long long g_ulp_census[UC_N][3]; /* (one copy per translation unit: no relocatable device code here) */
 /* adds this translation unit's counters to out[UC_N][3] and clears them */

@@ -19,6 +19,9 @@ int mp3mi_tables_digest(int rate_idx, uint64_t *hashes, const char **names, int 
 
 /* kernel launchers (one per .hip file); all take device pointers */
 struct mp3mi_geom {
+#if defined(MP3MI_ULP_CENSUS)
+    size_t census_cb_stride; /* diagnostic build: the shadow sums of census site UC_CW_REACH sit this many floats (and twice as many) behind cb_all */
+#endif
     int n_streams, channels, rate_idx;
     int n_frames;       /* frames per stream in this call (PCM extent = n_frames*1152 per channel) */
     int f0, nf;         /* frames [f0, f0+nf) form the current chunk */
@@ -57,6 +60,9 @@ static inline mp3mi_geom mp3mi_make_geom(int n_streams, int channels, int rate_i
     g.test_flags = 0;
     g.pcm_pitch = 0;
     g.n_samples = NULL;
+#if defined(MP3MI_ULP_CENSUS)
+    g.census_cb_stride = 0;
+#endif
     return g;
 }
 

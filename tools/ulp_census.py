@@ -76,8 +76,11 @@ def main():
         # every near step's float is moved one ulp down / up (both at once: the worst case)?
         reach_parts, reach_hits = int(buf[3 * 12]), int(buf[3 * 12 + 1])
         print("config %d  %-72s partitions with a near step %d, of which the sum that leaves k_part changes: %d" % (cid, "c_w: does a one-ulp float survive its partition?", reach_parts, reach_hits))
+        nb_reached, nb_changed = int(buf[3 * 13]), int(buf[3 * 13 + 1])
+        print("config %d  %-72s thresholds the changed sums reach %d, of which come out as another float: %d" % (cid, "c_w: does it reach a threshold nb?  [k_psy]", nb_reached, nb_changed))
         row = {"config": cid, "workload": cfg["name"], "frames": frames, "sites": sites,
                "cw_near_steps_partitions": reach_parts, "cw_near_steps_partitions_whose_sum_changes": reach_hits,
+               "cw_thresholds_reached_by_a_changed_sum": nb_reached, "cw_thresholds_that_change": nb_changed,
                "p_frame_differs_from_any_libm_within_one_ulp": adversarial / frames,
                "p_frame_differs_from_glibc_2_35_estimate": expected / frames}
         print("config %d: %d frames; per frame: <= %.2e against any libm within one ulp, ~ %.1e against glibc 2.35" % (
