@@ -76,13 +76,15 @@ typedef struct mp3mi_batch_options {
     int32_t dropin_lookahead; /* the drop-in symbols' look-ahead (mp3mi_dropin.h): -1 default = 1 both, 0 none, 2 the filterbank's only,
                                  3 L3psycho_anal's only.  Not a property of a batch: the hidden default stream of the drop-in symbols
                                  reads it through mp3mi_batch_options_from_env (MP3MI_DROPIN_LOOKAHEAD) */
+    int32_t dropin_stats;     /* the drop-in symbols print, at III_FlushBitstream, the frames they served, the time from the first frame's
+                                 first call to the flush and the waits for the device: 0 default, 1 (MP3MI_DROPIN_STATS) */
 } mp3mi_batch_options;
 /* mp3mi_batch_create_ex returns MP3MI_ERR_ARG for a value outside the ranges named above (the three-state fields take
  * -1, 0, 1; psy_beside -1 .. 2; dropin_lookahead -1 .. 3; loop_queue 0, 1; loop_part_streams a multiple of 64; unknown test flags). */
 void mp3mi_batch_options_default(mp3mi_batch_options *opt);
 /* The same, then overridden by the MP3MI_* environment variables that tools/ and tests/ use (MP3MI_SCRATCH_MB,
  * MP3MI_CHUNK_FRAMES, MP3MI_{NOISE,PHASE,PSY,QUANT,PREP,CW}_EXACT, MP3MI_CALL_OVERLAP, MP3MI_NO_GATE, MP3MI_NO_PLACE,
- * MP3MI_LOOP_PARTS, MP3MI_LOOP_PART_STREAMS, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE, MP3MI_DROPIN_LOOKAHEAD).  This is the ONLY place the library
+ * MP3MI_LOOP_PARTS, MP3MI_LOOP_PART_STREAMS, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE, MP3MI_DROPIN_LOOKAHEAD, MP3MI_DROPIN_STATS).  This is the ONLY place the library
  * reads its environment: mp3mi_batch_create calls it once; mp3mi_batch_create_ex never does. */
 void mp3mi_batch_options_from_env(mp3mi_batch_options *opt);
 

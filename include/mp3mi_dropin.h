@@ -154,17 +154,22 @@ void III_FlushBitstream(void);
 
 /* LOOK-AHEAD.  Served one call at a time, a frame of the reference's loop costs 79 waits for the device.  The library
  * therefore reads ahead -- only in memory the caller has already handed over:
+ *   - L3psycho_anal: when a channel's two calls of the frame BEFORE were given p and p + 576 and the first call of this
+ *     frame is given the same p, both granules are analysed at once -- and the other channel's with them when its calls of
+ *     the frame before show the same pattern (its buffer and its delay line were handed over then, at the addresses
+ *     remembered): one launch for the frame's four calls;
  *   - window_subband / filter_subband: the four L3psycho_anal calls of a frame were given &buffer[ch][0] and
  *     &buffer[ch][576] (src/musicin.c:754-758); when a channel's first window_subband of the frame starts at that same
- *     &buffer[ch][0], the 36 slots of both channels are computed in one launch and handed out call by call, while every
- *     call's pointer is where the previous one left it and its 32 samples are still what was read;
- *   - L3psycho_anal: when a channel's two calls of the frame BEFORE were given p and p + 576 and the first call of this
- *     frame is given the same p, both granules are analysed in one launch; the second call is served from it if its
- *     pointer, its samples and the delay line are what was read.
- * A caller that moves or rewrites its buffers in between gets the call-by-call service (the channel's state is put back
- * to where the calls served so far left it): tests/test_dropin.py, oracle/dropin_probe.c -- bit-exact either way.  6 waits
- * per frame instead of 79 under the reference's driver.  MP3MI_DROPIN_LOOKAHEAD = 0 none, 2 / 3 one of the two
- * (mp3mi_batch_options_from_env).  mp3mi_dropin_waits: waits for the device so far (tests, tools). */
+ *     &buffer[ch][0], the 36 slots of both channels are computed in one launch and handed out call by call;
+ *   - mdct_sub: launched right behind that filterbank kernel, from the subband samples it produced and the block types
+ *     L3psycho_anal handed out, and served if the caller's L3SBS and block types are exactly those.
+ * Every served call first checks that its pointer is where the previous call left it and that its samples (delay line,
+ * subband samples, block types) are still what was read; a caller that moves or rewrites its buffers in between gets the
+ * call-by-call service, with the channel's state put back to where the served calls left it: tests/test_dropin.py,
+ * oracle/dropin_probe.c -- bit-exact either way.  4 waits per frame instead of 79 under the reference's driver (a one-thread
+ * kernel stores a flag in host-mapped memory behind each call's launches; the host spins on it).  MP3MI_DROPIN_LOOKAHEAD =
+ * 0 none, 2 / 3 one of the two families (mp3mi_batch_options_from_env); MP3MI_DROPIN_STATS=1: a line at III_FlushBitstream.
+ * mp3mi_dropin_waits: waits for the device so far (tests, tools). */
 long mp3mi_dropin_waits(void);
 
 #ifdef __cplusplus

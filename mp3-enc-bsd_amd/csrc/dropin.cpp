@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "mp3mi_host.h"
 #include "mp3mi.h"
 #include "mp3mi_dropin.h"
@@ -21,7 +22,8 @@ void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double 
 void mp3mi_launch_window_filter(const mp3mi_tables *T, double *ring, int off, const mp3mi_dropin_samples &in, double *zs, hipStream_t st);
 void mp3mi_launch_mdct_sub(const mp3mi_tables *T, double *sb, const int32_t *bt, double *xr, int stereo, int mode_gr, hipStream_t st);
 void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
-                                      double *zs, hipStream_t st);
+                                      double *zs, double *sb_out, hipStream_t st);
+void mp3mi_launch_dropin_done(unsigned *flag, unsigned seq, hipStream_t st);
 void mp3mi_launch_part_wave(const mp3mi_tables *T, const mp3mi_geom &g, const float *energy_l, const double *cw_mid, const float *hist6,
                             const void *psy_state, double *eb_all, float *cb_all, hipStream_t st);
 void mp3mi_launch_prep_tail(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy, mp3mi_loop_prep *prep,
@@ -111,16 +113,29 @@ struct DropIn {
     const short *psy_ptr[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // this frame's L3psycho_anal buffers, [ch][gr]
     int psy_seen[2] = {0, 0};      // bit gr: seen since the channel's last window look-ahead
     const short *psy_prev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // the frame before
-    struct psy_ahead {
-        bool valid = false;
-        const short *p1 = nullptr; // where granule 1's samples were read
-        short smp1[576];           // ... and what they were
-        short save_after[1344];    // the delay line as the first call left it
-        mp3mi_psy_out out1;        // granule 1's result (the other channel's launch reuses the result buffer)
+    struct psy_ahead { // per channel: what the frame's look-ahead holds for the channel's calls still to come
+        bool valid[2] = {false, false}; // [granule]: analysed ahead, not handed out yet
+        const short *p[2] = {nullptr, nullptr}; // where the call's 576 samples were read
+        short smp[2][576];         // ... and what they were
+        short save_before[2][1344]; // the delay line the call must find (before its own shift)
+        mp3mi_psy_out out[2];
+        int served = 0;            // granules of the frame handed out from the look-ahead so far (replayed on a fall-back)
     } pa[2];
-    io_buf<mp3mi_psy_out> psy2;    // the two granules' results
+    const short *psy_save_ptr[2] = {nullptr, nullptr}; // the delay lines (savebuf) the channels' calls were given last
+    // mdct_sub ahead of its call: the filterbank look-ahead knows the frame's subband samples, L3psycho_anal has handed out its
+    // block types -- the transform is launched right behind the filterbank kernel (one wait for both) and mdct_sub hands its
+    // result out IF the caller's L3SBS and block types are what it was computed from (compared value by value)
+    int bt_pred[2][2] = {{0, 0}, {0, 0}}; // [gr][ch], as handed out by this frame's L3psycho_anal calls
+    int bt_known = 0;                     // bit gr * 2 + ch
+    struct { bool valid = false; int n_ch = 0; double prev[2][576]; } spec; // prev: granule slot 0 of the L3SBS before the launch
+    io_buf<mp3mi_psy_out> psy2;    // the look-ahead's results: [granule][channel]
     void *psy_snap = nullptr;      // [2] psychoacoustic state before a two-granule launch
+    io_buf<unsigned> done_flag;    // what the host spins on at the end of a call's launches (k_dropin_done)
+    unsigned done_seq = 0;
     long n_launch_waits = 0;       // (statistics: waits for the device, mp3mi_dropin_waits)
+    bool stats = false;            // options.dropin_stats: a line at III_FlushBitstream
+    double t_first = 0.0;          // when the first frame's first call came in (seconds, steady clock)
+    long frames_total = 0;
     // mdct
     io_buf<double> sb, xr;
     io_buf<int32_t> bt;
@@ -159,14 +174,14 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.T, sizeof(mp3mi_tables)));
     HIPOK(hipMemcpy(D.T, Th, sizeof(mp3mi_tables), hipMemcpyHostToDevice));
     free(Th);
-    D.pcm.alloc(2304 * sizeof(int16_t));
-    HIPOK(hipMalloc((void **) &D.el, 2 * MP3MI_HBLK_P * sizeof(float))); // (two records: a channel's two granules in one launch)
-    HIPOK(hipMalloc((void **) &D.part_eb, 2 * MP3MI_PART_P * sizeof(double)));
-    HIPOK(hipMalloc((void **) &D.part_cb, 2 * MP3MI_PART_P * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.es, 2 * 3 * MP3MI_HBLK_S * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.h6, 2 * 12 * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.bins, 2 * MP3MI_FFT_BINS * sizeof(float)));
-    HIPOK(hipMalloc((void **) &D.cw, 2 * 50 * sizeof(double)));
+    D.pcm.alloc(2 * 2304 * sizeof(int16_t)); // (two channels interleaved at most)
+    HIPOK(hipMalloc((void **) &D.el, 4 * MP3MI_HBLK_P * sizeof(float))); // (four records: a frame's two granules of two channels in one launch)
+    HIPOK(hipMalloc((void **) &D.part_eb, 4 * MP3MI_PART_P * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.part_cb, 4 * MP3MI_PART_P * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.es, 4 * 3 * MP3MI_HBLK_S * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.h6, 4 * 12 * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.bins, 4 * MP3MI_FFT_BINS * sizeof(float)));
+    HIPOK(hipMalloc((void **) &D.cw, 4 * 50 * sizeof(double)));
     HIPOK(hipMalloc((void **) &D.cw_fix, mp3mi_cw_fixlist_bytes(4)));
     HIPOK(hipMalloc((void **) &D.psy_state, 2 * mp3mi_psy_state_size()));
     HIPOK(hipMemset(D.psy_state, 0, 2 * mp3mi_psy_state_size()));
@@ -176,9 +191,10 @@ void ensure(int rate_idx)
     HIPOK(hipMalloc((void **) &D.s_d, 32 * sizeof(double)));
     HIPOK(hipHostMalloc((void **) &D.zs_h, (512 + 32) * sizeof(double), hipHostMallocMapped));
     HIPOK(hipHostGetDevicePointer((void **) &D.zs_d, D.zs_h, 0));
+    D.done_flag.alloc(64);
     D.wa_smp.alloc(2 * 1152 * sizeof(int16_t));
     D.wa_zs.alloc((size_t) 2 * 36 * 544 * sizeof(double));
-    D.psy2.alloc(2 * sizeof(mp3mi_psy_out));
+    D.psy2.alloc(4 * sizeof(mp3mi_psy_out));
     HIPOK(hipMalloc(&D.psy_snap, 2 * mp3mi_psy_state_size()));
     {
         mp3mi_batch_options o; // (the one place the library reads its environment: batch.cpp)
@@ -186,6 +202,7 @@ void ensure(int rate_idx)
         const int v = o.dropin_lookahead < 0 ? 1 : o.dropin_lookahead;
         D.lookahead = v == 1 || v == 2;
         D.lookahead_psy = v == 1 || v == 3;
+        D.stats = o.dropin_stats == 1;
     }
     D.sb.alloc(sizeof(L3SBS));
     D.xr.alloc(4 * 576 * sizeof(double));
@@ -235,7 +252,30 @@ void emit(long upto, long base)
 
 } // namespace
 
-static void psy_wait() { HIPOK(hipStreamSynchronize(D.st)); D.n_launch_waits++; }
+static double now_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+// Waits for everything launched on the hidden stream so far.  A flag in host-mapped memory, stored by a one-thread kernel behind the
+// call's launches, is seen by the spinning host a few microseconds after the store; hipStreamSynchronize alone takes ~25 us to
+// come back, and a frame has four such waits.  The spin is bounded (a device that does not answer within two seconds is the
+// runtime's business).
+static void dropin_wait()
+{
+    const unsigned seq = ++D.done_seq;
+    mp3mi_launch_dropin_done(D.done_flag.d, seq, D.st);
+    volatile unsigned *f = D.done_flag.h;
+    const double t0 = now_s();
+    for (unsigned spin = 0; *f != seq; spin++)
+        if ((spin & 0xfffu) == 0xfffu && now_s() - t0 > 2.0) break;
+    if (*f != seq) HIPOK(hipStreamSynchronize(D.st));
+    D.n_launch_waits++;
+}
+
+static void psy_wait() { dropin_wait(); }
 
 // the kernels behind one L3psycho_anal launch (g: one or two granules of a mono pseudo-stream).  The unpredictability comes
 // from the correctly rounded sines throughout (k_cw's second tier: MP3MI_TEST_CW_EXACT) and the partition sums from
@@ -263,14 +303,50 @@ static void psy_one_granule(const short *savebuf, int chn, mp3mi_psy_out *dst_d)
     psy_launch(g, chn, dst_d);
 }
 
-static void psy_hand_out(const mp3mi_psy_out &o, double ratio_d[21], double ratio_ds[12][3], double *pe, gr_info *cod_info)
+static void psy_hand_out(const mp3mi_psy_out &o, double ratio_d[21], double ratio_ds[12][3], double *pe, gr_info *cod_info, int gr, int ch)
 {
+    D.bt_pred[gr][ch] = o.block_type;
+    D.bt_known |= 1 << (gr * 2 + ch);
     memcpy(ratio_d, o.ratio_l, sizeof(o.ratio_l));
     memcpy(ratio_ds, o.ratio_s, sizeof(o.ratio_s));
     *pe = o.pe;
     cod_info->block_type = (unsigned) o.block_type;
     cod_info->window_switching_flag = (o.block_type == 0) ? 0 : 1;
     cod_info->mixed_block_flag = 0;
+}
+
+// The look-ahead of a frame: both granules of the channels [first, first + n_ch) in ONE launch.  P[c]: the channel's 1152
+// samples; delay[c]: its delay line as its first call of the frame finds it (for the channel whose call this is: see the
+// caller).  Fills D.pa[c] and leaves the results in D.psy2.h[granule * n_ch + (c - first)].
+static void psy_ahead_start(int first, int n_ch, const short *const P[2], const short *const delay_before[2])
+{
+    const size_t ss = mp3mi_psy_state_size();
+    HIPOK(hipMemcpyAsync((char *) D.psy_snap + (size_t) first * ss, (char *) D.psy_state + (size_t) first * ss, (size_t) n_ch * ss, hipMemcpyDeviceToDevice, D.st));
+    // the pseudo-stream of a channel: granule 2's window is samples [384, 1728) = the delay line after the first call's
+    // shift, granule 3's [960, 2304) = the same shifted by the second granule's samples
+    memset(D.pcm.h, 0, (size_t) 384 * n_ch * sizeof(int16_t));
+    for (int c = first; c < first + n_ch; c++) {
+        DropIn::psy_ahead &A = D.pa[c];
+        const int k = c - first;
+        for (int g = 0; g < 2; g++) {
+            A.valid[g] = true;
+            A.p[g] = P[c] + 576 * g;
+            memcpy(A.smp[g], P[c] + 576 * g, sizeof(A.smp[g]));
+        }
+        memcpy(A.save_before[0], delay_before[c], sizeof(A.save_before[0]));
+        memcpy(A.save_before[1], delay_before[c] + 576, 768 * sizeof(short)); // the first call's shift (src/l3psy.c:477-481)
+        memcpy(A.save_before[1] + 768, P[c], 576 * sizeof(short));
+        A.served = 0;
+        for (int i = 0; i < 1344; i++) D.pcm.h[(384 + i) * n_ch + k] = A.save_before[1][i];
+        for (int i = 0; i < 576; i++) D.pcm.h[(1728 + i) * n_ch + k] = P[c][576 + i];
+    }
+    mp3mi_geom g = mp3mi_make_geom(1, n_ch, D.rate_idx, 2, 1, 1);
+    g.g0 = 2;
+    g.n_gran = 2;
+    psy_launch(g, first, D.psy2.d);
+    psy_wait();
+    for (int c = first; c < first + n_ch; c++)
+        for (int gr = 0; gr < 2; gr++) D.pa[c].out[gr] = D.psy2.h[gr * n_ch + (c - first)];
 }
 
 extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int chn, int lay, float snr32[32],
@@ -281,68 +357,72 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
     if (lay != 3) DIE("L3psycho_anal: layer %d is not served by this library", lay);
     if (chn < 0 || chn > 1) DIE("L3psycho_anal: channel %d", chn);
     ensure(rate_index_of(sfreq));
+    if (D.t_first == 0.0) D.t_first = now_s();
     DropIn::psy_ahead &A = D.pa[chn];
-    if (A.valid) { // the channel's second granule was analysed with its first one: is this the call that was foreseen?
-        A.valid = false;
-        const bool same = buffer == A.p1 && memcmp(buffer, A.smp1, sizeof(A.smp1)) == 0 && memcmp(savebuf, A.save_after, sizeof(A.save_after)) == 0;
-        // delay line: drop the oldest 576 samples, append the new ones (src/l3psy.c:477-481)
-        memmove(savebuf, savebuf + 576, 768 * sizeof(short));
-        memcpy(savebuf + 768, buffer, 576 * sizeof(short));
-        D.psy_ptr[chn][1] = buffer;
-        D.psy_seen[chn] |= 2;
-        if (same) {
-            psy_hand_out(A.out1, ratio_d, ratio_ds, pe, cod_info);
-            return;
-        }
-        // not what was read ahead: the state goes back to before the pair, granule 0 is analysed again alone (from the
-        // delay line as the first call left it), then this call on its own
-        const size_t ss = mp3mi_psy_state_size();
-        HIPOK(hipMemcpyAsync((char *) D.psy_state + (size_t) chn * ss, (char *) D.psy_snap + (size_t) chn * ss, ss, hipMemcpyDeviceToDevice, D.st));
-        psy_one_granule(A.save_after, chn, D.psy1.d);
-        psy_wait(); // (D.pcm is host memory the kernels read: the next launch's samples may only be written now)
-        psy_one_granule(savebuf, chn, D.psy1.d);
-        psy_wait();
-        psy_hand_out(*D.psy1.h, ratio_d, ratio_ds, pe, cod_info);
-        return;
-    }
-    // a channel's first call of a frame (or any call when nothing was foreseen)
+    // which of the frame's calls is this (for the window look-ahead's bookkeeping)?
+    const bool first_of_frame = !(D.psy_seen[chn] & 1) || (D.psy_seen[chn] & 2);
+    const short *const prev0 = D.psy_ptr[chn][0], *const prev1 = D.psy_ptr[chn][1]; // the frame before, if this is a first call
+    const int ga = A.valid[0] ? 0 : (A.valid[1] ? 1 : -1); // the granule the look-ahead expects next for this channel
+    const bool foreseen = ga >= 0 && buffer == A.p[ga] && memcmp(buffer, A.smp[ga], sizeof(A.smp[ga])) == 0 &&
+                          memcmp(savebuf, A.save_before[ga], sizeof(A.save_before[ga])) == 0;
+    // delay line: drop the oldest 576 samples, append the new ones (src/l3psy.c:477-481)
     memmove(savebuf, savebuf + 576, 768 * sizeof(short));
     memcpy(savebuf + 768, buffer, 576 * sizeof(short));
-    const bool first_of_frame = !(D.psy_seen[chn] & 1) || (D.psy_seen[chn] & 2);
     if (first_of_frame) {
-        D.psy_prev[chn][0] = D.psy_ptr[chn][0]; D.psy_prev[chn][1] = D.psy_ptr[chn][1];
+        D.psy_prev[chn][0] = prev0; D.psy_prev[chn][1] = prev1;
         D.psy_ptr[chn][0] = buffer; D.psy_ptr[chn][1] = nullptr;
         D.psy_seen[chn] = 1;
-    } else { // the second granule of a frame whose first one was served alone
+    } else {
         D.psy_ptr[chn][1] = buffer;
         D.psy_seen[chn] |= 2;
     }
-    // both granules at once: the caller gave p and p + 576 last frame and gives the same p now -- [p, p + 1152) is memory
-    // it has handed over before
-    if (D.lookahead_psy && first_of_frame && D.psy_prev[chn][0] == buffer && D.psy_prev[chn][1] == buffer + 576) {
+    D.psy_save_ptr[chn] = savebuf;
+    if (ga >= 0) {
+        if (foreseen) { // the call the look-ahead was made for
+            A.valid[ga] = false;
+            A.served = ga + 1;
+            psy_hand_out(A.out[ga], ratio_d, ratio_ds, pe, cod_info, first_of_frame ? 0 : 1, chn);
+            return;
+        }
+        // not what was read ahead: the channel's state goes back to before the look-ahead, the granules handed out from it
+        // are analysed again one by one (from the delay lines they found), then this call on its own
         const size_t ss = mp3mi_psy_state_size();
-        HIPOK(hipMemcpyAsync((char *) D.psy_snap + (size_t) chn * ss, (char *) D.psy_state + (size_t) chn * ss, ss, hipMemcpyDeviceToDevice, D.st));
-        // the pseudo-stream: granule 2's window is [384, 1728) = the delay line now, granule 3's [960, 2304) = the same
-        // shifted by the next 576 samples
-        memset(D.pcm.h, 0, 384 * sizeof(int16_t));
-        memcpy(D.pcm.h + 384, savebuf, 1344 * sizeof(int16_t));
-        memcpy(D.pcm.h + 1728, buffer + 576, 576 * sizeof(int16_t));
-        mp3mi_geom g = mp3mi_make_geom(1, 1, D.rate_idx, 2, 1, 1);
-        g.g0 = 2;
-        g.n_gran = 2;
-        psy_launch(g, chn, D.psy2.d);
+        HIPOK(hipMemcpyAsync((char *) D.psy_state + (size_t) chn * ss, (char *) D.psy_snap + (size_t) chn * ss, ss, hipMemcpyDeviceToDevice, D.st));
+        for (int q = 0; q < A.served; q++) {
+            psy_one_granule(A.save_before[q + 1], chn, D.psy1.d); // (served <= 1: the delay line after the first call = what the second must find)
+            psy_wait(); // (D.pcm is host memory the kernels read: the next launch's samples may only be written now)
+        }
+        A.valid[0] = A.valid[1] = false;
+        psy_one_granule(savebuf, chn, D.psy1.d);
         psy_wait();
-        A.valid = true;
-        A.p1 = buffer + 576;
-        memcpy(A.smp1, buffer + 576, sizeof(A.smp1));
-        memcpy(A.save_after, savebuf, sizeof(A.save_after));
-        A.out1 = D.psy2.h[1];
-        psy_hand_out(D.psy2.h[0], ratio_d, ratio_ds, pe, cod_info);
+        psy_hand_out(*D.psy1.h, ratio_d, ratio_ds, pe, cod_info, first_of_frame ? 0 : 1, chn);
+        return;
+    }
+    // Nothing was read ahead for this channel.  A first call of a frame starts a look-ahead when the channel's calls of the
+    // frame BEFORE were given p and p + 576 and this one is given the same p: [p, p + 1152) is memory the caller has handed
+    // over before.  The other channel joins in when its own calls of the frame before show the same pattern -- its buffer
+    // and its delay line were handed over then, at the addresses remembered -- and nothing of it is pending.
+    if (D.lookahead_psy && first_of_frame && prev0 == buffer && prev1 == buffer + 576) {
+        const int o = chn ^ 1;
+        const bool both = chn == 0 && D.psy_ptr[o][0] && D.psy_ptr[o][1] == D.psy_ptr[o][0] + 576 && D.psy_save_ptr[o] &&
+                          !D.pa[o].valid[0] && !D.pa[o].valid[1];
+        // this channel's delay line "as its first call found it": the shift above has already happened and the 576 oldest
+        // samples are gone, but the look-ahead only derives the line AFTER the shift from it -- which is savebuf as it stands
+        short before[1344];
+        memset(before, 0, 576 * sizeof(short));
+        memcpy(before + 576, savebuf, 768 * sizeof(short));
+        const short *P[2] = {nullptr, nullptr}, *DL[2] = {nullptr, nullptr};
+        P[chn] = buffer; DL[chn] = before;
+        if (both) { P[o] = D.psy_ptr[o][0]; DL[o] = D.psy_save_ptr[o]; }
+        psy_ahead_start(both ? 0 : chn, both ? 2 : 1, P, DL);
+        A.valid[0] = false; // this call is the channel's first: served now
+        A.served = 1;
+        psy_hand_out(A.out[0], ratio_d, ratio_ds, pe, cod_info, 0, chn);
         return;
     }
     psy_one_granule(savebuf, chn, D.psy1.d);
     psy_wait();
-    psy_hand_out(*D.psy1.h, ratio_d, ratio_ds, pe, cod_info);
+    psy_hand_out(*D.psy1.h, ratio_d, ratio_ds, pe, cod_info, first_of_frame ? 0 : 1, chn);
 }
 
 // the ring of channel k is brought to where the slots handed out so far left it; the look-ahead of the channel ends
@@ -399,10 +479,24 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
             D.wa[c].next = 0;
             D.psy_seen[c] = 0; // (the next frame's calls have to be seen again)
         }
+        // the frame's mdct_sub behind the same wait, when all its inputs are in hand: both granules' block types of the
+        // channels covered (every channel of the frame: first == 0) and the previous frame's granule in D.sb
+        bool spec = first == 0;
+        for (int c = 0; c < n_ch; c++) spec = spec && (D.bt_known & (1 << c)) && (D.bt_known & (1 << (2 + c)));
+        if (spec) {
+            for (int c = 0; c < n_ch; c++) {
+                memcpy(D.spec.prev[c], D.sb.h + (size_t) c * 3 * 576, sizeof(D.spec.prev[c]));
+                D.bt.h[c] = D.bt_pred[0][c];
+                D.bt.h[2 + c] = D.bt_pred[1][c];
+            }
+        }
         mp3mi_launch_window_filter_frame(D.T, D.ring.d + 512 * first, D.off[first], D.off[first + n_ch - 1], D.wa_smp.d + 1152 * first, n_ch, 36,
-                                         D.wa_zs.d + (size_t) first * 36 * 544, D.st);
-        HIPOK(hipStreamSynchronize(D.st));
-        D.n_launch_waits++;
+                                         D.wa_zs.d + (size_t) first * 36 * 544, spec ? D.sb.d : NULL, D.st);
+        if (spec) mp3mi_launch_mdct_sub(D.T, D.sb.d, D.bt.d, D.xr.d, n_ch, 2, D.st);
+        D.spec.valid = spec;
+        D.spec.n_ch = n_ch;
+        D.bt_known = 0;
+        dropin_wait();
         window_subband(buffer, z, k); // handed out from what was just computed
         return;
     }
@@ -410,8 +504,7 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
     memcpy(in.v, *buffer, sizeof(in.v));
     *buffer += 32; // src/encode.c:307
     mp3mi_launch_window_filter(D.T, D.ring.d + 512 * k, D.off[k], in, D.zs_d, D.st);
-    HIPOK(hipStreamSynchronize(D.st));
-    D.n_launch_waits++;
+    dropin_wait();
     memcpy(z, D.zs_h, 512 * sizeof(double));
     memcpy(D.last_z, D.zs_h, 512 * sizeof(double));
     memcpy(D.last_s, D.zs_h + 512, 32 * sizeof(double));
@@ -442,10 +535,27 @@ extern "C" void mdct_sub(L3SBS *sb_sample, double (*mdct_freq)[2][576], int ster
     int32_t bt[4] = {0, 0, 0, 0};
     for (int gr = 0; gr < 2; gr++)
         for (int ch = 0; ch < stereo; ch++) bt[gr * 2 + ch] = (int32_t) l3_side->gr[gr].ch[ch].tt.block_type;
+    if (D.spec.valid) { // launched behind the frame's filterbank look-ahead: is this the call it was computed for?
+        D.spec.valid = false;
+        bool same = stereo == D.spec.n_ch;
+        const double *caller = (const double *) sb_sample;
+        for (int ch = 0; same && ch < stereo; ch++) {
+            same = bt[ch] == D.bt.h[ch] && bt[2 + ch] == D.bt.h[2 + ch] && memcmp(caller + (size_t) ch * 3 * 576, D.spec.prev[ch], sizeof(D.spec.prev[ch])) == 0;
+            for (int i = 0; same && i < 36; i++) // slot i of the frame: what filter_subband handed out for it
+                same = memcmp(caller + (size_t) ch * 3 * 576 + 576 + (size_t) i * 32, D.wa_zs.h + ((size_t) ch * 36 + i) * 544 + 512, 32 * sizeof(double)) == 0;
+        }
+        if (same) {
+            for (int ch = 0; ch < stereo; ch++) {
+                memcpy((double *) sb_sample + (size_t) ch * 3 * 576, D.sb.h + (size_t) ch * 3 * 576, 3 * 576 * sizeof(double));
+                for (int gr = 0; gr < 2; gr++) memcpy(mdct_freq[gr][ch], D.xr.h + ((size_t) gr * 2 + ch) * 576, 576 * sizeof(double));
+            }
+            return;
+        }
+    }
     memcpy(D.sb.h, sb_sample, sizeof(L3SBS));
     memcpy(D.bt.h, bt, sizeof(bt));
     mp3mi_launch_mdct_sub(D.T, D.sb.d, D.bt.d, D.xr.d, stereo, mode_gr, D.st);
-    HIPOK(hipStreamSynchronize(D.st));
+    dropin_wait();
     memcpy(sb_sample, D.sb.h, sizeof(L3SBS));
     for (int gr = 0; gr < 2; gr++)
         for (int ch = 0; ch < stereo; ch++) memcpy(mdct_freq[gr][ch], D.xr.h + ((size_t) gr * 2 + ch) * 576, 576 * sizeof(double));
@@ -490,7 +600,7 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
     mp3mi_launch_prep_tail(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.prep_fix, D.st);
     mp3mi_launch_prep(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.prep_fix, 0, D.st);
     mp3mi_launch_loop(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.bits.d, D.loop_state.d, D.ix.d, D.side.d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
-    HIPOK(hipStreamSynchronize(D.st));
+    dropin_wait();
     const int16_t (*ix)[576] = (const int16_t (*)[576]) D.ix.h;
     const mp3mi_frame_side &sd = *D.side.h;
     const loop_state_host &ls = *D.loop_state.h;
@@ -605,7 +715,7 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
     g.crc = crc;
     g.hdr_flags = ((info->mode_ext & 3) << 4) | ((info->copyright & 1) << 3) | ((info->original & 1) << 2) | (info->emphasis & 3);
     mp3mi_launch_format(D.T, g, D.ix.d, D.side.d, D.bits.d, D.bri.d, D.win.d, D.win_bytes, D.len_d, NULL, 0, NULL, D.st);
-    HIPOK(hipStreamSynchronize(D.st));
+    dropin_wait();
     // bytes that are final now = everything up to the end of this frame's main data
     long bits = sd.resvDrain;
     for (int gr = 0; gr < 2; gr++)
@@ -615,6 +725,7 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
     D.m_end = m0 + bits / 8;
     emit(emitted_upto(D.m_end, slot, frame_bytes, si_bytes), base);
     D.frames_done = n + 1;
+    D.frames_total++;
     // nextBackPtr (src/formatBitstream.c:78-79)
     l3_side->main_data_begin = (int) (D.frames_done * (long) slot - D.m_end);
 }
@@ -622,6 +733,11 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
 extern "C" void III_FlushBitstream(void)
 {
     if (!D.ready || D.frames_done == 0) return;
+    if (D.stats && D.t_first != 0.0) {
+        const double dt = now_s() - D.t_first;
+        fprintf(stderr, "mp3mi drop-in: %ld frames in %.4f s from the first frame's first call = %.1f frames/s, %ld waits for the device\n", D.frames_total, dt,
+                (double) D.frames_total / dt, D.n_launch_waits);
+    }
     const int slot = D.frame_bytes - D.si_bytes;
     const long rem = ((D.m_end + slot - 1) / slot) * slot - D.m_end;
     {   // BF_FlushBitstream's remainder call asks for a header the queue no longer has (k_format.hip, fmt_flush_dies)

@@ -57,9 +57,11 @@ __global__ void __launch_bounds__(64) k_window_filter(const mp3mi_tables *__rest
 // (src/encode.c:287-316) --; samples before the frame are read out of the ring as it stood at the frame's start (ring,
 // off0: neither is written here), where sample 32 q + j (q < 0) sits at (31 - j + off0 - 32 q) & 511.  z[512] and s[32]
 // go to zs[ch][i][544].  The arithmetic per slot is k_window_filter's, operation by operation.
+// sb_out (may be NULL): the caller's L3SBS as the reference's loop will have filled it by the time it calls mdct_sub --
+// s of slot i goes to [ch][1 + i / 18][i % 18][32] as well -- for the mdct_sub that dropin.cpp launches right behind this kernel.
 __global__ void __launch_bounds__(64) k_window_filter_frame(const mp3mi_tables *__restrict__ T, const double *__restrict__ ring_all,
                                                             int off0_a, int off0_b, const int16_t *__restrict__ samples, int n_slots,
-                                                            double *__restrict__ zs)
+                                                            double *__restrict__ zs, double *__restrict__ sb_out)
 {
     __shared__ double zl[512];
     __shared__ double y[64];
@@ -83,14 +85,30 @@ __global__ void __launch_bounds__(64) k_window_filter_frame(const mp3mi_tables *
     if (lane < 32) {
         double frow[31];
         for (int j = 0; j < 31; j++) frow[j] = T->filt[lane][j];
-        out[512 + lane] = fbm_matrix(y, frow);
+        const double sv = fbm_matrix(y, frow);
+        out[512 + lane] = sv;
+        if (sb_out) sb_out[(size_t) ch * 3 * 576 + (size_t) (1 + i / 18) * 576 + (size_t) (i % 18) * 32 + lane] = sv;
     }
 }
 
-void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
-                                      double *zs, hipStream_t st)
+// The end of a call's launches, as the host sees it: the last "kernel" of the sequence stores the call's number in
+// host-mapped memory and the host spins on it -- a few microseconds after the store instead of the ~25 us a
+// hipStreamSynchronize takes to come back (dropin.cpp, dropin_wait: four of them per frame).
+__global__ void k_dropin_done(volatile unsigned *flag, unsigned seq)
 {
-    hipLaunchKernelGGL(k_window_filter_frame, dim3((unsigned) (n_ch * n_slots)), dim3(64), 0, st, T, ring, off0_a, off0_b, samples, n_slots, zs);
+    __threadfence_system(); // (the stream is in order: every kernel of the call has finished; their stores to host-mapped memory first)
+    *flag = seq;
+}
+
+void mp3mi_launch_dropin_done(unsigned *flag, unsigned seq, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dropin_done, dim3(1), dim3(1), 0, st, (volatile unsigned *) flag, seq);
+}
+
+void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
+                                      double *zs, double *sb_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_window_filter_frame, dim3((unsigned) (n_ch * n_slots)), dim3(64), 0, st, T, ring, off0_a, off0_b, samples, n_slots, zs, sb_out);
 }
 
 // src/mdct.c:25-103: sb is the caller's L3SBS [2][3][18][32]; bt[gr][ch]; xr [gr][ch][576]

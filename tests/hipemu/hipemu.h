@@ -87,6 +87,7 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
     int l = (int) (threadIdx.x & 63) - (int) d;
     return __shfl(v, l < 0 ? (int) (threadIdx.x & 63) : l, width);
 }
+static inline void __threadfence_system() {}
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; } // fibers run one at a time
 static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; if (v > o) *p = v; return o; }
 #define __ATOMIC_RELEASE_EMU 0

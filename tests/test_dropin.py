@@ -96,6 +96,13 @@ def test_baseline_config0_through_the_reference_driver(product, tmp_path):
     t0 = time.perf_counter()
     run_cli("encode_dropin", tmp_path / "long.wav", tmp_path / "long.mp3", rate, kbps, False)
     dt_long = time.perf_counter() - t0
+    # ... and the library's own clock: from the first frame's first call to the flush (options.dropin_stats: MP3MI_DROPIN_STATS)
+    r = subprocess.run([os.path.join(REF, "encode_dropin"), "-s", "44.1", "-b", str(kbps), str(tmp_path / "long.wav"), str(tmp_path / "long2.mp3")],
+                       capture_output=True, text=True, env=dict(os.environ, MP3MI_DROPIN_STATS="1"), cwd=str(tmp_path))
+    line = [x for x in r.stderr.replace("\r", "\n").splitlines() if "mp3mi drop-in:" in x][-1]
+    in_process = {"frames": int(line.split("drop-in:")[1].split()[0]), "seconds": float(line.split(" in ")[1].split()[0]),
+                  "frames_per_s": float(line.split("= ")[1].split()[0]), "waits_for_the_device": int(line.split("frames/s, ")[1].split()[0])}
+    assert in_process["frames"] == 1149
     t0 = time.perf_counter()
     run_cli("encode", tmp_path / "long.wav", tmp_path / "long_ref.mp3", rate, kbps, False)
     dt_long_ref = time.perf_counter() - t0
@@ -111,10 +118,11 @@ def test_baseline_config0_through_the_reference_driver(product, tmp_path):
                "frames": 383, "seconds": round(dt, 3), "frames_per_s": round(383 / dt, 1), "bit_exact": True,
                "seconds_of_a_four_frame_run": round(dt_start, 3), "seconds_1149_frames": round(dt_long, 3),
                "frames_per_s_marginal": round(766 / max(dt_long - dt, 1e-9), 1),
+               "inside_the_process_1149_frames": in_process,
                "reference_binary_on_one_host_core": {"seconds_383_frames": round(dt_ref, 3), "seconds_1149_frames": round(dt_long_ref, 3),
                                                      "frames_per_s_marginal": round(766 / max(dt_long_ref - dt_ref, 1e-9), 1)},
-               "note": "the per-call surface over ONE hidden stream: with the look-ahead of mp3mi_dropin.h a frame is 6 launches-and-waits "
-                       "(two for the four L3psycho_anal calls, one for the 72 window_subband / filter_subband calls, mdct_sub, iteration_loop, "
+               "note": "the per-call surface over ONE hidden stream: with the look-ahead of mp3mi_dropin.h a frame is 4 launches-and-waits "
+                       "(one for the four L3psycho_anal calls, one for the 72 window_subband / filter_subband calls and mdct_sub, iteration_loop, "
                        "III_format_bitstream) instead of 79; half of what is left is k_loop's one wavefront; throughput comes from the batched API"},
               open(os.path.join(out, "dropin_config0.json"), "w"), indent=1)
 
