@@ -20,7 +20,11 @@ size_t mp3mi_psy_state_size(void);
 size_t mp3mi_loop_state_size(void);
 void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double *s, hipStream_t st);
 void mp3mi_launch_window_filter(const mp3mi_tables *T, double *ring, int off, const mp3mi_dropin_samples &in, double *zs, hipStream_t st);
-void mp3mi_launch_mdct_sub(const mp3mi_tables *T, double *sb, const int32_t *bt, double *xr, int stereo, int mode_gr, hipStream_t st);
+void mp3mi_launch_mdct_sub(const mp3mi_tables *T, const double *sb_in, double *sb_out, const int32_t *bt, double *xr, int stereo, int mode_gr,
+                           unsigned *zero_me, unsigned *flag, unsigned seq, unsigned *count, hipStream_t st);
+void mp3mi_launch_format_marked(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix, const mp3mi_frame_side *side,
+                                const int32_t *bits_per_frame, const int32_t *bitrate_index, uint8_t *out, size_t out_stride, uint32_t *out_len,
+                                unsigned *flag, unsigned seq_before, unsigned seq_done, hipStream_t st);
 void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
                                       double *zs, double *sb_out, hipStream_t st);
 void mp3mi_launch_dropin_done(unsigned *flag, unsigned seq, hipStream_t st);
@@ -102,7 +106,7 @@ struct DropIn {
     //     pointer, its 576 samples and the delay line are what was read ahead, otherwise the channel's state is put back
     //     (a device copy taken before the launch) and granule 0 is analysed again alone.
     // MP3MI_DROPIN_LOOKAHEAD=0 turns both off.
-    bool lookahead = true, lookahead_psy = true; // (MP3MI_DROPIN_LOOKAHEAD: 0 neither, 1 both, 2 the filterbank's only, 3 L3psycho_anal's only)
+    bool lookahead = true, lookahead_psy = true; // (MP3MI_DROPIN_LOOKAHEAD: 0 none, 1 all, 2 the filterbank's only, 3 L3psycho_anal's only, 4 all but iteration_loop's / III_format_bitstream's)
     struct win_ahead {
         bool valid = false;
         const short *p0 = nullptr; // where the channel's slot 0 was read
@@ -131,13 +135,38 @@ struct DropIn {
     io_buf<mp3mi_psy_out> psy2;    // the look-ahead's results: [granule][channel]
     void *psy_snap = nullptr;      // [2] psychoacoustic state before a two-granule launch
     io_buf<unsigned> done_flag;    // what the host spins on at the end of a call's launches (k_dropin_done)
-    unsigned done_seq = 0;
-    long n_launch_waits = 0;       // (statistics: waits for the device, mp3mi_dropin_waits)
+    unsigned done_seq = 0, done_seen = 0; // marks put on the stream so far / the latest one a call has waited for
+    long n_launch_waits = 0;       // (statistics: marks a call had to wait for, mp3mi_dropin_waits)
+    long n_loop_ahead = 0, n_fmt_ahead = 0; // (statistics: iteration_loop / III_format_bitstream calls served from a launch ahead of the call)
+    // iteration_loop and III_format_bitstream AHEAD of their calls.  k_format is launched right behind k_loop, from the records
+    // k_loop leaves on the device; III_format_bitstream hands its bytes out if the caller's l3_enc, side information and
+    // scalefactors still are what iteration_loop returned.  And when the frame's filterbank look-ahead has launched mdct_sub
+    // (spec) and L3psycho_anal's look-ahead holds all of the frame's records, both follow on the stream at once -- with the
+    // frame length, header bits and channel count of the frame BEFORE -- and iteration_loop hands the result out if its
+    // arguments (pe, ratio, block types, spectrum, mean_bits, header) are exactly what was read.  Anything else: the loop's
+    // state and the formatter's byte window are put back (copies taken before the launch) and the call is served on its own.
+    bool lookahead_loop = true;
+    struct frame_ahead {
+        bool loop_pending = false, fmt_pending = false; // launched, not handed out yet
+        bool have_last = false;        // the parameters below are a served frame's
+        int C = 0, crc = 0, bitsPerFrame = 0, bitrate_index = 0, mode = 0, hdr_flags = 0;
+        const mp3mi_psy_out *rec_h = nullptr; // (host view of) the records k_loop read
+        unsigned seq_loop = 0, seq_fmt = 0;
+        loop_state_host state_before;
+        uint8_t *win_before = nullptr;
+        size_t win_before_bytes = 0;
+    } fa;
+    int psy2_n_ch = 0, psy2_served = 0; // the frame's L3psycho_anal look-ahead: channels in D.psy2, records handed out as foreseen
+    bool win_for_run = false;      // the formatter's window exists for this run of frames (since the last III_FlushBitstream)
+    long win_slid_for = -1;        // frame the window has been positioned for
     bool stats = false;            // options.dropin_stats: a line at III_FlushBitstream
     double t_first = 0.0;          // when the first frame's first call came in (seconds, steady clock)
     long frames_total = 0;
-    // mdct
-    io_buf<double> sb, xr;
+    // mdct: the caller's L3SBS as mdct_sub finds it (sbuf[sb_cur]: block 0 = what the call before left there) and as it leaves it
+    // (sbuf[sb_cur ^ 1]); the two change places with every call (k_dropin.hip, k_mdct_sub)
+    io_buf<double> sbuf[2], xr;
+    int sb_cur = 0;
+    unsigned *mdct_count = nullptr; // (k_mdct_sub's workgroups count themselves out)
     io_buf<int32_t> bt;
     // loop
     io_buf<mp3mi_psy_out> psy4;
@@ -200,11 +229,15 @@ void ensure(int rate_idx)
         mp3mi_batch_options o; // (the one place the library reads its environment: batch.cpp)
         mp3mi_batch_options_from_env(&o);
         const int v = o.dropin_lookahead < 0 ? 1 : o.dropin_lookahead;
-        D.lookahead = v == 1 || v == 2;
-        D.lookahead_psy = v == 1 || v == 3;
+        D.lookahead = v == 1 || v == 2 || v == 4;
+        D.lookahead_psy = v == 1 || v == 3 || v == 4;
+        D.lookahead_loop = v == 1;
         D.stats = o.dropin_stats == 1;
     }
-    D.sb.alloc(sizeof(L3SBS));
+    D.sbuf[0].alloc(sizeof(L3SBS));
+    D.sbuf[1].alloc(sizeof(L3SBS));
+    HIPOK(hipMalloc((void **) &D.mdct_count, sizeof(unsigned)));
+    HIPOK(hipMemset(D.mdct_count, 0, sizeof(unsigned)));
     D.xr.alloc(4 * 576 * sizeof(double));
     D.bt.alloc(4 * sizeof(int32_t));
     D.psy4.alloc(4 * sizeof(mp3mi_psy_out));
@@ -259,23 +292,37 @@ static double now_s()
     return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
 }
 
-// Waits for everything launched on the hidden stream so far.  A flag in host-mapped memory, stored by a one-thread kernel behind the
-// call's launches, is seen by the spinning host a few microseconds after the store; hipStreamSynchronize alone takes ~25 us to
+// dropin_wait: waits for everything launched on the hidden stream so far; dropin_mark / dropin_wait_for: for everything launched up
+// to a mark.  A flag in host-mapped memory, stored by a one-thread kernel behind the
+// launches, is seen by the spinning host a few microseconds after the store; hipStreamSynchronize alone takes ~25 us to
 // come back, and a frame has four such waits.  The spin is bounded (a device that does not answer within two seconds is the
 // runtime's business).
-static void dropin_wait()
+static unsigned dropin_mark()
 {
     const unsigned seq = ++D.done_seq;
     mp3mi_launch_dropin_done(D.done_flag.d, seq, D.st);
+    return seq;
+}
+
+// (marks are waited for in the order they were put)
+static void dropin_wait_for(unsigned seq)
+{
+    if ((int) (D.done_seen - seq) >= 0) return;
     volatile unsigned *f = D.done_flag.h;
     const double t0 = now_s();
-    for (unsigned spin = 0; *f != seq; spin++)
+    for (unsigned spin = 0; (int) (*f - seq) < 0; spin++)
         if ((spin & 0xfffu) == 0xfffu && now_s() - t0 > 2.0) break;
-    if (*f != seq) HIPOK(hipStreamSynchronize(D.st));
+    if ((int) (*f - seq) < 0) HIPOK(hipStreamSynchronize(D.st));
+    D.done_seen = seq;
     D.n_launch_waits++;
 }
 
+static void dropin_wait() { dropin_wait_for(dropin_mark()); }
+
 static void psy_wait() { dropin_wait(); }
+static void frame_chain_launch(const mp3mi_psy_out *rec_d, const mp3mi_psy_out *rec_h, bool with_format, bool list_empty);
+static void frame_chain_cancel();
+static bool format_setup(int frame_bytes, int si_bytes);
 
 // the kernels behind one L3psycho_anal launch (g: one or two granules of a mono pseudo-stream).  The unpredictability comes
 // from the correctly rounded sines throughout (k_cw's second tier: MP3MI_TEST_CW_EXACT) and the partition sums from
@@ -358,6 +405,7 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
     if (chn < 0 || chn > 1) DIE("L3psycho_anal: channel %d", chn);
     ensure(rate_index_of(sfreq));
     if (D.t_first == 0.0) D.t_first = now_s();
+    frame_chain_cancel(); // (a frame's loop / formatter launched ahead whose calls never came: the next frame starts from the state they found)
     DropIn::psy_ahead &A = D.pa[chn];
     // which of the frame's calls is this (for the window look-ahead's bookkeeping)?
     const bool first_of_frame = !(D.psy_seen[chn] & 1) || (D.psy_seen[chn] & 2);
@@ -381,12 +429,14 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
         if (foreseen) { // the call the look-ahead was made for
             A.valid[ga] = false;
             A.served = ga + 1;
+            D.psy2_served++;
             psy_hand_out(A.out[ga], ratio_d, ratio_ds, pe, cod_info, first_of_frame ? 0 : 1, chn);
             return;
         }
         // not what was read ahead: the channel's state goes back to before the look-ahead, the granules handed out from it
         // are analysed again one by one (from the delay lines they found), then this call on its own
         const size_t ss = mp3mi_psy_state_size();
+        D.psy2_n_ch = 0; // (the frame's records are no longer all the look-ahead's)
         HIPOK(hipMemcpyAsync((char *) D.psy_state + (size_t) chn * ss, (char *) D.psy_snap + (size_t) chn * ss, ss, hipMemcpyDeviceToDevice, D.st));
         for (int q = 0; q < A.served; q++) {
             psy_one_granule(A.save_before[q + 1], chn, D.psy1.d); // (served <= 1: the delay line after the first call = what the second must find)
@@ -415,11 +465,14 @@ extern "C" void L3psycho_anal(short int *buffer, short int savebuf[1344], int ch
         P[chn] = buffer; DL[chn] = before;
         if (both) { P[o] = D.psy_ptr[o][0]; DL[o] = D.psy_save_ptr[o]; }
         psy_ahead_start(both ? 0 : chn, both ? 2 : 1, P, DL);
+        D.psy2_n_ch = (both || chn == 0) ? (both ? 2 : 1) : 0; // D.psy2 holds the frame's records [granule][channel] from channel 0 on
+        D.psy2_served = 1;
         A.valid[0] = false; // this call is the channel's first: served now
         A.served = 1;
         psy_hand_out(A.out[0], ratio_d, ratio_ds, pe, cod_info, 0, chn);
         return;
     }
+    D.psy2_n_ch = 0;
     psy_one_granule(savebuf, chn, D.psy1.d);
     psy_wait();
     psy_hand_out(*D.psy1.h, ratio_d, ratio_ds, pe, cod_info, first_of_frame ? 0 : 1, chn);
@@ -483,20 +536,35 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
         // channels covered (every channel of the frame: first == 0) and the previous frame's granule in D.sb
         bool spec = first == 0;
         for (int c = 0; c < n_ch; c++) spec = spec && (D.bt_known & (1 << c)) && (D.bt_known & (1 << (2 + c)));
+        io_buf<double> &SI = D.sbuf[D.sb_cur], &SO = D.sbuf[D.sb_cur ^ 1];
         if (spec) {
             for (int c = 0; c < n_ch; c++) {
-                memcpy(D.spec.prev[c], D.sb.h + (size_t) c * 3 * 576, sizeof(D.spec.prev[c]));
+                memcpy(D.spec.prev[c], SI.h + (size_t) c * 3 * 576, sizeof(D.spec.prev[c]));
                 D.bt.h[c] = D.bt_pred[0][c];
                 D.bt.h[2 + c] = D.bt_pred[1][c];
             }
         }
         mp3mi_launch_window_filter_frame(D.T, D.ring.d + 512 * first, D.off[first], D.off[first + n_ch - 1], D.wa_smp.d + 1152 * first, n_ch, 36,
-                                         D.wa_zs.d + (size_t) first * 36 * 544, spec ? D.sb.d : NULL, D.st);
-        if (spec) mp3mi_launch_mdct_sub(D.T, D.sb.d, D.bt.d, D.xr.d, n_ch, 2, D.st);
+                                         D.wa_zs.d + (size_t) first * 36 * 544, spec ? SI.d : NULL, D.st);
+        // (the transform tells the host itself when it is through, and empties the list of the kernels that may follow it)
+        unsigned seq_fb = 0;
+        if (spec) {
+            seq_fb = ++D.done_seq;
+            mp3mi_launch_mdct_sub(D.T, SI.d, SO.d, D.bt.d, D.xr.d, n_ch, 2, &D.prep_fix->count, D.done_flag.d, seq_fb, D.mdct_count, D.st);
+        } else
+            seq_fb = dropin_mark();
         D.spec.valid = spec;
         D.spec.n_ch = n_ch;
         D.bt_known = 0;
-        dropin_wait();
+        // ... and the frame's iteration_loop and III_format_bitstream behind that, when L3psycho_anal's look-ahead holds all of
+        // the frame's records (every one handed out as foreseen) and a frame has been served before: its frame length, header
+        // bits and channel count are taken for this one's (DropIn::frame_ahead).  They run while the host hands out the 72 slots.
+        DropIn::frame_ahead &A = D.fa;
+        if (spec && D.lookahead_loop && A.have_last && !A.loop_pending && !A.fmt_pending && n_ch == A.C && D.psy2_n_ch == n_ch &&
+            D.psy2_served == 2 * n_ch && D.frames_done > 0 && format_setup(A.bitsPerFrame / 8, (32 + 16 * A.crc + (A.C == 2 ? 256 : 136)) / 8))
+            frame_chain_launch(D.psy2.d, D.psy2.h, true, true);
+        D.psy2_n_ch = 0; // (used, or not usable)
+        dropin_wait_for(seq_fb);
         window_subband(buffer, z, k); // handed out from what was just computed
         return;
     }
@@ -545,21 +613,120 @@ extern "C" void mdct_sub(L3SBS *sb_sample, double (*mdct_freq)[2][576], int ster
                 same = memcmp(caller + (size_t) ch * 3 * 576 + 576 + (size_t) i * 32, D.wa_zs.h + ((size_t) ch * 36 + i) * 544 + 512, 32 * sizeof(double)) == 0;
         }
         if (same) {
+            const double *res = D.sbuf[D.sb_cur ^ 1].h;
             for (int ch = 0; ch < stereo; ch++) {
-                memcpy((double *) sb_sample + (size_t) ch * 3 * 576, D.sb.h + (size_t) ch * 3 * 576, 3 * 576 * sizeof(double));
-                for (int gr = 0; gr < 2; gr++) memcpy(mdct_freq[gr][ch], D.xr.h + ((size_t) gr * 2 + ch) * 576, 576 * sizeof(double));
+                memcpy((double *) sb_sample + (size_t) ch * 3 * 576, res + (size_t) ch * 3 * 576, 3 * 576 * sizeof(double));
+                for (int gr = 0; gr < 2; gr++) memcpy(mdct_freq[gr][ch], D.xr.h + ((size_t) gr * stereo + ch) * 576, 576 * sizeof(double));
             }
+            D.sb_cur ^= 1;
             return;
         }
     }
-    memcpy(D.sb.h, sb_sample, sizeof(L3SBS));
+    frame_chain_cancel(); // (a loop launched ahead read the spectrum this call is about to replace)
+    memcpy(D.sbuf[D.sb_cur].h, sb_sample, sizeof(L3SBS));
     memcpy(D.bt.h, bt, sizeof(bt));
-    mp3mi_launch_mdct_sub(D.T, D.sb.d, D.bt.d, D.xr.d, stereo, mode_gr, D.st);
+    mp3mi_launch_mdct_sub(D.T, D.sbuf[D.sb_cur].d, D.sbuf[D.sb_cur ^ 1].d, D.bt.d, D.xr.d, stereo, mode_gr, NULL, NULL, 0, D.mdct_count, D.st);
     dropin_wait();
-    memcpy(sb_sample, D.sb.h, sizeof(L3SBS));
+    D.sb_cur ^= 1;
+    memcpy(sb_sample, D.sbuf[D.sb_cur].h, sizeof(L3SBS));
     for (int gr = 0; gr < 2; gr++)
-        for (int ch = 0; ch < stereo; ch++) memcpy(mdct_freq[gr][ch], D.xr.h + ((size_t) gr * 2 + ch) * 576, 576 * sizeof(double));
+        for (int ch = 0; ch < stereo; ch++) memcpy(mdct_freq[gr][ch], D.xr.h + ((size_t) gr * stereo + ch) * 576, 576 * sizeof(double));
 }
+
+// ---- k_loop and k_format of a frame, back to back on the stream (DropIn::frame_ahead) ----
+
+// the formatter's byte window of this run of frames (a run ends with III_FlushBitstream); false: the frame length changed
+static bool format_setup(int frame_bytes, int si_bytes)
+{
+    if (D.frames_done == 0 && !D.win_for_run) {
+        D.frame_bytes = frame_bytes;
+        D.si_bytes = si_bytes;
+        D.win_bytes = (size_t) (WIN_FRAMES + 1) * frame_bytes;
+        if (D.win.h) HIPOK(hipHostFree(D.win.h));
+        D.win.alloc(D.win_bytes);
+        D.abs_emitted = 0;
+        D.m_end = 0;
+        D.win_for_run = true;
+        D.win_slid_for = -1;
+        return true;
+    }
+    return frame_bytes == D.frame_bytes && si_bytes == D.si_bytes;
+}
+
+// slide the byte window so that frame n sits at index min(n, WIN_FRAMES) (once per frame; the window is host memory that the
+// device writes: moved between two launches, with nothing in flight)
+static void format_position_window(long n)
+{
+    if (D.win_slid_for == n) return;
+    if (n > WIN_FRAMES) {
+        memmove(D.win.h, D.win.h + D.frame_bytes, D.win_bytes - (size_t) D.frame_bytes);
+        memset(D.win.h + D.win_bytes - (size_t) D.frame_bytes, 0, (size_t) D.frame_bytes);
+    }
+    D.win_slid_for = n;
+}
+
+static void format_launch(int C, int crc, int bitsPerFrame, int bitrate_index, int mode, int hdr_flags, bool marked = false, unsigned seq_before = 0, unsigned seq_done = 0)
+{
+    const long n = D.frames_done;
+    const int widx = (int) (n < WIN_FRAMES ? n : WIN_FRAMES);
+    *D.bits.h = bitsPerFrame;
+    *D.bri.h = bitrate_index;
+    mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1 << 30, widx, 1);
+    g.hdr_mode = mode;
+    g.crc = crc;
+    g.hdr_flags = hdr_flags;
+    if (marked) mp3mi_launch_format_marked(D.T, g, D.ix.d, D.side.d, D.bits.d, D.bri.d, D.win.d, D.win_bytes, D.len_d, D.done_flag.d, seq_before, seq_done, D.st);
+    else mp3mi_launch_format(D.T, g, D.ix.d, D.side.d, D.bits.d, D.bri.d, D.win.d, D.win_bytes, D.len_d, NULL, 0, NULL, D.st);
+}
+
+// Launches the frame's k_loop (records rec_d, spectrum D.xr) and, when with_format, its k_format behind it, with the parameters in
+// D.fa; copies of the loop's state and of the byte window are taken first.  Nothing may be in flight that writes either.
+static void frame_chain_launch(const mp3mi_psy_out *rec_d, const mp3mi_psy_out *rec_h, bool with_format, bool list_empty)
+{
+    DropIn::frame_ahead &A = D.fa;
+    memcpy(&A.state_before, D.loop_state.h, sizeof(A.state_before));
+    A.rec_h = rec_h;
+    *D.bits.h = A.bitsPerFrame;
+    mp3mi_geom g = mp3mi_make_geom(1, A.C, D.rate_idx, 1, 0, 1);
+    g.crc = A.crc;
+    // the loop's stateless head of the spectrum: k_mdct's tail as a kernel of its own, then the reference's walk for
+    // the records it lists as undecided (k_prep.hip; none, practically)
+    if (!list_empty) HIPOK(hipMemsetAsync(&D.prep_fix->count, 0, sizeof(unsigned), D.st)); // (k_mdct_sub, launched just before, has done it)
+    mp3mi_launch_prep_tail(D.T, g, D.xr.d, rec_d, D.prep4, D.prep_fix, D.st);
+    mp3mi_launch_prep(D.T, g, D.xr.d, rec_d, D.prep4, D.prep_fix, 0, D.st);
+    mp3mi_launch_loop(D.T, g, D.xr.d, rec_d, D.prep4, D.bits.d, D.loop_state.d, D.ix.d, D.side.d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
+    A.loop_pending = true;
+    A.fmt_pending = false;
+    if (!with_format) A.seq_loop = dropin_mark();
+    if (with_format) {
+        format_position_window(D.frames_done);
+        if (A.win_before_bytes < D.win_bytes) {
+            free(A.win_before);
+            A.win_before = (uint8_t *) malloc(D.win_bytes);
+            if (!A.win_before) DIE("out of memory");
+            A.win_before_bytes = D.win_bytes;
+        }
+        memcpy(A.win_before, D.win.h, D.win_bytes);
+        // (the formatter tells the host itself: as it starts, that k_loop is through; as it ends, that the bytes are in place)
+        A.seq_loop = ++D.done_seq;
+        A.seq_fmt = ++D.done_seq;
+        format_launch(A.C, A.crc, A.bitsPerFrame, A.bitrate_index, A.mode, A.hdr_flags, true, A.seq_loop, A.seq_fmt);
+        A.fmt_pending = true;
+    }
+}
+
+// what was launched ahead and not handed out is undone: the loop's state and the byte window as they were before the launch
+static void frame_chain_cancel()
+{
+    DropIn::frame_ahead &A = D.fa;
+    if (!A.loop_pending && !A.fmt_pending) return;
+    dropin_wait_for(A.fmt_pending ? A.seq_fmt : A.seq_loop);
+    if (A.loop_pending) memcpy(D.loop_state.h, &A.state_before, sizeof(A.state_before));
+    if (A.fmt_pending) memcpy(D.win.h, A.win_before, D.win_bytes);
+    A.loop_pending = A.fmt_pending = false;
+}
+
+static int header_flags_of(const layer *info) { return ((info->mode_ext & 3) << 4) | ((info->copyright & 1) << 3) | ((info->original & 1) << 2) | (info->emphasis & 3); }
 
 extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy_ratio *ratio, III_side_info_t *l3_side,
                                int l3_enc[2][2][576], int mean_bits, int stereo, double xr_dec[2][2][576],
@@ -574,33 +741,56 @@ extern "C" void iteration_loop(double pe[][2], double xr_org[2][2][576], III_psy
     const int C = stereo;
     const int crc = info->error_protection ? 1 : 0; // 16 more bits of side information (src/musicin.c:744-746)
     if (mean_bits != (bitsPerFrame - (32 + 16 * crc + (C == 1 ? 136 : 256))) / 2) DIE("iteration_loop: unexpected mean_bits %d", mean_bits);
+    DropIn::frame_ahead &A = D.fa;
+    const bool first_call = D.loop_first;
     if (D.loop_first) { // src/loop.c:250-257
         l3_side->main_data_begin = 0;
         D.loop_first = false;
     }
-    // records in the batch layout [gr][ch] for one stream, one frame
-    mp3mi_psy_out *rec = D.psy4.h;
-    double (*xr)[576] = (double (*)[576]) D.xr.h;
-    memset(rec, 0, 4 * sizeof(mp3mi_psy_out));
-    for (int gr = 0; gr < 2; gr++)
-        for (int ch = 0; ch < C; ch++) {
-            mp3mi_psy_out *r = &rec[gr * C + ch];
-            r->pe = pe[gr][ch];
-            memcpy(r->ratio_l, ratio->l[gr][ch], sizeof(r->ratio_l));
-            memcpy(r->ratio_s, ratio->s[gr][ch], sizeof(r->ratio_s));
-            r->block_type = (int32_t) l3_side->gr[gr].ch[ch].tt.block_type;
-            memcpy(xr[gr * C + ch], xr_org[gr][ch], sizeof(xr[0]));
-        }
-    *D.bits.h = bitsPerFrame;
-    mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1, 0, 1);
-    g.crc = crc;
-    // the loop's stateless head of the caller's spectrum: k_mdct's tail as a kernel of its own, then the reference's walk for
-    // the records it lists as undecided (k_prep.hip; none, practically)
-    HIPOK(hipMemsetAsync(&D.prep_fix->count, 0, sizeof(unsigned), D.st));
-    mp3mi_launch_prep_tail(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.prep_fix, D.st);
-    mp3mi_launch_prep(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.prep_fix, 0, D.st);
-    mp3mi_launch_loop(D.T, g, D.xr.d, D.psy4.d, D.prep4, D.bits.d, D.loop_state.d, D.ix.d, D.side.d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
-    dropin_wait();
+    const int frame_bytes = bitsPerFrame / 8, si_bytes = (32 + 16 * crc + (C == 2 ? 256 : 136)) / 8;
+    bool served = false;
+    if (A.loop_pending) { // launched behind the frame's filterbank look-ahead: is this the call it was computed for?
+        bool same = !first_call && C == A.C && crc == A.crc && bitsPerFrame == A.bitsPerFrame && (int) info->bitrate_index == A.bitrate_index &&
+                    (int) info->mode == A.mode && header_flags_of(info) == A.hdr_flags;
+        for (int gr = 0; same && gr < 2; gr++)
+            for (int ch = 0; same && ch < C; ch++) {
+                const mp3mi_psy_out &r = A.rec_h[gr * C + ch];
+                same = memcmp(&r.pe, &pe[gr][ch], sizeof(double)) == 0 && memcmp(r.ratio_l, ratio->l[gr][ch], sizeof(r.ratio_l)) == 0 &&
+                       memcmp(r.ratio_s, ratio->s[gr][ch], sizeof(r.ratio_s)) == 0 && r.block_type == (int32_t) l3_side->gr[gr].ch[ch].tt.block_type &&
+                       memcmp(D.xr.h + ((size_t) gr * C + ch) * 576, xr_org[gr][ch], 576 * sizeof(double)) == 0;
+            }
+        if (same) {
+            dropin_wait_for(A.seq_loop);
+            A.loop_pending = false;
+            served = true;
+            D.n_loop_ahead++;
+        } else
+            frame_chain_cancel();
+    } else
+        frame_chain_cancel(); // (a formatter launched ahead whose call never came)
+    if (!served) {
+        // records in the batch layout [gr][ch] for one stream, one frame
+        mp3mi_psy_out *rec = D.psy4.h;
+        double (*xr)[576] = (double (*)[576]) D.xr.h;
+        memset(rec, 0, 4 * sizeof(mp3mi_psy_out));
+        for (int gr = 0; gr < 2; gr++)
+            for (int ch = 0; ch < C; ch++) {
+                mp3mi_psy_out *r = &rec[gr * C + ch];
+                r->pe = pe[gr][ch];
+                memcpy(r->ratio_l, ratio->l[gr][ch], sizeof(r->ratio_l));
+                memcpy(r->ratio_s, ratio->s[gr][ch], sizeof(r->ratio_s));
+                r->block_type = (int32_t) l3_side->gr[gr].ch[ch].tt.block_type;
+                memcpy(xr[gr * C + ch], xr_org[gr][ch], sizeof(xr[0]));
+            }
+        A.C = C; A.crc = crc; A.bitsPerFrame = bitsPerFrame;
+        A.bitrate_index = (int) info->bitrate_index; A.mode = (int) info->mode; A.hdr_flags = header_flags_of(info);
+        // the formatter behind the loop, from the records the loop leaves on the device (a frame length other than the run's:
+        // III_format_bitstream will refuse it, in its own words)
+        frame_chain_launch(D.psy4.d, D.psy4.h, D.lookahead_loop && format_setup(frame_bytes, si_bytes), false);
+        dropin_wait_for(A.seq_loop);
+        A.loop_pending = false;
+    }
+    A.have_last = true;
     const int16_t (*ix)[576] = (const int16_t (*)[576]) D.ix.h;
     const mp3mi_frame_side &sd = *D.side.h;
     const loop_state_host &ls = *D.loop_state.h;
@@ -662,60 +852,84 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
     }
     D.bs = bs;
     const int frame_bytes = bitsPerFrame / 8, si_bytes = (32 + 16 * crc + (C == 2 ? 256 : 136)) / 8, slot = frame_bytes - si_bytes;
-    if (D.frames_done == 0) {
-        D.frame_bytes = frame_bytes;
-        D.si_bytes = si_bytes;
-        D.win_bytes = (size_t) (WIN_FRAMES + 1) * frame_bytes;
-        if (D.win.h) HIPOK(hipHostFree(D.win.h));
-        D.win.alloc(D.win_bytes);
-        D.abs_emitted = 0;
-        D.m_end = 0;
-    } else if (frame_bytes != D.frame_bytes)
-        DIE("III_format_bitstream: frame length changed (padding is never used by the reference driver)");
-    // signs of the spectrum go onto the quantised values, in place (src/l3bitstream.c:115-125)
+    if (!format_setup(frame_bytes, si_bytes)) DIE("III_format_bitstream: frame length changed (padding is never used by the reference driver)");
+    DropIn::frame_ahead &A = D.fa;
     int16_t (*ix)[576] = (int16_t (*)[576]) D.ix.h;
     mp3mi_frame_side &sd = *D.side.h;
-    memset(&sd, 0, sizeof(sd));
-    for (int gr = 0; gr < 2; gr++)
-        for (int ch = 0; ch < C; ch++) {
-            for (int i = 0; i < 576; i++) {
-                if (xr[gr][ch][i] < 0 && l3_enc[gr][ch][i] > 0) l3_enc[gr][ch][i] *= -1;
-                ix[gr * C + ch][i] = (int16_t) l3_enc[gr][ch][i];
-            }
-            const gr_info *g2 = &l3_side->gr[gr].ch[ch].tt;
-            mp3mi_gr_side *s = &sd.gr[gr][ch];
-            const bool shortb = g2->window_switching_flag && g2->block_type == 2;
-            s->part2_3_length = (int32_t) g2->part2_3_length; s->big_values = (int32_t) g2->big_values;
-            s->count1 = (int32_t) g2->count1; s->global_gain = (int32_t) g2->global_gain;
-            s->scalefac_compress = (int32_t) g2->scalefac_compress;
-            s->window_switching_flag = (int32_t) g2->window_switching_flag; s->block_type = (int32_t) g2->block_type;
-            for (int k = 0; k < 3; k++) s->table_select[k] = (int32_t) g2->table_select[k];
-            s->region0_count = (int32_t) g2->region0_count; s->region1_count = (int32_t) g2->region1_count;
-            s->preflag = (int32_t) g2->preflag; s->count1table_select = (int32_t) g2->count1table_select;
-            s->part2_length = (int32_t) g2->part2_length;
-            if (shortb) for (int i = 0; i < 36; i++) s->scalefac[i] = scalefac->s[gr][ch][i / 3][i % 3];
-            else for (int i = 0; i < 21; i++) s->scalefac[i] = scalefac->l[gr][ch][i];
-        }
-    sd.main_data_begin = l3_side->main_data_begin;
-    sd.resvDrain = l3_side->resvDrain;
-    for (int ch = 0; ch < C; ch++)
-        for (int b = 0; b < 4; b++) sd.scfsi[ch][b] = (int32_t) l3_side->scfsi[ch][b];
-    // slide the byte window so that this frame sits at index widx
     const long n = D.frames_done;
     const int widx = (int) (n < WIN_FRAMES ? n : WIN_FRAMES);
-    if (n > WIN_FRAMES) { // (the window is host memory that the device writes: moved here, between two launches)
-        memmove(D.win.h, D.win.h + frame_bytes, D.win_bytes - (size_t) frame_bytes);
-        memset(D.win.h + D.win_bytes - (size_t) frame_bytes, 0, (size_t) frame_bytes);
-    }
     const long base = (n - widx) * (long) frame_bytes;
-    *D.bits.h = bitsPerFrame;
-    *D.bri.h = info->bitrate_index;
-    mp3mi_geom g = mp3mi_make_geom(1, C, D.rate_idx, 1 << 30, widx, 1);
-    g.hdr_mode = info->mode;
-    g.crc = crc;
-    g.hdr_flags = ((info->mode_ext & 3) << 4) | ((info->copyright & 1) << 3) | ((info->original & 1) << 2) | (info->emphasis & 3);
-    mp3mi_launch_format(D.T, g, D.ix.d, D.side.d, D.bits.d, D.bri.d, D.win.d, D.win_bytes, D.len_d, NULL, 0, NULL, D.st);
-    dropin_wait();
+    bool served = false;
+    if (A.loop_pending) frame_chain_cancel(); // (an iteration_loop launched ahead whose call never came)
+    if (A.fmt_pending) {
+        // launched behind the frame's k_loop, from the records that kernel left in D.ix / D.side: is everything this call is given
+        // what iteration_loop handed out -- the values (their signs come from xr: src/l3bitstream.c:115-125), the side
+        // information, the scalefactors, the header?
+        bool same = C == A.C && crc == A.crc && bitsPerFrame == A.bitsPerFrame && (int) info->bitrate_index == A.bitrate_index &&
+                    (int) info->mode == A.mode && header_flags_of(info) == A.hdr_flags && (int) l3_side->main_data_begin == sd.main_data_begin &&
+                    (int) l3_side->resvDrain == sd.resvDrain;
+        for (int ch = 0; same && ch < C; ch++)
+            for (int b = 0; same && b < 4; b++) same = (int32_t) l3_side->scfsi[ch][b] == sd.scfsi[ch][b];
+        for (int gr = 0; same && gr < 2; gr++)
+            for (int ch = 0; same && ch < C; ch++) {
+                const gr_info *g2 = &l3_side->gr[gr].ch[ch].tt;
+                const mp3mi_gr_side *s = &sd.gr[gr][ch];
+                const bool shortb = g2->window_switching_flag && g2->block_type == 2;
+                same = s->part2_3_length == (int32_t) g2->part2_3_length && s->big_values == (int32_t) g2->big_values && s->count1 == (int32_t) g2->count1 &&
+                       s->global_gain == (int32_t) g2->global_gain && s->scalefac_compress == (int32_t) g2->scalefac_compress &&
+                       s->window_switching_flag == (int32_t) g2->window_switching_flag && s->block_type == (int32_t) g2->block_type &&
+                       s->region0_count == (int32_t) g2->region0_count && s->region1_count == (int32_t) g2->region1_count &&
+                       s->preflag == (int32_t) g2->preflag && s->count1table_select == (int32_t) g2->count1table_select && s->part2_length == (int32_t) g2->part2_length;
+                for (int k = 0; same && k < 3; k++) same = s->table_select[k] == (int32_t) g2->table_select[k];
+                if (shortb) for (int i = 0; same && i < 36; i++) same = s->scalefac[i] == scalefac->s[gr][ch][i / 3][i % 3];
+                else for (int i = 0; same && i < 21; i++) same = s->scalefac[i] == scalefac->l[gr][ch][i];
+                const int16_t *q = ix[gr * C + ch];
+                for (int i = 0; same && i < 576; i++) {
+                    int v = l3_enc[gr][ch][i];
+                    if (xr[gr][ch][i] < 0 && v > 0) v = -v;
+                    same = v == (int) q[i];
+                }
+            }
+        if (same) {
+            dropin_wait_for(A.seq_fmt);
+            A.fmt_pending = false;
+            served = true;
+            D.n_fmt_ahead++;
+        } else
+            frame_chain_cancel();
+    }
+    // signs of the spectrum go onto the quantised values, in place (src/l3bitstream.c:115-125)
+    for (int gr = 0; gr < 2; gr++)
+        for (int ch = 0; ch < C; ch++)
+            for (int i = 0; i < 576; i++)
+                if (xr[gr][ch][i] < 0 && l3_enc[gr][ch][i] > 0) l3_enc[gr][ch][i] *= -1;
+    if (!served) {
+        memset(&sd, 0, sizeof(sd));
+        for (int gr = 0; gr < 2; gr++)
+            for (int ch = 0; ch < C; ch++) {
+                for (int i = 0; i < 576; i++) ix[gr * C + ch][i] = (int16_t) l3_enc[gr][ch][i];
+                const gr_info *g2 = &l3_side->gr[gr].ch[ch].tt;
+                mp3mi_gr_side *s = &sd.gr[gr][ch];
+                const bool shortb = g2->window_switching_flag && g2->block_type == 2;
+                s->part2_3_length = (int32_t) g2->part2_3_length; s->big_values = (int32_t) g2->big_values;
+                s->count1 = (int32_t) g2->count1; s->global_gain = (int32_t) g2->global_gain;
+                s->scalefac_compress = (int32_t) g2->scalefac_compress;
+                s->window_switching_flag = (int32_t) g2->window_switching_flag; s->block_type = (int32_t) g2->block_type;
+                for (int k = 0; k < 3; k++) s->table_select[k] = (int32_t) g2->table_select[k];
+                s->region0_count = (int32_t) g2->region0_count; s->region1_count = (int32_t) g2->region1_count;
+                s->preflag = (int32_t) g2->preflag; s->count1table_select = (int32_t) g2->count1table_select;
+                s->part2_length = (int32_t) g2->part2_length;
+                if (shortb) for (int i = 0; i < 36; i++) s->scalefac[i] = scalefac->s[gr][ch][i / 3][i % 3];
+                else for (int i = 0; i < 21; i++) s->scalefac[i] = scalefac->l[gr][ch][i];
+            }
+        sd.main_data_begin = l3_side->main_data_begin;
+        sd.resvDrain = l3_side->resvDrain;
+        for (int ch = 0; ch < C; ch++)
+            for (int b = 0; b < 4; b++) sd.scfsi[ch][b] = (int32_t) l3_side->scfsi[ch][b];
+        format_position_window(n);
+        format_launch(C, crc, bitsPerFrame, (int) info->bitrate_index, (int) info->mode, header_flags_of(info));
+        dropin_wait();
+    }
     // bytes that are final now = everything up to the end of this frame's main data
     long bits = sd.resvDrain;
     for (int gr = 0; gr < 2; gr++)
@@ -732,11 +946,13 @@ extern "C" void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int 
 
 extern "C" void III_FlushBitstream(void)
 {
-    if (!D.ready || D.frames_done == 0) return;
+    if (!D.ready) return;
+    frame_chain_cancel(); // (launched ahead for calls that never came)
+    if (D.frames_done == 0) return;
     if (D.stats && D.t_first != 0.0) {
         const double dt = now_s() - D.t_first;
-        fprintf(stderr, "mp3mi drop-in: %ld frames in %.4f s from the first frame's first call = %.1f frames/s, %ld waits for the device\n", D.frames_total, dt,
-                (double) D.frames_total / dt, D.n_launch_waits);
+        fprintf(stderr, "mp3mi drop-in: %ld frames in %.4f s from the first frame's first call = %.1f frames/s, %ld waits for the device, %ld / %ld frames' loops / formatters launched ahead of their calls\n", D.frames_total, dt,
+                (double) D.frames_total / dt, D.n_launch_waits, D.n_loop_ahead, D.n_fmt_ahead);
     }
     const int slot = D.frame_bytes - D.si_bytes;
     const long rem = ((D.m_end + slot - 1) / slot) * slot - D.m_end;
@@ -753,4 +969,5 @@ extern "C" void III_FlushBitstream(void)
     D.frames_done = 0;
     D.abs_emitted = 0;
     D.m_end = 0;
+    D.win_for_run = false;
 }

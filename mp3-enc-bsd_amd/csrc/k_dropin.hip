@@ -111,29 +111,51 @@ void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring,
     hipLaunchKernelGGL(k_window_filter_frame, dim3((unsigned) (n_ch * n_slots)), dim3(64), 0, st, T, ring, off0_a, off0_b, samples, n_slots, zs, sb_out);
 }
 
-// src/mdct.c:25-103: sb is the caller's L3SBS [2][3][18][32]; bt[gr][ch]; xr [gr][ch][576]
-__global__ void __launch_bounds__(64) k_mdct_sub(const mp3mi_tables *__restrict__ T, double *__restrict__ sb,
-                                                 const int32_t *__restrict__ bt, double *__restrict__ xr, int mode_gr)
+// src/mdct.c:25-103: sb_in is the caller's L3SBS [2][3][18][32] as the call finds it, sb_out the same as the call leaves it;
+// bt[gr][2]; xr [gr][ch][576] with the call's number of channels (the layout k_loop reads).  One workgroup per (channel, granule): the reference transforms granule 0 from blocks 0 and 1,
+// granule 1 from blocks 1 and 2 -- after negating the odd slots of the odd subbands of blocks 1 and 2 in place (src/mdct.c:57-60)
+// -- and ends by copying block 2 over block 0 (src/mdct.c:98-103).  With the result in a buffer of its own the two granules of
+// a channel do not wait for each other: each reads its two blocks from sb_in (negating 1 and 2 as it reads) and writes
+// what the reference leaves of them.  flag != NULL: the last workgroup to finish tells the spinning host (dropin.cpp) --
+// count: zero before the launch, zero again after it.
+__global__ void __launch_bounds__(64) k_mdct_sub(const mp3mi_tables *__restrict__ T, const double *__restrict__ sb_in, double *__restrict__ sb_out,
+                                                 const int32_t *__restrict__ bt, double *__restrict__ xr, int mode_gr, unsigned *zero_me,
+                                                 volatile unsigned *flag, unsigned seq, unsigned *count)
 {
     __shared__ mdct_lds L;
-    const int lane = wave_lane(), ch = (int) blockIdx.x;
-    double *sbc = sb + (size_t) ch * 3 * 576;
+    const int lane = wave_lane(), ch = (int) blockIdx.x / mode_gr, gr = (int) blockIdx.x % mode_gr;
+    if (zero_me && blockIdx.x == 0 && lane == 0) *zero_me = 0u; // (the list of the kernels behind this one: a memset less on the stream)
+    const double *in = sb_in + (size_t) ch * 3 * 576;
+    double *outc = sb_out + (size_t) ch * 3 * 576;
     mdct_regs R;
     mdct_load_tables(L, R, T);
     __syncthreads();
-    for (int gr = 0; gr < mode_gr; gr++) {
-        for (int i = lane; i < 576; i += 64) { // mdct_sub negates odd slots of odd subbands in place (src/mdct.c:57-60)
-            const int slot = i / 32, sub = i % 32;
-            if ((sub & 1) && (slot & 1)) sbc[(gr + 1) * 576 + i] = sbc[(gr + 1) * 576 + i] * -1.0;
-        }
-        __syncthreads();
-        const int b = bt[gr * 2 + ch];
-        mdct_load_inputs(L, sbc + gr * 576, sbc + (gr + 1) * 576, b);
-        mdct_granule(L, R, T, b);
-        for (int i = lane; i < 576; i += 64) xr[((size_t) gr * 2 + ch) * 576 + i] = L.xr[i];
-        __syncthreads();
+    double vp[9], vc[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int i = lane + 64 * j, slot = i / 32, sub = i % 32;
+        const bool neg = (sub & 1) && (slot & 1);
+        const double p = in[gr * 576 + i], c = in[(gr + 1) * 576 + i];
+        vp[j] = (neg && gr > 0) ? p * -1.0 : p; // (block 0 is the frame before's block 2: negated then)
+        vc[j] = neg ? c * -1.0 : c;
+        outc[(gr + 1) * 576 + i] = vc[j];
+        if (gr == mode_gr - 1) outc[i] = vc[j];
     }
-    for (int i = lane; i < 576; i += 64) sbc[i] = sbc[mode_gr * 576 + i];
+    const int b = bt[gr * 2 + ch];
+    mdct_store_inputs(L, vp, vc, b);
+    mdct_granule(L, R, T, b);
+    for (int i = lane; i < 576; i += 64) xr[((size_t) gr * (gridDim.x / (unsigned) mode_gr) + ch) * 576 + i] = L.xr[i];
+    if (flag) {
+        __threadfence_system(); // (every lane: its stores to host-mapped memory first)
+        if (lane == 0) {
+            const unsigned n = gridDim.x;
+            if (n == 1 || atomicAdd(count, 1u) == n - 1u) {
+                if (n > 1) *count = 0u;
+                __threadfence_system();
+                *flag = seq;
+            }
+        }
+    }
 }
 
 void mp3mi_launch_window_filter(const mp3mi_tables *T, double *ring, int off, const mp3mi_dropin_samples &in, double *zs, hipStream_t st)
@@ -146,7 +168,9 @@ void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double 
     hipLaunchKernelGGL(k_filter_subband, dim3(1), dim3(64), 0, st, T, z, s);
 }
 
-void mp3mi_launch_mdct_sub(const mp3mi_tables *T, double *sb, const int32_t *bt, double *xr, int stereo, int mode_gr, hipStream_t st)
+void mp3mi_launch_mdct_sub(const mp3mi_tables *T, const double *sb_in, double *sb_out, const int32_t *bt, double *xr, int stereo, int mode_gr,
+                           unsigned *zero_me, unsigned *flag, unsigned seq, unsigned *count, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_mdct_sub, dim3((unsigned) stereo), dim3(64), 0, st, T, sb, bt, xr, mode_gr);
+    hipLaunchKernelGGL(k_mdct_sub, dim3((unsigned) (stereo * mode_gr)), dim3(64), 0, st, T, sb_in, sb_out, bt, xr, mode_gr, zero_me,
+                       (volatile unsigned *) flag, seq, count);
 }

@@ -112,16 +112,15 @@ MP3MI_DEVFN bool fmt_flush_dies(long n_done, long m_end, int slot)
     return queued >= 1 && written * slot == m_end && ((queued * (long) slot * 8) % 32) == 0;
 }
 
-__global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
-                                               const int16_t *__restrict__ ix_all,
-                                               const mp3mi_frame_side *__restrict__ side_all,
-                                               const int32_t *__restrict__ bits_per_frame,
-                                               const int32_t *__restrict__ bitrate_index,
-                                               uint8_t *__restrict__ out, size_t out_stride,
-                                               uint32_t *__restrict__ out_len, int32_t *__restrict__ loop_state,
-                                               int loop_state_words, unsigned *__restrict__ voided)
+#define FMT_KERNEL_ARGS const mp3mi_tables *__restrict__ T, mp3mi_geom geo, const int16_t *__restrict__ ix_all,                          \
+                        const mp3mi_frame_side *__restrict__ side_all, const int32_t *__restrict__ bits_per_frame,                 \
+                        const int32_t *__restrict__ bitrate_index, uint8_t *__restrict__ out, size_t out_stride,                   \
+                        uint32_t *__restrict__ out_len, int32_t *__restrict__ loop_state, int loop_state_words,                    \
+                        unsigned *__restrict__ voided
+
+// one frame of one stream, by one wavefront (the body of k_format and of k_format_marked)
+MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
 {
-    __shared__ fmt_lds L;
     const int lane = wave_lane();
     const int C = geo.channels, G = geo.n_gran;
     const int fl = (int) blockIdx.x % geo.nf, s = (int) blockIdx.x / geo.nf;
@@ -316,6 +315,26 @@ __global__ void __launch_bounds__(64) k_format(const mp3mi_tables *__restrict__ 
     }
 }
 
+
+__global__ void __launch_bounds__(64) k_format(FMT_KERNEL_ARGS)
+{
+    __shared__ fmt_lds L;
+    fmt_frame(L, T, geo, ix_all, side_all, bits_per_frame, bitrate_index, out, out_stride, out_len, loop_state, loop_state_words, voided);
+}
+
+// The drop-in symbols' formatter (dropin.cpp: one frame, one workgroup): it tells the spinning host that the kernel BEFORE it on
+// the stream has finished (k_loop: a kernel starts when the one before it has ended and its stores are visible) and, at its own
+// end, that the frame's bytes are in place -- two stores to host-mapped memory instead of two one-thread kernels between and behind
+// the two (4-5 us of dispatch latency each).
+__global__ void __launch_bounds__(64) k_format_marked(FMT_KERNEL_ARGS, volatile unsigned *flag, unsigned seq_before, unsigned seq_done)
+{
+    __shared__ fmt_lds L;
+    if (threadIdx.x == 0) *flag = seq_before;
+    fmt_frame(L, T, geo, ix_all, side_all, bits_per_frame, bitrate_index, out, out_stride, out_len, loop_state, loop_state_words, voided);
+    __threadfence_system(); // (every lane: its stores to the host's window first)
+    if (threadIdx.x == 0) *flag = seq_done;
+}
+
 // ---- streaming (mp3mi_batch_encode_next / mp3mi_batch_flush) ----
 // The file bytes of a stream become final in order: once m bytes of main data have been written, everything up
 // to the physical position of main-data byte m - 1 is final (the reference emits exactly these, src/formatBitstream.c
@@ -437,4 +456,12 @@ void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16
     const unsigned grid = (unsigned) (g.n_streams * g.nf);
     hipLaunchKernelGGL(k_format, dim3(grid), dim3(64), 0, st, T, g, ix, side, bits_per_frame, bitrate_index, out,
                        out_stride, out_len, loop_state, loop_state_words, voided);
+}
+
+void mp3mi_launch_format_marked(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix, const mp3mi_frame_side *side,
+                                const int32_t *bits_per_frame, const int32_t *bitrate_index, uint8_t *out, size_t out_stride, uint32_t *out_len,
+                                unsigned *flag, unsigned seq_before, unsigned seq_done, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_format_marked, dim3(1), dim3(64), 0, st, T, g, ix, side, bits_per_frame, bitrate_index, out, out_stride, out_len,
+                       (int32_t *) NULL, 0, (unsigned *) NULL, (volatile unsigned *) flag, seq_before, seq_done);
 }
