@@ -73,14 +73,14 @@ typedef struct mp3mi_batch_options {
     int32_t y_after_loop;     /* the filterbank / MDCT / prep kernels of a chunk wait for the loop kernel before it: -1 default (only with loop_queue), 0, 1 */
     int32_t psy_beside;       /* what of the psychoacoustic stage runs beside a loop kernel: -1 default (k_cw + k_part + k_psy beside a
                                  resident loop kernel, nothing beside the queue form), 0 nothing, 1 k_cw + k_part + k_psy, 2 k_psy only */
-    int32_t dropin_lookahead; /* the drop-in symbols' look-ahead (mp3mi_dropin.h): -1 default = 1 both, 0 none, 2 the filterbank's only,
-                                 3 L3psycho_anal's only.  Not a property of a batch: the hidden default stream of the drop-in symbols
+    int32_t dropin_lookahead; /* the drop-in symbols' look-ahead (mp3mi_dropin.h): -1 default = 1 all, 0 none, 2 the filterbank's only,
+                                 3 L3psycho_anal's only, 4 all but iteration_loop's / III_format_bitstream's.  Not a property of a batch: the hidden default stream of the drop-in symbols
                                  reads it through mp3mi_batch_options_from_env (MP3MI_DROPIN_LOOKAHEAD) */
     int32_t dropin_stats;     /* the drop-in symbols print, at III_FlushBitstream, the frames they served, the time from the first frame's
                                  first call to the flush and the waits for the device: 0 default, 1 (MP3MI_DROPIN_STATS) */
 } mp3mi_batch_options;
 /* mp3mi_batch_create_ex returns MP3MI_ERR_ARG for a value outside the ranges named above (the three-state fields take
- * -1, 0, 1; psy_beside -1 .. 2; dropin_lookahead -1 .. 3; loop_queue 0, 1; loop_part_streams a multiple of 64; unknown test flags). */
+ * -1, 0, 1; psy_beside -1 .. 2; dropin_lookahead -1 .. 4; loop_queue 0, 1; loop_part_streams a multiple of 64; unknown test flags). */
 void mp3mi_batch_options_default(mp3mi_batch_options *opt);
 /* The same, then overridden by the MP3MI_* environment variables that tools/ and tests/ use (MP3MI_SCRATCH_MB,
  * MP3MI_CHUNK_FRAMES, MP3MI_{NOISE,PHASE,PSY,QUANT,PREP,CW}_EXACT, MP3MI_CALL_OVERLAP, MP3MI_NO_GATE, MP3MI_NO_PLACE,

@@ -206,7 +206,7 @@ extern "C" void mp3mi_batch_options_from_env(mp3mi_batch_options *o)
     if ((e = getenv("MP3MI_Y_AFTER_LOOP"))) o->y_after_loop = atoi(e) != 0;
     if ((e = getenv("MP3MI_PSY_BESIDE"))) o->psy_beside = atoi(e) == 2 ? 2 : (atoi(e) ? 1 : 0);
     if (on(getenv("MP3MI_DROPIN_STATS"))) o->dropin_stats = 1;
-    if ((e = getenv("MP3MI_DROPIN_LOOKAHEAD")) && atoi(e) >= 0 && atoi(e) <= 3) o->dropin_lookahead = atoi(e);
+    if ((e = getenv("MP3MI_DROPIN_LOOKAHEAD")) && atoi(e) >= 0 && atoi(e) <= 4) o->dropin_lookahead = atoi(e);
 }
 
 // Fills *b step by step; on any failure the caller destroys the partially built object (every pointer and handle
@@ -390,7 +390,7 @@ extern "C" int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_
         opt = *opt_in;
         auto tri = [](int v) { return v >= -1 && v <= 1; }; // -1 default, 0 off, 1 on
         if ((opt.test_flags & ~(unsigned) (MP3MI_TEST_ALL_EXACT | MP3MI_TEST_PREP_LIST)) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||
-            (opt.loop_part_streams % 64) != 0 || opt.psy_beside < -1 || opt.psy_beside > 2 || opt.dropin_lookahead < -1 || opt.dropin_lookahead > 3 || (opt.dropin_stats != 0 && opt.dropin_stats != 1) || !tri(opt.call_overlap) || !tri(opt.gate) ||
+            (opt.loop_part_streams % 64) != 0 || opt.psy_beside < -1 || opt.psy_beside > 2 || opt.dropin_lookahead < -1 || opt.dropin_lookahead > 4 || (opt.dropin_stats != 0 && opt.dropin_stats != 1) || !tri(opt.call_overlap) || !tri(opt.gate) ||
             !tri(opt.placement) || !tri(opt.y_after_loop) || (opt.loop_queue != 0 && opt.loop_queue != 1))
             return MP3MI_ERR_ARG;
     }

@@ -20,11 +20,11 @@ size_t mp3mi_psy_state_size(void);
 size_t mp3mi_loop_state_size(void);
 void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double *s, hipStream_t st);
 void mp3mi_launch_window_filter(const mp3mi_tables *T, double *ring, int off, const mp3mi_dropin_samples &in, double *zs, hipStream_t st);
-void mp3mi_launch_mdct_sub(const mp3mi_tables *T, const double *sb_in, double *sb_out, const int32_t *bt, double *xr, int stereo, int mode_gr,
+void mp3mi_launch_mdct_sub(const mp3mi_tables *T, const double *sb_in, double *sb_out, const int32_t *bt, double *xr, double *xr_dev, int stereo, int mode_gr,
                            unsigned *zero_me, unsigned *flag, unsigned seq, unsigned *count, hipStream_t st);
 void mp3mi_launch_format_marked(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix, const mp3mi_frame_side *side,
                                 const int32_t *bits_per_frame, const int32_t *bitrate_index, uint8_t *out, size_t out_stride, uint32_t *out_len,
-                                unsigned *flag, unsigned seq_before, unsigned seq_done, hipStream_t st);
+                                unsigned *flag, unsigned seq_before, unsigned seq_done, int16_t *ix_host, mp3mi_frame_side *side_host, hipStream_t st);
 void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring, int off0_a, int off0_b, const int16_t *samples, int n_ch, int n_slots,
                                       double *zs, double *sb_out, hipStream_t st);
 void mp3mi_launch_dropin_done(unsigned *flag, unsigned seq, hipStream_t st);
@@ -167,6 +167,12 @@ struct DropIn {
     io_buf<double> sbuf[2], xr;
     int sb_cur = 0;
     unsigned *mdct_count = nullptr; // (k_mdct_sub's workgroups count themselves out)
+    // device-memory copies of what a frame's launches ahead hand to each other (the host-mapped buffers are for the host: a
+    // kernel that reads them in dependent steps waits for the bus every time): the spectrum (k_mdct_sub -> k_loop), the
+    // quantised values and the side information (k_loop -> k_format_marked, which writes the host's copies)
+    double *xr_dev = nullptr;
+    int16_t *ix_dev = nullptr;
+    mp3mi_frame_side *side_dev = nullptr;
     io_buf<int32_t> bt;
     // loop
     io_buf<mp3mi_psy_out> psy4;
@@ -237,6 +243,9 @@ void ensure(int rate_idx)
     D.sbuf[0].alloc(sizeof(L3SBS));
     D.sbuf[1].alloc(sizeof(L3SBS));
     HIPOK(hipMalloc((void **) &D.mdct_count, sizeof(unsigned)));
+    HIPOK(hipMalloc((void **) &D.xr_dev, 4 * 576 * sizeof(double)));
+    HIPOK(hipMalloc((void **) &D.ix_dev, 4 * 576 * sizeof(int16_t)));
+    HIPOK(hipMalloc((void **) &D.side_dev, sizeof(mp3mi_frame_side)));
     HIPOK(hipMemset(D.mdct_count, 0, sizeof(unsigned)));
     D.xr.alloc(4 * 576 * sizeof(double));
     D.bt.alloc(4 * sizeof(int32_t));
@@ -320,7 +329,7 @@ static void dropin_wait_for(unsigned seq)
 static void dropin_wait() { dropin_wait_for(dropin_mark()); }
 
 static void psy_wait() { dropin_wait(); }
-static void frame_chain_launch(const mp3mi_psy_out *rec_d, const mp3mi_psy_out *rec_h, bool with_format, bool list_empty);
+static void frame_chain_launch(const mp3mi_psy_out *rec_d, const mp3mi_psy_out *rec_h, bool with_format, bool behind_mdct);
 static void frame_chain_cancel();
 static bool format_setup(int frame_bytes, int si_bytes);
 
@@ -550,7 +559,7 @@ extern "C" void window_subband(short **buffer, double z[512], int k)
         unsigned seq_fb = 0;
         if (spec) {
             seq_fb = ++D.done_seq;
-            mp3mi_launch_mdct_sub(D.T, SI.d, SO.d, D.bt.d, D.xr.d, n_ch, 2, &D.prep_fix->count, D.done_flag.d, seq_fb, D.mdct_count, D.st);
+            mp3mi_launch_mdct_sub(D.T, SI.d, SO.d, D.bt.d, D.xr.d, D.xr_dev, n_ch, 2, &D.prep_fix->count, D.done_flag.d, seq_fb, D.mdct_count, D.st);
         } else
             seq_fb = dropin_mark();
         D.spec.valid = spec;
@@ -625,7 +634,7 @@ extern "C" void mdct_sub(L3SBS *sb_sample, double (*mdct_freq)[2][576], int ster
     frame_chain_cancel(); // (a loop launched ahead read the spectrum this call is about to replace)
     memcpy(D.sbuf[D.sb_cur].h, sb_sample, sizeof(L3SBS));
     memcpy(D.bt.h, bt, sizeof(bt));
-    mp3mi_launch_mdct_sub(D.T, D.sbuf[D.sb_cur].d, D.sbuf[D.sb_cur ^ 1].d, D.bt.d, D.xr.d, stereo, mode_gr, NULL, NULL, 0, D.mdct_count, D.st);
+    mp3mi_launch_mdct_sub(D.T, D.sbuf[D.sb_cur].d, D.sbuf[D.sb_cur ^ 1].d, D.bt.d, D.xr.d, NULL, stereo, mode_gr, NULL, NULL, 0, D.mdct_count, D.st);
     dropin_wait();
     D.sb_cur ^= 1;
     memcpy(sb_sample, D.sbuf[D.sb_cur].h, sizeof(L3SBS));
@@ -675,13 +684,13 @@ static void format_launch(int C, int crc, int bitsPerFrame, int bitrate_index, i
     g.hdr_mode = mode;
     g.crc = crc;
     g.hdr_flags = hdr_flags;
-    if (marked) mp3mi_launch_format_marked(D.T, g, D.ix.d, D.side.d, D.bits.d, D.bri.d, D.win.d, D.win_bytes, D.len_d, D.done_flag.d, seq_before, seq_done, D.st);
+    if (marked) mp3mi_launch_format_marked(D.T, g, D.ix_dev, D.side_dev, D.bits.d, D.bri.d, D.win.d, D.win_bytes, D.len_d, D.done_flag.d, seq_before, seq_done, D.ix.d, D.side.d, D.st);
     else mp3mi_launch_format(D.T, g, D.ix.d, D.side.d, D.bits.d, D.bri.d, D.win.d, D.win_bytes, D.len_d, NULL, 0, NULL, D.st);
 }
 
 // Launches the frame's k_loop (records rec_d, spectrum D.xr) and, when with_format, its k_format behind it, with the parameters in
 // D.fa; copies of the loop's state and of the byte window are taken first.  Nothing may be in flight that writes either.
-static void frame_chain_launch(const mp3mi_psy_out *rec_d, const mp3mi_psy_out *rec_h, bool with_format, bool list_empty)
+static void frame_chain_launch(const mp3mi_psy_out *rec_d, const mp3mi_psy_out *rec_h, bool with_format, bool behind_mdct)
 {
     DropIn::frame_ahead &A = D.fa;
     memcpy(&A.state_before, D.loop_state.h, sizeof(A.state_before));
@@ -689,12 +698,17 @@ static void frame_chain_launch(const mp3mi_psy_out *rec_d, const mp3mi_psy_out *
     *D.bits.h = A.bitsPerFrame;
     mp3mi_geom g = mp3mi_make_geom(1, A.C, D.rate_idx, 1, 0, 1);
     g.crc = A.crc;
+    // behind_mdct: k_mdct_sub, launched just before, has emptied the list and left a copy of the spectrum in device memory
+    const double *xr = behind_mdct ? D.xr_dev : D.xr.d;
+    // with the formatter behind it k_loop writes to device memory; k_format_marked writes the host's copies
+    int16_t *ix = with_format ? D.ix_dev : D.ix.d;
+    mp3mi_frame_side *side = with_format ? D.side_dev : D.side.d;
     // the loop's stateless head of the spectrum: k_mdct's tail as a kernel of its own, then the reference's walk for
     // the records it lists as undecided (k_prep.hip; none, practically)
-    if (!list_empty) HIPOK(hipMemsetAsync(&D.prep_fix->count, 0, sizeof(unsigned), D.st)); // (k_mdct_sub, launched just before, has done it)
-    mp3mi_launch_prep_tail(D.T, g, D.xr.d, rec_d, D.prep4, D.prep_fix, D.st);
-    mp3mi_launch_prep(D.T, g, D.xr.d, rec_d, D.prep4, D.prep_fix, 0, D.st);
-    mp3mi_launch_loop(D.T, g, D.xr.d, rec_d, D.prep4, D.bits.d, D.loop_state.d, D.ix.d, D.side.d, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
+    if (!behind_mdct) HIPOK(hipMemsetAsync(&D.prep_fix->count, 0, sizeof(unsigned), D.st));
+    mp3mi_launch_prep_tail(D.T, g, xr, rec_d, D.prep4, D.prep_fix, D.st);
+    mp3mi_launch_prep(D.T, g, xr, rec_d, D.prep4, D.prep_fix, 0, D.st);
+    mp3mi_launch_loop(D.T, g, xr, rec_d, D.prep4, D.bits.d, D.loop_state.d, ix, side, NULL, mp3mi_loop_place{NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0}, D.st);
     A.loop_pending = true;
     A.fmt_pending = false;
     if (!with_format) A.seq_loop = dropin_mark();

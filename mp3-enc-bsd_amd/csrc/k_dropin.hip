@@ -119,8 +119,8 @@ void mp3mi_launch_window_filter_frame(const mp3mi_tables *T, const double *ring,
 // what the reference leaves of them.  flag != NULL: the last workgroup to finish tells the spinning host (dropin.cpp) --
 // count: zero before the launch, zero again after it.
 __global__ void __launch_bounds__(64) k_mdct_sub(const mp3mi_tables *__restrict__ T, const double *__restrict__ sb_in, double *__restrict__ sb_out,
-                                                 const int32_t *__restrict__ bt, double *__restrict__ xr, int mode_gr, unsigned *zero_me,
-                                                 volatile unsigned *flag, unsigned seq, unsigned *count)
+                                                 const int32_t *__restrict__ bt, double *__restrict__ xr, double *__restrict__ xr_dev, int mode_gr,
+                                                 unsigned *zero_me, volatile unsigned *flag, unsigned seq, unsigned *count)
 {
     __shared__ mdct_lds L;
     const int lane = wave_lane(), ch = (int) blockIdx.x / mode_gr, gr = (int) blockIdx.x % mode_gr;
@@ -144,7 +144,10 @@ __global__ void __launch_bounds__(64) k_mdct_sub(const mp3mi_tables *__restrict_
     const int b = bt[gr * 2 + ch];
     mdct_store_inputs(L, vp, vc, b);
     mdct_granule(L, R, T, b);
-    for (int i = lane; i < 576; i += 64) xr[((size_t) gr * (gridDim.x / (unsigned) mode_gr) + ch) * 576 + i] = L.xr[i];
+    const size_t xo = ((size_t) gr * (gridDim.x / (unsigned) mode_gr) + ch) * 576;
+    for (int i = lane; i < 576; i += 64) xr[xo + i] = L.xr[i];
+    if (xr_dev) // (a copy in device memory for the kernels launched behind this one: xr is the host's)
+        for (int i = lane; i < 576; i += 64) xr_dev[xo + i] = L.xr[i];
     if (flag) {
         __threadfence_system(); // (every lane: its stores to host-mapped memory first)
         if (lane == 0) {
@@ -168,9 +171,9 @@ void mp3mi_launch_filter_subband(const mp3mi_tables *T, const double *z, double 
     hipLaunchKernelGGL(k_filter_subband, dim3(1), dim3(64), 0, st, T, z, s);
 }
 
-void mp3mi_launch_mdct_sub(const mp3mi_tables *T, const double *sb_in, double *sb_out, const int32_t *bt, double *xr, int stereo, int mode_gr,
+void mp3mi_launch_mdct_sub(const mp3mi_tables *T, const double *sb_in, double *sb_out, const int32_t *bt, double *xr, double *xr_dev, int stereo, int mode_gr,
                            unsigned *zero_me, unsigned *flag, unsigned seq, unsigned *count, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_mdct_sub, dim3((unsigned) (stereo * mode_gr)), dim3(64), 0, st, T, sb_in, sb_out, bt, xr, mode_gr, zero_me,
+    hipLaunchKernelGGL(k_mdct_sub, dim3((unsigned) (stereo * mode_gr)), dim3(64), 0, st, T, sb_in, sb_out, bt, xr, xr_dev, mode_gr, zero_me,
                        (volatile unsigned *) flag, seq, count);
 }

@@ -326,9 +326,15 @@ __global__ void __launch_bounds__(64) k_format(FMT_KERNEL_ARGS)
 // the stream has finished (k_loop: a kernel starts when the one before it has ended and its stores are visible) and, at its own
 // end, that the frame's bytes are in place -- two stores to host-mapped memory instead of two one-thread kernels between and behind
 // the two (4-5 us of dispatch latency each).
-__global__ void __launch_bounds__(64) k_format_marked(FMT_KERNEL_ARGS, volatile unsigned *flag, unsigned seq_before, unsigned seq_done)
+__global__ void __launch_bounds__(64) k_format_marked(FMT_KERNEL_ARGS, volatile unsigned *flag, unsigned seq_before, unsigned seq_done,
+                                                      unsigned *__restrict__ ix_host, unsigned *__restrict__ side_host)
 {
     __shared__ fmt_lds L;
+    // k_loop left the frame's values and side information in device memory (this kernel reads them many times over, in dependent
+    // steps: from host-mapped memory that was most of its time); the host's copies are written here, before the host is told
+    for (int i = (int) threadIdx.x; i < geo.channels * 2 * 576 / 2; i += 64) ix_host[i] = ((const unsigned *) ix_all)[i];
+    for (int i = (int) threadIdx.x; i < (int) (sizeof(mp3mi_frame_side) / 4); i += 64) side_host[i] = ((const unsigned *) side_all)[i];
+    __threadfence_system();
     if (threadIdx.x == 0) *flag = seq_before;
     fmt_frame(L, T, geo, ix_all, side_all, bits_per_frame, bitrate_index, out, out_stride, out_len, loop_state, loop_state_words, voided);
     __threadfence_system(); // (every lane: its stores to the host's window first)
@@ -460,8 +466,8 @@ void mp3mi_launch_format(const mp3mi_tables *T, const mp3mi_geom &g, const int16
 
 void mp3mi_launch_format_marked(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t *ix, const mp3mi_frame_side *side,
                                 const int32_t *bits_per_frame, const int32_t *bitrate_index, uint8_t *out, size_t out_stride, uint32_t *out_len,
-                                unsigned *flag, unsigned seq_before, unsigned seq_done, hipStream_t st)
+                                unsigned *flag, unsigned seq_before, unsigned seq_done, int16_t *ix_host, mp3mi_frame_side *side_host, hipStream_t st)
 {
     hipLaunchKernelGGL(k_format_marked, dim3(1), dim3(64), 0, st, T, g, ix, side, bits_per_frame, bitrate_index, out, out_stride, out_len,
-                       (int32_t *) NULL, 0, (unsigned *) NULL, (volatile unsigned *) flag, seq_before, seq_done);
+                       (int32_t *) NULL, 0, (unsigned *) NULL, (volatile unsigned *) flag, seq_before, seq_done, (unsigned *) ix_host, (unsigned *) side_host);
 }

@@ -200,3 +200,47 @@ def test_lookahead_survives_a_caller_that_breaks_its_assumptions_emulated(tmp_pa
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "dropin_probe")) and os.path.exists(os.path.join(REF, "dropin_probe_ref"))), reason="oracle/_ref/dropin_probe* not built")
 def test_lookahead_survives_a_caller_that_breaks_its_assumptions_gpu(tmp_path):
     probe_case("dropin_probe", tmp_path)
+
+
+def run_frame_probe(binary, tmp_path, tag, frames, lookahead=None):
+    env = dict(os.environ, MP3MI_DROPIN_STATS="1")
+    if lookahead is not None:
+        env["MP3MI_DROPIN_LOOKAHEAD"] = str(lookahead)
+    dump, mp3 = tmp_path / (tag + ".bin"), tmp_path / (tag + ".mp3")
+    r = subprocess.run([os.path.join(REF, binary), str(dump), str(mp3), str(frames)], check=True, capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    ahead = None
+    for line in r.stderr.splitlines():
+        if line.startswith("mp3mi drop-in:"):  # "... N waits for the device, A / B frames' loops / formatters launched ahead of their calls"
+            a, b = line.split("waits for the device, ")[1].split(" frames'")[0].split(" / ")
+            ahead = (int(a), int(b))
+    return open(dump, "rb").read(), open(mp3, "rb").read(), ahead
+
+
+def frame_probe_case(binary, tmp_path, frames=12):
+    """oracle/dropin_probe_frame.c: all seven functions, frame by frame, from a caller that changes a subband sample before
+    mdct_sub, lines of the spectrum or a perceptual entropy before iteration_loop, the signs' spectrum or a header bit before
+    III_format_bitstream, and the buffer it hands over: every returned value and the bitstream equal what the reference's own
+    functions give that caller -- with mdct_sub / iteration_loop / III_format_bitstream launched ahead of their calls and
+    without; the launches ahead were used where the caller behaved and dropped where it did not"""
+    ref_dump, ref_mp3, _ = run_frame_probe("dropin_probe_frame_ref", tmp_path, "ref", frames)
+    ahead = {}
+    for mode in (0, 1, 4):
+        dump, mp3, ahead[mode] = run_frame_probe(binary, tmp_path, "m%d" % mode, frames, lookahead=mode)
+        assert dump == ref_dump, "look-ahead mode %d: the library's values differ from the reference's" % mode
+        assert mp3 == ref_mp3, "look-ahead mode %d: the bitstream differs from the reference's" % mode
+    hostile_fmt = sum(1 for f in range(frames) if f % 7 in (4, 5))
+    assert ahead[0] == (0, 0) and ahead[4] == (0, 0), ahead
+    assert 0 < ahead[1][0] < frames and ahead[1][1] == frames - hostile_fmt, ahead
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "dropin_probe_frame_emu")) and os.path.exists(os.path.join(REF, "dropin_probe_frame_ref"))),
+                    reason="oracle/_ref/dropin_probe_frame* not built")
+def test_launches_ahead_survive_a_caller_that_changes_what_it_was_handed_emulated(tmp_path):
+    frame_probe_case("dropin_probe_frame_emu", tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "dropin_probe_frame")) and os.path.exists(os.path.join(REF, "dropin_probe_frame_ref"))),
+                    reason="oracle/_ref/dropin_probe_frame* not built")
+def test_launches_ahead_survive_a_caller_that_changes_what_it_was_handed_gpu(tmp_path):
+    frame_probe_case("dropin_probe_frame", tmp_path, frames=40)
