@@ -147,9 +147,10 @@ MP3MI_DEVFN float loop_rescale34(float y34, int n)
     const float c = n == 1 ? 1.2968395546510096f : (n == 2 ? 1.681792830507429f : (n == 3 ? 2.1810154653305154f : 1.0f));
     return y34 * c;
 }
-// upper bound of the largest y34 after such a rescaling (only the all-zero shortcut of the
-// bisection reads it, and that runs before the first amplification)
+// upper bound of the largest y34 after such a rescaling (the all-zero shortcut of the bisection reads it, which runs
+// before the first amplification, and the quantiser, to know that no line reaches the table's end: loop_quantize)
 #define LOOP_Y34MAX_GROW 2.1810157f
+#define LOOP_Y34MAX_AMP 1.29684f /* one amplification (n = 1) */
 
 MP3MI_DEVFN float loop_estimate(float y34, float cq) { return __builtin_fmaf(y34, cq, 0.4054f); } // of x^(3/4) + 0.4054
 
@@ -169,7 +170,7 @@ struct loop_qinfo {
 };
 
 // force_exact (MP3MI_QUANT_EXACT=1, tests): every line is settled against the exact table, whatever the estimate says.
-MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], int q, bool all_zero, bool force_exact, bool shortb)
+MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], float y34max, int q, bool all_zero, bool force_exact, bool shortb)
 {
     const int lane = wave_lane_here();
     loop_qinfo qi = {0, 0, 0, 0};
@@ -189,14 +190,20 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
     // maximum of that sum over the nine lines, one compare); which ones is found again in the rare branch.
     const float guard = 0.5f - 2e-6f;
     float gmax = 0.0f;
+    // estimate f of x^(3/4) + 0.4054 (>= 0.4054); from 2047.5 on the answer is the table's last entry.  Whether any line gets
+    // there is known from the granule's largest y34 (an upper bound, wave-uniform): almost never -- so the nine clamps are not
+    // in the pass but behind this test (a line beyond the end may send the wave through the exact tier below for nothing:
+    // that tier clamps its own estimate and leaves such a line alone)
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-        // estimate f of x^(3/4) + 0.4054 (>= 0.4054); from 2047.5 on the answer is the table's last entry
-        float f = loop_estimate(y34[j], cq);
-        f = __builtin_fminf(f, 2047.5f);
+        const float f = loop_estimate(y34[j], cq);
         p[j] = (int) f; // f >= 0.4054: the conversion truncates = floor
         const float d = __builtin_fabsf(LOOP_FRACTF(f) - 0.5f); // f - floor(f), exact
         gmax = __builtin_fmaxf(gmax, __builtin_fmaf(3.5e-6f, f, d));
+    }
+    if (!(loop_estimate(y34max, cq) < 2047.0f)) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) p[j] = p[j] < 2047 ? p[j] : 2047;
     }
     if (force_exact || wave_any(gmax > guard)) {
         const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
@@ -364,7 +371,7 @@ MP3MI_DEVFN int loop_pick_v(int da, int s01, int s2, int *sum)
 template <bool ESC, bool NC3>
 MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int lane, int lo, int hi, int dA, int dB, int *a01, int *a2)
 {
-    const int ylen = (dA >> 15) & 31, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
+    const int ylen2 = 2 * ((dA >> 15) & 31), dB2 = 2 * dB, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
     int s01 = 0, s2 = 0;
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
     for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // (one to three steps: unrolling only adds scalar bookkeeping)
@@ -374,7 +381,14 @@ MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int l
         const unsigned xy = ixw[w];
         const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
         const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
-        const int e = GL[(dB + xc * ylen + yc) & in];
+        // (a pair past the end of the region prices some cell of the group all the same -- xc, yc <= 15 keep the index inside the
+        // table whatever the padding holds -- and is masked out of the sums: masking the index as well was an instruction per step;
+        // the cell's byte address from the doubled descriptor values: a multiply-add and a shift-add)
+        unsigned cell = 2u * (unsigned) yc + (unsigned) dB2; // (kept apart: re-associated, the sum takes three instructions instead of two)
+#if !defined(MP3MI_EMU)
+        asm volatile("" : "+v"(cell));
+#endif
+        const int e = *(const uint16_t *) ((const char *) GL + ((unsigned) (xc * ylen2) + cell));
         int c = (e & 31) | (((e >> 5) & 31) << 16);
         if (ESC) c += ((x > 14) + (y > 14)) * lb01;
         s01 += c & in;
@@ -640,21 +654,29 @@ MP3MI_DEVFN int loop_part2_length(const loop_gr &g, int scfsi_m)
 // same loop with its own range (a partial-sum job, or a whole band for the exact tier).
 MP3MI_DEVFN double loop_noise_sum(const mp3mi_tables *T, const loop_lds &L, double step, int first, int count, int stride)
 {
+    // (addresses as in loop_noise_jobs: 32-bit byte offsets, all shifts of the one line index)
+    const char *lds = (const char *) &L.xr[0];
+    const unsigned ix_off = (unsigned) ((const char *) &L.ix[0] - (const char *) &L.xr[0]);
+    const char *tab = (const char *) &T->pow43[0];
     double sum = 0.0;
+    unsigned line = (unsigned) first;
     int k = 0;
-    for (; k + 4 <= count; k += 4) { // four terms in flight, added in order
-        double t[4];
+    for (; k + 2 <= count; k += 2) { // two terms in flight, added in order (the rare tier: it must not be what sets the kernel's register count)
+        double t[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int line = first + (k + u) * stride;
-            t[u] = __builtin_fabs(L.xr[line]) - T->pow43[L.ix[line]] * step;
+        for (int u = 0; u < 2; u++) {
+            const unsigned ln = line + (unsigned) (u * stride);
+            const unsigned q = *(const uint16_t *) (lds + ix_off + 2u * ln);
+            t[u] = __builtin_fabs(*(const double *) (lds + 8u * ln)) - *(const double *) (tab + (size_t) (8u * q)) * step;
         }
+        line += (unsigned) (2 * stride);
 #pragma unroll
-        for (int u = 0; u < 4; u++) sum = sum + t[u] * t[u];
+        for (int u = 0; u < 2; u++) sum = sum + t[u] * t[u];
     }
     for (; k < count; k++) {
-        const int line = first + k * stride;
-        const double t = __builtin_fabs(L.xr[line]) - T->pow43[L.ix[line]] * step;
+        const unsigned q = *(const uint16_t *) (lds + ix_off + 2u * line);
+        const double t = __builtin_fabs(*(const double *) (lds + 8u * line)) - *(const double *) (tab + (size_t) (8u * q)) * step;
+        line += (unsigned) stride;
         sum = sum + t * t;
     }
     return sum;
@@ -665,14 +687,24 @@ MP3MI_DEVFN double loop_noise_sum(const mp3mi_tables *T, const loop_lds &L, doub
 // of dropping out: no divergent loop, no remainder loop, four loads in flight throughout.
 MP3MI_DEVFN double loop_noise_jobs(const mp3mi_tables *T, const loop_lds &L, double step, int first, int count, int stride, int kmax)
 {
+    // Addresses as 32-bit byte offsets from three bases, all shifts of the one line index: as `L.ix[line]` and
+    // `T->pow43[L.ix[line]]` the compiler derived the second LDS address from the first by a 64-bit multiply-add (a quarter-rate
+    // instruction) and sign-extended the table index to 64 bits -- 15 issue slots per term where 10 do (L.ix holds magnitudes).
+    const char *lds = (const char *) &L.xr[0];
+    const unsigned ix_off = (unsigned) ((const char *) &L.ix[0] - (const char *) &L.xr[0]);
+    const char *tab = (const char *) &T->pow43[0];
     double sum = 0.0;
+    unsigned line = (unsigned) first;
     for (int k = 0; k < kmax; k += 4) {
         double t[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int line = k + u < count ? first + (k + u) * stride : 576;
-            t[u] = __builtin_fabs(L.xr[line]) - T->pow43[L.ix[line]] * step;
+            const unsigned ln = (unsigned) (k + u) < (unsigned) count ? line + (unsigned) (u * stride) : 576u;
+            const double x = *(const double *) (lds + 8u * ln);
+            const unsigned q = *(const uint16_t *) (lds + ix_off + 2u * ln);
+            t[u] = __builtin_fabs(x) - *(const double *) (tab + (size_t) (8u * q)) * step;
         }
+        line += (unsigned) (4 * stride);
 #pragma unroll
         for (int u = 0; u < 4; u++) sum = sum + t[u] * t[u];
     }
@@ -962,7 +994,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                                 const bool quant_exact = (tflags & 8) != 0; // MP3MI_QUANT_EXACT=1: the quantiser's exact tier only (tests)
                                 const bool az = !quant_exact && loop_all_zero(y34max, g.q);
                                 work += 4;
-                                const loop_qinfo qi = loop_quantize(T, L, y34, g.q, az, quant_exact, shortb);
+                                const loop_qinfo qi = loop_quantize(T, L, y34, y34max, g.q, az, quant_exact, shortb);
                                 PROF(2);
                                 bits = loop_count_bits(T, R, L, GL, g, qi, az CBPROF_PASS);
                                 PROF(3);
@@ -1084,21 +1116,19 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                             over = __popcll(ampmask);
                             if (over) {
                                 // The amplified bands are a few runs of consecutive lines, so most of the nine slots of 64
-                                // lines hold none of them: a slot is skipped as a whole (one compare into a scalar mask),
+                                // lines hold none of them: a slot is skipped as a whole,
                                 // and inside a slot only the amplified lines touch the LDS.  ampmask only has bits of
                                 // band lanes, so lines above the last band (b >= nband) find a zero bit.
 #pragma unroll
                                 for (int j = 0; j < 9; j++) {
                                     const unsigned b = (unsigned) ((bandpack >> (6 * j)) & 63ull);
                                     const bool f = ((ampmask >> b) & 1ull) != 0;
-                                    if (__ballot(f)) {
-                                        if (f) {
-                                            L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * ifqstep;
-                                            y34[j] = y34[j] * 1.2968395546510096f; // loop_rescale34(y34, 1)
-                                        }
+                                    if (f) { // (a slot none of whose lines is amplified: the branch over an empty execution mask)
+                                        L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * ifqstep;
+                                        y34[j] = y34[j] * 1.2968395546510096f; // loop_rescale34(y34, 1)
                                     }
                                 }
-                                y34max = y34max * LOOP_Y34MAX_GROW;
+                                y34max = y34max * LOOP_Y34MAX_AMP;
                             }
                         }
                         wave_sync(); // amplified lines in L.xr are read by other lanes' noise sums
