@@ -242,9 +242,7 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
         }
 #else
         // min(p, 2) of the lane's nine lines as 2-bit fields of one word, slot j in bits 2j, 2j + 1: its highest set bit
-        // names the lane's last non-zero line, the highest set ODD bit its last line above 1; line + 1 = 64 slot + lane
-        // + 1 is the lane's key (an empty word gives slot -1: a key <= 0), and two wave maxima in lock-step are the run
-        // lengths.  All vector work: a scalar instruction costs this kernel more than a vector one.
+        // names the lane's last non-zero line, the highest set ODD bit its last line above 1.
         unsigned w = 0;
 #pragma unroll
         for (int j = 0; j < 9; j++) {
@@ -252,11 +250,23 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
             w |= c << (2 * j);
             L.ix[lane + 64 * j] = (int16_t) p[j];
         }
+#if !defined(LOOP_RUNLEN_KEYS)
+        // ONE reduction -- the OR of the words names the last slot that holds a non-zero line / a line above 1 -- and a
+        // lane mask per run length for the last lane of that slot.  (LOOP_RUNLEN_KEYS, the first form of round 4: a key per lane,
+        // 64 slot + lane + 1, and two wave maxima -- 18 vector instructions more, 17 scalar ones less per pass; 219.4 vs 218.0 ms per step)
+        const unsigned wo = wave_or_u32(w);
+        const int t_nz = 31 - __clz((int) wo), t_big = 31 - __clz((int) (wo & 0x2AAAAu)); // -1 for an empty word
+        const int j_nz = t_nz >> 1, j_big = t_big >> 1;
+        const unsigned long long m_nz = __ballot((w & (3u << ((2 * j_nz) & 31))) != 0u), m_big = __ballot((w & (2u << ((2 * j_big) & 31))) != 0u);
+        qi.n_nz = t_nz < 0 ? 0 : 64 * j_nz + 64 - __clzll((long long) m_nz);
+        qi.n_big = t_big < 0 ? 0 : 64 * j_big + 64 - __clzll((long long) m_big);
+#else
         const int t_nz = 31 - __clz((int) w), t_big = 31 - __clz((int) (w & 0x2AAAAu)); // -1 for an empty word
         int kv[2] = {((t_nz >> 1) << 6) + lane + 1, ((t_big >> 1) << 6) + lane + 1};
         wave_reduce_i32<0, 2>(kv); // (an empty lane's key is lane - 63 <= 0, and lane 63's is exactly 0: the maxima are >= 0)
         qi.n_nz = kv[0];
         qi.n_big = kv[1];
+#endif
 #endif
     }
     wave_sync();
@@ -448,9 +458,12 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
             if (64 * k >= g.count1) break;
             const int qd = lane + 64 * k;
             const bool in = qd < g.count1;
-            const int w0 = in ? g.big_values + 2 * qd : 0;
+            // (quadruples past the end are read all the same -- still inside this wavefront's LDS -- and masked out of the sum)
+            const int w0 = g.big_values + 2 * qd;
             const unsigned a = ixw[w0], b = ixw[w0 + 1];
-            const int pp = (int) ((a & 1u) | ((a >> 15) & 2u) | ((b & 1u) << 2) | ((b >> 13) & 8u));
+            // values 0 / 1 in the four halves of two words: v | w << 16 and x | y << 16 -> v + 2 w + 4 x + 8 y in three instructions
+            const unsigned t = a | (b << 2);
+            const int pp = (int) ((t | (t >> 15)) & 15u);
             const int e = GL[GL_C1 + pp]; // code length + sign bits: table A | table B << 5
             const int c = (e & 31) | ((e >> 5) << 16);
             s01 += in ? c : 0;

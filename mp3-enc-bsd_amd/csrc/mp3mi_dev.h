@@ -371,6 +371,25 @@ MP3MI_DEVFN void wave_reduce_keep_i32(int (&v)[NSUM + NMAX])
 #undef MP3MI_RSTEP
 #endif
 }
+/* OR of a word over the wavefront (wave-uniform result) */
+MP3MI_DEVFN unsigned wave_or_u32(unsigned v)
+{
+#if defined(MP3MI_EMU)
+    int x = (int) v;
+    for (int m = 32; m >= 1; m >>= 1) x |= __shfl_xor(x, m);
+    return (unsigned) x;
+#else
+    const int ident = 0;
+    int x = (int) v;
+    x |= MP3MI_DPP(x, 0xB1, 0xf);
+    x |= MP3MI_DPP(x, 0x4E, 0xf);
+    x |= MP3MI_DPP(x, 0x141, 0xf);
+    x |= MP3MI_DPP(x, 0x140, 0xf);
+    x |= MP3MI_DPP(x, 0x142, 0xf);
+    x |= MP3MI_DPP(x, 0x143, 0xf);
+    return (unsigned) __builtin_amdgcn_readlane(x, 63);
+#endif
+}
 /* wave maximum of unsigned values: DPP steps with the maximum folded into the move (a lane without a source reads 0) */
 MP3MI_DEVFN unsigned wave_max_u32(unsigned v)
 {
