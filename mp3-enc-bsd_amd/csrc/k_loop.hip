@@ -598,31 +598,25 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     // region, and a scalar instruction costs this kernel more than a vector one.  An empty
     // region's descriptor and sums are zero: table 0, no bits, as src/loop.c:1771-1777 leaves it.
     {
-        int tot, ts[3];
+        // ... and for the three regions AT ONCE: the sums of regions 0, 1, 2 are moved to lanes 61, 62, 63 of one register (the
+        // reductions leave each in lane 63 of its own), their descriptors to the same lanes of another, and one run of the
+        // decision serves all three; a sum over the three lanes is the bit count, three lane reads are the tables.
+        int dav = wave_put_lane<63>(wave_put_lane<62>(wave_put_lane<61>(0, da[0]), da[1]), da[2]);
+        int best, choice;
         if (third) { // five reductions in lock-step
             int fs[5] = {s01p[0], s01p[1], s01p[2], s2p[0] | (s2p[1] << 16), s2p[2]};
             wave_reduce_keep_i32<5, 0>(fs);
-            const int s2k[3] = {fs[3] & 0xffff, (int) ((unsigned) fs[3] >> 16), fs[4]};
-            tot = 0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                int best;
-                ts[r] = loop_pick_v<true>(da[r], fs[r], s2k[r], &best);
-                tot += best;
-            }
+            const int x01 = wave_tail_place(wave_tail_place(fs[2], fs[1], 1), fs[0], 2);
+            const int x2 = wave_tail_place(wave_tail_place(fs[4], (int) ((unsigned) fs[3] >> 16), 1), fs[3] & 0xffff, 2);
+            choice = loop_pick_v<true>(dav, x01, x2, &best);
         } else {
             wave_reduce_keep_i32<3, 0>(s01p);
-            tot = 0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                int best;
-                ts[r] = loop_pick_v<false>(da[r], s01p[r], 0, &best);
-                tot += best;
-            }
+            const int x01 = wave_tail_place(wave_tail_place(s01p[2], s01p[1], 1), s01p[0], 2);
+            choice = loop_pick_v<false>(dav, x01, 0, &best);
         }
-        bits += wave_readlane_i32(tot, 63);
+        bits += wave_tail_sum3(best);
 #pragma unroll
-        for (int r = 0; r < 3; r++) g.table_select[r] = wave_readlane_i32(ts[r], 63);
+        for (int r = 0; r < 3; r++) g.table_select[r] = wave_readlane_i32(choice, 61 + r);
     }
     CBPROF(4); // cost reductions + picks
     return bits;

@@ -371,6 +371,39 @@ MP3MI_DEVFN void wave_reduce_keep_i32(int (&v)[NSUM + NMAX])
 #undef MP3MI_RSTEP
 #endif
 }
+/* The tails of three reductions side by side: what lane 63 of `src` holds goes to lane 63 - n of `old` (n = 1, 2), the lanes
+ * from 63 - n + 1 up keep `old`, what the lanes below 63 - n hold afterwards is unspecified.  wave_put_lane: one lane takes a
+ * wave-uniform value.  wave_tail_sum3: lane 61's + lane 62's + lane 63's value, wave-uniform. */
+MP3MI_DEVFN int wave_tail_place(int old, int src, int n)
+{
+#if defined(MP3MI_EMU)
+    const int v = __shfl(src, 63);
+    return wave_lane() == 63 - n ? v : old;
+#else
+    return n == 1 ? __builtin_amdgcn_update_dpp(old, src, 0x101, 0x8, 0x8, false)  /* row_shl:1, row 3, lanes 60..63 */
+                  : __builtin_amdgcn_update_dpp(old, src, 0x102, 0x8, 0x8, false); /* row_shl:2 */
+#endif
+}
+template <int LANE> MP3MI_DEVFN int wave_put_lane(int old, int uniform_value)
+{
+#if defined(MP3MI_EMU)
+    return wave_lane() == LANE ? uniform_value : old;
+#else
+    int r = old;
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(r) : "s"(uniform_value), "i"(LANE));
+    return r;
+#endif
+}
+MP3MI_DEVFN int wave_tail_sum3(int v)
+{
+#if defined(MP3MI_EMU)
+    return __shfl(v, 61) + __shfl(v, 62) + __shfl(v, 63);
+#else
+    int t = v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0x8, 0x8, true); /* row_shr:1: lane 63 takes lane 62's */
+    t += __builtin_amdgcn_update_dpp(0, v, 0x112, 0x8, 0x8, true);        /* row_shr:2: ... and lane 61's */
+    return __builtin_amdgcn_readlane(t, 63);
+#endif
+}
 /* OR of a word over the wavefront (wave-uniform result) */
 MP3MI_DEVFN unsigned wave_or_u32(unsigned v)
 {
