@@ -378,32 +378,42 @@ MP3MI_DEVFN int loop_pick_v(int da, int s01, int s2, int *sum)
 // Cost of the pairs of lines [lo, hi) under the candidate tables of one group (descriptor dA/dB), per lane:
 // *a01 = candidate 0 | candidate 1 << 16, *a2 = third candidate.  Walks 64 pairs per step straight out of
 // L.ix.  ESC: the group's tables have linbits (x or y > 14 then costs them); NC3: it has a third candidate.
+template <bool ESC, bool NC3, bool LAST>
+MP3MI_DEVFN void loop_walk_step(const uint16_t *GL, const unsigned *ixw, int w, int hi, int ylen2, int dB2, int lb01, int &s01, int &s2)
+{
+    const unsigned xy = ixw[w];
+    const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
+    const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
+    // (a pair past the end of the region prices some cell of the group all the same -- xc, yc <= 15 keep the index inside the
+    // table whatever the padding holds -- and is masked out of the sums: masking the index as well was an instruction per step;
+    // the cell's byte address from the doubled descriptor values: a multiply-add and a shift-add)
+    unsigned cell = 2u * (unsigned) yc + (unsigned) dB2; // (kept apart: re-associated, the sum takes three instructions instead of two)
+#if !defined(MP3MI_EMU)
+    asm volatile("" : "+v"(cell));
+#endif
+    const int e = *(const uint16_t *) ((const char *) GL + ((unsigned) (xc * ylen2) + cell));
+    int c = (e & 31) | (((e >> 5) & 31) << 16);
+    if (ESC) c += ((x > 14) + (y > 14)) * lb01;
+    if (LAST) { // only a region's last step of 64 pairs can reach past its end
+        const int in = (2 * w - hi) >> 31; // all ones inside the region
+        s01 += c & in;
+        if (NC3) s2 += (e >> 10) & 31 & in;
+    } else {
+        s01 += c;
+        if (NC3) s2 += (e >> 10) & 31;
+    }
+}
+
 template <bool ESC, bool NC3>
 MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int lane, int lo, int hi, int dA, int dB, int *a01, int *a2)
 {
     const int ylen2 = 2 * ((dA >> 15) & 31), dB2 = 2 * dB, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
     int s01 = 0, s2 = 0;
+    int w0 = lo >> 1; // (one to three steps: unrolling only adds scalar bookkeeping)
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
-    for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // (one to three steps: unrolling only adds scalar bookkeeping)
-        // pairs past the end of the region are read all the same (L.ix is padded) and masked out of the sums
-        const int w = w0 + lane;
-        const int in = (2 * w - hi) >> 31; // all ones inside the region
-        const unsigned xy = ixw[w];
-        const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
-        const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
-        // (a pair past the end of the region prices some cell of the group all the same -- xc, yc <= 15 keep the index inside the
-        // table whatever the padding holds -- and is masked out of the sums: masking the index as well was an instruction per step;
-        // the cell's byte address from the doubled descriptor values: a multiply-add and a shift-add)
-        unsigned cell = 2u * (unsigned) yc + (unsigned) dB2; // (kept apart: re-associated, the sum takes three instructions instead of two)
-#if !defined(MP3MI_EMU)
-        asm volatile("" : "+v"(cell));
-#endif
-        const int e = *(const uint16_t *) ((const char *) GL + ((unsigned) (xc * ylen2) + cell));
-        int c = (e & 31) | (((e >> 5) & 31) << 16);
-        if (ESC) c += ((x > 14) + (y > 14)) * lb01;
-        s01 += c & in;
-        if (NC3) s2 += (e >> 10) & 31 & in;
-    }
+    for (; 2 * (w0 + 64) <= hi; w0 += 64) loop_walk_step<ESC, NC3, false>(GL, ixw, w0 + lane, hi, ylen2, dB2, lb01, s01, s2);
+    // pairs past the end of the region are read all the same (L.ix is padded) and masked out of the sums
+    if (2 * w0 < hi) loop_walk_step<ESC, NC3, true>(GL, ixw, w0 + lane, hi, ylen2, dB2, lb01, s01, s2);
     *a01 = s01;
     *a2 = s2;
 }
@@ -549,8 +559,15 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     auto region_max = [&](int lo, int hi) {
         hi = hi < nzend ? hi : nzend; // both even
         int m = 0;
+        int w0 = lo >> 1; // pair index of lane 0
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
-        for (int w0 = lo >> 1; 2 * w0 < hi; w0 += 64) { // pair index of lane 0
+        for (; 2 * (w0 + 64) <= hi; w0 += 64) { // whole steps of 64 pairs: nothing to mask
+            const unsigned xy = ixw[w0 + lane];
+            const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
+            const int v = x > y ? x : y;
+            m = v > m ? v : m;
+        }
+        if (2 * w0 < hi) {
             const int w = w0 + lane;
             // read unconditionally (L.ix is padded: pairs past the end exist) and mask: a conditional load costs
             // three scalar instructions and two branches per step
