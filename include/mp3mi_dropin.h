@@ -153,7 +153,7 @@ void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int l3_enc[2][2
 void III_FlushBitstream(void);
 
 /* LOOK-AHEAD.  Served one call at a time, a frame of the reference's loop costs 79 waits for the device.  The library
- * therefore reads ahead -- only in memory the caller has already handed over:
+ * therefore reads ahead -- only in memory the caller has already handed over, or in what it has handed out itself:
  *   - L3psycho_anal: when a channel's two calls of the frame BEFORE were given p and p + 576 and the first call of this
  *     frame is given the same p, both granules are analysed at once -- and the other channel's with them when its calls of
  *     the frame before show the same pattern (its buffer and its delay line were handed over then, at the addresses
@@ -161,15 +161,19 @@ void III_FlushBitstream(void);
  *   - window_subband / filter_subband: the four L3psycho_anal calls of a frame were given &buffer[ch][0] and
  *     &buffer[ch][576] (src/musicin.c:754-758); when a channel's first window_subband of the frame starts at that same
  *     &buffer[ch][0], the 36 slots of both channels are computed in one launch and handed out call by call;
- *   - mdct_sub: launched right behind that filterbank kernel, from the subband samples it produced and the block types
- *     L3psycho_anal handed out, and served if the caller's L3SBS and block types are exactly those.
- * Every served call first checks that its pointer is where the previous call left it and that its samples (delay line,
- * subband samples, block types) are still what was read; a caller that moves or rewrites its buffers in between gets the
- * call-by-call service, with the channel's state put back to where the served calls left it: tests/test_dropin.py,
- * oracle/dropin_probe.c -- bit-exact either way.  4 waits per frame instead of 79 under the reference's driver (a one-thread
- * kernel stores a flag in host-mapped memory behind each call's launches; the host spins on it).  MP3MI_DROPIN_LOOKAHEAD =
- * 0 none, 2 / 3 one of the two families (mp3mi_batch_options_from_env); MP3MI_DROPIN_STATS=1: a line at III_FlushBitstream.
- * mp3mi_dropin_waits: waits for the device so far (tests, tools). */
+ *   - mdct_sub, iteration_loop, III_format_bitstream: launched right behind that filterbank kernel -- the transform from the
+ *     subband samples it produced and the block types L3psycho_anal handed out, the loop from the transform's spectrum and
+ *     L3psycho_anal's records with the frame length, header bits and channel count of the frame before, the formatter from
+ *     the loop's records -- and each served if the call's arguments are exactly what its launch read: L3SBS and block types;
+ *     pe, ratio, spectrum, mean_bits, header; l3_enc, side information, scalefactors, the spectrum's signs, header.
+ * Every served call first checks that its pointer is where the previous call left it and that its inputs are still what
+ * was read; a caller that moves or rewrites its buffers, or changes what it was handed between two calls, gets the
+ * call-by-call service, with the library's state (psychoacoustic state, bit reservoir, the formatter's bytes) put back to
+ * where the served calls left it: tests/test_dropin.py, oracle/dropin_probe.c, oracle/dropin_probe_frame.c -- bit-exact
+ * either way.  Two launches and two waits per frame instead of 79 under the reference's driver (the kernels that end a stage
+ * store a flag in host-mapped memory; the host spins on it).  MP3MI_DROPIN_LOOKAHEAD = 0 none, 2 / 3 the filterbank's /
+ * L3psycho_anal's only, 4 all but the third family (mp3mi_batch_options_from_env); MP3MI_DROPIN_STATS=1: a line at
+ * III_FlushBitstream.  mp3mi_dropin_waits: stages a call waited for so far (tests, tools). */
 long mp3mi_dropin_waits(void);
 
 #ifdef __cplusplus

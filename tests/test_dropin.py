@@ -121,9 +121,10 @@ def test_baseline_config0_through_the_reference_driver(product, tmp_path):
                "inside_the_process_1149_frames": in_process,
                "reference_binary_on_one_host_core": {"seconds_383_frames": round(dt_ref, 3), "seconds_1149_frames": round(dt_long_ref, 3),
                                                      "frames_per_s_marginal": round(766 / max(dt_long_ref - dt_ref, 1e-9), 1)},
-               "note": "the per-call surface over ONE hidden stream: with the look-ahead of mp3mi_dropin.h a frame is 4 launches-and-waits "
-                       "(one for the four L3psycho_anal calls, one for the 72 window_subband / filter_subband calls and mdct_sub, iteration_loop, "
-                       "III_format_bitstream) instead of 79; half of what is left is k_loop's one wavefront; throughput comes from the batched API"},
+               "note": "the per-call surface over ONE hidden stream: with the look-ahead of mp3mi_dropin.h a frame is two launches "
+                       "(one for the four L3psycho_anal calls, one for the 72 window_subband / filter_subband calls, mdct_sub, iteration_loop and "
+                       "III_format_bitstream, each served from it if its arguments are what the launch read) "
+                       "instead of 79; 60 % of what is left is k_loop's one wavefront; throughput comes from the batched API"},
               open(os.path.join(out, "dropin_config0.json"), "w"), indent=1)
 
 
