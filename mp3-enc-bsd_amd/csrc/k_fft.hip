@@ -527,6 +527,13 @@ MP3MI_DEVFN void cw_record(const float *__restrict__ bins, double *__restrict__ 
 __global__ void __launch_bounds__(64) k_cw(const float *__restrict__ bins, double *__restrict__ cw_mid, float *__restrict__ hist6,
                                           int force_exact, int exact_sc)
 {
+#if !defined(MP3MI_EMU)
+    // beside k_loop (batch.cpp) this kernel gets what that one leaves: with the highest wave priority it is through in its
+    // stand-alone time instead of three times that, and the chain k_cw -> k_part -> k_psy -> k_filter -> k_mdct ends before
+    // the k_loop launch it runs beside does (profiles/r04_experiments.txt, prioA)
+    __builtin_amdgcn_s_setprio(3);
+#endif
+
     cw_record<true>(bins, cw_mid, hist6, blockIdx.x, force_exact);
     if (exact_sc) cw_record<false>(bins, cw_mid, hist6, blockIdx.x, force_exact);
 }

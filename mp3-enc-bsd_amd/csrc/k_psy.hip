@@ -194,6 +194,13 @@ __global__ void __launch_bounds__(64) k_part(const mp3mi_tables *__restrict__ T,
                                              double *__restrict__ eb_all, float *__restrict__ cb_all,
                                              mp3mi_cw_fixlist *__restrict__ fix, int second)
 {
+#if !defined(MP3MI_EMU)
+    // beside k_loop (batch.cpp) this kernel gets what that one leaves: with the highest wave priority it is through in its
+    // stand-alone time instead of three times that, and the chain k_cw -> k_part -> k_psy -> k_filter -> k_mdct ends before
+    // the k_loop launch it runs beside does (profiles/r04_experiments.txt, prioA)
+    __builtin_amdgcn_s_setprio(3);
+#endif
+
     // second == 0: the lanes are the 64 consecutive records of block blockIdx.x.  With fix given, cw_mid holds k_cw's
     // FIRST tier: every rounding it feeds is checked (part_cw_safe) and a record with one that could go either way is
     // put on the list.  second == 1: the lanes are the records of the list, on the second-tier values k_cw_fix has
@@ -375,6 +382,13 @@ __global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__res
                                             const float *__restrict__ energy_s, const float *__restrict__ hist6,
                                             mp3mi_psy_state *__restrict__ state, mp3mi_psy_out *__restrict__ out)
 {
+#if !defined(MP3MI_EMU)
+    // beside k_loop (batch.cpp) this kernel gets what that one leaves: with the highest wave priority it is through in its
+    // stand-alone time instead of three times that, and the chain k_cw -> k_part -> k_psy -> k_filter -> k_mdct ends before
+    // the k_loop launch it runs beside does (profiles/r04_experiments.txt, prioA)
+    __builtin_amdgcn_s_setprio(3);
+#endif
+
     __shared__ psy_lds LL[PSY_W];
     __shared__ double s3rows[SPARSE ? PSY_S3_W : 1][64];
     const int wv = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
