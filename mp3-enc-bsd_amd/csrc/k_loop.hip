@@ -1063,11 +1063,12 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                                 // the band's sum in its first job's lane, where the band lane fetches it.  Any order
                                 // of these non-negative terms is as good as another here (see above).
                                 double v = loop_noise_jobs(T, L, noise_step, jfirst, jcount, sstride, jmax4);
-#pragma unroll
-                                for (int d = 1; d <= 16; d <<= 1) {
-                                    const double o = __shfl_down(v, (unsigned) d);
-                                    v = v + ((jseg & d) ? o : 0.0);
-                                }
+                                // (a band has at most 16 jobs -- tables_host.cpp refuses a table with more -- so four doublings do)
+                                const int lane4 = 4 * lane;
+                                { const double o = wave_down_f64<1>(v, lane4); v = v + ((jseg & 1) ? o : 0.0); }
+                                { const double o = wave_down_f64<2>(v, lane4); v = v + ((jseg & 2) ? o : 0.0); }
+                                { const double o = wave_down_f64<4>(v, lane4); v = v + ((jseg & 4) ? o : 0.0); }
+                                { const double o = wave_down_f64<8>(v, lane4); v = v + ((jseg & 8) ? o : 0.0); }
                                 const double sum = __shfl(v, pj0);
                                 xfsf_r = bandlane ? sum / (double) scount : 0.0;
                                 if (wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) xfsf_exact = true;

@@ -404,6 +404,20 @@ MP3MI_DEVFN int wave_tail_sum3(int v)
     return __builtin_amdgcn_readlane(t, 63);
 #endif
 }
+/* the double that lane (this lane + D) mod 64 holds: two ds_bpermute_b32 whose lane offset is the instruction's immediate
+ * (lane4 = 4 * this lane) -- __shfl_down computes the partner's address and clamps it at the wavefront's end, three vector
+ * instructions a call that a caller who discards what comes from beyond its segment does not need */
+template <int D> MP3MI_DEVFN double wave_down_f64(double v, int lane4)
+{
+#if defined(MP3MI_EMU)
+    return __shfl(v, (wave_lane() + D) & 63);
+#else
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(lane4 + 4 * D, (int) (unsigned) b);
+    const int hi = __builtin_amdgcn_ds_bpermute(lane4 + 4 * D, (int) (unsigned) (b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long) (unsigned) hi << 32) | (unsigned long long) (unsigned) lo);
+#endif
+}
 /* OR of a word over the wavefront (wave-uniform result) */
 MP3MI_DEVFN unsigned wave_or_u32(unsigned v)
 {

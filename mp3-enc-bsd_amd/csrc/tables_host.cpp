@@ -576,7 +576,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
             }
             /* segment flags for the band sums by doubling (k_loop): job j of band b, bit d: job j + d is of band b too */
             for (int b = 0; b < nb; b++) {
-                if (T->nj_njobs[t][b] >= 32) return -7;
+                if (T->nj_njobs[t][b] > 16) return -7; /* (k_loop sums a band's jobs in four doublings) */
                 for (int q = 0; q < T->nj_njobs[t][b]; q++)
                     for (int d = 1; d <= 16; d <<= 1)
                         if (q + d < T->nj_njobs[t][b]) T->nj_seg[t][T->nj_job0[t][b] + q] |= (uint8_t) d;
