@@ -21,7 +21,12 @@ makes the run FAIL (exit 1, value null).  tools/full_parity.py compares every st
 reference's default bitrate for the layer (src/musicin.c:371-372: 288 / 160 kbps): 4096 streams x 10 s of 44.1 kHz stereo.
 The default (--layer 3) is the metric of BASELINE.json.
 
+The default line (N = 1, configs[1], Layer III) also carries `end_to_end` -- the same K steps with PCM and bytes in page-locked
+host memory, crossing PCIe beside the kernels; `value` stays the resident rate -- and `other_workloads`:
+two steps each of configs[3] and configs[4] and one Layer II step, each with its own oracle spot check.
+
     python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, one per GPU, and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -34,7 +39,8 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
-import torch
+
+torch = None  # imported by main() in the processes that run a rank: the launcher of `--gpus N` never loads it
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -89,7 +95,7 @@ class Workload:
 # What bounds each kernel (measured stand-alone durations against bytes moved and instructions
 # issued).  A label, not a measurement: the measurements are in the profile the bench line names.
 KERNEL_BOUND = {
-    "k_loop": "valu+salu issue (4 wavefronts per SIMD, serial per stream)", "k_loop_queue": "valu+salu issue",
+    "k_loop": "valu+salu issue (4 wavefronts per SIMD, serial per stream)",
     "k_fft": "lds pipe (bank conflicts of the butterfly program)", "k_cw": "valu issue (f64)", "k_cw_fix": "valu issue (f64)",
     "k_part": "hbm (one lane per record, 2 KB rows)", "k_psy": "latency (one wavefront per track, serial over granules)",
     "k_filter": "valu issue (f64) + hbm", "k_mdct": "hbm + valu issue (the loop's stateless head in its tail)", "k_prep": "idle (the records k_mdct lists: none)", "k_format": "latency (bit scatter)",
@@ -354,6 +360,117 @@ def main_l12(args, mp3, dev, cdev, rank, world, distributed):
         raise SystemExit("bench.py: PARITY FAILURE -- the GPU bitstream differs from the reference on %d sampled streams" % int(n_bad.item()))
 
 
+def other_workloads(mp3, dev, steps=2):
+    """configs[3], configs[4] (Layer III) and the Layer II batch, `steps` timed steps each after one warm-up, every one with
+    its own oracle spot check (8 streams spread over the batch, whole files byte for byte).  Short, so that the default
+    bench run carries driver-visible figures for them; tools/full_parity.py and the -m gpu tests hold their parity proper."""
+    from mp3common import Oracle, oracle_l12
+    orc = Oracle()
+    rows = []
+    for cid in (3, 4):
+        cfg = CONFIGS[cid]
+        S, nf, C, rate = cfg["streams"], cfg["frames"], cfg["channels"], cfg["rate"]
+        wl = Workload(mp3, cfg, dev, stream0=0)
+        wl.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.encode()
+        wl.batch.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        idx = sorted(set(np.linspace(0, S - 1, 8).astype(int).tolist()))
+        out_h, len_h = wl.out[idx].cpu().numpy(), wl.out_len[idx].cpu().numpy()
+        pcm_h = [wl.pcm[i].cpu().numpy() for i in idx]
+        with ThreadPoolExecutor(max_workers=len(idx)) as ex:
+            refs = list(ex.map(lambda k: orc.encode(pcm_h[k], rate, wl.kbps[idx[k]], C)[0], range(len(idx))))
+        ok = all(out_h[k, : len_h[k]].tobytes() == refs[k] for k in range(len(idx)))
+        rows.append({"config_id": cid, "workload": "%d x %d frames, %.0f kHz %s, %s kbps (%s)" % (S, nf, rate / 1000.0, "stereo" if C == 2 else "mono",
+                                                                                                 "64-320 mixed" if cfg["kbps"] == "mix48" else cfg["kbps"], cfg["name"]),
+                     "value": round(S * nf * steps / dt, 1) if ok else None, "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+                     "algorithmic_bytes_per_frame": round(wl.alg_bytes_per_frame(), 1), "bit_exact": ok, "streams_checked": len(idx)})
+        wl.close()
+        del wl
+        torch.cuda.empty_cache()
+    layer, rate, C, kbps, S, nf = 2, 44100, 2, 160, 4096, 383
+    batch = mp3.BatchL12(layer, S, rate, C, kbps, nf)
+    pcm = torch.empty((S, nf * 1152 * C), dtype=torch.int16, device=dev)
+    mp3.synth_pcm_device(pcm, nf * 1152, C, rate, stream0=0, seed=SEED)
+    out = torch.zeros((S, batch.out_stride(nf)), dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(S, dtype=torch.int32, device=dev)
+    batch.encode(pcm, nf, out, out_len)
+    batch.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.encode(pcm, nf, out, out_len)
+    batch.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    idx = sorted(set(np.linspace(0, S - 1, 8).astype(int).tolist()))
+    out_h, len_h = out[idx].cpu().numpy(), out_len[idx].cpu().numpy()
+    pcm_h = [pcm[i].cpu().numpy() for i in idx]
+    with ThreadPoolExecutor(max_workers=len(idx)) as ex:
+        refs = list(ex.map(lambda p: oracle_l12(orc, layer, rate, kbps, "s", p)[0], pcm_h))
+    ok = all(out_h[k, : len_h[k]].tobytes() == refs[k] for k in range(len(idx)))
+    rows.append({"layer": 2, "workload": "%d x %d Layer II frames, 44.1 kHz stereo, %d kbps, psychoacoustic model 2 (SURVEY 8(f) row 4)" % (S, nf, kbps),
+                 "value": round(S * nf * steps / dt, 1) if ok else None, "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+                 "algorithmic_bytes_per_frame": 1152 * C * 2 + mp3.frame_bytes_l12(layer, rate, kbps), "bit_exact": ok, "streams_checked": len(idx)})
+    batch.close()
+    return rows
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: start N copies of this script, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), relay rank 0's
+    standard output -- the one JSON line -- and return non-zero if any rank does.  The launcher makes no GPU call and no
+    torch.cuda query (it does not even import torch) and is never replaced by another program; a rank that fails takes
+    the others down with it (by their exact PIDs), so that nobody waits at a barrier for ever.
+    The serial loop this replaces: /root/reference/src/musicin.c:585 (one stream, one process)."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        # rank 0's stdout is this process's stdout; the other ranks print nothing there, and what they might goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr, stderr=None))
+    rc = 0
+    try:
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    sys.stderr.write("bench.py: rank %d ended with %d: stopping the other ranks\n" % (r, code))
+                    for o in alive:
+                        procs[o].send_signal(signal.SIGTERM)
+            if alive:
+                time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        deadline = time.time() + 10
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,20 +486,40 @@ def main():
     ap.add_argument("--host-io", action="store_true",
                     help="after the resident measurement (which stays `value`), time the same K steps through "
                          "mp3mi_batch_encode_host_async -- PCM in page-locked host memory, file bytes back to it, both crossing PCIe "
-                         "chunk by chunk beside the kernels -- and add an `end_to_end` object to the line (SURVEY 8(d))")
+                         "chunk by chunk beside the kernels -- and add an `end_to_end` object to the line (SURVEY 8(d)).  On by default "
+                         "for the Layer III line; this flag forces it where --no-cpu-baseline would drop it")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the end_to_end leg")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short runs of configs[3], configs[4] and Layer II that the default line (N = 1, configs[1] at its own "
+                         "size) carries as `other_workloads`")
     ap.add_argument("--no-cpu-baseline", action="store_true",
-                    help="skip the timed CPU baseline (profiling passes); a small oracle parity check remains")
+                    help="profiling pass: skip the timed CPU baseline, the end_to_end leg and the other workloads (only the "
+                         "headline pipeline's kernels are launched); a small oracle parity check remains")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+
+    # `--gpus N` without a launcher around it: this process becomes the launcher of N ranks and never touches the GPU itself
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to report a line whose n_gpus "
+                         "is not what was asked for" % (args.gpus, world))
     distributed = world > 1
+    global torch
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the encoder has no CPU path")
     # (test hook: MP3MI_BENCH_ONE_GPU=1 runs every rank on device 0 over gloo, so that the multi-rank code path -- stream
     # ranges per rank, barriers, max-over-ranks time, parity vote -- can be exercised on a one-GPU box)
     one_gpu = os.environ.get("MP3MI_BENCH_ONE_GPU") == "1"
+    if not one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but this node shows %d device(s): one rank per GPU, no sharing (MP3MI_BENCH_ONE_GPU=1 is the "
+                         "one-GPU rehearsal hook of the tests)" % (world, torch.cuda.device_count()))
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -441,10 +578,11 @@ def main():
 
     # End to end with PCIe (--host-io): the same K steps with the PCM in page-locked host memory and the bytes delivered to it.
     end_to_end = None
-    if args.host_io:
-        h_pcm = wl.pcm.cpu().pin_memory()
-        h_out = torch.empty(wl.out.shape, dtype=torch.uint8).pin_memory()
-        h_len = torch.empty(S, dtype=torch.int32).pin_memory()
+    if args.host_io or not (args.no_host_io or args.no_cpu_baseline):
+        h_pcm = torch.empty(wl.pcm.shape, dtype=torch.int16, pin_memory=True)  # page-locked from the start: no staging copy
+        h_pcm.copy_(wl.pcm)
+        h_out = torch.empty(wl.out.shape, dtype=torch.uint8, pin_memory=True)
+        h_len = torch.empty(S, dtype=torch.int32, pin_memory=True)
         for _ in range(max(args.warmup, 1)):
             wl.batch.encode_host_async(h_pcm, nf, h_out, h_len)
             wl.batch.sync()
@@ -526,10 +664,8 @@ def main():
         avg_launch_s = loop_ms / 1e3 / max(launches, 1)
         achieved = alg * frames_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         lps = launches // max(args.steps, 1)
-        # (a batch of more streams than the kernel holds resident -- 16 wavefronts per CU -- goes through it in parts,
-        # one launch each; MP3MI_LOOP_PARTS=0 selects one launch of the queue form instead)
-        queue = os.environ.get("MP3MI_LOOP_PARTS", "1") == "0" and S > 16 * torch.cuda.get_device_properties(dev).multi_processor_count
-        kname = "k_loop_queue" if queue else "k_loop"
+        # (a batch of more streams than the kernel holds resident -- 16 wavefronts per CU -- goes through it in parts, one launch each)
+        kname = "k_loop"
         # Counter figures cannot be read from inside the timed run: they come from the committed profile that
         # profiles/CURRENT names -- if, and only if, it was taken on the sources this library was built from.
         src_hash = mp3.lib().mp3mi_source_hash().decode()
@@ -579,13 +715,26 @@ def main():
             "parity_spot_check": {"streams_per_rank": len(idx), "bit_exact": parity_ok, "mismatching_streams_rank0": bad,
                                   "witness": "oracle/liboracle.so" + (" + oracle/_ref/encode" if cpu and cpu["kind"] == "reference" else "")},
         }
-        print(json.dumps(result), flush=True)
     wl.close()
+    del wl
+    others_ok = True
+    if rank == 0:
+        # The other workloads, driver-visible (short runs; the headline above is untouched by them: its batch is closed).
+        # Only on the default line: one GPU, configs[1] at its own size.
+        if world == 1 and cfg_id == 1 and default_size and not (args.no_other_workloads or args.no_cpu_baseline):
+            torch.cuda.empty_cache()
+            result["other_workloads"] = other_workloads(mp3, dev)
+            others_ok = all(o["bit_exact"] for o in result["other_workloads"])
+            if not others_ok:
+                result["value"] = None
+        print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     if not parity_ok:
         raise SystemExit("bench.py: PARITY FAILURE -- the GPU bitstream differs from the reference on %d sampled streams" % int(n_bad.item()))
+    if not others_ok:
+        raise SystemExit("bench.py: PARITY FAILURE in other_workloads")
 
 
 if __name__ == "__main__":

@@ -67,24 +67,22 @@ typedef struct mp3mi_batch_options {
     int32_t call_overlap;     /* a call's feed-forward kernels may start beside the loop kernels of the call before: -1 default (on), 0, 1 */
     int32_t gate;             /* the start census that orders the two HIP streams' kernels on the chip: -1 default (on), 0, 1 */
     int32_t placement;        /* streams placed on SIMDs by their cost in the chunk before: -1 default (on for >= 2 streams per SIMD), 0, 1 */
-    int32_t loop_queue;       /* batches larger than the resident wavefronts: 0 default = k_loop in parts (one launch per stream range),
-                                 1 = one launch whose wavefronts take streams in turn */
     int32_t loop_part_streams; /* streams per part (multiple of 64); 0 = the resident wavefronts of the device */
-    int32_t y_after_loop;     /* the filterbank / MDCT / prep kernels of a chunk wait for the loop kernel before it: -1 default (only with loop_queue), 0, 1 */
+    int32_t y_after_loop;     /* the filterbank / MDCT / prep kernels of a chunk wait for the loop kernel before it: -1 default (only for a part larger than the resident wavefronts), 0, 1 */
     int32_t psy_beside;       /* what of the psychoacoustic stage runs beside a loop kernel: -1 default (k_cw + k_part + k_psy beside a
-                                 resident loop kernel, nothing beside the queue form), 0 nothing, 1 k_cw + k_part + k_psy, 2 k_psy only */
-    int32_t dropin_lookahead; /* the drop-in symbols' look-ahead (mp3mi_dropin.h): -1 default = 1 all, 0 none, 2 the filterbank's only,
+                                 resident loop kernel), 0 nothing, 1 k_cw + k_part + k_psy, 2 k_psy only */
+    int32_t dropin_lookahead; /* the drop-in symbols' look-ahead (mp3mi_dropin.h): -1 default = 2 the filterbank's (and mdct_sub behind it: memory of the current frame only), 0 none, 1 all (buffer lifetime requirement: mp3mi_dropin.h),
                                  3 L3psycho_anal's only, 4 all but iteration_loop's / III_format_bitstream's.  Not a property of a batch: the hidden default stream of the drop-in symbols
                                  reads it through mp3mi_batch_options_from_env (MP3MI_DROPIN_LOOKAHEAD) */
     int32_t dropin_stats;     /* the drop-in symbols print, at III_FlushBitstream, the frames they served, the time from the first frame's
                                  first call to the flush and the waits for the device: 0 default, 1 (MP3MI_DROPIN_STATS) */
 } mp3mi_batch_options;
 /* mp3mi_batch_create_ex returns MP3MI_ERR_ARG for a value outside the ranges named above (the three-state fields take
- * -1, 0, 1; psy_beside -1 .. 2; dropin_lookahead -1 .. 4; loop_queue 0, 1; loop_part_streams a multiple of 64; unknown test flags). */
+ * -1, 0, 1; psy_beside -1 .. 2; dropin_lookahead -1 .. 4; loop_part_streams a multiple of 64; unknown test flags). */
 void mp3mi_batch_options_default(mp3mi_batch_options *opt);
 /* The same, then overridden by the MP3MI_* environment variables that tools/ and tests/ use (MP3MI_SCRATCH_MB,
  * MP3MI_CHUNK_FRAMES, MP3MI_{NOISE,PHASE,PSY,QUANT,PREP,CW}_EXACT, MP3MI_CALL_OVERLAP, MP3MI_NO_GATE, MP3MI_NO_PLACE,
- * MP3MI_LOOP_PARTS, MP3MI_LOOP_PART_STREAMS, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE, MP3MI_DROPIN_LOOKAHEAD, MP3MI_DROPIN_STATS).  This is the ONLY place the library
+ * MP3MI_LOOP_PART_STREAMS, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE, MP3MI_DROPIN_LOOKAHEAD, MP3MI_DROPIN_STATS).  This is the ONLY place the library
  * reads its environment: mp3mi_batch_create calls it once; mp3mi_batch_create_ex never does. */
 void mp3mi_batch_options_from_env(mp3mi_batch_options *opt);
 
@@ -129,7 +127,8 @@ int mp3mi_batch_sync(mp3mi_batch *b);
  * mp3mi_batch_stream_status waits for the work issued so far and copies the status of every stream of the most recent
  * streams (since the last reset / whole-file call; after mp3mi_batch_flush: of the streams it ended, until the next
  * encode starts new ones) to status_host[n_streams]: 0, or code | frame << 8 where frame is the
- * index of the frame it happened in (the number of frames for the final flush).  Returns the number of streams with a
+ * index of the frame it happened in (the number of frames for the final flush; the field is 22 bits wide and saturates
+ * at 4194303, ~30 h of audio fed call by call).  Returns the number of streams with a
  * non-zero status, or a negative MP3MI_ERR_*. */
 enum { MP3MI_STREAM_OK = 0, MP3MI_STREAM_ABORT_GLOBAL_GAIN = 1, MP3MI_STREAM_ABORT_HUFF_BITS = 2, MP3MI_STREAM_ABORT_FLUSH_SLOT = 3 };
 int mp3mi_batch_stream_status(mp3mi_batch *b, int32_t *status_host);

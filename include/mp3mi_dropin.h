@@ -153,7 +153,14 @@ void III_format_bitstream(int bitsPerFrame, frame_params *fr_ps, int l3_enc[2][2
 void III_FlushBitstream(void);
 
 /* LOOK-AHEAD.  Served one call at a time, a frame of the reference's loop costs 79 waits for the device.  The library
- * therefore reads ahead -- only in memory the caller has already handed over, or in what it has handed out itself:
+ * therefore reads ahead -- only in memory the caller has already handed over, or in what it has handed out itself.
+ * BY DEFAULT (MP3MI_DROPIN_LOOKAHEAD unset = 2) only in memory handed over during the CURRENT frame: the filterbank's
+ * look-ahead and mdct_sub behind it.  MP3MI_DROPIN_LOOKAHEAD=1 adds L3psycho_anal's look-ahead and the launches ahead of
+ * iteration_loop / III_format_bitstream that feed on it.  BUFFER LIFETIME REQUIREMENT of that mode: the sample buffers
+ * and delay lines given to L3psycho_anal must stay allocated, at the same addresses, from one frame to the next (the
+ * library reads &buffer[ch][576 ..] and the other channel's buffer and savebuf at the addresses it was given in the
+ * frame BEFORE; changed CONTENT is detected and handled, a freed or moved buffer is a read of memory the caller no
+ * longer owns).  The reference's driver satisfies it: its buffers are static arrays (src/musicin.c:475-503).
  *   - L3psycho_anal: when a channel's two calls of the frame BEFORE were given p and p + 576 and the first call of this
  *     frame is given the same p, both granules are analysed at once -- and the other channel's with them when its calls of
  *     the frame before show the same pattern (its buffer and its delay line were handed over then, at the addresses
@@ -170,9 +177,9 @@ void III_FlushBitstream(void);
  * was read; a caller that moves or rewrites its buffers, or changes what it was handed between two calls, gets the
  * call-by-call service, with the library's state (psychoacoustic state, bit reservoir, the formatter's bytes) put back to
  * where the served calls left it: tests/test_dropin.py, oracle/dropin_probe.c, oracle/dropin_probe_frame.c -- bit-exact
- * either way.  Two launches and two waits per frame instead of 79 under the reference's driver (the kernels that end a stage
- * store a flag in host-mapped memory; the host spins on it).  MP3MI_DROPIN_LOOKAHEAD = 0 none, 2 / 3 the filterbank's /
- * L3psycho_anal's only, 4 all but the third family (mp3mi_batch_options_from_env); MP3MI_DROPIN_STATS=1: a line at
+ * either way.  With all of it (mode 1): two launches and two waits per frame instead of 79 under the reference's driver (the kernels that end a stage
+ * store a flag in host-mapped memory; the host spins on it).  MP3MI_DROPIN_LOOKAHEAD = 0 none, 1 all (see the lifetime
+ * requirement above), 2 (default) / 3 the filterbank's / L3psycho_anal's only, 4 all but the third family (mp3mi_batch_options_from_env); MP3MI_DROPIN_STATS=1: a line at
  * III_FlushBitstream.  mp3mi_dropin_waits: stages a call waited for so far (tests, tools). */
 long mp3mi_dropin_waits(void);
 

@@ -64,7 +64,7 @@ struct mp3mi_batch {
     int n_simd;
     mp3mi_batch_options opt; // as given at create time (defaults resolved where a field says "-1 default")
     unsigned *voided;        // device counter: streams whose file a call voided (the reference dies on them), since the last sync
-    int32_t *status_dev;     // [S]: scratch of mp3mi_batch_stream_status
+    int32_t *status_dev;     // [S]: what mp3mi_batch_stream_status copies out; between a flush and the next encode / reset it HOLDS the ended streams' status
     bool status_kept;        // status_dev holds the status of the streams the last flush ended (their state is reset)
     int prep_exact;          // MP3MI_TEST_PREP_EXACT: k_prep over every record, its second tier only, instead of k_mdct's tail (tests)
     int test_flags;          // mp3mi_geom::test_flags
@@ -201,7 +201,6 @@ extern "C" void mp3mi_batch_options_from_env(mp3mi_batch_options *o)
     if ((e = getenv("MP3MI_CALL_OVERLAP"))) o->call_overlap = atoi(e) != 0;
     if (on(getenv("MP3MI_NO_GATE"))) o->gate = 0;
     if (on(getenv("MP3MI_NO_PLACE"))) o->placement = 0;
-    if ((e = getenv("MP3MI_LOOP_PARTS")) && !atoi(e)) o->loop_queue = 1;
     if ((e = getenv("MP3MI_LOOP_PART_STREAMS")) && atoi(e) >= 64) o->loop_part_streams = atoi(e) / 64 * 64;
     if ((e = getenv("MP3MI_Y_AFTER_LOOP"))) o->y_after_loop = atoi(e) != 0;
     if ((e = getenv("MP3MI_PSY_BESIDE"))) o->psy_beside = atoi(e) == 2 ? 2 : (atoi(e) ? 1 : 0);
@@ -266,13 +265,11 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
         CHK(hipStreamCreateWithPriority(&b->lstream, hipStreamDefault, greatest));
     }
     {   // parts: as few as hold the batch with at most mp3mi_loop_resident() streams each, equal in size (a multiple of
-        // 64); options.loop_part_streams overrides (tests); options.loop_queue: one
-        // part whatever the size, k_loop in its queue form
+        // 64); options.loop_part_streams overrides (tests)
         const int resident = mp3mi_loop_resident();
         int np = (n_streams + resident - 1) / resident;
         int ps = ((n_streams + np - 1) / np + 63) / 64 * 64;
         if (opt.loop_part_streams >= 64) ps = opt.loop_part_streams;
-        if (opt.loop_queue) ps = (n_streams + 63) / 64 * 64;
         b->part_streams = ps;
         b->n_parts = (n_streams + ps - 1) / ps;
         b->ev_front.assign(2 * (size_t) b->n_parts, (hipEvent_t) 0);
@@ -391,7 +388,7 @@ extern "C" int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_
         auto tri = [](int v) { return v >= -1 && v <= 1; }; // -1 default, 0 off, 1 on
         if ((opt.test_flags & ~(unsigned) (MP3MI_TEST_ALL_EXACT | MP3MI_TEST_PREP_LIST)) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||
             (opt.loop_part_streams % 64) != 0 || opt.psy_beside < -1 || opt.psy_beside > 2 || opt.dropin_lookahead < -1 || opt.dropin_lookahead > 4 || (opt.dropin_stats != 0 && opt.dropin_stats != 1) || !tri(opt.call_overlap) || !tri(opt.gate) ||
-            !tri(opt.placement) || !tri(opt.y_after_loop) || (opt.loop_queue != 0 && opt.loop_queue != 1))
+            !tri(opt.placement) || !tri(opt.y_after_loop))
             return MP3MI_ERR_ARG;
     }
     // argument errors first: they are the caller's, whatever the machine
@@ -437,9 +434,9 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
         if (e) hipEventDestroy(e);
     for (int k = 0; k < 2; k++)
         for (size_t i = 0; i < b->ts[k].loop_ev.size(); i++) hipEventDestroy(b->ts[k].loop_ev[i]);
-    if (b->hio.ready) {
-        hipStreamSynchronize(b->hio.h2d);
-        hipStreamSynchronize(b->hio.d2h);
+    {   // (whatever of the host-buffer state exists, also after an allocation that failed half-way)
+        if (b->hio.h2d) hipStreamSynchronize(b->hio.h2d);
+        if (b->hio.d2h) hipStreamSynchronize(b->hio.d2h);
         for (int i = 0; i < 2; i++) {
             if (b->hio.pcm[i]) hipFree(b->hio.pcm[i]);
             if (b->hio.out[i]) hipFree(b->hio.out[i]);
@@ -549,6 +546,7 @@ extern "C" int mp3mi_batch_reset(mp3mi_batch *b)
 {
     if (!b) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
+    b->status_kept = false; // an explicit reset starts new streams: what a flush kept of the ones it ended goes with them
     return reset_impl(b);
 }
 
@@ -748,11 +746,10 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         const item_view v = view(k);
         const mp3mi_geom &g = v.g;
         const size_t r = v.rec0;
-        // A part larger than the resident wavefronts (options.loop_queue) runs k_loop in its queue form: every wavefront
-        // takes a fixed share of the streams and stays to the end, so the feed-forward kernels of the next item find no
-        // freed slots beside it, only cycles to take from wavefronts whose share does not shrink (every millisecond of
-        // work beside it cost two to four, measured at 8192 x 383 and 16384 x 278): there stage Y waits for k_loop.
-        bool y_after_loop = mp3mi_loop_waves(g.n_streams) < g.n_streams;
+        // A part larger than the resident wavefronts (options.loop_part_streams, tests only) keeps every SIMD full to its
+        // end, so the feed-forward kernels of the next item find no freed slots beside it, only cycles to take: there
+        // stage Y waits for k_loop.
+        bool y_after_loop = g.n_streams > mp3mi_loop_resident();
         if (b->opt.y_after_loop >= 0) y_after_loop = b->opt.y_after_loop != 0;
         // what of stage X runs beside k_loop (bits as for stage_x): all but the FFTs -- k_cw, k_part, k_psy are small in
         // registers and LDS, the item's FFTs were done before that launch started, and the region k_psy writes was read
@@ -780,7 +777,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipGetLastError());
         if (k + 1 < n_items) {
             const item_view nv = view(k + 1);
-            const bool ny = b->opt.y_after_loop >= 0 ? b->opt.y_after_loop != 0 : mp3mi_loop_waves(nv.g.n_streams) < nv.g.n_streams;
+            const bool ny = b->opt.y_after_loop >= 0 ? b->opt.y_after_loop != 0 : nv.g.n_streams > mp3mi_loop_resident();
             int nbeside = ny ? 0 : 14;
             if (b->opt.psy_beside >= 0) nbeside = b->opt.psy_beside == 2 ? 8 : (b->opt.psy_beside ? 14 : 0);
             if (stage_x(k + 1, 15 & ~nbeside) != MP3MI_OK) return MP3MI_ERR_HIP;
@@ -791,7 +788,7 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipEventRecord(ts.loop_ev[2 * k], b->lstream));
         {
             const int n = g.n_streams;
-            b->gate_total += (unsigned) mp3mi_loop_waves(n);
+            b->gate_total += (unsigned) n; // a wavefront per stream counts itself in
             b->gate_first = b->gate_total; // the census once this launch is resident: the next item's kernels start behind it
             mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
             if (b->place_order) { // rank the part's streams by their cost in the previous chunk, hand the tables to k_loop
@@ -1017,22 +1014,24 @@ static int host_io_harvest(mp3mi_batch *b, int sl)
     return MP3MI_OK;
 }
 
-static int host_io_init(mp3mi_batch *b)
+// The copy streams with the first host-buffer call, a slot's device copies with the first call that uses the slot: a
+// one-shot call (mp3mi_encode_host) pays for one slot, the second exists once two calls are in flight.  What a failed
+// allocation leaves behind is freed by mp3mi_batch_destroy.
+static int host_io_init(mp3mi_batch *b, int sl)
 {
     mp3mi_batch::host_io &H = b->hio;
-    if (H.ready) return MP3MI_OK;
     const size_t S = (size_t) b->n_streams;
-    H.out_stride = mp3mi_batch_out_stride(b, b->max_frames);
-    CHK(hipStreamCreateWithFlags(&H.h2d, hipStreamNonBlocking));
-    CHK(hipStreamCreateWithFlags(&H.d2h, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-        CHK(hipMalloc((void **) &H.pcm[i], S * (size_t) b->max_frames * 1152 * (size_t) b->channels * sizeof(int16_t)));
-        CHK(hipMalloc((void **) &H.out[i], S * H.out_stride));
-        CHK(hipMalloc((void **) &H.len[i], S * sizeof(uint32_t)));
-        CHK(hipEventCreateWithFlags(&H.pcm_free[i], hipEventDisableTiming));
-        CHK(hipEventCreateWithFlags(&H.out_free[i], hipEventDisableTiming));
+    if (!H.ready) {
+        H.out_stride = mp3mi_batch_out_stride(b, b->max_frames);
+        if (!H.h2d) CHK(hipStreamCreateWithFlags(&H.h2d, hipStreamNonBlocking));
+        if (!H.d2h) CHK(hipStreamCreateWithFlags(&H.d2h, hipStreamNonBlocking));
+        H.ready = true;
     }
-    H.ready = true;
+    if (!H.pcm[sl]) CHK(hipMalloc((void **) &H.pcm[sl], S * (size_t) b->max_frames * 1152 * (size_t) b->channels * sizeof(int16_t)));
+    if (!H.out[sl]) CHK(hipMalloc((void **) &H.out[sl], S * H.out_stride));
+    if (!H.len[sl]) CHK(hipMalloc((void **) &H.len[sl], S * sizeof(uint32_t)));
+    if (!H.pcm_free[sl]) CHK(hipEventCreateWithFlags(&H.pcm_free[sl], hipEventDisableTiming));
+    if (!H.out_free[sl]) CHK(hipEventCreateWithFlags(&H.out_free[sl], hipEventDisableTiming));
     return MP3MI_OK;
 }
 
@@ -1042,13 +1041,14 @@ extern "C" int mp3mi_batch_encode_host_async(mp3mi_batch *b, const int16_t *pcm_
     if (!b || !pcm_host || !out_host || !out_len_host || n_frames <= 0 || n_frames > b->max_frames) return MP3MI_ERR_ARG;
     if (out_stride < (size_t) n_frames * (size_t) b->max_frame_bytes + 1) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
-    if (host_io_init(b) != MP3MI_OK) return MP3MI_ERR_HIP;
     mp3mi_batch::host_io &H = b->hio;
     const int sl = (int) (H.call_no & 1);
+    if (host_io_init(b, sl) != MP3MI_OK) return MP3MI_ERR_HIP;
     if (host_io_harvest(b, sl) != MP3MI_OK) return MP3MI_ERR_HIP; // (waits for the call two before this one: at most two in flight)
     const host_call hc = {pcm_host, out_host, out_stride, out_len_host, sl};
-    H.call_no++;
-    return encode_impl(b, H.pcm[sl], NULL, n_frames, H.out[sl], H.out_stride, H.len[sl], true, &hc);
+    const int rc = encode_impl(b, H.pcm[sl], NULL, n_frames, H.out[sl], H.out_stride, H.len[sl], true, &hc);
+    if (rc == MP3MI_OK) H.call_no++; // (a call that failed took no slot)
+    return rc;
 }
 
 extern "C" int mp3mi_batch_host_io_stats(mp3mi_batch *b, mp3mi_host_io_stats *st)

@@ -106,7 +106,7 @@ struct DropIn {
     //     pointer, its 576 samples and the delay line are what was read ahead, otherwise the channel's state is put back
     //     (a device copy taken before the launch) and granule 0 is analysed again alone.
     // MP3MI_DROPIN_LOOKAHEAD=0 turns both off.
-    bool lookahead = true, lookahead_psy = true; // (MP3MI_DROPIN_LOOKAHEAD: 0 none, 1 all, 2 the filterbank's only, 3 L3psycho_anal's only, 4 all but iteration_loop's / III_format_bitstream's)
+    bool lookahead = true, lookahead_psy = false; // (MP3MI_DROPIN_LOOKAHEAD: 0 none, 1 all, 2 the filterbank's only, 3 L3psycho_anal's only, 4 all but iteration_loop's / III_format_bitstream's)
     struct win_ahead {
         bool valid = false;
         const short *p0 = nullptr; // where the channel's slot 0 was read
@@ -145,7 +145,7 @@ struct DropIn {
     // frame length, header bits and channel count of the frame BEFORE -- and iteration_loop hands the result out if its
     // arguments (pe, ratio, block types, spectrum, mean_bits, header) are exactly what was read.  Anything else: the loop's
     // state and the formatter's byte window are put back (copies taken before the launch) and the call is served on its own.
-    bool lookahead_loop = true;
+    bool lookahead_loop = false;
     struct frame_ahead {
         bool loop_pending = false, fmt_pending = false; // launched, not handed out yet
         bool have_last = false;        // the parameters below are a served frame's
@@ -234,7 +234,12 @@ void ensure(int rate_idx)
     {
         mp3mi_batch_options o; // (the one place the library reads its environment: batch.cpp)
         mp3mi_batch_options_from_env(&o);
-        const int v = o.dropin_lookahead < 0 ? 1 : o.dropin_lookahead;
+        // Default 2: the filterbank's look-ahead (with mdct_sub behind it) reads only memory handed over during the CURRENT
+        // frame.  L3psycho_anal's (and with it the loop's and the formatter's launches ahead, which need its records) reads
+        // buffers at the addresses REMEMBERED from the frame before -- fine under the reference's driver, whose buffers are
+        // static arrays, a use-after-free under a caller that allocates or rotates them per frame: opt-in (1), with the
+        // lifetime requirement stated in mp3mi_dropin.h.
+        const int v = o.dropin_lookahead < 0 ? 2 : o.dropin_lookahead;
         D.lookahead = v == 1 || v == 2 || v == 4;
         D.lookahead_psy = v == 1 || v == 3 || v == 4;
         D.lookahead_loop = v == 1;

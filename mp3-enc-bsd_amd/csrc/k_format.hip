@@ -305,7 +305,7 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
         uint32_t len = (uint32_t) (n_frames_s * frame_bytes - rem + 1);
         if (loop_state) {
             int32_t *st = &loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)];
-            if (*st == 0 && fmt_flush_dies(n_frames_s, mend, slot)) *st = MP3MI_DEV_ABORT_FLUSH_SLOT | (int32_t) (n_frames_s << 8);
+            if (*st == 0 && fmt_flush_dies(n_frames_s, mend, slot)) *st = MP3MI_DEV_STATUS(MP3MI_DEV_ABORT_FLUSH_SLOT, n_frames_s);
             if (*st != 0) { // the reference died on this stream: there is no file
                 len = 0;
                 if (voided) atomicAdd(voided, 1u);
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(64) k_stream_tail(mp3mi_geom geo, int flush, i
         for (int i = lane; i < n; i += 64) row[i] = i < have ? cr[i] : (uint8_t) 0;
         if (lane == 0) {
             int32_t *st = &loop_state[(size_t) s * loop_state_words + (loop_state_words - 1)];
-            if (*st == 0 && fmt_flush_dies(n_done, m_end, slot)) *st = MP3MI_DEV_ABORT_FLUSH_SLOT | (int32_t) (n_done << 8);
+            if (*st == 0 && fmt_flush_dies(n_done, m_end, slot)) *st = MP3MI_DEV_STATUS(MP3MI_DEV_ABORT_FLUSH_SLOT, n_done);
             if (*st != 0 && !(*st & MP3MI_DEV_ABORT_REPORTED)) { // (an earlier call of the stream may have reported it already)
                 *st |= MP3MI_DEV_ABORT_REPORTED;
                 if (voided) atomicAdd(voided, 1u);

@@ -69,7 +69,7 @@ struct loop_lds {
 // die for one stream: the first such event is recorded in the stream's state (code | frame index << 8; wave-uniform, so
 // it lives in a scalar register until the state goes back to memory), the search goes on with something harmless, and
 // k_format / k_stream_tail void the stream's output (mp3mi.h, mp3mi_batch_stream_status).
-#define LOOP_REF_ABORT(code, frame) do { if (ref_abort == 0) ref_abort = (code) | (int) ((frame) << 8); } while (0)
+#define LOOP_REF_ABORT(code, frame) do { if (ref_abort == 0) ref_abort = MP3MI_DEV_STATUS(code, frame); } while (0)
 
 // Wavefronts (streams) per workgroup.  They share nothing but the code-length tables in LDS (1.9 KB that every stream
 // would otherwise hold a copy of) and synchronise only per wavefront.
@@ -197,7 +197,11 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
 #pragma unroll
     for (int j = 0; j < 9; j++) {
         const float f = loop_estimate(y34[j], cq);
+#if defined(MP3MI_EMU) // (the device's conversion saturates, and the clamp below then yields 2047; on the host it is undefined from 2^31 on)
+        p[j] = (int) __builtin_fminf(f, 2147483520.0f);
+#else
         p[j] = (int) f; // f >= 0.4054: the conversion truncates = floor
+#endif
         const float d = __builtin_fabsf(LOOP_FRACTF(f) - 0.5f); // f - floor(f), exact
         gmax = __builtin_fmaxf(gmax, __builtin_fmaf(3.5e-6f, f, d));
     }
@@ -332,23 +336,8 @@ MP3MI_DEVFN int loop_pair_cost3(const uint16_t *GL, int da, int db, int x, int y
     return spread + nesc * lb;
 }
 
-// new_choose_table's decision from the candidates' bit sums (src/loop.c:1819-1897): '<=' moves to
-// the later table among tables without linbits, '<' among the linbits pair
-MP3MI_DEVFN int loop_pick(int da, int s0, int s1, int s2, int *sum)
-{
-    const int c0 = da & 31, c1 = (da >> 5) & 31, c2 = (da >> 10) & 31;
-    int choice = c0, best = s0;
-    if (c0 >= 15) { // maximum >= 15: the two candidates were found through linmax
-        if (s1 < s0) { choice = c1; best = s1; }
-    } else {
-        if (c1 && s1 <= best) { choice = c1; best = s1; }
-        if (c2 && s2 <= best) { choice = c2; best = s2; }
-    }
-    *sum = best;
-    return choice;
-}
-
-// The same decision on values that live in ONE LANE of vector registers (the sums as the reduction leaves them): the
+// new_choose_table's decision from the candidates' bit sums (src/loop.c:1819-1897): '<=' moves to the later table among
+// tables without linbits, '<' among the linbits pair -- taken on values that live in ONE LANE of vector registers (the sums as the reduction leaves them): the
 // descriptor is taken into a vector register too, so that every instruction of the decision is a vector one.
 // s01 = candidate 0's sum | candidate 1's << 16.  NC3: some region of the pass has a third candidate.
 template <bool NC3>
@@ -607,11 +596,9 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     loop_region_cost(GL, ixw, lane, a2, e2, m2, da[2], db[2], &s01p[2], &s2p[2]);
     CBPROF(3); // descriptors + region walks
     const bool third = (((da[0] | da[1] | da[2]) >> 10) & 31) != 0; // (descriptors of empty regions are zero)
-    int s2v[3] = {0, 0, 0};
-#if !defined(LOOP_PICK_SCALAR)
     // The sums stay where the reduction leaves them -- lane 63 of a vector register -- and new_choose_table's decision
     // is taken THERE, by vector instructions on values no other lane holds; four lane reads bring back the bit count and
-    // the three tables.  As scalar code (until round 4: LOOP_PICK_SCALAR) the decision cost ~20 scalar instructions per
+    // the three tables.  As scalar code (until round 4) the decision cost ~20 scalar instructions per
     // region, and a scalar instruction costs this kernel more than a vector one.  An empty
     // region's descriptor and sums are zero: table 0, no bits, as src/loop.c:1771-1777 leaves it.
     {
@@ -634,27 +621,6 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
         bits += wave_tail_sum3(best);
 #pragma unroll
         for (int r = 0; r < 3; r++) g.table_select[r] = wave_readlane_i32(choice, 61 + r);
-    }
-    CBPROF(4); // cost reductions + picks
-    return bits;
-#endif
-    if (third) { // five reductions in lock-step
-        int fs[5] = {s01p[0], s01p[1], s01p[2], s2p[0] | (s2p[1] << 16), s2p[2]};
-        wave_reduce_i32<5, 0>(fs);
-        s01p[0] = fs[0]; s01p[1] = fs[1]; s01p[2] = fs[2];
-        s2v[0] = fs[3] & 0xffff; s2v[1] = (fs[3] >> 16) & 0xffff; s2v[2] = fs[4];
-    } else
-        wave_reduce_i32<3, 0>(s01p);
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        if (mx[r] == 0) continue;
-        const int s01 = s01p[r];
-        const int s2 = ((da[r] >> 10) & 31) ? s2v[r] : 0;
-        int best;
-        g.table_select[r] = loop_pick(da[r], s01 & 0xffff, (s01 >> 16) & 0xffff, s2, &best);
-        // bigv_bitcount (src/loop.c:1997-2011) counts region r over the same range (address3 == e2
-        // whenever region 2 is not empty)
-        bits += best;
     }
     CBPROF(4); // cost reductions + picks
     return bits;
@@ -822,17 +788,16 @@ void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st)
 }
 
 // 80 VGPRs: four resident wavefronts per SIMD leave 192 of its 512 registers to the kernels of the next chunk.
-// One stream, start to end, by one wavefront (k_loop below).  round: streams this wavefront has finished before.
-template <bool QUEUE>
+// One stream, start to end, by one wavefront (k_loop below).
 MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geom &geo,
                              const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
                              const mp3mi_loop_prep *__restrict__ prep,
                              const int32_t *__restrict__ bits_per_frame,
                              mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
                              mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
-                             const mp3mi_loop_place &place, loop_lds &L, const uint16_t *GL, int block, int round)
+                             const mp3mi_loop_place &place, loop_lds &L, const uint16_t *GL, int block)
 {
-    const int lane = QUEUE ? wave_lane_here() : wave_lane(); // (nothing derived from the lane index is carried from one stream to the next)
+    const int lane = wave_lane();
     const int s = loop_place_stream(place, geo.n_streams, block), C = geo.channels, G = 2 * geo.nf;
     int work = 0; // cost of this stream in this launch: 4 per quantise+count pass, 5 per distortion-loop iteration
     const int bitsPerFrame = bits_per_frame[s];
@@ -840,7 +805,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
     PROF_DECL;
     // Residency census (batch.cpp, k_gate): every wavefront counts itself in when it starts.  The
     // counter only ever grows; nothing in this kernel waits on it.
-    if (gate_count && lane == 0 && round == 0) atomicAdd(gate_count, 1u);
+    if (gate_count && lane == 0) atomicAdd(gate_count, 1u);
 #if !defined(MP3MI_EMU)
     // this wavefront is on the critical path of the whole batch: let it issue ahead of the
     // feed-forward kernels of the next chunk that run beside it (batch.cpp); adjusted
@@ -1275,9 +1240,9 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
             const unsigned done_all = __builtin_amdgcn_readfirstlane((int) (lane == 0 ? atomicAdd(gate_count + 1, 1u) + 1u : 0u));
             // (frames per wavefront so far against the average over the wavefronts of the launch: a wavefront on its
             // second stream has that stream's frames on top of the first one's)
-            int n_act = (QUEUE && geo.n_streams > (int) gridDim.x * LOOP_W) ? (int) gridDim.x * LOOP_W : geo.n_streams;
+            int n_act = geo.n_streams;
             asm volatile("" : "+s"(n_act)); // converted here, once per frame, instead of living in a register for the whole kernel
-            const float lead = (float) ((QUEUE ? round * geo.nf : 0) + fl + 1) - (float) done_all / (float) n_act;
+            const float lead = (float) (fl + 1) - (float) done_all / (float) n_act;
             if (lead < -1.0f) __builtin_amdgcn_s_setprio(3);
             else if (lead < 0.0f) __builtin_amdgcn_s_setprio(2);
             else if (lead < 1.0f) __builtin_amdgcn_s_setprio(1);
@@ -1319,21 +1284,7 @@ __global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP
 {
     LOOP_KERNEL_PROLOGUE;
     const int block = (int) blockIdx.x * LOOP_W + wv;
-    if (block < geo.n_streams) loop_stream<false>(T, geo, xr_all, psy, prep, bits_per_frame, state, ix_out, side_out, gate_count, place, L, GL, block, 0);
-}
-
-// More streams than wavefronts that are resident together (mp3mi_launch_loop): the grid is the resident wavefronts
-// and one that has finished its stream takes another until none is left, so that every SIMD stays four deep to the
-// end -- the hardware would otherwise start a fifth workgroup per CU first (5120 streams) and run the rest at three per
-// SIMD.  A kernel of its own because the stream loop costs registers, and with more than 80 the feed-forward kernels
-// of the next chunk no longer fit beside four resident wavefronts: the one-stream case keeps its 80.
-__global__ void __attribute__((amdgpu_num_vgpr(72))) __launch_bounds__(64 * LOOP_W) k_loop_queue(LOOP_KERNEL_ARGS)
-{
-    LOOP_KERNEL_PROLOGUE;
-    for (int block = (int) blockIdx.x * LOOP_W + wv, round = 0; block < geo.n_streams; block += (int) gridDim.x * LOOP_W, round++) {
-        loop_stream<true>(T, geo, xr_all, psy, prep, bits_per_frame, state, ix_out, side_out, gate_count, place, L, GL, block, round);
-        wave_sync();
-    }
+    if (block < geo.n_streams) loop_stream(T, geo, xr_all, psy, prep, bits_per_frame, state, ix_out, side_out, gate_count, place, L, GL, block);
 }
 
 #if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
@@ -1377,24 +1328,16 @@ static int loop_wg_cap(void) { return mp3mi_current_cu_count() * 4; }
 // streams one launch of k_loop holds resident, a wavefront each
 int mp3mi_loop_resident(void) { return loop_wg_cap() * LOOP_W; }
 
-// wavefronts of a launch over n_streams streams = what the start census (gate_count[0]) grows by
-int mp3mi_loop_waves(int n_streams)
-{
-    const int cap = loop_wg_cap() * LOOP_W;
-    return n_streams < cap ? n_streams : cap;
-}
-
+// A wavefront per stream.  batch.cpp cuts a batch into parts of at most mp3mi_loop_resident() streams, so that a launch is
+// resident at once; a larger launch (options.loop_part_streams, tests) is valid all the same: the hardware starts the
+// workgroups beyond the resident ones as others end.
 void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double *xr, const mp3mi_psy_out *psy,
                        const mp3mi_loop_prep *prep, const int32_t *bits_per_frame, void *loop_state, int16_t *ix,
                        mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place, hipStream_t st)
 {
-    const int want = (g.n_streams + LOOP_W - 1) / LOOP_W, wg_cap = loop_wg_cap();
-    if (want <= wg_cap)
-        hipLaunchKernelGGL(k_loop, dim3((unsigned) want), dim3(64 * LOOP_W), 0, st, T, g, xr, psy, prep, bits_per_frame,
-                           (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
-    else
-        hipLaunchKernelGGL(k_loop_queue, dim3((unsigned) wg_cap), dim3(64 * LOOP_W), 0, st, T, g, xr, psy, prep, bits_per_frame,
-                           (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
+    const int want = (g.n_streams + LOOP_W - 1) / LOOP_W;
+    hipLaunchKernelGGL(k_loop, dim3((unsigned) want), dim3(64 * LOOP_W), 0, st, T, g, xr, psy, prep, bits_per_frame,
+                       (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
 }
 
 // Holds the front stream back until the k_loop launch whose census target is `target` has (all but

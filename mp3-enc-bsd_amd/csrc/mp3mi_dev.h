@@ -71,6 +71,10 @@ static inline int mp3mi_fft_swz_rt(int p)
 #define MP3MI_DEV_ABORT_HUFF_BITS 2   /* assert( max_bits >= 0 ), src/loop.c:579 */
 #define MP3MI_DEV_ABORT_FLUSH_SLOT 3  /* assert( l ), src/formatBitstream.c:390, from BF_FlushBitstream's remainder call */
 #define MP3MI_DEV_ABORT_REPORTED 0x40000000 /* set in the status word once a streaming call has counted the stream in `voided` (k_format.hip) */
+/* the status word: the frame field is 22 bits wide and SATURATES (a stream fed call by call passes frame 2^22 after ~30 h of
+ * audio), so that it never reaches the flag above or the sign */
+#define MP3MI_DEV_STATUS_FRAME_MAX 0x3fffff
+#define MP3MI_DEV_STATUS(code, frame) ((int32_t) (code) | (int32_t) (((frame) < MP3MI_DEV_STATUS_FRAME_MAX ? (frame) : MP3MI_DEV_STATUS_FRAME_MAX) << 8))
 
 /* Data movement the reference's FFT ends with; folded into the read-out tables fft_rd_* (tables_host.cpp) */
 enum {

@@ -114,7 +114,6 @@ void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double 
                        void *loop_state, int16_t *ix, mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place,
                        hipStream_t st);
 /* bounded wait (one wavefront) until k_loop's start census reaches `target` -- see k_loop.hip */
-int mp3mi_loop_waves(int n_streams);
 int mp3mi_loop_resident(void);
 void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_ticks, hipStream_t st);
 /* streaming plumbing around k_format (k_format.hip): the bytes of a stream that are not final yet -- the unfilled

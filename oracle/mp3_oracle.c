@@ -121,6 +121,8 @@ struct mp3o_stream {
     size_t out_bits, out_cap;
     int closed;
     size_t out_len;
+    fft_seam_t *fft_seam; /* where psy_granule leaves the transforms' outputs of its next call (NULL: nowhere) */
+    long fft_seam_left;   /* records the buffer still takes */
 };
 
 /* ------------------------------------------------------------------------- */
@@ -466,6 +468,14 @@ static void psy_granule(mp3o_stream *s, const short *buffer, int chn, double rat
 
     for (j = 0; j < 1024; j++) wsamp[j] = T->window[j] * savebuf[j];
     fft_energy_phase(T, wsamp, energy, phi, 1024);
+    if (s->fft_seam) { /* (fft_seam.h; wsamp holds the spectrum: re at [i], im at [N - i]) */
+        memcpy(s->fft_seam->energy_l, energy, sizeof(s->fft_seam->energy_l));
+        for (j = 0; j < 6; j++) {
+            s->fft_seam->phi_l[j] = phi[j];
+            s->fft_seam->re_l[j] = wsamp[j];
+            s->fft_seam->im_l[j] = j ? wsamp[1024 - j] : 0.0f;
+        }
+    }
 
     for (j = 0; j < 6; j++) { /* :496-512 */
         double r_prime = 2.0 * s->r[chn][old][j] - s->r[chn][oldest][j];
@@ -483,6 +493,18 @@ static void psy_granule(mp3o_stream *s, const short *buffer, int chn, double rat
     for (sblock = 0; sblock < 3; sblock++) { /* :518-527 */
         for (j = 0, k = 128 * (2 + sblock); j < 256; j++, k++) wsamp[j] = T->window_s[j] * savebuf[k];
         fft_energy_phase(T, wsamp, energy_s[sblock], phi_s[sblock], 256);
+        if (s->fft_seam) {
+            memcpy(s->fft_seam->energy_s[sblock], energy_s[sblock], sizeof(s->fft_seam->energy_s[sblock]));
+            for (j = 0; j < 50; j++) {
+                s->fft_seam->phi_s[sblock][j] = phi_s[sblock][2 + j];
+                s->fft_seam->re_s[sblock][j] = wsamp[2 + j];
+                s->fft_seam->im_s[sblock][j] = wsamp[256 - 2 - j];
+            }
+        }
+    }
+    if (s->fft_seam) { /* the next call's record follows this one: call order = [frame][gr][ch] */
+        if (--s->fft_seam_left > 0) s->fft_seam++;
+        else s->fft_seam = NULL;
     }
     for (j = 6; j < 206; j += 4) { /* :531-549 */
         double r_prime, phi_prime, r2, phi2, t1, t2, t3;
@@ -1852,6 +1874,39 @@ size_t mp3o_encode_pcm_ex(int rate_hz, int kbps, int channels, const char *mode,
     memcpy(*out, p, len);
     mp3o_close(s);
     return len;
+}
+
+/* The whole stream again, for the FFT seam only (fft_seam.h): seams[] receives one record per L3psycho_anal call of the
+ * first max_frames frames, in call order ([frame][gr][ch]).  Returns the number of records written. */
+long mp3o_encode_pcm_fft_seam(int rate_hz, int kbps, int channels, const int16_t *pcm, size_t n_total, fft_seam_t *seams, int max_frames)
+{
+    mp3o_stream *s = mp3o_open(rate_hz, kbps, channels);
+    size_t per_frame = (size_t) 1152 * (size_t) channels, pos = 0;
+    int16_t buf[2][1152];
+    int frame = 0, j;
+    const long want = (long) max_frames * 2 * channels;
+    if (!s || !seams || max_frames <= 0) { mp3o_close(s); return 0; }
+    s->fft_seam = seams;
+    s->fft_seam_left = want;
+    while (pos < n_total && frame < max_frames && !s->ref_abort) {
+        size_t n = n_total - pos < per_frame ? n_total - pos : per_frame;
+        memset(buf, 0, sizeof(buf));
+        for (j = 0; j < 1152; j++) {
+            if (channels == 2) {
+                buf[0][j] = ((size_t) (2 * j) < n) ? pcm[pos + 2 * j] : 0;
+                buf[1][j] = ((size_t) (2 * j + 1) < n) ? pcm[pos + 2 * j + 1] : 0;
+            } else
+                buf[0][j] = ((size_t) j < n) ? pcm[pos + j] : 0;
+        }
+        pos += n;
+        mp3o_encode_frame(s, (const int16_t (*)[1152]) buf, NULL);
+        frame++;
+    }
+    {
+        const long left = s->fft_seam ? s->fft_seam_left : 0;
+        mp3o_close(s);
+        return want - left;
+    }
 }
 
 /* Layers I and II: the same translation unit, because they share the window, the FFT, the

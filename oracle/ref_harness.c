@@ -7,6 +7,7 @@
  * pinned stage by stage against the real reference.
  *
  * usage: ref_harness in.wav out.mp3 <rate_hz> <kbps> <s|m|d>[e][c][o] [dump.bin]
+ *        ref_harness_fft (the same source with -DFFT_SEAM): ... [dump.bin] [fft_seam.bin]
  *        (the mode letter as the driver's -m; e / c / o = its -e, -c, -o options, src/musicin.c:263-275)
  *
  * Only compiled when /root/reference exists (this container); nothing here
@@ -23,6 +24,38 @@
 #include "loop.h"
 #include "l3bitstream.h"
 #include "stage_dump.h"
+#ifdef FFT_SEAM
+/* The direct FFT seam (oracle/fft_seam.h): the reference's own fft() -- an external-linkage function of src/subs.c that
+ * the unmodified l3psy.o calls -- is intercepted at link time (-Wl,--wrap=fft) and what it returns is copied.  A call of
+ * L3psycho_anal makes four: the long transform, then the three short ones (src/l3psy.c:494, 527). */
+#include "fft_seam.h"
+static fft_seam_t fft_rec;
+static int fft_calls;
+void __real_fft(float x_real[], float x_imag[], float energy[], float phi[], int N);
+void __wrap_fft(float x_real[], float x_imag[], float energy[], float phi[], int N)
+{
+    int i;
+    __real_fft(x_real, x_imag, energy, phi, N);
+    if (N == 1024) {
+        memcpy(fft_rec.energy_l, energy, sizeof(fft_rec.energy_l));
+        for (i = 0; i < 6; i++) {
+            fft_rec.phi_l[i] = phi[i];
+            fft_rec.re_l[i] = x_real[i];
+            fft_rec.im_l[i] = i ? x_real[N - i] : 0.0f;
+        }
+        fft_calls = 1;
+    } else {
+        int w = fft_calls++ - 1;
+        if (w < 0 || w > 2) { fprintf(stderr, "ref_harness: unexpected fft call order\n"); exit(3); }
+        memcpy(fft_rec.energy_s[w], energy, sizeof(fft_rec.energy_s[w]));
+        for (i = 0; i < 50; i++) {
+            fft_rec.phi_s[w][i] = phi[2 + i];
+            fft_rec.re_s[w][i] = x_real[2 + i];
+            fft_rec.im_s[w][i] = x_real[N - 2 - i];
+        }
+    }
+}
+#endif
 
 /* globals the reference objects expect from its driver (src/musicin.c:148-156) */
 FILE *musicin;
@@ -53,6 +86,9 @@ int main(int argc, char **argv)
     frame_params fr_ps;
     layer info;
     FILE *dump = NULL;
+#ifdef FFT_SEAM
+    FILE *fft_dump = NULL;
+#endif
     struct stat sb;
     unsigned long num_samples;
     int stereo, whole_SpF, gr, ch, j, i, k, kbps;
@@ -79,6 +115,9 @@ int main(int argc, char **argv)
     info.bitrate_index = BitrateIndex(3, kbps, info.version);
     if (info.sampling_frequency < 0 || info.bitrate_index < 0 || info.version != 1) return 2;
     if (argc > 6) dump = fopen(argv[6], "wb");
+#ifdef FFT_SEAM
+    if (argc > 7) fft_dump = fopen(argv[7], "wb"); /* [dump.bin] [fft_seam.bin] */
+#endif
 
     musicin = fopen(argv[1], "rb");
     if (!musicin) { perror(argv[1]); return 1; }
@@ -111,6 +150,13 @@ int main(int argc, char **argv)
                               &ratio.l[gr][ch][0], &ratio.s[gr][ch][0], &pe[gr][ch],
                               &l3_side.gr[gr].ch[ch].tt);
                 d.psy_block_type[gr][ch] = l3_side.gr[gr].ch[ch].tt.block_type;
+#ifdef FFT_SEAM
+                if (fft_dump) {
+                    if (fft_calls != 4) { fprintf(stderr, "ref_harness: %d fft calls in one L3psycho_anal\n", fft_calls); return 3; }
+                    fwrite(&fft_rec, sizeof(fft_rec), 1, fft_dump);
+                }
+                fft_calls = 0;
+#endif
             }
         memcpy(d.pe, pe, sizeof(pe));
         memcpy(d.ratio_l, ratio.l, sizeof(ratio.l));
@@ -168,6 +214,9 @@ int main(int argc, char **argv)
     III_FlushBitstream();
     close_bit_stream_w(&bs);
     if (dump) fclose(dump);
+#ifdef FFT_SEAM
+    if (fft_dump) fclose(fft_dump);
+#endif
     fclose(musicin);
     return 0;
 }

@@ -6,6 +6,8 @@ import pytest
 
 import hashlib
 
+import abort_cases
+
 from golden_util import aborting_cases, case_pcm, case_stages, encoding_cases, manifest
 from mp3common import pad_frames
 from stage_check import compare_stages, run_batch_with_stages
@@ -58,81 +60,15 @@ def test_emulated_kernels_report_where_the_reference_dies(emu, case):
 
 
 def test_an_aborting_stream_leaves_its_neighbours_alone(emu, oracle):
-    """one stream of a batch is an input the reference dies on: its file is voided, the other streams' bytes are the
-    oracle's, and the status survives until the next reset"""
-    from mp3common import BatchRun
-    case = [c for c in aborting_cases() if c["name"] == "abort_global_gain"][0]
-    bad, nf = pad_frames(case_pcm(case, emu.synth), 2)
-    good = emu.synth(nf * 1152, 2, 44100, 77)
-    run = BatchRun(emu, 3, 44100, 2, 128, nf, pcm=np.stack([good, bad, good]))
-    try:
-        out, lens = run.encode(expect_abort=True)
-        ref = oracle.encode(good, 44100, 128, 2)[0]
-        assert lens[1] == 0 and out[0, :lens[0]].tobytes() == ref and out[2, :lens[2]].tobytes() == ref
-        st = run.status()
-        assert st[0] == 0 and st[2] == 0 and st[1] & 255 == 1
-        assert emu.lib.mp3mi_batch_sync(run.b) == 0  # reported once
-    finally:
-        run.close()
+    abort_cases.neighbours_case(emu, oracle)
 
 
 def test_host_wrapper_delivers_the_neighbours_of_an_aborting_stream(emu, oracle):
-    """mp3mi_encode_host with an input the reference dies on between two good ones: the call returns
-    MP3MI_ERR_REFERENCE_ABORT AND the outputs -- that stream's out_len 0, the others' bytes the oracle's (mp3mi.h)"""
-    from mp3common import ERR_REFERENCE_ABORT
-    case = [c for c in aborting_cases() if c["name"] == "abort_global_gain"][0]
-    bad, nf = pad_frames(case_pcm(case, emu.synth), 2)
-    good = emu.synth(nf * 1152, 2, 44100, 78)
-    pcm = np.ascontiguousarray(np.stack([good, bad, good]), dtype=np.int16)
-    stride = (nf * 418 + 1 + 255) // 256 * 256
-    out = np.full((3, stride), 0xAA, np.uint8)
-    lens = np.full(3, 0xDEADBEEF, np.uint32)
-    rc = emu.lib.mp3mi_encode_host(3, 44100, 2, None, 128, pcm.ctypes.data, nf, out.ctypes.data, stride, lens.ctypes.data)
-    assert rc == ERR_REFERENCE_ABORT
-    ref = oracle.encode(good, 44100, 128, 2)[0]
-    assert lens[1] == 0 and out[0, :lens[0]].tobytes() == ref and out[2, :lens[2]].tobytes() == ref
+    abort_cases.host_wrapper_case(emu, oracle)
 
 
 def test_a_streaming_call_reports_the_abort_when_it_happens(emu, oracle):
-    """streaming: the sync after the call in which a stream dies returns MP3MI_ERR_REFERENCE_ABORT -- once -- while the
-    status says which frame; later calls and the flush deliver nothing for it and do not report it again; the status is
-    still readable after the flush"""
-    from mp3common import BatchRun, ERR_REFERENCE_ABORT
-    case = [c for c in aborting_cases() if c["name"] == "abort_global_gain"][0]
-    bad, nf = pad_frames(case_pcm(case, emu.synth), 2)
-    good = emu.synth(nf * 1152, 2, 44100, 79)
-    run = BatchRun(emu, 2, 44100, 2, 128, nf, pcm=np.stack([good, bad]))
-    L = emu.lib
-    try:
-        whole = np.stack([good, bad])
-        got, seen, f0 = b"", [], 0
-        frame = case["reference_aborts"]["frame"]
-        for nfp in (2, frame - 2 + 1, nf - frame - 1):  # the second call holds the fatal frame
-            piece = np.ascontiguousarray(whole[:, f0 * 2304:(f0 + nfp) * 2304])
-            d_piece = run.mem.alloc(piece.nbytes)
-            run.mem.upload(d_piece, piece)
-            assert L.mp3mi_batch_encode_next(run.b, d_piece, nfp, run.d_out, run.stride, run.d_len) == 0
-            seen.append(L.mp3mi_batch_sync(run.b))
-            st = run.status()
-            lens = run.mem.download(run.d_len, (2,), np.uint32)
-            out = run.mem.download(run.d_out, (2, run.stride), np.uint8)
-            got += out[0, :lens[0]].tobytes()
-            if seen[-1] == ERR_REFERENCE_ABORT:
-                assert (st[1] & 255, st[1] >> 8) == (1, frame) and st[0] == 0
-            if len(seen) >= 2:
-                assert lens[1] == 0
-            f0 += nfp
-        assert seen == [0, ERR_REFERENCE_ABORT, 0], seen
-        assert L.mp3mi_batch_flush(run.b, run.d_out, run.stride, run.d_len) == 0
-        assert L.mp3mi_batch_sync(run.b) == 0  # (reported already)
-        lens = run.mem.download(run.d_len, (2,), np.uint32)
-        out = run.mem.download(run.d_out, (2, run.stride), np.uint8)
-        got += out[0, :lens[0]].tobytes()
-        assert lens[1] == 0 and got == oracle.encode(good, 44100, 128, 2)[0]
-        st = run.status()  # the flush reset the streams, their status is kept until the next encode
-        assert (st[1] & 255, st[1] >> 8) == (1, frame) and st[0] == 0
-    finally:
-        run.close()
+    abort_cases.streaming_case(emu, oracle)
 
 
 def test_options_out_of_range_are_refused(emu):
@@ -140,7 +76,7 @@ def test_options_out_of_range_are_refused(emu):
     from mp3common import BatchOptions
     L = emu.lib
     for field, bad in (("gate", 2), ("gate", -2), ("placement", 5), ("call_overlap", -3), ("y_after_loop", 2), ("psy_beside", -2),
-                       ("psy_beside", 3), ("loop_queue", 2), ("loop_queue", -1)):
+                       ("psy_beside", 3), ("loop_part_streams", 100), ("loop_part_streams", -64)):
         o = BatchOptions()
         L.mp3mi_batch_options_default(ctypes.byref(o))
         setattr(o, field, bad)

@@ -92,18 +92,21 @@ def test_schedule_between_the_tuned_sizes(product, oracle):
 
 @pytest.mark.parametrize("layer", [3, 2])
 def test_two_ranks_share_the_gpu(layer):
-    """bench.py's N > 1 path rehearsed on the one-GPU box: two ranks (gloo for the barrier and the max-over-ranks time,
-    both on device 0: MP3MI_BENCH_ONE_GPU=1) each encode their own stream range and check it against the oracle; the
-    line says bit_exact and names two disjoint ranges with different bytes.  A child process: this one is not replaced."""
+    """bench.py's N > 1 path rehearsed on the one-GPU box, as the driver would start it: plain `python bench.py --gpus 2`.
+    bench.py itself starts the two ranks (gloo for the barrier and the max-over-ranks time, both on device 0:
+    MP3MI_BENCH_ONE_GPU=1); each encodes its own stream range and checks it against the oracle; the line says n_gpus 2,
+    bit_exact, and names two disjoint ranges with different bytes.  A child process: this one is not replaced."""
     import json
     import sys
-    env = dict(os.environ, MP3MI_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29517 + layer), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    env = dict(os.environ, MP3MI_BENCH_ONE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--streams", "1024", "--frames", "48", "--layer", str(layer)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's), relayed by the launcher"
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["parity_spot_check"]["bit_exact"] and d["value"] > 0
     ranks = sorted(d["ranks"], key=lambda x: x["rank"])
     assert [x["rank"] for x in ranks] == [0, 1]
@@ -113,3 +116,25 @@ def test_two_ranks_share_the_gpu(layer):
     # names the bound the kernel runs against beside its HBM figure
     assert d["cpu_baseline"] is not None and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     assert d["roofline"]["bound"] == "valu-issue" and d["roofline"]["unit"] == "GB/s" and 0 < d["roofline"]["frac"] < 1
+    if layer == 3:  # the PCIe leg is part of the Layer III line at every N
+        e = d["end_to_end"]
+        assert e is not None and e["bytes_equal_resident_path"] and e["frames_per_s"] > 0
+
+
+def test_under_an_external_launcher_the_flag_must_match():
+    """`--gpus` is what the line will say; a launcher that started another number of ranks is refused (before any GPU work),
+    and so is asking for more ranks than the node has devices."""
+    import sys
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MP3MI_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--streams", "64", "--frames", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one rank per GPU" in r.stderr and not r.stdout.strip()

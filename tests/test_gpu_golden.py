@@ -9,6 +9,7 @@ import hashlib
 
 import pytest
 
+import abort_cases
 from golden_util import aborting_cases, case_pcm, case_stages, encoding_cases
 from mp3common import pad_frames
 from stage_check import compare_stages, run_batch_with_stages
@@ -42,3 +43,19 @@ def test_gpu_reports_where_the_reference_dies(product, case):
     assert got[0] == b""
     assert st["status"][0] & 255 == case["reference_aborts"]["status"]
     assert st["status"][0] >> 8 == case["reference_aborts"]["frame"]
+
+
+def test_gpu_an_aborting_stream_leaves_its_neighbours_alone(product, oracle):
+    abort_cases.neighbours_case(product, oracle)
+
+
+def test_gpu_host_wrapper_delivers_the_neighbours_of_an_aborting_stream(product, oracle):
+    """mp3mi_encode_host (the host-buffer path: PCM up and bytes down beside the kernels) with a dying stream between two
+    good ones: MP3MI_ERR_REFERENCE_ABORT AND the neighbours' files (csrc/batch.cpp, encode_host_impl)"""
+    abort_cases.host_wrapper_case(product, oracle)
+
+
+def test_gpu_a_streaming_call_reports_the_abort_when_it_happens(product, oracle):
+    """k_stream_tail's bookkeeping on the device: the abort is reported by the sync after the call in which it happened,
+    once; later calls and the flush deliver nothing for the stream; the status survives the flush (csrc/k_format.hip)"""
+    abort_cases.streaming_case(product, oracle)

@@ -65,3 +65,27 @@ def test_shard_ranges_cover_everything():
         r = [shard(n, k, w) for k in range(w)]
         assert r[0][0] == 0 and r[-1][1] == n
         assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+
+
+def _bench(args, **envkw):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(envkw)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_launches_its_own_ranks_and_fails_with_them():
+    """`python bench.py --gpus 2` starts two ranks itself (RANK / WORLD_SIZE / MASTER_* per child).  Without a GPU every
+    rank refuses to run (the encoder has no CPU path), and the launcher -- which makes no GPU call of its own -- must come
+    back non-zero with nothing on standard output, not hang at a barrier."""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--streams", "64", "--frames", "2"])
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert r.stderr.count("bench.py needs a GPU") == 2 if not torch.cuda.is_available() else True
+
+
+def test_bench_refuses_a_world_size_other_than_the_flag():
+    r = _bench(["--gpus", "4"], RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+    r = _bench(["--gpus", "1"], RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
