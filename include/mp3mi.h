@@ -236,7 +236,10 @@ int mp3mi_encode_host_ex(int n_streams, int rate_hz, int channels, const int *kb
  * 1 = xr (f64[576] per granule-channel), 2 = quantised values (int16[576]), 3 = side info
  * (mp3mi_frame_side per frame), 4 = raw subband samples (f64[576], enabled by
  * mp3mi_batch_debug_enable), 5 = the loop's stateless head (csrc/mp3mi_dev.h: mp3mi_loop_prep, 472 bytes per
- * granule-channel).  Returns the number of bytes written, or a negative error. */
+ * granule-channel); the psychoacoustic transforms' outputs (src/subs.c:38-123): 6 = long energies (f32, rows of 544
+ * per granule-channel: lines 0..512, the rest padding), 7 = short energies (f32[3][129]), 8 = raw lines (f32[312]:
+ * (re, im) of short lines 2..51 of the three windows, then re[6], im[6] of long lines 0..5).  Returns the number of
+ * bytes written, or a negative error. */
 long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst, size_t cap);
 void mp3mi_batch_debug_enable(mp3mi_batch *b, int on);
 

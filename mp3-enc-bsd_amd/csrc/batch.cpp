@@ -980,6 +980,10 @@ extern "C" long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst
     case 3: src = b->side; n = (size_t) b->n_streams * (size_t) b->last_nf * sizeof(mp3mi_frame_side); break;
     case 4: src = b->sb_dbg; n = ngc * 576 * sizeof(double); break;
     case 5: src = b->prep[b->last_slot]; n = ngc * sizeof(mp3mi_loop_prep); break;
+    // the transforms' outputs as k_fft hands them to k_cw / k_part / k_psy (the direct FFT seam: oracle/fft_seam.h)
+    case 6: src = b->energy_l; n = ngc * MP3MI_HBLK_P * sizeof(float); break;
+    case 7: src = b->energy_s; n = ngc * 3 * MP3MI_HBLK_S * sizeof(float); break;
+    case 8: src = b->fft_bins; n = ngc * MP3MI_FFT_BINS * sizeof(float); break;
     default: return MP3MI_ERR_ARG;
     }
     if (!src || n > cap) return MP3MI_ERR_ARG;

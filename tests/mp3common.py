@@ -28,6 +28,10 @@ GI = {n: i for i, n in enumerate([
     "subblock_gain1", "subblock_gain2", "region0_count", "region1_count", "preflag", "scalefac_scale",
     "count1table_select", "part2_length"])}
 
+# oracle/fft_seam.h: one record per L3psycho_anal call, in call order [frame][gr][ch]
+FFT_SEAM_DT = np.dtype([("energy_l", "<f4", (513,)), ("phi_l", "<f4", (6,)), ("re_l", "<f4", (6,)), ("im_l", "<f4", (6,)),
+                        ("energy_s", "<f4", (3, 129)), ("phi_s", "<f4", (3, 50)), ("re_s", "<f4", (3, 50)), ("im_s", "<f4", (3, 50))])
+
 # mp3-enc-bsd_amd/csrc/mp3mi_dev.h
 PSY_DT = np.dtype([("pe", "<f8"), ("ratio_l", "<f8", (21,)), ("ratio_s", "<f8", (12, 3)), ("block_type", "<i4"), ("pad", "<i4")])
 PREP_DT = np.dtype([("xmin", "<f8", (36,)), ("sc_en", "<i4", (21,)), ("sc_xm", "<i4", (21,)), ("sc_en_tot", "<i4"), ("sc_xrmax", "<i4"),
@@ -66,8 +70,21 @@ class Oracle:
         self.lib.mp3o_encode_pcm_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p,
                                                 ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_int)]
+        self.lib.mp3o_encode_pcm_fft_seam.restype = ctypes.c_long
+        self.lib.mp3o_encode_pcm_fft_seam.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                      ctypes.c_void_p, ctypes.c_int]
         self.libc = ctypes.CDLL("libc.so.6")
         self.libc.free.argtypes = [ctypes.c_void_p]
+
+    def fft_seam(self, pcm, rate, kbps, channels, frames):
+        """the transforms' outputs of every L3psycho_anal call of the first `frames` frames (oracle/fft_seam.h):
+        records [frames][2][channels] of FFT_SEAM_DT"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        assert FFT_SEAM_DT.itemsize == 4 * (513 + 18 + 3 * 129 + 9 * 50)
+        seam = np.zeros((frames, 2, channels), dtype=FFT_SEAM_DT)
+        n = self.lib.mp3o_encode_pcm_fft_seam(rate, kbps, channels, pcm.ctypes.data, pcm.size, seam.ctypes.data, frames)
+        assert n == frames * 2 * channels, (n, frames)
+        return seam
 
     def encode(self, pcm, rate, kbps, channels, dumps=0, mode=None):
         """pcm: int16 array, interleaved; mode: None or the driver's -m letter (s / d / m) followed by e / c / o for

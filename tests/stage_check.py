@@ -64,7 +64,11 @@ def run_batch_with_stages(lib, pcm, rate, channels, kbps, n_frames, mode=None, e
         st["side"] = np.zeros((S, n_frames), SIDE_DT)
         st["sb"] = np.zeros((S, G, channels, 18, 32))
         st["prep"] = np.zeros((S, G, channels), PREP_DT)
-        for what, key in ((0, "psy"), (1, "xr"), (2, "ix"), (3, "side"), (4, "sb"), (5, "prep")):
+        # the psychoacoustic transforms' outputs (oracle/fft_seam.h): long energies in rows of 544, short energies, raw lines
+        st["energy_l"] = np.zeros((S, G, channels, 544), np.float32)
+        st["energy_s"] = np.zeros((S, G, channels, 3, 129), np.float32)
+        st["fft_bins"] = np.zeros((S, G, channels, 312), np.float32)
+        for what, key in ((0, "psy"), (1, "xr"), (2, "ix"), (3, "side"), (4, "sb"), (5, "prep"), (6, "energy_l"), (7, "energy_s"), (8, "fft_bins")):
             n = L.mp3mi_batch_debug_fetch(b, what, st[key].ctypes.data, st[key].nbytes)
             assert n == st[key].nbytes, (key, n, st[key].nbytes)
         st["status"] = np.zeros(S, np.int32)
@@ -134,3 +138,34 @@ def compare_prep_records(a, b, psy):
         bad = np.argwhere((a[name] != b[name]) & ~short[..., None])
         assert bad.size == 0, (name, bad[:4])
     return int(a.size)
+
+
+def compare_fft_seam(st, s, seam, channels, frames=None):
+    """seam[k] (FFT_SEAM_DT records [gr][ch], oracle/fft_seam.h) is the reference's / the oracle's record of frame
+    frames[k] (default: k): what fft() / enphinew() returned to L3psycho_anal (src/subs.c:38-123).  Compared bit for
+    bit with what k_fft handed on: the 513 long and 3 x 129 short energies (floor applied, src/subs.c:70-74) and the raw
+    lines the unpredictability is computed from (long 0..5, short 2..51: src/l3psy.c:496-549).  Returns mismatches."""
+    bad = []
+
+    def chk(where, name, a, b):
+        a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        if not np.array_equal(a.view(np.uint32), b.view(np.uint32)):
+            bad.append("%s %s (%d of %d differ)" % (where, name, int(np.sum(a.view(np.uint32) != b.view(np.uint32))), a.size))
+
+    seam = np.asarray(seam).reshape(-1, 2, channels)
+    for k, f in enumerate(frames if frames is not None else range(len(seam))):
+        for gr in range(2):
+            for c in range(channels):
+                g, r = 2 * f + gr, seam[k, gr, c]
+                w = "stream %d frame %d gr %d ch %d" % (s, f, gr, c)
+                chk(w, "energy_l", st["energy_l"][s, g, c, :513], r["energy_l"])
+                chk(w, "energy_s", st["energy_s"][s, g, c], r["energy_s"])
+                bins = st["fft_bins"][s, g, c]
+                sh = bins[:300].reshape(3, 50, 2)
+                chk(w, "short lines re", sh[:, :, 0], r["re_s"])
+                chk(w, "short lines im", sh[:, :, 1], r["im_s"])
+                chk(w, "long lines re", bins[300:306], r["re_l"])
+                chk(w, "long lines im", bins[307:312], r["im_l"][1:])  # (line 0 is real: the kernel stores -0 so that atan2(-im, re) is atan2(0, re))
+                if bins[306] != 0.0:
+                    bad.append(w + " long line 0 im")
+    return bad
