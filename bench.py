@@ -40,7 +40,16 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-torch = None  # imported by main() in the processes that run a rank: the launcher of `--gpus N` never loads it
+torch = None  # loaded by the processes that run a rank (load_torch): the launcher of `--gpus N` never imports it
+
+
+def load_torch():
+    global torch
+    if torch is None:
+        import torch as _t
+        torch = _t
+    return torch
+
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -65,6 +74,7 @@ class Workload:
     """A config's batch on one GPU: encoder, deterministic PCM in HBM, output buffers."""
 
     def __init__(self, mp3, cfg, dev, stream0):
+        load_torch()  # (tools/full_parity.py builds a Workload without going through main())
         self.cfg, self.dev, self.stream0 = cfg, dev, stream0
         S, nf, C, rate = cfg["streams"], cfg["frames"], cfg["channels"], cfg["rate"]
         self.kbps = [kbps_of(cfg, stream0 + s) for s in range(S)]
@@ -510,8 +520,7 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to report a line whose n_gpus "
                          "is not what was asked for" % (args.gpus, world))
     distributed = world > 1
-    global torch
-    import torch
+    load_torch()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the encoder has no CPU path")
     # (test hook: MP3MI_BENCH_ONE_GPU=1 runs every rank on device 0 over gloo, so that the multi-rank code path -- stream
