@@ -74,6 +74,9 @@ typedef struct mp3mi_batch_options {
     int32_t dropin_lookahead; /* the drop-in symbols' look-ahead (mp3mi_dropin.h): -1 default = 2 the filterbank's (and mdct_sub behind it: memory of the current frame only), 0 none, 1 all (buffer lifetime requirement: mp3mi_dropin.h),
                                  3 L3psycho_anal's only, 4 all but iteration_loop's / III_format_bitstream's.  Not a property of a batch: the hidden default stream of the drop-in symbols
                                  reads it through mp3mi_batch_options_from_env (MP3MI_DROPIN_LOOKAHEAD) */
+    int32_t call_hold;        /* the LAST loop kernel of a call waits (on the device, at most 20 ms) until the call after it has run its first
+                                 transforms, or until a call that waits for results lets it go (sync, stream_status, timing, flush, reset,
+                                 destroy): calls issued back to back then lose no pipeline fill: -1 default (on), 0, 1 */
     int32_t dropin_stats;     /* the drop-in symbols print, at III_FlushBitstream, the frames they served, the time from the first frame's
                                  first call to the flush and the waits for the device: 0 default, 1 (MP3MI_DROPIN_STATS) */
 } mp3mi_batch_options;
@@ -82,7 +85,7 @@ typedef struct mp3mi_batch_options {
 void mp3mi_batch_options_default(mp3mi_batch_options *opt);
 /* The same, then overridden by the MP3MI_* environment variables that tools/ and tests/ use (MP3MI_SCRATCH_MB,
  * MP3MI_CHUNK_FRAMES, MP3MI_{NOISE,PHASE,PSY,QUANT,PREP,CW}_EXACT, MP3MI_CALL_OVERLAP, MP3MI_NO_GATE, MP3MI_NO_PLACE,
- * MP3MI_LOOP_PART_STREAMS, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE, MP3MI_DROPIN_LOOKAHEAD, MP3MI_DROPIN_STATS).  This is the ONLY place the library
+ * MP3MI_LOOP_PART_STREAMS, MP3MI_CALL_HOLD, MP3MI_Y_AFTER_LOOP, MP3MI_PSY_BESIDE, MP3MI_DROPIN_LOOKAHEAD, MP3MI_DROPIN_STATS).  This is the ONLY place the library
  * reads its environment: mp3mi_batch_create calls it once; mp3mi_batch_create_ex never does. */
 void mp3mi_batch_options_from_env(mp3mi_batch_options *opt);
 

@@ -55,6 +55,12 @@ struct mp3mi_batch {
     hipEvent_t ev_hist;      // the front stream's last work of a call (the PCM history hand-over) is enqueued
     bool have_done;
     bool overlap_calls;      // a call's front stream does not wait for the call before it (MP3MI_CALL_OVERLAP=0: it does)
+    // The last k_loop of a call is HELD on the device (k_hold, k_loop.hip) until the next call's first transforms are through:
+    // hold_flag is one word of host memory mapped into the device's address space, hold_seq the ticket of the hold in
+    // force (tickets only grow), held = a hold is in force that neither a next call nor the host has let go yet
+    unsigned *hold_flag_h, *hold_flag_d;
+    unsigned hold_seq;
+    bool held, hold_calls;
     int slot_base;           // parity of the double-buffer slot the next call's chunk 0 takes
     unsigned *gate_count;    // start census of k_loop's wavefronts (device memory, only ever grows), NULL = gate off
     unsigned gate_total;     // census value once every wavefront launched so far has started
@@ -175,12 +181,21 @@ static_assert((int) MP3MI_STREAM_ABORT_GLOBAL_GAIN == MP3MI_DEV_ABORT_GLOBAL_GAI
 
 extern "C" void mp3mi_batch_destroy(mp3mi_batch *b);
 
+// The host lets the held k_loop of the last call go (mp3mi_batch::held): whoever is about to WAIT for that call's results,
+// or to put work on the front stream that waits for it, calls this first.
+static void hold_release(mp3mi_batch *b)
+{
+    if (!b->held) return;
+    __atomic_store_n(b->hold_flag_h + 1, b->hold_seq, __ATOMIC_RELEASE); // (this hold, not the ones before it: k_hold)
+    b->held = false;
+}
+
 extern "C" void mp3mi_batch_options_default(mp3mi_batch_options *o)
 {
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->struct_size = (uint32_t) sizeof(*o);
-    o->call_overlap = o->gate = o->placement = o->y_after_loop = o->psy_beside = o->dropin_lookahead = -1;
+    o->call_overlap = o->gate = o->placement = o->y_after_loop = o->psy_beside = o->dropin_lookahead = o->call_hold = -1;
 }
 
 // The one place the library reads its environment (mp3mi.h): the knobs of tools/ and tests/.
@@ -204,6 +219,7 @@ extern "C" void mp3mi_batch_options_from_env(mp3mi_batch_options *o)
     if ((e = getenv("MP3MI_LOOP_PART_STREAMS")) && atoi(e) >= 64) o->loop_part_streams = atoi(e) / 64 * 64;
     if ((e = getenv("MP3MI_Y_AFTER_LOOP"))) o->y_after_loop = atoi(e) != 0;
     if ((e = getenv("MP3MI_PSY_BESIDE"))) o->psy_beside = atoi(e) == 2 ? 2 : (atoi(e) ? 1 : 0);
+    if ((e = getenv("MP3MI_CALL_HOLD"))) o->call_hold = atoi(e) != 0;
     if (on(getenv("MP3MI_DROPIN_STATS"))) o->dropin_stats = 1;
     if ((e = getenv("MP3MI_DROPIN_LOOKAHEAD")) && atoi(e) >= 0 && atoi(e) <= 4) o->dropin_lookahead = atoi(e);
 }
@@ -292,6 +308,12 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     b->hdr_mode = (channels == 1) ? 3 : 0;
     b->crc = 0;
     b->gate_count = NULL; b->gate_total = 0; b->gate_first = 0;
+    b->hold_calls = opt.call_hold != 0 && opt.call_overlap != 0 && opt.gate != 0;
+    if (b->hold_calls) {
+        CHK(hipHostMalloc((void **) &b->hold_flag_h, 64, hipHostMallocMapped));
+        b->hold_flag_h[0] = b->hold_flag_h[1] = 0;
+        CHK(hipHostGetDevicePointer((void **) &b->hold_flag_d, b->hold_flag_h, 0));
+    }
     if (opt.gate != 0) {
         CHK(hipMalloc((void **) &b->gate_count, 2 * sizeof(unsigned))); // [0] start census, [1] frames finished in this launch
         CHK(hipMemset(b->gate_count, 0, 2 * sizeof(unsigned)));
@@ -388,7 +410,7 @@ extern "C" int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_
         auto tri = [](int v) { return v >= -1 && v <= 1; }; // -1 default, 0 off, 1 on
         if ((opt.test_flags & ~(unsigned) (MP3MI_TEST_ALL_EXACT | MP3MI_TEST_PREP_LIST)) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||
             (opt.loop_part_streams % 64) != 0 || opt.psy_beside < -1 || opt.psy_beside > 2 || opt.dropin_lookahead < -1 || opt.dropin_lookahead > 4 || (opt.dropin_stats != 0 && opt.dropin_stats != 1) || !tri(opt.call_overlap) || !tri(opt.gate) ||
-            !tri(opt.placement) || !tri(opt.y_after_loop))
+            !tri(opt.placement) || !tri(opt.y_after_loop) || !tri(opt.call_hold))
             return MP3MI_ERR_ARG;
     }
     // argument errors first: they are the caller's, whatever the machine
@@ -420,6 +442,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
 {
     if (!b) return;
     device_scope ds(b->device);
+    hold_release(b);
     if (b->stream) hipStreamSynchronize(b->stream);
     if (b->lstream) hipStreamSynchronize(b->lstream);
     void *bufs[] = {b->T, b->bits_per_frame, b->bitrate_index, b->energy_l, b->energy_s, b->hist6, b->fft_bins, b->cw_mid, b->cw_fix,
@@ -451,6 +474,7 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b)
     }
     if (b->stream) hipStreamDestroy(b->stream);
     if (b->lstream) hipStreamDestroy(b->lstream);
+    if (b->hold_flag_h) hipHostFree(b->hold_flag_h);
     delete b;
 }
 
@@ -547,6 +571,7 @@ extern "C" int mp3mi_batch_reset(mp3mi_batch *b)
     if (!b) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
     b->status_kept = false; // an explicit reset starts new streams: what a flush kept of the ones it ended goes with them
+    hold_release(b); // (the front stream is about to wait for the call before)
     return reset_impl(b);
 }
 
@@ -573,6 +598,7 @@ extern "C" int mp3mi_batch_flush(mp3mi_batch *b, uint8_t *out_dev, size_t out_st
 {
     if (!b || !out_dev || !out_len_dev || out_stride < (size_t) MP3MI_CARRY_BYTES + 1) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
+    hold_release(b);
     if (b->fresh) { // nothing was encoded since the reset: no file body (the reference would write one byte; see mp3mi.h)
         CHK(hipMemsetAsync(out_len_dev, 0, sizeof(uint32_t) * (size_t) b->n_streams, b->lstream));
         return MP3MI_OK;
@@ -612,7 +638,10 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
     // this call's feed-forward kernels start at once and fill the chip while the last k_loop of the call before -- 4096
     // wavefronts, serial, nothing beside them -- runs out: back-to-back calls lose no pipeline fill.
     // (options.call_overlap = 0: the front stream waits for the whole call before, as reset / flush still do.)
-    if (b->have_done && !b->overlap_calls) CHK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
+    if (b->have_done && !b->overlap_calls) {
+        hold_release(b);
+        CHK(hipStreamWaitEvent(b->stream, b->ev_done, 0));
+    }
     // a whole-file call starts every stream afresh; a streaming call continues (the first one after create / reset /
     // flush / a whole-file call starts afresh too)
     if (whole_file || (b->frames_done == 0 && !b->fresh)) {
@@ -741,29 +770,53 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         }
         return MP3MI_OK;
     };
-    if (stage_x(0, 15) != MP3MI_OK) return MP3MI_ERR_HIP;
+    // which of stage X runs beside the k_loop before the item's own, and whether the item's stage Y waits for that k_loop (below)
+    auto y_after = [&](const item_view &iv) {
+        return b->opt.y_after_loop >= 0 ? b->opt.y_after_loop != 0 : iv.g.n_streams > mp3mi_loop_resident();
+    };
+    auto beside_of = [&](const item_view &iv) {
+        int bs = y_after(iv) ? 0 : 14;
+        if (b->opt.psy_beside >= 0) bs = b->opt.psy_beside == 2 ? 8 : (b->opt.psy_beside ? 14 : 0);
+        return bs;
+    };
+    // The call before this one may have left its last k_loop HELD (k_hold): this call's first item then takes the place
+    // "the next item" has inside a call -- its transforms run now, in front of that k_loop, the hold is let go behind them,
+    // and the rest of the item runs beside that k_loop, behind the gate, like every item after it.
+    bool joined = false;
+    {
+        const item_view v0 = view(0);
+        if (b->held && !y_after(v0) && b->gate_count) {
+            if (stage_x(0, 15 & ~beside_of(v0)) != MP3MI_OK) return MP3MI_ERR_HIP;
+            mp3mi_launch_hold_release(b->hold_flag_d, b->hold_seq, b->stream);
+            CHK(hipGetLastError());
+            b->held = false;
+            joined = true;
+        } else {
+            hold_release(b);
+            if (stage_x(0, 15) != MP3MI_OK) return MP3MI_ERR_HIP;
+        }
+    }
     for (int k = 0; k < n_items; k++) {
         const item_view v = view(k);
         const mp3mi_geom &g = v.g;
         const size_t r = v.rec0;
+        const bool follows = k >= 1 || joined; // a k_loop runs (or is about to) that this item's kernels go beside
         // A part larger than the resident wavefronts (options.loop_part_streams, tests only) keeps every SIMD full to its
         // end, so the feed-forward kernels of the next item find no freed slots beside it, only cycles to take: there
         // stage Y waits for k_loop.
-        bool y_after_loop = g.n_streams > mp3mi_loop_resident();
-        if (b->opt.y_after_loop >= 0) y_after_loop = b->opt.y_after_loop != 0;
+        const bool y_after_loop = y_after(v);
         // what of stage X runs beside k_loop (bits as for stage_x): all but the FFTs -- k_cw, k_part, k_psy are small in
         // registers and LDS, the item's FFTs were done before that launch started, and the region k_psy writes was read
         // last by the launch before it: 238.2 vs 247.2 ms per 4096 x 383 step with them between the launches.
         // options.psy_beside = 0 / 1 / 2: nothing / all three / k_psy only.
-        int beside = y_after_loop ? 0 : 14;
-        if (b->opt.psy_beside >= 0) beside = b->opt.psy_beside == 2 ? 8 : (b->opt.psy_beside ? 14 : 0);
+        const int beside = beside_of(v);
         // ---- front stream: everything that does not depend on the bit reservoir ----
         if (k >= 1 && y_after_loop) { // (the k_loop before this item's: view(k - 1))
             const item_view pv = view(k - 1);
             CHK(hipStreamWaitEvent(b->stream, b->ev_loop[pv.ev], 0));
-        } else if (k >= 1 && b->gate_count) // this item's kernels run behind k_loop(k - 1), once that is resident (<= 300 us)
+        } else if (follows && b->gate_count) // this item's kernels run behind k_loop(k - 1), once that is resident (<= 300 us)
             mp3mi_launch_gate(b->gate_count, b->gate_first - 16u, 30000u, b->stream);
-        if (beside && k >= 1 && stage_x(k, beside) != MP3MI_OK) return MP3MI_ERR_HIP;
+        if (beside && follows && stage_x(k, beside) != MP3MI_OK) return MP3MI_ERR_HIP;
         mp3mi_launch_filter(b->T, g, pcm_dev + v.s0 * pcm_pitch, b->sbs + v.s0 * (size_t) (g.n_gran + 1) * (size_t) C * 576,
                             b->debug ? b->sb_dbg + r * 576 : NULL, b->stream);
         CHK(hipGetLastError());
@@ -776,15 +829,19 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         mp3mi_launch_prep(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r, b->prep_exact ? NULL : b->prep_fix, b->prep_exact, b->stream);
         CHK(hipGetLastError());
         if (k + 1 < n_items) {
-            const item_view nv = view(k + 1);
-            const bool ny = b->opt.y_after_loop >= 0 ? b->opt.y_after_loop != 0 : nv.g.n_streams > mp3mi_loop_resident();
-            int nbeside = ny ? 0 : 14;
-            if (b->opt.psy_beside >= 0) nbeside = b->opt.psy_beside == 2 ? 8 : (b->opt.psy_beside ? 14 : 0);
-            if (stage_x(k + 1, 15 & ~nbeside) != MP3MI_OK) return MP3MI_ERR_HIP;
+            if (stage_x(k + 1, 15 & ~beside_of(view(k + 1))) != MP3MI_OK) return MP3MI_ERR_HIP;
         }
         CHK(hipEventRecord(b->ev_front[v.ev], b->stream));
         // ---- loop stream: the serial search and the formatter ----
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[v.ev], 0));
+        if (b->hold_calls && k == n_items - 1) {
+            // the call's LAST k_loop: held until the next call's first transforms are through (its first item then runs beside
+            // this launch), the host lets go (hold_release), or 20 ms have passed
+            b->hold_seq++;
+            mp3mi_launch_hold(b->hold_flag_d, b->hold_seq, 2000000u, b->lstream);
+            CHK(hipGetLastError());
+            b->held = true;
+        }
         CHK(hipEventRecord(ts.loop_ev[2 * k], b->lstream));
         {
             const int n = g.n_streams;
@@ -887,6 +944,7 @@ extern "C" int mp3mi_batch_sync(mp3mi_batch *b)
 {
     if (!b) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
+    hold_release(b);
     CHK(hipStreamSynchronize(b->stream));
     CHK(hipStreamSynchronize(b->lstream));
     if (b->hio.ready) { // host-buffer calls: the results are in the caller's memory when this returns
@@ -908,6 +966,7 @@ extern "C" int mp3mi_batch_stream_status(mp3mi_batch *b, int32_t *status_host)
 {
     if (!b || !status_host) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
+    hold_release(b);
     // (the state of the most recent streams: a whole-file call leaves it behind, the next call's reset clears it; a
     // flush gathers it before its reset)
     if (!b->status_kept) {
@@ -926,6 +985,7 @@ extern "C" int mp3mi_batch_debug_cw_fixups(mp3mi_batch *b, int *n_listed, int *n
 {
     if (!b || !n_listed || !n_records) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
+    hold_release(b);
     mp3mi_cw_fixlist h;
     CHK(hipMemcpy(&h, b->cw_fix, sizeof(h), hipMemcpyDeviceToHost));
     *n_listed = (int) h.count;
@@ -937,6 +997,7 @@ extern "C" int mp3mi_batch_debug_prep_fixups(mp3mi_batch *b, int *n_listed)
 {
     if (!b || !n_listed) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
+    hold_release(b);
     mp3mi_prep_fixlist h;
     if (hipStreamSynchronize(b->stream) != hipSuccess) return MP3MI_ERR_HIP;
     CHK(hipMemcpy(&h, b->prep_fix, sizeof(h), hipMemcpyDeviceToHost));
@@ -948,6 +1009,7 @@ extern "C" int mp3mi_batch_last_timing(mp3mi_batch *b, float *loop_kernel_ms, fl
 {
     if (!b || !b->have_done || b->call_no == 0) return MP3MI_ERR_ARG; // nothing has been encoded yet
     ON_DEVICE(b);
+    hold_release(b);
     if (harvest_timing(b, (int) (b->call_no & 1)) != MP3MI_OK || harvest_timing(b, (int) ((b->call_no - 1) & 1)) != MP3MI_OK) return MP3MI_ERR_HIP;
     if (loop_kernel_ms) *loop_kernel_ms = b->last_loop_ms;
     if (all_kernels_ms) *all_kernels_ms = b->last_all_ms;
@@ -959,6 +1021,7 @@ extern "C" int mp3mi_batch_total_timing(mp3mi_batch *b, double *loop_kernel_ms, 
 {
     if (!b) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
+    hold_release(b);
     if (harvest_timing(b, (int) (b->call_no & 1)) != MP3MI_OK || harvest_timing(b, (int) ((b->call_no - 1) & 1)) != MP3MI_OK) return MP3MI_ERR_HIP;
     if (loop_kernel_ms) *loop_kernel_ms = b->tot_loop_ms;
     if (all_kernels_ms) *all_kernels_ms = b->tot_all_ms;
@@ -988,6 +1051,7 @@ extern "C" long mp3mi_batch_debug_fetch(mp3mi_batch *b, int what, void *host_dst
     }
     if (!src || n > cap) return MP3MI_ERR_ARG;
     ON_DEVICE(b);
+    hold_release(b);
     if (hipStreamSynchronize(b->stream) != hipSuccess || hipStreamSynchronize(b->lstream) != hipSuccess) return MP3MI_ERR_HIP;
     if (hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return MP3MI_ERR_HIP;
     return (long) n;
@@ -1061,6 +1125,7 @@ extern "C" int mp3mi_batch_host_io_stats(mp3mi_batch *b, mp3mi_host_io_stats *st
     ON_DEVICE(b);
     memset(st, 0, sizeof(*st));
     if (!b->hio.ready) return MP3MI_OK;
+    hold_release(b);
     if (host_io_harvest(b, 0) != MP3MI_OK || host_io_harvest(b, 1) != MP3MI_OK) return MP3MI_ERR_HIP;
     st->calls = b->hio.tot_calls;
     st->h2d_bytes = b->hio.tot_up_bytes; st->d2h_bytes = b->hio.tot_dn_bytes;

@@ -1361,4 +1361,41 @@ void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_tick
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, count, target, max_ticks);
 }
 
+// Holds the loop stream back in front of the LAST k_loop of a call until the call AFTER it has had its first transforms
+// (k_fft takes whole CUs' LDS: run behind that k_loop's start they would wait for its end, and everything of the next
+// call's first chunk with them -- 20 ms of an otherwise idle chip per call), or until the host lets go (a call that waits
+// for results: batch.cpp, hold_release), or until max_ticks of the 100 MHz counter have passed: the hold only ever
+// changes WHEN the kernel behind it starts, never what it computes, so running out is harmless.  flag[] is host memory
+// mapped into the device's address space; tickets only ever grow.  flag[0]: the highest ticket a NEXT CALL has let go
+// (k_hold_release, on the device, behind that call's first transforms); flag[1]: the ticket the HOST lets go -- that one and
+// no other: the host runs far ahead of the device, and when it waits for the last call it must not let go the holds of the
+// calls before it, which the device has not reached yet and whose successors are already queued.
+__global__ void __launch_bounds__(64) k_hold(const unsigned *flag, unsigned ticket, unsigned max_ticks)
+{
+#if !defined(MP3MI_EMU)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int) (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - ticket) < 0 &&
+           __hip_atomic_load(flag + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ticket) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long) max_ticks) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+#endif
+}
+__global__ void __launch_bounds__(64) k_hold_release(unsigned *flag, unsigned ticket)
+{
+#if defined(MP3MI_EMU)
+    if (threadIdx.x == 0 && (int) (*flag - ticket) < 0) *flag = ticket;
+#else
+    if (threadIdx.x == 0) __hip_atomic_fetch_max(flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+void mp3mi_launch_hold(const unsigned *flag, unsigned ticket, unsigned max_ticks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, st, flag, ticket, max_ticks);
+}
+void mp3mi_launch_hold_release(unsigned *flag, unsigned ticket, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_hold_release, dim3(1), dim3(64), 0, st, flag, ticket);
+}
+
 ULP_CENSUS_ACCESSOR(mp3mi_debug_ulp_census_loop)

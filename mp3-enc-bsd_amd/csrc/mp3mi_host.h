@@ -116,6 +116,8 @@ void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double 
 /* bounded wait (one wavefront) until k_loop's start census reaches `target` -- see k_loop.hip */
 int mp3mi_loop_resident(void);
 void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_ticks, hipStream_t st);
+void mp3mi_launch_hold(const unsigned *flag, unsigned ticket, unsigned max_ticks, hipStream_t st);
+void mp3mi_launch_hold_release(unsigned *flag, unsigned ticket, hipStream_t st);
 /* streaming plumbing around k_format (k_format.hip): the bytes of a stream that are not final yet -- the unfilled
    part of the bit reservoir's slots and the headers in between, at most MP3MI_CARRY_BYTES -- wait in `carry` */
 #define MP3MI_CARRY_BYTES 2048

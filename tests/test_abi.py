@@ -68,14 +68,14 @@ def test_options_struct(product):
     import sys
     o = product.options()
     assert o.struct_size == ctypes.sizeof(o) and o.scratch_mb == 0 and o.chunk_frames == 0 and o.test_flags == 0
-    assert (o.call_overlap, o.gate, o.placement, o.y_after_loop, o.psy_beside, o.loop_part_streams) == (-1, -1, -1, -1, -1, 0)
+    assert (o.call_overlap, o.gate, o.placement, o.y_after_loop, o.psy_beside, o.loop_part_streams, o.call_hold) == (-1, -1, -1, -1, -1, 0, -1)
     code = ("import sys, ctypes; sys.path.insert(0, %r); from mp3common import Mp3mi, BatchOptions; m = Mp3mi(); o = BatchOptions(); "
             "m.lib.mp3mi_batch_options_from_env(ctypes.byref(o)); "
-            "print(o.chunk_frames, o.scratch_mb, o.test_flags, o.gate, o.placement, o.loop_part_streams, o.psy_beside)" % os.path.join(ROOT, "tests"))
+            "print(o.chunk_frames, o.scratch_mb, o.test_flags, o.gate, o.placement, o.loop_part_streams, o.psy_beside, o.call_hold)" % os.path.join(ROOT, "tests"))
     env = dict(os.environ, MP3MI_CHUNK_FRAMES="7", MP3MI_SCRATCH_MB="100", MP3MI_PSY_EXACT="1", MP3MI_CW_EXACT="1", MP3MI_NO_GATE="1",
-               MP3MI_NO_PLACE="1", MP3MI_LOOP_PART_STREAMS="200", MP3MI_PSY_BESIDE="2")
+               MP3MI_NO_PLACE="1", MP3MI_CALL_HOLD="0", MP3MI_LOOP_PART_STREAMS="200", MP3MI_PSY_BESIDE="2")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
-    assert [int(x) for x in out] == [7, 100, 4 | 32, 0, 0, 192, 2]
+    assert [int(x) for x in out] == [7, 100, 4 | 32, 0, 0, 192, 2, 0]
     b = ctypes.c_void_p()
     o.struct_size = 8
     assert product.lib.mp3mi_batch_create_ex(ctypes.byref(b), 4, 44100, 2, None, 128, 8, ctypes.byref(o)) == -1

@@ -76,7 +76,7 @@ def test_options_out_of_range_are_refused(emu):
     from mp3common import BatchOptions
     L = emu.lib
     for field, bad in (("gate", 2), ("gate", -2), ("placement", 5), ("call_overlap", -3), ("y_after_loop", 2), ("psy_beside", -2),
-                       ("psy_beside", 3), ("loop_part_streams", 100), ("loop_part_streams", -64)):
+                       ("psy_beside", 3), ("loop_part_streams", 100), ("loop_part_streams", -64), ("call_hold", 2)):
         o = BatchOptions()
         L.mp3mi_batch_options_default(ctypes.byref(o))
         setattr(o, field, bad)

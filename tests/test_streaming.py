@@ -71,8 +71,10 @@ def test_streaming_full_chip_batch_gpu(product, oracle):
         run.close()
 
 
-def unsynced_case(mp, oracle, rate, ch, kbps, S, pieces, n_oracle, chunk, monkeypatch):
+def unsynced_case(mp, oracle, rate, ch, kbps, S, pieces, n_oracle, chunk, monkeypatch, hold=None):
     monkeypatch.setenv("MP3MI_CHUNK_FRAMES", str(chunk))
+    if hold is not None:
+        monkeypatch.setenv("MP3MI_CALL_HOLD", str(hold))
     run = BatchRun(mp, S, rate, ch, kbps, sum(pieces))
     try:
         kb = [kbps] * S if np.isscalar(kbps) else list(kbps)
@@ -90,15 +92,41 @@ def test_back_to_back_calls_without_sync_emulated(emu, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("S,pieces,chunk", [
-    (4096, [5, 3, 6, 1, 4], 2),   # odd and even numbers of chunks per call: the double-buffer slots change sides between calls
-    (600, [40, 7, 33], 9),
+@pytest.mark.parametrize("S,pieces,chunk,hold", [
+    (4096, [5, 3, 6, 1, 4], 2, None),   # odd and even numbers of chunks per call: the double-buffer slots change sides between calls
+    (600, [40, 7, 33], 9, None),
+    (4096, [5, 3, 6, 1, 4], 2, 0),      # options.call_hold off: a call's last k_loop does not wait for the next call's transforms
+    (6000, [4, 1, 3], 2, 1),            # two parts per chunk: the held launch is the last part's, the joining item the first part's
 ])
-def test_back_to_back_calls_without_sync_gpu(product, oracle, monkeypatch, S, pieces, chunk):
+def test_back_to_back_calls_without_sync_gpu(product, oracle, monkeypatch, S, pieces, chunk, hold):
     """A whole-file call, streaming calls and the flush issued without a sync between them: every call's feed-forward
-    kernels overlap with the loop kernels of the call before (encode_impl).  The bytes must be those of
-    synchronised calls -- the oracle's."""
-    unsynced_case(product, oracle, 44100, 2, [(96, 128, 160, 128)[s % 4] for s in range(S)], S, pieces, 12, chunk, monkeypatch)
+    kernels overlap with the loop kernels of the call before, and a call's LAST k_loop is held on the device until the
+    next call's first transforms are through (encode_impl, k_hold; calls of one chunk chain hold to hold).  The bytes must
+    be those of synchronised calls -- the oracle's."""
+    unsynced_case(product, oracle, 44100, 2, [(96, 128, 160, 128)[s % 4] for s in range(S)], S, pieces, 12, chunk, monkeypatch, hold)
+
+
+@pytest.mark.gpu
+def test_a_held_call_ends_without_a_successor(product, oracle):
+    """the hold in front of a call's last k_loop is let go by whatever waits for the call (sync here, then status and
+    destroy with another call in flight) -- and runs out by itself (20 ms) for a caller who polls a HIP stream of his own"""
+    import time
+    S, nf = 64, 6
+    run = BatchRun(product, S, 44100, 2, 128, nf)
+    try:
+        L = product.lib
+        t0 = time.perf_counter()
+        assert L.mp3mi_batch_encode(run.b, run.d_pcm, nf, run.d_out, run.stride, run.d_len) == 0
+        assert L.mp3mi_batch_sync(run.b) == 0
+        assert time.perf_counter() - t0 < 5.0
+        lens = run.mem.download(run.d_len, (S,), np.uint32)
+        out = run.mem.download(run.d_out, (S, run.stride), np.uint8)
+        assert out[3, :lens[3]].tobytes() == oracle.encode(run.pcm_of(3), 44100, 128, 2)[0]
+        assert L.mp3mi_batch_encode(run.b, run.d_pcm, nf, run.d_out, run.stride, run.d_len) == 0
+        assert all(x == 0 for x in run.status())  # (waits for the call)
+        assert L.mp3mi_batch_encode(run.b, run.d_pcm, nf, run.d_out, run.stride, run.d_len) == 0
+    finally:
+        run.close()  # destroy with a held call in flight
 
 
 def test_flush_without_frames_and_argument_errors_emulated(emu):

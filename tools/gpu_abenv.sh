@@ -38,7 +38,7 @@ if f:
     rows = [(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")) for r in csv.DictReader(open(f[0]))]
     rows = sorted([r for r in rows if r[0].startswith("k_") and not r[0].startswith("k_synth")], key=lambda r: r[1])
     loops = [i for i, r in enumerate(rows) if r[0] == "k_loop"]
-    i0 = max(0, loops[-5] - 14) if len(loops) >= 5 else 0
+    i0 = max(0, loops[-6] - 6) if len(loops) >= 6 else 0
     t0 = rows[i0][1]
     with open(sys.argv[1], "w") as o:
         for n, s, e, q in rows[i0:]:
