@@ -829,10 +829,28 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         mp3mi_launch_prep(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r, b->prep_exact ? NULL : b->prep_fix, b->prep_exact, b->stream);
         CHK(hipGetLastError());
         if (k + 1 < n_items) {
+            // (The next item's transforms take whole CUs' LDS: they run BETWEEN two k_loop launches.  Nothing but the queue behind
+            // a busy chip sees to that -- this item's kernels take longer than the k_loop they run beside -- and an explicit wait
+            // for that k_loop's end costs 1.4 ms per step, because the transforms then no longer slip in as its last CUs drain:
+            // profiles/r05_experiments.txt, E7.)
             if (stage_x(k + 1, 15 & ~beside_of(view(k + 1))) != MP3MI_OK) return MP3MI_ERR_HIP;
         }
         CHK(hipEventRecord(b->ev_front[v.ev], b->stream));
         // ---- loop stream: the serial search and the formatter ----
+        // (what k_loop needs of its own stream is prepared AHEAD of the wait for the front stream -- in the shadow of the transforms that
+        // run between two k_loop launches, not behind them: the ranking of the part's streams by their cost in the chunk before,
+        // 0.19 ms for 4096 streams, and the two counters' reset)
+        mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
+        if (b->place_order) { // rank the part's streams by their cost in the previous chunk, hand the tables to k_loop
+            mp3mi_launch_rank(b->place_cost + v.s0, b->place_order + v.s0, g.n_streams, b->lstream);
+            CHK(hipGetLastError());
+            CHK(hipMemsetAsync(b->place_zero, 0, sizeof(unsigned) * ((size_t) S + 2 * MP3MI_PLACE_KEYS + 2), b->lstream));
+            place.order = b->place_order + v.s0; place.cost = b->place_cost + v.s0; place.taken = b->place_zero;
+            place.simd_slots = b->place_zero + S; place.simd_idx = place.simd_slots + MP3MI_PLACE_KEYS;
+            place.ticket = place.simd_idx + MP3MI_PLACE_KEYS; place.scan = place.ticket + 1;
+            place.n_simd = b->n_simd;
+        }
+        if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[v.ev], 0));
         if (b->hold_calls && k == n_items - 1) {
             // the call's LAST k_loop: held until the next call's first transforms are through (its first item then runs beside
@@ -847,17 +865,6 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
             const int n = g.n_streams;
             b->gate_total += (unsigned) n; // a wavefront per stream counts itself in
             b->gate_first = b->gate_total; // the census once this launch is resident: the next item's kernels start behind it
-            mp3mi_loop_place place = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0};
-            if (b->place_order) { // rank the part's streams by their cost in the previous chunk, hand the tables to k_loop
-                mp3mi_launch_rank(b->place_cost + v.s0, b->place_order + v.s0, n, b->lstream);
-                CHK(hipGetLastError());
-                CHK(hipMemsetAsync(b->place_zero, 0, sizeof(unsigned) * ((size_t) S + 2 * MP3MI_PLACE_KEYS + 2), b->lstream));
-                place.order = b->place_order + v.s0; place.cost = b->place_cost + v.s0; place.taken = b->place_zero;
-                place.simd_slots = b->place_zero + S; place.simd_idx = place.simd_slots + MP3MI_PLACE_KEYS;
-                place.ticket = place.simd_idx + MP3MI_PLACE_KEYS; place.scan = place.ticket + 1;
-                place.n_simd = b->n_simd;
-            }
-            if (b->gate_count) CHK(hipMemsetAsync(b->gate_count + 1, 0, sizeof(unsigned), b->lstream));
             mp3mi_launch_loop(b->T, g, b->xr[v.slot] + r * 576, b->psy[v.slot] + r, b->prep[v.slot] + r, b->bits_per_frame + v.s0,
                               (char *) b->loop_state + v.s0 * loop_state_bytes, b->ix + r * 576, b->side + v.s0 * (size_t) g.nf,
                               b->gate_count, place, b->lstream);
