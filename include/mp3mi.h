@@ -74,7 +74,7 @@ typedef struct mp3mi_batch_options {
     int32_t dropin_lookahead; /* the drop-in symbols' look-ahead (mp3mi_dropin.h): -1 default = 2 the filterbank's (and mdct_sub behind it: memory of the current frame only), 0 none, 1 all (buffer lifetime requirement: mp3mi_dropin.h),
                                  3 L3psycho_anal's only, 4 all but iteration_loop's / III_format_bitstream's.  Not a property of a batch: the hidden default stream of the drop-in symbols
                                  reads it through mp3mi_batch_options_from_env (MP3MI_DROPIN_LOOKAHEAD) */
-    int32_t call_hold;        /* the LAST loop kernel of a call waits (on the device, at most 20 ms) until the call after it has run its first
+    int32_t call_hold;        /* the LAST loop kernel of a call waits (on the device, at most 20 ms -- 0.4 ms per frame of a chunk where that is more, at most 200 ms --) until the call after it has run its first
                                  transforms, or until a call that waits for results lets it go (sync, stream_status, timing, flush, reset,
                                  destroy): calls issued back to back then lose no pipeline fill: -1 default (on), 0, 1 */
     int32_t dropin_stats;     /* the drop-in symbols print, at III_FlushBitstream, the frames they served, the time from the first frame's

@@ -854,9 +854,11 @@ static int encode_impl(mp3mi_batch *b, const int16_t *pcm_dev, const int32_t *n_
         CHK(hipStreamWaitEvent(b->lstream, b->ev_front[v.ev], 0));
         if (b->hold_calls && k == n_items - 1) {
             // the call's LAST k_loop: held until the next call's first transforms are through (its first item then runs beside
-            // this launch), the host lets go (hold_release), or 20 ms have passed
+            // this launch), the host lets go (hold_release), or the bound has passed: 20 ms, more for chunks so long that what the
+            // front stream still holds of this item plus the next call's transforms take longer (0.4 ms per frame of a chunk)
             b->hold_seq++;
-            mp3mi_launch_hold(b->hold_flag_d, b->hold_seq, 2000000u, b->lstream);
+            const unsigned hold_ticks = 100000u * (unsigned) (g.nf * 4 / 10 > 20 ? (g.nf * 4 / 10 < 200 ? g.nf * 4 / 10 : 200) : 20); // 100 MHz
+            mp3mi_launch_hold(b->hold_flag_d, b->hold_seq, hold_ticks, b->lstream);
             CHK(hipGetLastError());
             b->held = true;
         }
