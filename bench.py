@@ -493,6 +493,7 @@ def main():
                     help="3: the Layer III path (BASELINE.json's metric, the default); 1 / 2: the Layer I / II path of SURVEY 8(f) row 4")
     ap.add_argument("--streams", type=int, default=0, help="override: streams per GPU")
     ap.add_argument("--frames", type=int, default=0, help="override: frames per stream")
+    ap.add_argument("--kbps", type=int, default=0, help="override: one bitrate for every stream (measurements of the schedule at other rates)")
     ap.add_argument("--host-io", action="store_true",
                     help="after the resident measurement (which stays `value`), time the same K steps through "
                          "mp3mi_batch_encode_host_async -- PCM in page-locked host memory, file bytes back to it, both crossing PCIe "
@@ -545,7 +546,9 @@ def main():
         return main_l12(args, mp3, dev, cdev, rank, world, distributed)
     cfg_id = args.config
     cfg = dict(CONFIGS[cfg_id])
-    default_size = not (args.streams or args.frames)
+    default_size = not (args.streams or args.frames or args.kbps)
+    if args.kbps:
+        cfg["kbps"] = args.kbps
     if args.streams:
         cfg["streams"] = args.streams
     if args.frames:
