@@ -52,6 +52,20 @@ MP3MI_DEVFN void fmt_put(unsigned *img, int pos, unsigned val, int n)
 // exclusive prefix sum over the wave; *total receives the wave sum
 MP3MI_DEVFN int fmt_scan(int v, int *total)
 {
+#if !defined(MP3MI_EMU)
+    // inclusive scan inside every row of 16 lanes by four shifts (a lane without a source adds 0), then the totals of row 0
+    // into row 1 and of row 2 into row 3 (row_bcast15), then lane 31's -- rows 0 + 1 -- into rows 2 and 3 (row_bcast31): six
+    // vector instructions, where six __shfl_up cost an LDS-pipe instruction, an address and a select each
+    int incl = v;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false); // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false); // row_bcast15 into rows 1 and 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false); // row_bcast31 into rows 2 and 3
+    *total = __builtin_amdgcn_readlane(incl, 63);
+    return incl - v;
+#else
     const int lane = wave_lane();
     int incl = v;
     for (int d = 1; d < 64; d <<= 1) {
@@ -60,6 +74,7 @@ MP3MI_DEVFN int fmt_scan(int v, int *total)
     }
     *total = __shfl(incl, 63);
     return incl - v;
+#endif
 }
 
 // code word(s) of one big-value pair (src/huffcode.h:16-139): code/cbits then ext/xbits
@@ -210,15 +225,26 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
                 if (n) fmt_put(L.words, pos + ofs, (unsigned) g->scalefac[lane], n);
                 pos += total;
             }
+            // Code words: EVERYTHING THAT COMES OUT OF MEMORY FIRST -- the pairs and quadruples of every step of the granule and the
+            // table entries they select (two dependent round trips a step) are independent of the bit positions, so all of the
+            // granule's (at most five + three) steps are asked for together; the positions -- a scan per step -- and the puts follow.
+            // (One step at a time, load - look up - scan - put, the kernel spent 77 % of its wavefronts' time waiting, and its
+            // 315 000 one-wavefront workgroups kept the transforms' and k_mdct's out of the CUs for 3.4 ms between two k_loop launches.)
             const int bigvalues = g->big_values * 2;
-            if (bigvalues) {
-                const int r1s = shortb ? 0 : L.sfb_l[g->region0_count + 1];
-                const int r2s = shortb ? 0 : L.sfb_l[g->region0_count + g->region1_count + 2];
-                const int npairs = shortb ? 288 : bigvalues / 2;
-                for (int base = 0; base < npairs; base += 64) {
-                    const int e = base + lane;
-                    unsigned code = 0, ext = 0;
-                    int cb = 0, xb = 0;
+            const int r1s = (shortb || !bigvalues) ? 0 : L.sfb_l[g->region0_count + 1];
+            const int r2s = (shortb || !bigvalues) ? 0 : L.sfb_l[g->region0_count + g->region1_count + 2];
+            // (a granule has 576 lines: at most 288 pairs -- five steps of 64 -- and 144 quadruples -- three)
+            const int npairs = bigvalues ? (shortb ? 288 : (bigvalues / 2 < 288 ? bigvalues / 2 : 288)) : 0;
+            const int nquad = g->count1 < 144 ? g->count1 : 144;
+            const int ts0 = g->table_select[0], ts1 = g->table_select[1], ts2 = g->table_select[2];
+            const int toff = T->ht_off[32 + g->count1table_select];
+            unsigned code[5], ext[5], qval[3];
+            int cb[5], xb[5], qnb[3];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                code[j] = 0; ext[j] = 0; cb[j] = 0; xb[j] = 0;
+                if (64 * j < npairs) {
+                    const int e = 64 * j + lane;
                     if (e < npairs) {
                         int x, y, t;
                         if (shortb) { // sfb -> window -> line order (src/l3bitstream.c:556-579)
@@ -228,28 +254,23 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
                             const int r = e - 3 * start / 2, w = r / half, line = start + 2 * (r - w * half);
                             x = ix[line * 3 + w];
                             y = ix[(line + 1) * 3 + w];
-                            t = (start < 12) ? g->table_select[0] : g->table_select[1];
+                            t = (start < 12) ? ts0 : ts1;
                         } else {
                             const int i = 2 * e;
                             x = ix[i];
                             y = ix[i + 1];
-                            t = (i < r1s) ? g->table_select[0] : (i < r2s ? g->table_select[1] : g->table_select[2]);
+                            t = (i < r1s) ? ts0 : (i < r2s ? ts1 : ts2);
                         }
-                        fmt_pair(T, t, x, y, &code, &cb, &ext, &xb);
+                        fmt_pair(T, t, x, y, &code[j], &cb[j], &ext[j], &xb[j]);
                     }
-                    const int ofs = fmt_scan(cb + xb, &total);
-                    if (cb) fmt_put(L.words, pos + ofs, code, cb);
-                    if (xb) fmt_put(L.words, pos + ofs + cb, ext, xb);
-                    pos += total;
                 }
             }
-            { // count1 quadruples (src/l3bitstream.c:727-767)
-                const int toff = T->ht_off[32 + g->count1table_select];
-                for (int base = 0; base < g->count1; base += 64) {
-                    const int qd = base + lane;
-                    unsigned val = 0;
-                    int nb = 0;
-                    if (qd < g->count1) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { // count1 quadruples (src/l3bitstream.c:727-767): at most 144
+                qval[j] = 0; qnb[j] = 0;
+                if (64 * j < nquad) {
+                    const int qd = 64 * j + lane;
+                    if (qd < nquad) {
                         const int i = bigvalues + 4 * qd;
                         int q[4];
                         unsigned sg[4];
@@ -258,13 +279,29 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
                             if (q[k] > 0) sg[k] = 0; else { q[k] = -q[k]; sg[k] = 1; }
                         }
                         const int p = q[0] + (q[1] << 1) + (q[2] << 2) + (q[3] << 3);
-                        val = T->ht_code[toff + p];
-                        nb = T->ht_len[toff + p];
+                        unsigned val = T->ht_code[toff + p];
+                        int nb = T->ht_len[toff + p];
                         for (int k = 0; k < 4; k++)
                             if (q[k]) { val = (val << 1) | sg[k]; nb += 1; }
+                        qval[j] = val;
+                        qnb[j] = nb;
                     }
-                    const int ofs = fmt_scan(nb, &total);
-                    if (nb) fmt_put(L.words, pos + ofs, val, nb);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                if (64 * j < npairs) {
+                    const int ofs = fmt_scan(cb[j] + xb[j], &total);
+                    if (cb[j]) fmt_put(L.words, pos + ofs, code[j], cb[j]);
+                    if (xb[j]) fmt_put(L.words, pos + ofs + cb[j], ext[j], xb[j]);
+                    pos += total;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (64 * j < nquad) {
+                    const int ofs = fmt_scan(qnb[j], &total);
+                    if (qnb[j]) fmt_put(L.words, pos + ofs, qval[j], qnb[j]);
                     pos += total;
                 }
             }
