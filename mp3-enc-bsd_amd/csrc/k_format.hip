@@ -20,6 +20,9 @@ struct fmt_lds {
     unsigned words[640];  // main data image, big-endian bit order inside each word
     unsigned si[12];      // header + side info image (<= 36 bytes)
     int sfb_l[23], sfb_s[14];
+    unsigned ht_meta[34]; // Huffman table t: first cell | ylen << 16 | linbits << 24 (a code word's cell then is ONE round trip away)
+    mp3mi_frame_side side; // the frame's side information: one coalesced read, then every field from here (the kernel reads some
+                           // sixty of them, one by one and in dependent steps: from memory that was a round trip each)
 };
 
 __device__ static const int FMT_SLEN1[16] = {0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
@@ -78,7 +81,7 @@ MP3MI_DEVFN int fmt_scan(int v, int *total)
 }
 
 // code word(s) of one big-value pair (src/huffcode.h:16-139): code/cbits then ext/xbits
-MP3MI_DEVFN void fmt_pair(const mp3mi_tables *T, int t, int x, int y, unsigned *code, int *cbits,
+MP3MI_DEVFN void fmt_pair(const mp3mi_tables *T, const unsigned *ht_meta, int t, int x, int y, unsigned *code, int *cbits,
                           unsigned *ext, int *xbits)
 {
     *code = 0; *cbits = 0; *ext = 0; *xbits = 0;
@@ -86,14 +89,15 @@ MP3MI_DEVFN void fmt_pair(const mp3mi_tables *T, int t, int x, int y, unsigned *
     unsigned signx = 0, signy = 0;
     if (x < 0) { x = -x; signx = 1; }
     if (y < 0) { y = -y; signy = 1; }
-    const int ylen = T->ht_ylen[t], linbits = T->ht_linbits[t];
+    const unsigned meta = ht_meta[t];
+    const int ylen = (int) ((meta >> 16) & 255u), linbits = (int) (meta >> 24), toff = (int) (meta & 0xffffu);
     if (t > 15) {
         unsigned lx = 0, ly = 0, e = 0;
         int xb = 0;
         const int x0 = x, y0 = y;
         if (x > 14) { lx = (unsigned) (x - 15); x = 15; }
         if (y > 14) { ly = (unsigned) (y - 15); y = 15; }
-        const int idx = T->ht_off[t] + x * ylen + y;
+        const int idx = toff + x * ylen + y;
         *code = T->ht_code[idx];
         *cbits = T->ht_len[idx];
         if (x0 > 14) { e |= lx; xb += linbits; }
@@ -103,7 +107,7 @@ MP3MI_DEVFN void fmt_pair(const mp3mi_tables *T, int t, int x, int y, unsigned *
         *ext = e;
         *xbits = xb;
     } else {
-        const int idx = T->ht_off[t] + x * ylen + y;
+        const int idx = toff + x * ylen + y;
         unsigned c = T->ht_code[idx];
         int cb = T->ht_len[idx];
         if (x != 0) { c = (c << 1) | signx; cb += 1; }
@@ -147,7 +151,21 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
         if (n_frames_s == 0 && n_call == 0 && geo.whole_file && wave_lane() == 0) out_len[s] = 0; // no samples, no file body
         return;
     }
-    const mp3mi_frame_side *sd = &side_all[(size_t) s * geo.nf + fl];
+    {
+        const int32_t *src = (const int32_t *) &side_all[(size_t) s * geo.nf + fl];
+        for (int i = lane; i < (int) (sizeof(mp3mi_frame_side) / 4); i += 64) ((int32_t *) &L.side)[i] = src[i];
+    }
+    const mp3mi_frame_side *sd = &L.side; // (valid behind the barrier below)
+    // ... and the frame's quantised values as pairs, a word a lane and step, for all four (granule, channel) records at once:
+    // where they are does not depend on the side information, so they travel together with it (pair e = lines 2 e, 2 e + 1)
+    unsigned pw[4][5];
+#pragma unroll
+    for (int gc = 0; gc < 4; gc++) {
+        const size_t rec = ((size_t) s * G + (2 * fl + (gc >= C ? 1 : 0))) * C + (gc >= C ? gc - C : gc);
+        const unsigned *ixw = (const unsigned *) (ix_all + rec * 576);
+#pragma unroll
+        for (int j = 0; j < 5; j++) pw[gc][j] = (gc < 2 * C && 64 * j + lane < 288) ? ixw[64 * j + lane] : 0u;
+    }
     const int frame_bytes = bits_per_frame[s] / 8;
     const int crc_bits = geo.crc ? 16 : 0; // the reference's CRC word for Layer III is always 0 (src/l3bitstream.c:312, 338-342)
     const int si_bytes = (32 + crc_bits + (C == 2 ? 256 : 136)) / 8;
@@ -159,6 +177,7 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
     if (lane < 12) L.si[lane] = 0;
     if (lane < 23) L.sfb_l[lane] = T->sfb_l[lane];
     if (lane < 14) L.sfb_s[lane] = T->sfb_s[lane];
+    if (lane < 34) L.ht_meta[lane] = (unsigned) T->ht_off[lane] | ((unsigned) T->ht_ylen[lane] << 16) | ((unsigned) T->ht_linbits[lane] << 24);
     __syncthreads();
 
     // ---- header and side information (src/l3bitstream.c:314-458) ----
@@ -206,8 +225,10 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
 
     // ---- main data (src/l3bitstream.c:174-310, 516-716) ----
     int gpos = 0; // bit position of the current granule-channel in the image
-    for (int gr = 0; gr < 2; gr++)
-        for (int ch = 0; ch < C; ch++) {
+#pragma unroll
+    for (int gc = 0; gc < 4; gc++) {
+        if (gc < 2 * C) {
+            const int gr = gc >= C ? 1 : 0, ch = gc >= C ? gc - C : gc;
             const mp3mi_gr_side *g = &sd->gr[gr][ch];
             const size_t rec = ((size_t) s * G + (2 * fl + gr)) * C + ch;
             const int16_t *ix = ix_all + rec * 576;
@@ -237,7 +258,7 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
             const int npairs = bigvalues ? (shortb ? 288 : (bigvalues / 2 < 288 ? bigvalues / 2 : 288)) : 0;
             const int nquad = g->count1 < 144 ? g->count1 : 144;
             const int ts0 = g->table_select[0], ts1 = g->table_select[1], ts2 = g->table_select[2];
-            const int toff = T->ht_off[32 + g->count1table_select];
+            const int toff = (int) (L.ht_meta[32 + g->count1table_select] & 0xffffu);
             unsigned code[5], ext[5], qval[3];
             int cb[5], xb[5], qnb[3];
 #pragma unroll
@@ -257,11 +278,11 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
                             t = (start < 12) ? ts0 : ts1;
                         } else {
                             const int i = 2 * e;
-                            x = ix[i];
-                            y = ix[i + 1];
+                            x = (int) (int16_t) (pw[gc][j] & 0xffffu);
+                            y = (int) (int16_t) (pw[gc][j] >> 16);
                             t = (i < r1s) ? ts0 : (i < r2s ? ts1 : ts2);
                         }
-                        fmt_pair(T, t, x, y, &code[j], &cb[j], &ext[j], &xb[j]);
+                        fmt_pair(T, L.ht_meta, t, x, y, &code[j], &cb[j], &ext[j], &xb[j]);
                     }
                 }
             }
@@ -314,6 +335,7 @@ MP3MI_DEVFN void fmt_frame(fmt_lds &L, FMT_KERNEL_ARGS)
                 gpos = endpos;
             }
         }
+    }
     gpos += sd->resvDrain; // zeros (src/l3bitstream.c:492-509)
     __syncthreads();
 
