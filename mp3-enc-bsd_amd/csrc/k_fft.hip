@@ -40,8 +40,8 @@ __device__ unsigned long long g_fft_prof[8];
 // butterfly fetches and stores both channels of an operand with one 8-byte LDS access.  The three short
 // transforms are one program over elements [256 sb, 256 sb + 256) and reuse the space once the long
 // spectrum is consumed; elements 1024 + lane are what idle lanes work on.
-template <int C> struct fft_wave_lds {
-    float x[C * (MP3MI_FFT_DUMMY + 64)];
+template <int C, bool LONG> struct fft_wave_lds {
+    float x[C * ((LONG ? MP3MI_FFT_DUMMY : MP3MI_FFT_DUMMY_S) + 64)];
 };
 // fft_vec<C>: the C channels of one element.  For two channels a native 2-vector, so that the channel pair
 // of an operand is one 8-byte LDS access and one packed instruction (v_pk_add_f32 / v_pk_mul_f32: the same
@@ -73,10 +73,30 @@ template <> struct fft_vec<2> {
     FFT_MEMFN float get(V v, int c) { return v[c]; }
     FFT_MEMFN void set(V &v, int c, float f) { v[c] = f; }
 };
-template <int C, int W, int PW> struct fft_lds { // PW: capacity of the program in words
+// a workgroup's LDS: the program, the rotation rows of the register rounds and the read-out table -- everything a task
+// looks up per lane, one LDS round trip away instead of one to the L2 -- and the W wavefronts' arrays
+template <int C, int W, bool LONG> struct fft_lds {
+    static constexpr int PW = LONG ? MP3MI_FFT_PROG_WORDS : MP3MI_FFT_PROG_WORDS_S;  // capacity of the program in words
+    static constexpr int ROWS = LONG ? MP3MI_FFT_REG_ROWS_L : 1, NRD = LONG ? MP3MI_HBLK : MP3MI_HBLK_S;
     uint32_t prog[PW] __attribute__((aligned(16)));
-    fft_wave_lds<C> w[W];
+    uint4 regtw[ROWS * 64];
+    uint32_t rd[(NRD + 63) / 64 * 64];
+    float win[LONG ? 1024 : 256];
+    fft_wave_lds<C, LONG> w[W];
 };
+// the workgroup's copy of the tables (all its wavefronts; a barrier follows)
+template <int C, int W, bool LONG> MP3MI_DEVFN void fft_lds_fill(fft_lds<C, W, LONG> &LL, const mp3mi_tables *__restrict__ T, int tid)
+{
+    const int nw4 = (LONG ? T->fft_nword_l : T->fft_nword_s) / 4;
+    const uint4 *src = (const uint4 *) (LONG ? T->fft_prog_l : T->fft_prog_s);
+    for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = src[i];
+    const uint4 *rsrc = (const uint4 *) (LONG ? T->fft_regtw_l : T->fft_regtw_s);
+    for (int i = tid; i < fft_lds<C, W, LONG>::ROWS * 64; i += 64 * W) LL.regtw[i] = rsrc[i];
+    const uint32_t *dsrc = LONG ? T->fft_rd_l : T->fft_rd_s;
+    for (int i = tid; i < fft_lds<C, W, LONG>::NRD; i += 64 * W) LL.rd[i] = dsrc[i];
+    const float *wsrc = LONG ? T->window : T->window_s;
+    for (int i = tid; i < (LONG ? 1024 : 256); i += 64 * W) LL.win[i] = wsrc[i];
+}
 
 // Operand of a record word: LDS element position in its low (hi = 0) or high half.  xw = the workgroup's
 // arrays as bytes, woff = byte offset of this wavefront's array: position * element size + woff is ONE
@@ -163,7 +183,8 @@ template <int C, int H> struct fft_round {
         for (int k = 0; k < N; k++) v[k] = *p[k];
     }
 
-    MP3MI_DEVFN_M void finish()
+    // the arithmetic: the operands in v[] become the results that take their places
+    MP3MI_DEVFN_M void compute()
     {
         const uint32_t flags = tw1.w;
         if (N == 4) { // steps 1-4 of rsrec for one n (src/subs.c:465-498), or two length-2 butterflies
@@ -172,7 +193,7 @@ template <int C, int H> struct fft_round {
             V u1 = a - b;
             V u2 = F::flip(c - d, flags & 0x80000000u); // src/subs.c:475-479
             fft_twiddle<C, ROT, SQ>(u1, u2, flags, false, tw1.x, tw1.y, tw1.z);
-            *p[0] = oa; *p[1] = u1; *p[2] = oc; *p[3] = u2;
+            v[0] = oa; v[1] = u1; v[2] = oc; v[3] = u2;
         } else { // steps 1-4 of srrec for one n
             const V ar0 = v[0], ar1 = v[1], br0 = v[2], br1 = v[3], ai0 = v[4 % N], ai1 = v[5 % N], bi0 = v[6 % N], bi1 = v[7 % N];
             // step 1 (src/subs.c:288-298)
@@ -183,10 +204,75 @@ template <int C, int H> struct fft_round {
             // steps 3 and 4 (src/subs.c:327-342)
             fft_twiddle<C, ROT, SQ>(r1, i1, flags, false, tw1.x, tw1.y, tw1.z);
             fft_twiddle<C, ROT, SQ>(r2, i2, flags, true, tw3.x, tw3.y, tw3.z);
-            *p[0] = o0; *p[1] = r1; *p[2] = o2; *p[3] = r2; *p[4 % N] = o4; *p[5 % N] = i1; *p[6 % N] = o6; *p[7 % N] = i2;
+            v[0] = o0; v[1] = r1; v[2] = o2; v[3] = r2; v[4 % N] = o4; v[5 % N] = i1; v[6 % N] = o6; v[7 % N] = i2;
         }
     }
+
+    MP3MI_DEVFN_M void finish()
+    {
+        compute();
+#pragma unroll
+        for (int k = 0; k < N; k++) *p[k] = v[k];
+    }
 };
+
+// The blocks of 256 points and more IN REGISTERS.  With element e of a transform in register e / 64 of lane e % 64 (which
+// is how the windowed samples arrive), the four or eight operands of a butterfly of a block of m >= 256 points -- m / 2
+// and m / 4 apart -- are registers of one lane: R(1024), R(512), C(256) and R(256) of the long transform, R(256) of each
+// short one run here, before the data ever reaches LDS -- a third of all operand traffic, 8 of the long program's 24
+// rounds and 3 of the short one's 16, with their address words, and two dependent LDS round trips each.  The same
+// arithmetic as a round of the program (fft_round::compute); what a lane needs beside its registers is its row of rotations
+// (tables_host.cpp, FftGen::reg_row), 16 bytes a butterfly from T->fft_regtw_*.
+template <int C, int H> MP3MI_DEVFN void fft_reg4(typename fft_vec<C>::V &a, typename fft_vec<C>::V &b, typename fft_vec<C>::V &c,
+                                                  typename fft_vec<C>::V &d, const uint4 tw)
+{
+    fft_round<C, H & 6> r; // (a, b, c, d) = x[n], x[n + m/2], x[n + m/4], x[n + 3m/4]
+    r.v[0] = a; r.v[1] = b; r.v[2] = c; r.v[3] = d;
+    r.tw1 = tw;
+    r.compute();
+    a = r.v[0]; b = r.v[1]; c = r.v[2]; d = r.v[3];
+}
+// The windowed samples of the long transform, x[k] = element 64 k + lane, and the register rounds on them; rt = the
+// workgroup's copy of T->fft_regtw_l, at this lane.
+template <int C> MP3MI_DEVFN void fft_reg_long(typename fft_vec<C>::V (&x)[16], const uint32_t (&smp)[16], const float *window,
+                                               const uint4 *rt, int lane)
+{
+    typedef fft_vec<C> F;
+    uint4 tw[MP3MI_FFT_REG_ROWS_L];
+    {
+        float wl[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) wl[k] = window[lane + 64 * k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                F::set(x[k], c, wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16))); // src/l3psy.c:485, src/psy.c:264
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MP3MI_FFT_REG_ROWS_L; r++) tw[r] = rt[64 * r];
+    // R(1024): n = lane + 64 j; lane 0 of j = 2 is n = m / 8, the SQHALF rotation
+    fft_reg4<C, 2>(x[0], x[8], x[4], x[12], tw[0]);
+    fft_reg4<C, 2>(x[1], x[9], x[5], x[13], tw[1]);
+    fft_reg4<C, 6>(x[2], x[10], x[6], x[14], tw[2]);
+    fft_reg4<C, 2>(x[3], x[11], x[7], x[15], tw[3]);
+    // R(512) on elements 0..511 (n = m / 8 = 64: lane 0 of j = 1)
+    fft_reg4<C, 2>(x[0], x[4], x[2], x[6], tw[4]);
+    fft_reg4<C, 6>(x[1], x[5], x[3], x[7], tw[5]);
+    // C(256): xr = elements 512..767, xi = 768..1023, n = lane (n = m / 8 = 32)
+    {
+        fft_round<C, 7> r;
+        r.v[0] = x[8]; r.v[1] = x[10]; r.v[2] = x[9]; r.v[3] = x[11];
+        r.v[4] = x[12]; r.v[5] = x[14]; r.v[6] = x[13]; r.v[7] = x[15];
+        r.tw1 = tw[6]; r.tw3 = tw[7];
+        r.compute();
+        x[8] = r.v[0]; x[10] = r.v[1]; x[9] = r.v[2]; x[11] = r.v[3];
+        x[12] = r.v[4]; x[14] = r.v[5]; x[13] = r.v[6]; x[15] = r.v[7];
+    }
+    // R(256) on elements 0..255
+    fft_reg4<C, 6>(x[0], x[2], x[1], x[3], tw[8]);
+}
 
 // The sequence of rounds is a compile-time constant (MP3MI_FFT_HDRS_*, checked against the generator at
 // table build): the program runs as straight-line code, every block a constant offset from the lane's
@@ -293,68 +379,78 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
                                                 const int16_t *__restrict__ pcm_all, float *__restrict__ energy_l,
                                                 float *__restrict__ energy_s, float *__restrict__ bins)
 {
-    __shared__ fft_lds<C, W, LONG ? MP3MI_FFT_PROG_WORDS : MP3MI_FFT_PROG_WORDS_S> LL;
+    typedef fft_vec<C> F;
+    __shared__ fft_lds<C, W, LONG> LL;
     const int lane = wave_lane(), tid = (int) threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform, and known to be
-    fft_wave_lds<C> &L = LL.w[wv];
+    fft_wave_lds<C, LONG> &L = LL.w[wv];
     const int G = geo.n_gran, n_task = geo.n_streams * G;
     const long n_pitch = (long) geo.n_frames * 1152; // row pitch of the PCM buffer
     const int lane_swz = MP3MI_FFT_SWZ(lane);
+    constexpr int NS = LONG ? 16 : 8; // words of samples a lane holds per task
     PROF_DECL;
-    {
-        const int nw4 = (LONG ? T->fft_nword_l : T->fft_nword_s) / 4;
-        const uint4 *src = (const uint4 *) (LONG ? T->fft_prog_l : T->fft_prog_s);
-        for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = src[i];
-    }
-    __syncthreads();
-    PROF(0);
+    fft_lds_fill<C, W, LONG>(LL, T, tid);
 
-    for (int batch = (int) blockIdx.x; batch * W < n_task; batch += (int) gridDim.x) {
-        int task = batch * W + wv;
-        const bool valid = task < n_task; // the last batch may have idle wavefronts: they compute, but do not store
-        task = valid ? task : n_task - 1;
+    // A task's samples: the 1024-sample window from savebuf[0] on (src/l3psy.c:477-485), or -- the short windows are samples
+    // 256 + 128 sb + jj, sb < 3 (src/l3psy.c:520-523) -- the 512 samples from savebuf[256] on.  They are asked for a task
+    // AHEAD, in front of the read-out of the task before: what a wavefront waited for at the top of every task was this trip
+    // to memory (a seventh of its time), and behind the program the registers to hold sixteen words are there.
+    auto task_of = [&](int batch) { const int t = batch * W + wv; return t < n_task ? t : n_task - 1; };
+    auto load_task = [&](int task, uint32_t (&smp)[NS]) {
         const int gl = task % G, s = task / G;
-        const size_t rec0 = ((size_t) s * G + gl) * C;
-        const long gabs = (long) geo.g0 + gl;
         const long n_per_ch = geo.n_samples ? (long) geo.n_samples[s] : n_pitch; // valid samples: the rest reads as zero (src/encode.c:162-166)
         const int16_t *pcm = pcm_all + (size_t) s * (size_t) n_pitch * (size_t) C;
         const int16_t *hist = geo.hist ? geo.hist + (size_t) s * MP3MI_PCM_HIST * (size_t) C : NULL;
-        const long t0 = 576 * gabs - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
+        const long t0 = 576 * ((long) geo.g0 + gl) - 768; // time of savebuf[0]  (src/l3psy.c:477-481)
+        fft_load_pcm<C, NS>(pcm, hist, LONG ? t0 : t0 + 256, n_per_ch, lane, smp);
+    };
+    uint32_t smp[NS];
+    if ((int) blockIdx.x * W < n_task) load_task(task_of((int) blockIdx.x), smp);
+    __syncthreads();
+    PROF(LONG ? 0 : 4);
 
-        if (LONG) {
-            // the 1024-sample window of all channels: every load is issued before the first use
+    for (int batch = (int) blockIdx.x; batch * W < n_task; batch += (int) gridDim.x) {
+        const bool valid = batch * W + wv < n_task; // the last batch may have idle wavefronts: they compute, but do not store
+        const int task = task_of(batch);
+        const int gl = task % G, s = task / G;
+        const size_t rec0 = ((size_t) s * G + gl) * C;
+        const int next = batch + (int) gridDim.x;
+        const bool more = next * W < n_task; // (workgroup-uniform)
+
+        if constexpr (LONG) {
             {
-                float wl[16];
-                uint32_t smp[16];
-                fft_load_pcm<C, 16>(pcm, hist, t0, n_per_ch, lane, smp);
+                typename F::V x[16];
+                fft_reg_long<C>(x, smp, LL.win, LL.regtw + lane, lane);
 #pragma unroll
-                for (int k = 0; k < 16; k++) wl[k] = T->window[lane + 64 * k];
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    fft_pair<C> v;
-#pragma unroll
-                    for (int c = 0; c < C; c++)
-                        v.c[c] = wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16)); // src/l3psy.c:485
-                    *(fft_pair<C> *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(64 * k)) * C) = v; // == SWZ(lane + 64 k): the map is linear
-                }
+                for (int k = 0; k < 16; k++)
+                    *(typename F::V *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(64 * k)) * C) = x[k]; // == SWZ(lane + 64 k): the map is linear
             }
             wave_sync();
             PROF(1);
-            fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
+            fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, true>)), LL.prog, lane);
             PROF(2);
+            if (more) load_task(task_of(next), smp);
+            // energies of the 513 lines: the read-out words of all nine steps first, then the spectrum, then the stores
             float *el0 = energy_l + rec0 * MP3MI_HBLK_P;
-#pragma unroll 3
-            for (int i = lane; i < MP3MI_HBLK; i += 64) {
-                const fft_pair<C> e = fft_energy<C>(L.x, T->fft_rd_l[i], i == 0 || i == 512);
-                if (valid) {
+            uint32_t rdw[9];
 #pragma unroll
-                    for (int c = 0; c < C; c++) el0[c * MP3MI_HBLK_P + i] = e.c[c];
+            for (int k = 0; k < 9; k++) rdw[k] = LL.rd[lane + 64 * k < MP3MI_HBLK ? lane + 64 * k : 0];
+            fft_pair<C> e[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) e[k] = fft_energy<C>(L.x, rdw[k], lane + 64 * k == 0 || lane + 64 * k == 512);
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    if (k < 8 || lane == 0) {
+#pragma unroll
+                        for (int c = 0; c < C; c++) el0[c * MP3MI_HBLK_P + lane + 64 * k] = e[k].c[c];
+                    }
                 }
             }
             // raw bins 0..5 for k_cw: re, im (bin 0 is real: im = -0 makes atan2(-im, re) the reference's atan2(0.0, x[0]))
             if (lane < 6 && valid) {
                 fft_pair<C> re, im;
-                fft_bin<C>(L.x, T->fft_rd_l[lane], &re, &im);
+                fft_bin<C>(L.x, rdw[0], &re, &im);
 #pragma unroll
                 for (int c = 0; c < C; c++) {
                     bins[(rec0 + c) * MP3MI_FFT_BINS + 300 + lane] = re.c[c];
@@ -364,37 +460,40 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             wave_sync(); // the spectrum is dead: the next task's samples take its place
             PROF(3);
         } else {
-            // short windows: samples 256 + 128 sb + jj, sb < 3 (src/l3psy.c:520-523); the second half of every
-            // window is also the first half of the next.  Sample 256 + lane + 64 k: sb = k >> 1, jj = lane + 64 (k & 1).
-            uint32_t smp[8];
-            float wsv[4];
-            fft_load_pcm<C, 8>(pcm, hist, t0 + 256, n_per_ch, lane, smp);
+            // Element 64 q + lane of window sb is sample 64 (2 sb + q) + lane (the second half of every window is also the
+            // first half of the next): four registers a window, and R(256) of each window -- one rotation row for the
+            // three -- runs on them before they go to LDS (fft_reg4).
+            {
+                float wsv[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) wsv[k] = T->window_s[lane + 64 * k];
+                for (int k = 0; k < 4; k++) wsv[k] = LL.win[lane + 64 * k];
+                const uint4 rtw = LL.regtw[lane];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int sb = k >> 1, jj = lane + 64 * (k & 1);
-                fft_pair<C> v0, v1;
+                for (int sb = 0; sb < 3; sb++) {
+                    typename F::V x[4];
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const float v = (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16));
-                    v0.c[c] = wsv[k & 1] * v;
-                    v1.c[c] = wsv[2 + (k & 1)] * v;
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t w = smp[2 * sb + q];
+#pragma unroll
+                        for (int c = 0; c < C; c++) F::set(x[q], c, wsv[q] * (float) (int) (int16_t) (c == 0 ? (w & 0xffffu) : (w >> 16)));
+                    }
+                    fft_reg4<C, 6>(x[0], x[2], x[1], x[3], rtw);
+                    // (element sb * 256 + 64 q + lane of the 768-element array of the three windows; the map is linear)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) *(typename F::V *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(sb * 256 + 64 * q)) * C) = x[q];
                 }
-                // (element sb * 256 + jj of the 768-element array of the three windows; the map is linear)
-                if (sb < 3) *(fft_pair<C> *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(sb * 256 + 64 * (k & 1))) * C) = v0;
-                if (sb >= 1) *(fft_pair<C> *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ((sb - 1) * 256 + 128 + 64 * (k & 1))) * C) = v1;
             }
             wave_sync();
-            PROF(1);
-            fft_run<C, false, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
-            PROF(2);
+            PROF(5);
+            fft_run<C, false, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, false>)), LL.prog, lane);
+            PROF(6);
+            if (more) load_task(task_of(next), smp);
             // energies of the three short spectra (bin k of window sb, both channels per LDS read) and the raw
             // short lines 2..51 for k_cw (src/l3psy.c:531-549 reads these only); plain nested loops, no div/mod
             uint32_t rds[3];
 #pragma unroll
-            for (int t = 0; t < 3; t++) rds[t] = T->fft_rd_s[lane + 64 * t < MP3MI_HBLK_S ? lane + 64 * t : 0];
-            const uint32_t rdb = T->fft_rd_s[lane < 50 ? 2 + lane : 0];
+            for (int t = 0; t < 3; t++) rds[t] = LL.rd[lane + 64 * t < MP3MI_HBLK_S ? lane + 64 * t : 0];
+            const uint32_t rdb = LL.rd[lane < 50 ? 2 + lane : 0];
 #pragma unroll
             for (int sb = 0; sb < 3; sb++) {
                 float *es0 = energy_s + rec0 * (3 * MP3MI_HBLK_S) + sb * MP3MI_HBLK_S;
@@ -424,7 +523,7 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
                 }
             }
             wave_sync(); // the spectra are dead: the next task's samples take their place
-            PROF(3);
+            PROF(7);
         }
     }
     PROF_END;
@@ -559,19 +658,15 @@ template <int C, int W>
 __global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict__ T, l12_geom geo,
                                                   const int16_t *__restrict__ pcm_all, float *__restrict__ erp)
 {
-    __shared__ fft_lds<C, W, MP3MI_FFT_PROG_WORDS> LL;
+    __shared__ fft_lds<C, W, true> LL;
     const int lane = wave_lane(), tid = (int) threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    fft_wave_lds<C> &L = LL.w[wv];
+    fft_wave_lds<C, true> &L = LL.w[wv];
     const int NP = geo.np, n_task = geo.n_streams * NP;
     const long n_pitch = (long) geo.n_frames * geo.spf;
     const int lane_swz = MP3MI_FFT_SWZ(lane);
     const bool force_exact = (geo.test_flags >> 1) & 1;
-    {
-        const int nw4 = T->fft_nword_l / 4;
-        const uint4 *src = (const uint4 *) T->fft_prog_l;
-        for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = src[i];
-    }
+    fft_lds_fill<C, W, true>(LL, T, tid);
     __syncthreads();
     for (int batch = (int) blockIdx.x; batch * W < n_task; batch += (int) gridDim.x) {
         int task = batch * W + wv;
@@ -586,22 +681,16 @@ __global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict
         const long t0 = (long) geo.spp * (qr + 1) - geo.span; // time of savebuf[0], from the call's first sample  (src/psy.c:258-262)
         const int16_t *hist = geo.hist ? geo.hist + (size_t) s * L12_PCM_HIST * (size_t) C : NULL;
         {
-            float wl[16];
+            typedef fft_vec<C> F;
             uint32_t smp[16];
+            typename F::V x[16];
             fft_load_pcm<C, 16>(pcm, hist, t0, n_per_ch, lane, smp, L12_PCM_HIST);
+            fft_reg_long<C>(x, smp, LL.win, LL.regtw + lane, lane); // windowing (src/psy.c:264) + the blocks of 256 points and more
 #pragma unroll
-            for (int k = 0; k < 16; k++) wl[k] = T->window[lane + 64 * k];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                fft_pair<C> v;
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    v.c[c] = wl[k] * (float) (int) (int16_t) (c == 0 ? (smp[k] & 0xffffu) : (smp[k] >> 16)); // src/psy.c:264
-                *(fft_pair<C> *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(64 * k)) * C) = v;
-            }
+            for (int k = 0; k < 16; k++) *(typename F::V *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(64 * k)) * C) = x[k];
         }
         wave_sync();
-        fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C>)), LL.prog, lane);
+        fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, true>)), LL.prog, lane);
         // energy, magnitude and phase of every line straight from the spectrum in LDS (src/subs.c:53-123, src/psy.c:285-286):
         // erp[rec] = {energy, r = (float) sqrt((double) energy), phi}, rows of L12_ROW floats.  The transform is bound by
         // the LDS pipe and leaves the vector pipe idle more than half of the time: the phases' double-precision chain runs
@@ -612,7 +701,7 @@ __global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict
             const int i = lane + 64 * k;
             const bool on = i < L12_HBLK; // (k = 8: line 512 only)
             fft_pair<C> re, im;
-            fft_bin<C>(L.x, T->fft_rd_l[on ? i : 0], &re, &im);
+            fft_bin<C>(L.x, LL.rd[on ? i : 0], &re, &im);
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 const bool real = i == 0 || i == 512;
@@ -675,7 +764,7 @@ void mp3mi_launch_fft(const mp3mi_tables *T, const mp3mi_geom &g, const int16_t 
     const int n_cu = mp3mi_current_cu_count();
     if (!(which & 1)) {
     } else if (g.channels == 2) {
-        const int W = 12, WS = 15, nb = (n_task + W - 1) / W, nbs = (n_task + WS - 1) / WS;
+        const int W = 12, WS = 16, nb = (n_task + W - 1) / W, nbs = (n_task + WS - 1) / WS;
         hipLaunchKernelGGL((k_fft<2, W, true>), dim3((unsigned) (nb < n_cu ? nb : n_cu)), dim3(64 * W), 0, st, T, g, pcm, energy_l, energy_s, bins);
         hipLaunchKernelGGL((k_fft<2, WS, false>), dim3((unsigned) (nbs < n_cu ? nbs : n_cu)), dim3(64 * WS), 0, st, T, g, pcm, energy_l, energy_s, bins);
     } else {

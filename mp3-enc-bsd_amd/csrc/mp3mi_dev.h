@@ -50,14 +50,16 @@ static inline int mp3mi_fft_swz_rt(int p)
 #endif
 /* FFT butterfly programs (tables_host.cpp): rounds of 64 fused butterflies, one per lane */
 #define MP3MI_FFT_DUMMY 1024      /* elements 1024 + lane: what the idle lanes of a round work on */
+#define MP3MI_FFT_DUMMY_S 768     /* the same behind the three 256-point transforms */
 #define MP3MI_FFT_MAX_ROUNDS 48
-#define MP3MI_FFT_PROG_WORDS 12288 /* capacity of the long program in 32-bit words; checked at table build */
-#define MP3MI_FFT_PROG_WORDS_S 8192 /* capacity of the short program */
+#define MP3MI_FFT_REG_ROWS_L 9    /* rows of fft_regtw_l */
+#define MP3MI_FFT_PROG_WORDS 7168 /* capacity of the long program in 32-bit words; checked at table build */
+#define MP3MI_FFT_PROG_WORDS_S 5504 /* capacity of the short program */
 /* the header words of the rounds of the long and of the short program (fft_hdr_* below): k_fft is compiled
    for exactly these sequences -- straight-line code, no per-round dispatch -- and table build checks that the
    generator still produces them (MP3MI_FFT_INFO=1 prints the lists) */
-#define MP3MI_FFT_HDRS_L 2, 2, 2, 14, 2, 6, 15, 6, 15, 6, 15, 6, 15, 6, 15, 6, 15, 4, 1, 13, 0, 9, 0, 8
-#define MP3MI_FFT_HDRS_S 2, 2, 14, 2, 14, 6, 15, 6, 15, 6, 15, 4, 13, 0, 9, 8
+#define MP3MI_FFT_HDRS_L 15, 6, 15, 6, 15, 6, 15, 6, 15, 4, 1, 13, 0, 9, 0, 8
+#define MP3MI_FFT_HDRS_S 2, 14, 6, 15, 6, 15, 6, 15, 4, 13, 0, 9, 8
 #define MP3MI_PCM_HIST 1056   /* samples per channel a call needs from before its first sample: the filterbank of the granule
                                  before the call (k_filter recomputes it: 576 + 480 taps); the FFT window reaches back 768 */
 #define MP3MI_POW43_N 8208
@@ -127,6 +129,9 @@ typedef struct {
     uint32_t fft_hdr_l[MP3MI_FFT_MAX_ROUNDS], fft_hdr_s[MP3MI_FFT_MAX_ROUNDS];
     uint32_t fft_prog_l[MP3MI_FFT_PROG_WORDS] __attribute__((aligned(16))), fft_prog_s[MP3MI_FFT_PROG_WORDS_S] __attribute__((aligned(16)));
     uint32_t fft_rd_l[MP3MI_HBLK], fft_rd_s[MP3MI_HBLK_S];
+    /* the rotations of the butterflies k_fft runs in registers, before the program: [row][lane] {cn, spcn, smcn, flags}
+       (tables_host.cpp, FftGen::build) */
+    uint32_t fft_regtw_l[MP3MI_FFT_REG_ROWS_L * 256] __attribute__((aligned(16))), fft_regtw_s[256] __attribute__((aligned(16)));
     /* filterbank + MDCT */
     double enwindow[512];
     double filt[32][32];             /* the 31 used columns per subband: 0..15, 33..47  */

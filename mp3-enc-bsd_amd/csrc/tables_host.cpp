@@ -163,6 +163,7 @@ Twiddle make_twiddle(int logm, bool three)
  * kind: 0 none, 1 twiddle rotation, 2 SQHALF rotation. */
 struct FusedOp {
     int cls, kind, neg;
+    int logm; /* the block it belongs to has 2^logm points (k_fft.hip runs the blocks of 256 points and more in registers) */
     int id; /* window * (butterflies of the rank) + index within the rank: names the butterfly in a stored placement */
     unsigned p[8];
     float tw[6];
@@ -194,6 +195,7 @@ struct FftGen {
         memset(&o, 0, sizeof(o));
         if (logm == 1) {
             o.cls = 0;
+            o.logm = 1;
             o.p[0] = xr; o.p[1] = xr + 1; o.p[2] = xi; o.p[3] = xi + 1;
             add(rank, o);
             return;
@@ -203,6 +205,7 @@ struct FftGen {
         for (int n = 0, e = 0; n < m4; n++) {
             memset(&o, 0, sizeof(o));
             o.cls = 1;
+            o.logm = logm;
             o.p[0] = xr + n; o.p[1] = xr + n + m2; o.p[2] = xr + n + m4; o.p[3] = xr + n + m4 + m2;
             o.p[4] = xi + n; o.p[5] = xi + n + m2; o.p[6] = xi + n + m4; o.p[7] = xi + n + m4 + m2;
             if (n == 0) o.kind = 0;
@@ -226,6 +229,7 @@ struct FftGen {
         memset(&o, 0, sizeof(o));
         if (logm == 1) {
             o.cls = 0;
+            o.logm = 1;
             o.p[0] = o0; o.p[1] = o0 + 1; o.p[2] = dummy; o.p[3] = dummy;
             add(rank, o);
             return;
@@ -235,6 +239,7 @@ struct FftGen {
         for (int n = 0, e = 0; n < m4; n++) {
             memset(&o, 0, sizeof(o));
             o.cls = 0;
+            o.logm = logm;
             o.neg = 1; /* step 2, src/subs.c:475-479 */
             o.p[0] = o0 + n; o.p[1] = o0 + n + m2; o.p[2] = o0 + n + m4; o.p[3] = o0 + n + m4 + m2;
             if (n == 0) o.kind = 0;
@@ -274,13 +279,53 @@ struct FftGen {
     }
 
     /* nwin transforms of 2^logN points at element offsets w << logN; returns the number of program words */
-    int build(int logN, int nwin, uint32_t *hdr, int max_rounds, int32_t *n_rounds, uint32_t *prog, int max_words, uint32_t *rd)
+    /* The butterflies of the blocks of 256 points and more -- R(1024), R(512), C(256), R(256) of the long transform, R(256) of
+       each short one -- are not part of the program: with element e of a transform in register e / 64 of lane e % 64 all their
+       operands are registers of ONE lane (m / 4 >= 64), and k_fft.hip runs them there before the data ever reaches LDS.
+       What a lane needs for them is regtw[r][lane] = {cn, spcn, smcn, flags} (a second row {c3n, spc3n, smc3n, 0} for C(256)):
+       long: r = 0..3 R(1024) n = lane + 64 r; 4, 5 R(512) n = lane + 64 (r - 4); 6, 7 C(256) n = lane; 8 R(256) n = lane;
+       short: r = 0 R(256) n = lane, the same for the three windows. */
+    static bool in_registers(const FusedOp &o) { return o.logm >= 8; }
+    void reg_row(uint32_t *dst, bool cplx_blk, int logm, int n0, int second) const
+    {
+        const int m = 1 << logm, m8 = m / 8;
+        const Twiddle &tw = cplx_blk ? tw_sr[logm] : tw_rs[logm];
+        for (int l = 0; l < 64; l++) {
+            const int n = n0 + l, kind = n == 0 ? 0 : (n == m8 ? 2 : 1);
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (kind == 1) {
+                const int e = n - 1 - (n > m8 ? 1 : 0);
+                for (int k = 0; k < 3; k++) memcpy(&w[k], &tw.t[(size_t) (3 * second + k) * tw.nel + e], 4);
+            }
+            if (!second) w[3] = (kind == 1 ? 1u : 0u) | (kind == 2 ? 2u : 0u) | (cplx_blk ? 0u : 0x80000000u);
+            memcpy(dst + 4 * l, w, 16);
+        }
+    }
+    /* the row and lane of regtw that serve butterfly o of a transform whose window starts at element w0 */
+    static bool reg_slot(int logN, const FusedOp &o, int first_elem, int *row, int *lane)
+    {
+        const int n_abs = first_elem; /* p[0] before the swizzle, relative to the window */
+        if (logN == 10) {
+            if (o.cls == 0 && o.logm == 10) { *row = n_abs / 64; *lane = n_abs % 64; return n_abs < 256; }
+            if (o.cls == 0 && o.logm == 9) { *row = 4 + n_abs / 64; *lane = n_abs % 64; return n_abs < 128; }
+            if (o.cls == 1 && o.logm == 8) { *row = 6; *lane = n_abs - 512; return n_abs >= 512 && n_abs < 576; }
+            if (o.cls == 0 && o.logm == 8) { *row = 8; *lane = n_abs; return n_abs < 64; }
+            return false;
+        }
+        if (o.cls == 0 && o.logm == 8) { *row = 0; *lane = n_abs; return n_abs < 64; }
+        return false;
+    }
+
+    int build(int logN, int nwin, uint32_t *hdr, int max_rounds, int32_t *n_rounds, uint32_t *prog, int max_words, uint32_t *rd, uint32_t *regtw)
     {
         const int N = 1 << logN;
+        const unsigned dummy = logN == 10 ? MP3MI_FFT_DUMMY : MP3MI_FFT_DUMMY_S; /* where the idle lanes of a round work: behind the transforms */
+        for (int e = 0; e < nwin * N; e++)
+            if (MP3MI_FFT_SWZ(e) < 0 || MP3MI_FFT_SWZ(e) >= nwin * N) { fprintf(stderr, "mp3mi: the fft swizzle leaves the array\n"); abort(); }
         rank_ops.clear();
         post1.clear();
         post2.clear();
-        real(0, logN, 0, MP3MI_FFT_DUMMY);
+        real(0, logN, 0, dummy);
         /* read-out: where bin i's real and imaginary part are once the butterflies are done, and with which sign */
         {
             std::vector<int> src((size_t) N), sg((size_t) N, 0);
@@ -325,12 +370,37 @@ struct FftGen {
                     nd.o = rank_ops[rank][i];
                     nd.o.id = (int) nodes.size();
                     const int nop = nd.o.cls ? 8 : 4;
-                    for (int k = 0; k < 8; k++) nd.lp[k] = (k < nop && nd.o.p[k] != MP3MI_FFT_DUMMY) ? w * N + (int) nd.o.p[k] : -1;
+                    for (int k = 0; k < 8; k++) nd.lp[k] = (k < nop && nd.o.p[k] != dummy) ? w * N + (int) nd.o.p[k] : -1;
                     for (int k = 0; k < nop; k++)
-                        nd.o.p[k] = (nd.o.p[k] == MP3MI_FFT_DUMMY) ? nd.o.p[k] : (unsigned) MP3MI_FFT_SWZ(w * N + (int) nd.o.p[k]);
+                        nd.o.p[k] = (nd.o.p[k] == dummy) ? nd.o.p[k] : (unsigned) MP3MI_FFT_SWZ(w * N + (int) nd.o.p[k]);
                     nd.npred = 0; nd.height = 1; nd.done = false;
                     nodes.push_back(nd);
                 }
+        if (logN == 10) {
+            for (int r = 0; r < 4; r++) reg_row(regtw + 256 * r, false, 10, 64 * r, 0);
+            for (int r = 0; r < 2; r++) reg_row(regtw + 256 * (4 + r), false, 9, 64 * r, 0);
+            reg_row(regtw + 256 * 6, true, 8, 0, 0);
+            reg_row(regtw + 256 * 7, true, 8, 0, 1);
+            reg_row(regtw + 256 * 8, false, 8, 0, 0);
+        } else reg_row(regtw, false, 8, 0, 0);
+        {   /* every butterfly that is left to the registers has its row there, with exactly its rotation */
+            size_t n_reg = 0;
+            for (size_t i = 0; i < nodes.size(); i++) {
+                const FusedOp &o = nodes[i].o;
+                if (!in_registers(o)) continue;
+                int row = 0, lane = 0;
+                bool ok = reg_slot(logN, o, nodes[i].lp[0] % N, &row, &lane);
+                uint32_t want[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (o.kind == 1) memcpy(want, o.tw, 12);
+                want[3] = (o.kind == 1 ? 1u : 0u) | (o.kind == 2 ? 2u : 0u) | (o.neg ? 0x80000000u : 0u);
+                if (o.cls && o.kind == 1) memcpy(want + 4, o.tw + 3, 12);
+                ok = ok && memcmp(regtw + 256 * row + 4 * lane, want, 16) == 0;
+                if (ok && o.cls) ok = memcmp(regtw + 256 * (row + 1) + 4 * lane, want + 4, 16) == 0;
+                if (!ok) { fprintf(stderr, "mp3mi: fft register rounds do not match the butterflies of the recursion\n"); abort(); }
+                n_reg++;
+            }
+            if (n_reg != (size_t) nwin * (logN == 10 ? 256 + 128 + 64 + 64 : 64)) { fprintf(stderr, "mp3mi: fft register rounds: %zu butterflies\n", n_reg); abort(); }
+        }
         {
             std::vector<int> last_writer((size_t) nwin * (size_t) N, -1);
             for (size_t i = 0; i < nodes.size(); i++) { /* (rank order: a butterfly's producers come before it) */
@@ -468,7 +538,10 @@ struct FftGen {
             for (int cls = 0; cls < 2 && li + (size_t) cls < sched.size(); cls++) {
                 const int nopnd = cls ? 8 : 4;
                 std::vector<FusedOp> placed;
-                for (size_t i = 0; i < sched[li + (size_t) cls].size(); i++) placed.push_back(nodes[(size_t) sched[li + (size_t) cls][i]].o);
+                for (size_t i = 0; i < sched[li + (size_t) cls].size(); i++)
+                    if (!in_registers(nodes[(size_t) sched[li + (size_t) cls][i]].o)) placed.push_back(nodes[(size_t) sched[li + (size_t) cls][i]].o);
+                if (MP3MI_FFT_INFO_ON && placed.size() != sched[li + (size_t) cls].size())
+                    fprintf(stderr, "mp3mi: fft 2^%d step %zu class %d: %zu of %zu butterflies left to the program\n", logN, li / 2, cls, placed.size(), sched[li + (size_t) cls].size());
                 /* rounds of 64: block 0 = operand positions (R: 2 words per lane, C: 4), then either the
                    twiddle block(s) {cn, spc, smc, flags} (C: a second one {c3n, spc3n, smc3n, 0}) or, in a round
                    without rotations, one word of flags per lane.  flags: bit 0 rotation, bit 1 SQHALF rotation,
@@ -487,9 +560,9 @@ struct FftGen {
                         if (r0 + (size_t) l < placed.size()) o = placed[r0 + (size_t) l];
                         if (o.cls < 0) { /* idle lane: works on its own dummy element */
                             memset(&o, 0, sizeof(o));
-                            for (int k = 0; k < 8; k++) o.p[k] = (unsigned) (MP3MI_FFT_DUMMY + l);
+                            for (int k = 0; k < 8; k++) o.p[k] = (unsigned) (dummy + l);
                         }
-                        for (int k = 0; k < nopnd; k++) if (o.p[k] == MP3MI_FFT_DUMMY) o.p[k] = (unsigned) (MP3MI_FFT_DUMMY + l);
+                        for (int k = 0; k < nopnd; k++) if (o.p[k] == dummy) o.p[k] = (unsigned) (dummy + l);
                         const uint32_t flags = (o.kind == 1 ? 1u : 0u) | (o.kind == 2 ? 2u : 0u) | (o.neg ? 0x80000000u : 0u);
                         const int aw = cls ? 4 : 2;
                         for (int k = 0; k < aw; k++) blk[l * aw + k] = o.p[2 * k] | (o.p[2 * k + 1] << 16);
@@ -691,8 +764,8 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
         FftGen *g = new FftGen();
         g->stored_order = fft_stored_order;
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
-        T->fft_nword_l = g->build(10, 1, T->fft_hdr_l, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_l, T->fft_prog_l, MP3MI_FFT_PROG_WORDS, T->fft_rd_l);
-        T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS_S, T->fft_rd_s);
+        T->fft_nword_l = g->build(10, 1, T->fft_hdr_l, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_l, T->fft_prog_l, MP3MI_FFT_PROG_WORDS, T->fft_rd_l, T->fft_regtw_l);
+        T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS_S, T->fft_rd_s, T->fft_regtw_s);
         {   /* the kernel is compiled for exactly this sequence of rounds (k_fft.hip) */
             static const uint8_t hl[] = {MP3MI_FFT_HDRS_L}, hs[] = {MP3MI_FFT_HDRS_S};
             bool same = T->fft_nround_l == (int) sizeof(hl) && T->fft_nround_s == (int) sizeof(hs);
@@ -894,7 +967,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
     X(nj_seg) X(lane_bands) X(lane_jobs) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
     X(part_s_covered) X(minval) X(qthr_l) X(norm_l) X(qthr_s) X(exp_snr_s) X(s3_l) X(s3_lt) X(s3_lo) X(s3_hi) X(bu_l) X(bo_l) X(bu_s) \
     X(bo_s) X(w1_l) X(w2_l) X(w1_s) X(w2_s) X(fft_nround_l) X(fft_nround_s) X(fft_nword_l) X(fft_nword_s) X(fft_hdr_l) \
-    X(fft_hdr_s) X(fft_prog_l) X(fft_prog_s) X(fft_rd_l) X(fft_rd_s) X(enwindow) X(filt) X(mdct_win) X(cos_s) X(cos_l) X(ca) \
+    X(fft_hdr_s) X(fft_prog_l) X(fft_prog_s) X(fft_rd_l) X(fft_rd_s) X(fft_regtw_l) X(fft_regtw_s) X(enwindow) X(filt) X(mdct_win) X(cos_s) X(cos_l) X(ca) \
     X(cs) X(mdct_vidx) X(mdct_nterm) X(mdct_full_row) X(mdct_small_row) X(mdct_g_ops) X(mdct_h_ops) X(mdct_vcoef) \
     X(pow_nint_tab) X(pow43) X(step) X(pretab_xr) X(pretab_xmin) X(sqrt2) X(log2) X(ht_off) X(ht_xlen) X(ht_ylen) \
     X(ht_linbits) X(ht_linmax) X(ht_len) X(ht_code) X(glut)

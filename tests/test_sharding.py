@@ -81,7 +81,8 @@ def test_bench_launches_its_own_ranks_and_fails_with_them():
     back non-zero with nothing on standard output, not hang at a barrier."""
     r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--streams", "64", "--frames", "2"])
     assert r.returncode != 0 and not r.stdout.strip()
-    assert r.stderr.count("bench.py needs a GPU") == 2 if not torch.cuda.is_available() else True
+    # (one refusal at least: the launcher takes the other rank down as soon as the first one fails, possibly before it spoke)
+    assert 1 <= r.stderr.count("bench.py needs a GPU") <= 2 if not torch.cuda.is_available() else True
 
 
 def test_bench_refuses_a_world_size_other_than_the_flag():

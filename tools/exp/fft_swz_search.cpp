@@ -4,7 +4,9 @@
 // serves 16 lanes a cycle, an 8-byte load 32).  (b) is simulated annealing over swaps of butterflies of the same kind;
 // its result is written as mp3-enc-bsd_amd/csrc/fft_placement.h, which tables_host.cpp replays.
 //   g++ -O2 -std=c++17 -DMP3MI_EMU -DMP3MI_FFT_SWZ_RUNTIME -Imp3-enc-bsd_amd/csrc -Iinclude -Itests/hipemu \
-//       tools/exp/fft_swz_search.cpp tests/hipemu/hipemu.cpp -o /tmp/fft_swz_search
+//       tools/exp/fft_swz_search.cpp tests/hipemu/hipemu.cpp tests/hipemu/_build/tables_blob.o -o /tmp/fft_swz_search
+//   (the blob object comes out of make -C tests/hipemu; the butterflies of the blocks of 256 points and more run in
+//   registers and are no part of the programs the search sees)
 //   /tmp/fft_swz_search search <seconds>                         candidates for the swizzle (greedy placement as the yardstick)
 //   /tmp/fft_swz_search anneal <c4> .. <c9> <sweeps> [out.h]     anneal the placement under one swizzle, write the header
 #include "../../mp3-enc-bsd_amd/csrc/tables_host.cpp"
@@ -21,7 +23,8 @@ static uint32_t hdr[256], rdl[MP3MI_HBLK], rds_[MP3MI_HBLK_S];
 static int cost_of(int logN, int nwin, uint32_t *prog, int maxw, uint32_t *rd, int *rounds, bool verbose)
 {
     int32_t nr = 0;
-    const int nw = G->build(logN, nwin, hdr, 256, &nr, prog, 4 * maxw, rd);
+    static uint32_t regtw[MP3MI_FFT_REG_ROWS_L * 256];
+    const int nw = G->build(logN, nwin, hdr, 256, &nr, prog, 4 * maxw, rd, regtw);
     int off = 0, tot = (nw > maxw || nr > MP3MI_FFT_MAX_ROUNDS) ? 1000000 : 0; // must fit the product's tables
     for (int r = 0; r < nr; r++) {
         const int h = (int) hdr[r], N = (h & 1) ? 8 : 4;
