@@ -188,15 +188,13 @@ template <int N> MP3MI_DEVFN double mdct_group_reg(const double (&fin)[36], cons
 }
 
 // long window (src/mdct.c:199-509): prev = the band's 18 samples of the previous granule (this lane's column of an LDS
-// block, stride 64), cur = those of this one (memory, stride 32); park = where cur goes for its second use (the same
+// block, stride 64), c = those of this one (read by the caller, all in flight together); park = where cur goes for its second use (the same
 // column -- it takes prev's place -- or, for a pass that is not the last one over these inputs, scratch)
-MP3MI_DEVFN void mdct_long_reg(const double *prev, const double *cur, double *park, const mp3mi_tables *T, double (&o)[18])
+MP3MI_DEVFN void mdct_long_reg(const double *prev, const double (&c)[18], double *park, const mp3mi_tables *T, double (&o)[18])
 {
     double V[26];
     {
-        double fin[36], c[18];
-#pragma unroll
-        for (int k = 0; k < 18; k++) c[k] = cur[32 * k]; // all in flight together
+        double fin[36];
 #pragma unroll
         for (int k = 0; k < 18; k++) {
             fin[k] = T->mdct_win[0][k] * prev[64 * k];
@@ -232,11 +230,11 @@ MP3MI_DEVFN void mdct_long_reg(const double *prev, const double *cur, double *pa
 }
 
 // the other block types; bt (1, 2, 3) is the same for all lanes that keep the result
-MP3MI_DEVFN void mdct_other_reg(const double *prev, const double *cur, double *park, const mp3mi_tables *T, int bt, double (&o)[18])
+MP3MI_DEVFN void mdct_other_reg(const double *prev, const double (&c)[18], double *park, const mp3mi_tables *T, int bt, double (&o)[18])
 {
     double in[36];
 #pragma unroll
-    for (int k = 0; k < 18; k++) in[18 + k] = cur[32 * k];
+    for (int k = 0; k < 18; k++) in[18 + k] = c[k];
 #pragma unroll
     for (int k = 0; k < 18; k++) {
         in[k] = prev[64 * k];
@@ -458,12 +456,33 @@ __device__ __attribute__((noinline)) void mdct_prep_tail(const mp3mi_tables *T, 
     if (band == 0 && wr && ((am >> (32 * h)) & 0xffffffffull) != 0) fix->list[atomicAdd(&fix->count, 1u)] = rec;
 }
 
+// Diagnostic build only (-DMP3MI_MDCT_PROFILE, tools/mdct_profile.py): a wavefront's cycles per phase, summed over all of them
+#if defined(MP3MI_MDCT_PROFILE) && !defined(MP3MI_EMU)
+__device__ unsigned long long g_mdct_prof[8];
+#define MDCT_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MDCT_PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += n_ - prof_t; prof_t = n_; } while (0)
+#define MDCT_PROF_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MDCT_PROF_END do { if (wave_lane() == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_mdct_prof[i_], prof_acc[i_]); } while (0)
+extern "C" void mp3mi_debug_mdct_profile(unsigned long long *out)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mdct_prof), sizeof(z));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_mdct_prof), z, sizeof(z));
+}
+#else
+#define MDCT_PROF_DECL
+#define MDCT_PROF(i)
+#define MDCT_PROF_WAIT
+#define MDCT_PROF_END
+#endif
 __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                                 const double *__restrict__ sbs, const mp3mi_psy_out *__restrict__ psy,
                                                 double *__restrict__ xr_out, mp3mi_loop_prep *__restrict__ prep,
                                                 mp3mi_prep_fixlist *__restrict__ fix)
 {
     __shared__ mdct_out_lds L;
+    MDCT_PROF_DECL;
     const int lane = wave_lane(), band = lane & 31, h = lane >> 5;
     const int C = geo.channels, G = geo.n_gran, NR = (G + MDCT_RUN - 1) / MDCT_RUN, NT = geo.n_streams * C;
     int bid = (int) blockIdx.x;
@@ -489,9 +508,15 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
         WL = wave_max_i32(band < 21 ? T->sfb_l[band + 1] - T->sfb_l[band] : 0);
         WS = wave_max_i32(band < 12 ? T->sfb_s[band + 1] - T->sfb_s[band] : 0);
     }
+    MDCT_PROF(0);
     for (int kk = 0; kk < n; kk++) {
         // (this granule's samples are read where they are used, once, and parked in LDS for the next granule)
         const double *cur = blk + (size_t) (kk + 1) * pitch;
+        double c[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) c[k] = cur[32 * k]; // all in flight together
+        MDCT_PROF_WAIT;
+        MDCT_PROF(1);
         const int bt0 = wave_readlane_i32(btv, kk), bt1 = wave_readlane_i32(btv, 32 + kk);
         const int bt = h ? bt1 : bt0;
         double o[18];
@@ -504,14 +529,15 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
             // the last pass over these inputs parks them in prev's place; the first of two parks into L.x, which is
             // scratch until the pass writes its results there (same layout: [18][64] doubles)
             double *park = (pass == (mixed ? 1 : 0)) ? prev : &L.x[0][0] + lane;
-            if (v == 0) mdct_long_reg(prev, cur, park, Tk, o);
-            else mdct_other_reg(prev, cur, park, Tk, v, o);
+            if (v == 0) mdct_long_reg(prev, c, park, Tk, o);
+            else mdct_other_reg(prev, c, park, Tk, v, o);
             if (mixed) __syncthreads(); // (every lane is done with L.x as scratch before results go there)
             if (bt == v) {
 #pragma unroll
                 for (int m = 0; m < 18; m++) own[m] = o[m];
             }
         }
+        MDCT_PROF(2);
         __syncthreads();
         if (mixed) {
 #pragma unroll
@@ -534,11 +560,13 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
             }
         }
         __syncthreads();
+        MDCT_PROF(3);
         // ---- the loop's stateless head for these two granules (see above); BEFORE the spectrum's stores: a function
         //      begins by waiting for every memory operation in flight ----
         if (prep)
             mdct_prep_tail(T, (MDCT_LDS_PTR(const double)) &L.x[h][0], h == 0 || two, bt, bt0 != 2 || bt1 != 2, bt0 == 2 || bt1 == 2, WL, WS, (geo.test_flags & 32) != 0,
                            &psy[rec0 + (size_t) kk * C], &prep[rec0 + (size_t) kk * C], fix, (unsigned) (rec0 + (size_t) kk * C));
+        MDCT_PROF(4);
         // element lane + 64 j of the two [band][18] blocks: j < 9 the lower track's, then the upper one's
         double *out_lo = xr_out + (rec_lo + (size_t) kk * C) * 576, *out_hi = xr_out + (rec_hi + (size_t) kk * C) * 576;
         const double *flat = &L.x[0][0];
@@ -549,7 +577,9 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
             for (int j = 0; j < 9; j++) out_hi[lane + 64 * j] = flat[576 + lane + 64 * j];
         }
         __syncthreads(); // the next granule's results take the same place
+        MDCT_PROF(5);
     }
+    MDCT_PROF_END;
 }
 
 // The loop's stateless head for a spectrum that does not come out of k_mdct: the drop-in iteration_loop, whose xr is the
