@@ -591,10 +591,26 @@ def main():
     # End to end with PCIe (--host-io): the same K steps with the PCM in page-locked host memory and the bytes delivered to it.
     end_to_end = None
     if args.host_io or not (args.no_host_io or args.no_cpu_baseline):
-        h_pcm = torch.empty(wl.pcm.shape, dtype=torch.int16, pin_memory=True)  # page-locked from the start: no staging copy
+        # (every rank page-locks its own copy -- 7.9 GB at the default size; a rank that cannot says so, and ALL ranks then leave the
+        # leg out together: a rank missing at the barriers below would hang the others)
+        h_pcm = h_out = h_len = None
+        try:
+            h_pcm = torch.empty(wl.pcm.shape, dtype=torch.int16, pin_memory=True)  # page-locked from the start: no staging copy
+            h_out = torch.empty(wl.out.shape, dtype=torch.uint8, pin_memory=True)
+            h_len = torch.empty(S, dtype=torch.int32, pin_memory=True)
+        except RuntimeError as e:
+            print("bench.py: rank %d could not page-lock the host buffers of the end-to-end leg (%s)" % (rank, str(e).splitlines()[0]), file=sys.stderr)
+            h_pcm = None
+        have = torch.tensor([1 if h_pcm is not None else 0], dtype=torch.int32, device=cdev)
+        if distributed:
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if int(have.item()) == 0:
+            end_to_end = {"skipped": "a rank could not page-lock its host buffers"}
+            h_pcm = None
+    else:
+        h_pcm = None
+    if h_pcm is not None:
         h_pcm.copy_(wl.pcm)
-        h_out = torch.empty(wl.out.shape, dtype=torch.uint8, pin_memory=True)
-        h_len = torch.empty(S, dtype=torch.int32, pin_memory=True)
         for _ in range(max(args.warmup, 1)):
             wl.batch.encode_host_async(h_pcm, nf, h_out, h_len)
             wl.batch.sync()
