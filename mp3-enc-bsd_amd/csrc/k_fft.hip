@@ -4,11 +4,12 @@
 // Replaces fft()/rsfft()/enphinew() (src/subs.c:38-123, 412-534) and src/l3psy.c:477-549 for
 // every (stream, granule, channel) of a chunk at once: k_fft<.., true> (the long transform) and
 // k_fft<.., false> (the three short ones), one wavefront per (stream, granule) task and all channels,
-// then k_cw.  The FFT arithmetic is single precision with the reference's exact butterfly DAG: the
-// recursion is flattened on the host (tables_host.cpp) into rounds of 64 independent FUSED
-// butterflies -- steps 1-4 of one recursion level for one index, 4 or 8 operands -- which the
-// lanes execute from LDS; the data movement the reference ends with (step 5, bit reversal) is
-// folded into the read-out.
+// then k_cw.  The FFT arithmetic is single precision with the reference's exact butterfly DAG, as FUSED
+// butterflies -- steps 1-4 of one recursion level for one index, 4 or 8 operands.  Those of the blocks of
+// 256 points and more run in the lanes' registers, where the windowed samples arrive (fft_reg_long,
+// fft_reg4); the rest of the recursion is flattened on the host (tables_host.cpp) into rounds of 64
+// independent butterflies which the lanes execute from LDS; the data movement the reference ends with
+// (step 5, bit reversal) is folded into the read-out.
 //
 // Output per (granule, channel), consumed by k_psy:
 //   energy_l[513] f32, energy_s[3][129] f32, cw_mid[50] f64 (cw of lines 6+4n..9+4n),
