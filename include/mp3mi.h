@@ -278,6 +278,10 @@ int mp3mi_debug_dmath(int fn, const double *x, const double *y, double *out, siz
  * of [1, 4); out[1] raw exp2 at the 801 step sizes the search can ask for; out[2] raw exp2 over 2^24 arguments
  * of [-80, 80].  tests/test_gpu_tiers.py asserts that their sum stays inside the guard band's 7e-7 budget. */
 int mp3mi_debug_fastmath_bounds(double out[3]);
+/* What v_cvt_pknorm_u16_f32 -- the rounding step of the quantiser's first tier -- returns on this device, over every float of the
+ * range the quantiser feeds it (csrc/k_debug.hip): out[0] = max |n - a * 65535| (the proof in csrc/k_loop.hip needs <= 0.5),
+ * out[1] = non-monotone neighbours, out[2] = clamp / half mismatches (both 0). */
+int mp3mi_debug_pknorm_bound(double out[3]);
 /* diagnostics: of the (granule, channel) records of the last call's LAST chunk, how many needed the second tier of
  * the unpredictability (k_part's check); *n_records receives their number.  Call after
  * mp3mi_batch_sync. */

@@ -69,7 +69,54 @@ extern "C" int mp3mi_debug_dmath(int fn, const double *x, const double *y, doubl
 // Each thread folds its relative errors into max_err[what] (non-negative doubles order like their bits).
 #if defined(MP3MI_EMU)
 extern "C" int mp3mi_debug_fastmath_bounds(double out[3]) { (void) out; return MP3MI_ERR_NO_DEVICE; } // a statement about the hardware
+extern "C" int mp3mi_debug_pknorm_bound(double out[3]) { (void) out; return MP3MI_ERR_NO_DEVICE; }
 #else
+// ---- what v_cvt_pknorm_u16_f32 returns (the quantiser's rounding step, k_loop.hip: loop_quant_pair) ----
+// For EVERY float a of [2^-31, 2048.5 / 65535] (218 M arguments) and the floats around both clamps: the result n against
+// a * 65535 in double (exact: a 24-bit by a 16-bit factor).  out[0] = max |n - a * 65535| (0.5: a correctly rounded product; the
+// quantiser's proof needs <= 0.5), out[1] = arguments whose successor converts to a SMALLER n (0: monotone), out[2] = arguments
+// on which the two halves of the instruction or the clamps (a < 0 -> 0, a > 1 -> 65535) misbehave (0).
+__global__ void __launch_bounds__(256) k_debug_pknorm(unsigned first_bits, unsigned count, unsigned long long *__restrict__ res)
+{
+    double w = 0.0;
+    unsigned nm = 0, bad = 0;
+    for (unsigned k = blockIdx.x * 256u + threadIdx.x; k < count; k += gridDim.x * 256u) {
+        const float a = __builtin_bit_cast(float, first_bits + k), b = __builtin_bit_cast(float, first_bits + k + 1);
+        const unsigned r = LOOP_PKNORM_U16(a, b), r2 = LOOP_PKNORM_U16(b, a);
+        const double d = (double) (r & 0xffffu) - (double) a * 65535.0;
+        w = __builtin_fabs(d) > w ? __builtin_fabs(d) : w;
+        nm += (r >> 16) < (r & 0xffffu) ? 1u : 0u;
+        bad += (r2 >> 16) != (r & 0xffffu) || (r2 & 0xffffu) != (r >> 16) ? 1u : 0u; // both halves convert alike
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        bad += LOOP_PKNORM_U16(-1.0f, 2.0f) != 0xffff0000u ? 1u : 0u;
+        bad += LOOP_PKNORM_U16(-0.0f, 1.0f) != 0xffff0000u ? 1u : 0u;
+        bad += LOOP_PKNORM_U16(-1e-30f, 1.0000001f) != 0xffff0000u ? 1u : 0u;
+    }
+    atomicMax(&res[0], __builtin_bit_cast(unsigned long long, w));
+    if (nm) atomicAdd(&res[1], (unsigned long long) nm);
+    if (bad) atomicAdd(&res[2], (unsigned long long) bad);
+}
+extern "C" int mp3mi_debug_pknorm_bound(double out[3])
+{
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return MP3MI_ERR_NO_DEVICE;
+    unsigned long long *d = NULL, h[3];
+    int rc = MP3MI_ERR_HIP;
+    if (hipMalloc((void **) &d, sizeof(h)) == hipSuccess && hipMemset(d, 0, sizeof(h)) == hipSuccess) {
+        const unsigned b0 = 0x30000000u /* 2^-31 */, b1 = __builtin_bit_cast(unsigned, 2048.5f / 65535.0f);
+        hipLaunchKernelGGL(k_debug_pknorm, dim3(8192), dim3(256), 0, 0, b0, b1 - b0 + 1u, d);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            out[0] = __builtin_bit_cast(double, h[0]);
+            out[1] = (double) h[1];
+            out[2] = (double) h[2];
+            rc = MP3MI_OK;
+        }
+    }
+    if (d) hipFree(d);
+    return rc;
+}
+
 __global__ void k_debug_fastmath(int what, unsigned long long *__restrict__ max_err)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;

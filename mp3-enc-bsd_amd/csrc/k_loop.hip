@@ -4,10 +4,11 @@
 // Replaces iteration_loop (src/loop.c:232-362) with everything below it (src/loop.c:369-2140,
 // src/pow_nint.h, src/reservoir.c) for a whole batch.  The search is serial per stream (the
 // reservoir size threads through every granule), so ONE WAVEFRONT OWNS ONE STREAM and walks its
-// frames in order; the 64 lanes share each granule's 576 lines (line i belongs to lane i%64,
-// slot i/64), all loop decisions are wave-uniform, bit counts are wave-reduced (DPP, several
-// reductions in lock-step).  The spectrum and the quantised values live in LDS; what stays in
-// registers between passes is |xr|^(3/4) of the lane's nine lines and the per-band state.
+// frames in order; the 64 lanes share each granule's 288 PAIRS of lines (pair p = lines 2p, 2p + 1 -- what the
+// Huffman tables code together -- belongs to lane p%64, slot p/64; slot 4 is half empty), all loop
+// decisions are wave-uniform, bit counts are wave-reduced (DPP, several reductions in lock-step).
+// The spectrum and the quantised values live in LDS; what stays in registers between passes is
+// |xr|^(3/4) of the lane's ten lines and the per-band state.
 //
 // The stateless head of the loop (calc_xmin, quantanf_init, the values calc_scfsi stores) comes
 // from k_mdct's tail (k_fbmdct.hip; k_prep.hip).  Band noise -- only ever compared with the allowed distortion -- is summed in
@@ -47,11 +48,11 @@ struct loop_gr { // wave-uniform working copy of gr_info (src/l3side.h:60-87)
 // wavefronts per CU that 4096 streams on 256 CUs need take 129 KB of its 160 KB of LDS, and at 80 VGPRs 320 of a SIMD's
 // 512 registers -- the feed-forward kernels of the next chunk find room beside them (batch.cpp).
 struct loop_lds {
-    double xr[576 + 1]; // the granule's spectrum (amplified in place; [576] = 0: the line a finished noise job
-                      // reads on, ix[576] = 0 too): kept here, not in registers, because the
+    double xr[576 + 2] __attribute__((aligned(16))); // the granule's spectrum (amplified in place; [576] = [577] = 0: the pair a finished noise job
+                      // reads on, ix[576] = ix[577] = 0 too): kept here, not in registers, because the
                       // quantise/count passes only need |xr|^(3/4) (registers) and the 18 VGPRs decide
                       // between 4 wavefronts per SIMD with and without scratch spills
-    int16_t ix[576 + 128]; // padded: the region walks read whole 64-pair steps and mask what lies past the end
+    int16_t ix[576 + 128] __attribute__((aligned(4))); // padded: the region walks read whole 64-pair steps and mask what lies past the end; pair p as one word
     int sf_gr0[2][21];
     // per-band state of the distortion loop, lane b = band b (long) / sfb * 3 + window (short): it is touched once per
     // iteration, between two runs of quantise+count passes, and lives here -- not in registers -- across them
@@ -127,11 +128,19 @@ MP3MI_DEVFN int loop_nint(double in) { return (in < 0) ? (int) (in - 0.5) : (int
 // mp3mi_debug_fastmath_bounds, and asserted by tests/test_gpu_tiers.py)
 // Returns the largest y34 of the granule (wave-uniform): a step size that quantises it to zero
 // quantises everything to zero.
-MP3MI_DEVFN float loop_power34(const double xr[9], float y34[9])
+// ---- which lines a lane owns ----
+// Lane l holds pairs l, l + 64, .. l + 256 (LOOP_SLOTS slots; the pairs from 288 on -- slot 4 of lanes 32..63 -- do not exist:
+// their y34 is 0, they quantise to 0, and what is stored for them lands in L.ix's padding).  Value j of a lane is line
+// 2 * (l + 64 * (j / 2)) + j % 2.
+#define LOOP_SLOTS 5
+#define LOOP_NV (2 * LOOP_SLOTS)
+MP3MI_DEVFN int loop_pair_of(int lane, int k) { return lane + 64 * k; }
+
+MP3MI_DEVFN float loop_power34(const double xr[LOOP_NV], float y34[LOOP_NV])
 {
     float m = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 9; j++) {
+    for (int j = 0; j < LOOP_NV; j++) {
         const float a = (float) __builtin_fabs(xr[j]);
         y34[j] = LOOP_FAST_SQRTF(a * LOOP_FAST_SQRTF(a));
         m = y34[j] > m ? y34[j] : m;
@@ -154,8 +163,9 @@ MP3MI_DEVFN float loop_rescale34(float y34, int n)
 
 MP3MI_DEVFN float loop_estimate(float y34, float cq) { return __builtin_fmaf(y34, cq, 0.4054f); } // of x^(3/4) + 0.4054
 
-// true: every line quantises to 0 at this step (wave-uniform).  Uses the same estimate as the
-// quantiser, which is monotone in y34, so the quantiser would leave every line at 0 unflagged.
+// true: every line quantises to 0 at this step (wave-uniform).  loop_estimate is monotone in y34 and lies above the upper
+// estimate the quantiser rounds (see loop_quantize: (1 + 3.5e-6) y34 cq + 0.4054 + 2e-6 < 0.999 + 3.5e-6 + 2e-6 < 1 <=> below 0.5 after
+// the quantiser's - 0.5), so the quantiser would leave every line at 0 unflagged.
 MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
 {
     return loop_estimate(y34max, LOOP_FAST_EXP2F(-0.1875f * (float) q)) < 0.999f;
@@ -163,115 +173,128 @@ MP3MI_DEVFN bool loop_all_zero(float y34max, int q)
 
 // What a pass needs to know about the quantised values besides the values themselves (which go to L.ix): the run
 // lengths of calc_runlen for long blocks, the two region maxima of short blocks.  Taken while every value is still
-// in a register, so that the nine values of a lane are never alive across the counting.
+// in a register, so that the values of a lane are never alive across the counting.
 struct loop_qinfo {
-    int n_nz, n_big; // lines up to the last non-zero one / the last one above 1 (as line + 1; 0 = none)
+    int n_nz, n_big; // lines up to the last non-zero PAIR / the last pair with a value above 1 (2 * pairs: even; 0 = none)
     int m1, m2;      // short blocks: this lane's maximum over lines [0, 36) / [36, 576)
 };
 
+// The quantiser's first tier, two lines -- a pair -- at a time.  With t = x^(3/4) + 0.4054 the answer is floor(t) (clamped to the
+// table's end).  u = y34 * cq + 0.4054 - 0.5 estimates t - 0.5 with an error below 2.8e-6 y34 cq relative (the two 1-ulp roots,
+// exp2, the roundings, at most 17 rescalings of y34 by loop_rescale34: 16 amplifications, one pre-emphasis) plus the roundings of
+// what is computed here (the constants' products and the multiply-add: 2e-7 relative).  An UPPER and a LOWER estimate
+//     u_hi = y34 * cq (1 + 3.5e-6) + (0.4054 - 0.5 + 2e-6),   u_lo = y34 * cq (1 - 3.5e-6) + (0.4054 - 0.5 - 2e-6)
+// bracket t - 0.5, and v_cvt_pknorm_u16_f32 -- on a / 65535 it returns a rounded to the NEAREST integer, computed from the exact
+// product and clamped to [0, 65535] (every float of the range against double arithmetic: mp3mi_debug_pknorm_bound, k_debug.hip;
+// tests/test_gpu_tiers.py) -- rounds both, a pair per instruction, straight into the halves of the pair word x | y << 16:
+//     n_hi >= u_hi - 0.5 > t - 1  =>  n_hi >= floor(t);     n_lo <= u_lo + 0.5 < t  =>  n_lo <= floor(t)
+// (n_lo < t gives n_lo <= floor(t) also for an integer t).  So a line whose two roundings agree is settled, whatever the quality
+// of the estimate; the others -- those within the band of a table boundary: small values, the common case, almost never --
+// are settled against the exact table.  Five instructions per pair: two packed multiply-adds, two conversions, one compare-accumulate.
+// scale = 1 / 65535: the conversion's; the constants are rounded ONCE, here, by the compiler.
+#define LOOP_Q_HI ((1.0 + 3.5e-6) / 65535.0)
+#define LOOP_Q_LO ((1.0 - 3.5e-6) / 65535.0)
+#define LOOP_Q_CHI ((0.4054 - 0.5 + 2e-6) / 65535.0)
+#define LOOP_Q_CLO ((0.4054 - 0.5 - 2e-6) / 65535.0)
+struct loop_qscale { float a_hi, a_lo; };
+MP3MI_DEVFN loop_qscale loop_quant_scale(int q)
+{
+    const float cq = LOOP_FAST_EXP2F(-0.1875f * (float) q);
+    loop_qscale s = {cq * (float) LOOP_Q_HI, cq * (float) LOOP_Q_LO};
+    return s;
+}
+MP3MI_DEVFN unsigned loop_quant_pair(float y0, float y1, float a, float c)
+{
+#if defined(MP3MI_EMU)
+    return LOOP_PKNORM_U16(__builtin_fmaf(y0, a, c), __builtin_fmaf(y1, a, c));
+#else
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 y = {y0, y1}, av = {a, a}, cv = {c, c};
+    const f32x2 u = __builtin_elementwise_fma(y, av, cv); // v_pk_fma_f32: both lines in one instruction
+    return LOOP_PKNORM_U16(u.x, u.y);
+#endif
+}
+
+// ix = max{p in [0,2047] : tab[p] <= x}  (src/pow_nint.h:15-49, src/loop.c:1360-1428) for the lane's ten lines: the pair
+// words go to L.ix (followed by a barrier).  y34[j] = |xr[j]|^(3/4) in float (loop_power34), so that x^(3/4) = y34 * 2^(-3q/16)
+// costs one multiply per pass.  Only an estimate (the quantiser settles borderline lines exactly), so the raw 1-ulp hardware
+// square root is enough; the correctly rounded expansion costs ~20 instructions per root.
+// (LOOP_FAST_SQRTF / LOOP_FAST_EXP2F: mp3mi_dev.h; their error on the device is measured by k_debug.hip,
+// mp3mi_debug_fastmath_bounds, and asserted by tests/test_gpu_tiers.py)
 // force_exact (MP3MI_QUANT_EXACT=1, tests): every line is settled against the exact table, whatever the estimate says.
-MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[9], float y34max, int q, bool all_zero, bool force_exact, bool shortb)
+MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const float y34[LOOP_NV], float y34max, int q, bool all_zero, bool force_exact, bool shortb)
 {
     const int lane = wave_lane_here();
+    unsigned *ixw = (unsigned *) L.ix; // pair p as one word: x | y << 16
     loop_qinfo qi = {0, 0, 0, 0};
     if (all_zero && !force_exact) {
 #pragma unroll
-        for (int j = 0; j < 9; j++) L.ix[lane + 64 * j] = 0;
+        for (int k = 0; k < LOOP_SLOTS; k++) ixw[loop_pair_of(lane, k)] = 0u;
         wave_sync();
         return qi;
     }
-    int p[9];
-    const float cq = LOOP_FAST_EXP2F(-0.1875f * (float) q);
-    // Near a table boundary a line is settled exactly.  The estimate's error is relative: < 7e-7 f from the two
-    // 1-ulp roots, exp2 and two roundings, plus < 1.2e-7 f for each of the at most 17 rescalings of y34 by
-    // loop_rescale34 (16 amplifications, one pre-emphasis) = 2.8e-6 f.  The guard band 3.5e-6 f + 2e-6 scales
-    // with f; small values -- the common case -- are almost never ambiguous.  With d = |frac - 1/2|: within the
-    // band of an integer <=> d + 3.5e-6 f > 1/2 - 2e-6.  The pass only needs to know whether ANY line is (the
-    // maximum of that sum over the nine lines, one compare); which ones is found again in the rare branch.
-    const float guard = 0.5f - 2e-6f;
-    float gmax = 0.0f;
-    // estimate f of x^(3/4) + 0.4054 (>= 0.4054); from 2047.5 on the answer is the table's last entry.  Whether any line gets
-    // there is known from the granule's largest y34 (an upper bound, wave-uniform): almost never -- so the nine clamps are not
-    // in the pass but behind this test (a line beyond the end may send the wave through the exact tier below for nothing:
-    // that tier clamps its own estimate and leaves such a line alone)
+    unsigned pw[LOOP_SLOTS];
+    const loop_qscale qs = loop_quant_scale(q);
+    unsigned differ = 0u; // some line's upper and lower estimate round to different integers
 #pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const float f = loop_estimate(y34[j], cq);
-#if defined(MP3MI_EMU) // (the device's conversion saturates, and the clamp below then yields 2047; on the host it is undefined from 2^31 on)
-        p[j] = (int) __builtin_fminf(f, 2147483520.0f);
-#else
-        p[j] = (int) f; // f >= 0.4054: the conversion truncates = floor
-#endif
-        const float d = __builtin_fabsf(LOOP_FRACTF(f) - 0.5f); // f - floor(f), exact
-        gmax = __builtin_fmaxf(gmax, __builtin_fmaf(3.5e-6f, f, d));
+    for (int k = 0; k < LOOP_SLOTS; k++) {
+        pw[k] = loop_quant_pair(y34[2 * k], y34[2 * k + 1], qs.a_hi, (float) LOOP_Q_CHI);
+        const unsigned lo = loop_quant_pair(y34[2 * k], y34[2 * k + 1], qs.a_lo, (float) LOOP_Q_CLO);
+        differ += pw[k] ^ lo; // (five terms below 2^28: no overflow; v_xad_u32)
     }
-    if (!(loop_estimate(y34max, cq) < 2047.0f)) {
-#pragma unroll
-        for (int j = 0; j < 9; j++) p[j] = p[j] < 2047 ? p[j] : 2047;
-    }
-    if (force_exact || wave_any(gmax > guard)) {
+    // The rare tier.  From 2047.5 on the answer is the table's last entry; whether any line gets there is known from the granule's
+    // largest y34 (an upper bound, wave-uniform): almost never -- so the clamps are not in the pass but in here, where the
+    // lines whose two estimates differ are settled against the exact table.
+    const bool over = !(loop_estimate(y34max, qs.a_hi * 65535.0f) < 2047.0f);
+    if (force_exact || over || wave_any(differ != 0u)) {
         const double ostep = 1.0 / T->step[q - MP3MI_STEP_MIN];
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const float f = __builtin_fminf(loop_estimate(y34[j], cq), 2047.5f);
-            const float d = __builtin_fabsf(LOOP_FRACTF(f) - 0.5f);
-            if (force_exact || __builtin_fmaf(3.5e-6f, f, d) > guard) {
-                const double x = __builtin_fabs(L.xr[lane + 64 * j]) * ostep;
-                int pp = p[j];
+        for (int j = 0; j < LOOP_NV; j++) {
+            const int k = j >> 1, sh = 16 * (j & 1);
+            // (the lower estimate again, here: nothing of it lives through the common path)
+            unsigned lo = (loop_quant_pair(y34[2 * k], y34[2 * k + 1], qs.a_lo, (float) LOOP_Q_CLO) >> sh) & 0xffffu;
+            int pp = (int) ((pw[k] >> sh) & 0xffffu);
+            lo = lo < 2047u ? lo : 2047u;
+            pp = pp < 2047 ? pp : 2047;
+            const int line = 2 * loop_pair_of(lane, k) + (j & 1);
+            if ((force_exact || lo != (unsigned) pp) && line < 576) {
+                const double x = __builtin_fabs(L.xr[line]) * ostep;
                 while (pp > 0 && x < T->pow_nint_tab[pp]) pp--;
                 while (pp < 2047 && x >= T->pow_nint_tab[pp + 1]) pp++;
-                p[j] = pp;
             }
+            pw[k] = (pw[k] & ~(0xffffu << sh)) | ((unsigned) pp << sh);
         }
     }
-    // Run lengths (calc_runlen, src/loop.c:1488-1520): slot j's lines are 64 j + lane, so the highest set bit of the
-    // lane mask of `p[j] != 0` in the highest non-empty slot is the answer: nine compares into scalar masks and scalar
-    // bit scans instead of 9 x (compare, select) per maximum and a wave reduction.  And the short-block maxima.
+#pragma unroll
+    for (int k = 0; k < LOOP_SLOTS; k++) ixw[loop_pair_of(lane, k)] = pw[k];
+    // Run lengths (calc_runlen, src/loop.c:1488-1520), by pairs: big_values and count1 only ask for the last PAIR that holds a
+    // non-zero value / a value above 1 (loop_count_bits).  And the short-block maxima.
     if (shortb) { // (a short block's big_values is 288 whatever the values: no run lengths)
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const int i = lane + 64 * j;
-            qi.m1 = (i < 36 && p[j] > qi.m1) ? p[j] : qi.m1;
-            qi.m2 = (i >= 36 && p[j] > qi.m2) ? p[j] : qi.m2;
-            L.ix[i] = (int16_t) p[j];
+        for (int k = 0; k < LOOP_SLOTS; k++) {
+            const int x = (int) (pw[k] & 0xffffu), y = (int) (pw[k] >> 16);
+            const int v = x > y ? x : y;
+            const bool low = loop_pair_of(lane, k) < 18; // lines [0, 36)
+            qi.m1 = (low && v > qi.m1) ? v : qi.m1;
+            qi.m2 = (!low && v > qi.m2) ? v : qi.m2;
         }
     } else {
-#if defined(LOOP_RUNLEN_BALLOT) // (until round 4: nine pairs of lane masks and scalar bit scans, ~95 scalar instructions per pass)
-#pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const unsigned long long nz = __ballot(p[j] != 0), big = __ballot(p[j] > 1);
-            qi.n_nz = nz ? 64 * j + 64 - __clzll((long long) nz) : qi.n_nz;
-            qi.n_big = big ? 64 * j + 64 - __clzll((long long) big) : qi.n_big;
-            L.ix[lane + 64 * j] = (int16_t) p[j];
-        }
-#else
-        // min(p, 2) of the lane's nine lines as 2-bit fields of one word, slot j in bits 2j, 2j + 1: its highest set bit
-        // names the lane's last non-zero line, the highest set ODD bit its last line above 1.
+        // min(x | y, 2) of the lane's five pairs as 2-bit fields of one word, slot k in bits 2k, 2k + 1: its highest set bit
+        // names the lane's last non-zero pair, the highest set ODD bit its last pair with a value above 1.
         unsigned w = 0;
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const unsigned c = (unsigned) (p[j] < 2 ? p[j] : 2);
-            w |= c << (2 * j);
-            L.ix[lane + 64 * j] = (int16_t) p[j];
+        for (int k = 0; k < LOOP_SLOTS; k++) {
+            const unsigned o = (pw[k] & 0xffffu) | (pw[k] >> 16);
+            w |= (o < 2u ? o : 2u) << (2 * k);
         }
-#if !defined(LOOP_RUNLEN_KEYS)
-        // ONE reduction -- the OR of the words names the last slot that holds a non-zero line / a line above 1 -- and a
-        // lane mask per run length for the last lane of that slot.  (LOOP_RUNLEN_KEYS, the first form of round 4: a key per lane,
-        // 64 slot + lane + 1, and two wave maxima -- 18 vector instructions more, 17 scalar ones less per pass; 219.4 vs 218.0 ms per step)
+        // ONE reduction -- the OR of the words names the last slot that holds a non-zero pair / a pair with a value above 1 -- and a
+        // lane mask per run length for the last lane of that slot.
         const unsigned wo = wave_or_u32(w);
-        const int t_nz = 31 - __clz((int) wo), t_big = 31 - __clz((int) (wo & 0x2AAAAu)); // -1 for an empty word
-        const int j_nz = t_nz >> 1, j_big = t_big >> 1;
-        const unsigned long long m_nz = __ballot((w & (3u << ((2 * j_nz) & 31))) != 0u), m_big = __ballot((w & (2u << ((2 * j_big) & 31))) != 0u);
-        qi.n_nz = t_nz < 0 ? 0 : 64 * j_nz + 64 - __clzll((long long) m_nz);
-        qi.n_big = t_big < 0 ? 0 : 64 * j_big + 64 - __clzll((long long) m_big);
-#else
-        const int t_nz = 31 - __clz((int) w), t_big = 31 - __clz((int) (w & 0x2AAAAu)); // -1 for an empty word
-        int kv[2] = {((t_nz >> 1) << 6) + lane + 1, ((t_big >> 1) << 6) + lane + 1};
-        wave_reduce_i32<0, 2>(kv); // (an empty lane's key is lane - 63 <= 0, and lane 63's is exactly 0: the maxima are >= 0)
-        qi.n_nz = kv[0];
-        qi.n_big = kv[1];
-#endif
-#endif
+        const int t_nz = 31 - __clz((int) wo), t_big = 31 - __clz((int) (wo & 0x2AAu)); // -1 for an empty word
+        const int k_nz = t_nz >> 1, k_big = t_big >> 1;
+        const unsigned long long m_nz = __ballot((w & (3u << ((2 * k_nz) & 31))) != 0u), m_big = __ballot((w & (2u << ((2 * k_big) & 31))) != 0u);
+        qi.n_nz = t_nz < 0 ? 0 : 2 * (64 * k_nz + 64 - __clzll((long long) m_nz));
+        qi.n_big = t_big < 0 ? 0 : 2 * (64 * k_big + 64 - __clzll((long long) m_big));
     }
     wave_sync();
     return qi;
@@ -419,7 +442,7 @@ MP3MI_DEVFN void loop_region_cost(const uint16_t *GL, const unsigned *ixw, int l
 }
 
 // calc_runlen + count1_bitcount + subdivide + bigv_tab_select + bigv_bitcount
-// (src/loop.c:1488-2014) on the freshly quantised values (p[] in registers, L.ix in LDS).
+// (src/loop.c:1488-2014) on the freshly quantised values (pair words in registers, L.ix in LDS).
 // Returns the Huffman bit count and fills g.  Written branch-free over the lanes: region
 // membership is a predicate, never a divergent branch.
 MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_lds &L, const uint16_t *GL, loop_gr &g, const loop_qinfo &qi, bool all_zero CBPROF_ARG)
@@ -545,8 +568,7 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     // by the region it belongs to, with that region's wave-uniform descriptor; lines from slot nslot on are
     // zero.  (Written out per region: arrays indexed by the region would live in scratch memory.)
     const int nzend = 64 * nslot;
-    auto region_max = [&](int lo, int hi) {
-        hi = hi < nzend ? hi : nzend; // both even
+    auto region_max = [&](int lo, int hi) {        hi = hi < nzend ? hi : nzend; // both even
         int m = 0;
         int w0 = lo >> 1; // pair index of lane 0
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
@@ -673,30 +695,81 @@ MP3MI_DEVFN double loop_noise_sum(const mp3mi_tables *T, const loop_lds &L, doub
 }
 
 // The partial-sum jobs of the first tier: all lanes take the same number of steps (kmax, the longest job,
-// a multiple of 4) and a job that is through reads line 576 -- xr = 0, ix = 0, a term of exactly +0 -- instead
-// of dropping out: no divergent loop, no remainder loop, four loads in flight throughout.
-MP3MI_DEVFN double loop_noise_jobs(const mp3mi_tables *T, const loop_lds &L, double step, int first, int count, int stride, int kmax)
+// a multiple of 4) and a job that is through reads pair 288 -- xr = 0, ix = 0, terms of exactly +0 -- instead
+// of dropping out: no divergent loop, no remainder loop.
+// LONG blocks: a job is a run of whole PAIRS of lines (tables_host.cpp: first and count are even), two pairs a step: per pair ONE
+// 16-byte read of the spectrum, ONE word of quantised values, two table reads -- four terms in flight on half the address
+// arithmetic and half the LDS reads of a line-by-line walk.
+typedef double loop_f64x2 __attribute__((ext_vector_type(2)));
+MP3MI_DEVFN double loop_noise_jobs_long(const mp3mi_tables *T, const loop_lds &L, double step, int first, int count, int kmax)
 {
-    // Addresses as 32-bit byte offsets from three bases, all shifts of the one line index: as `L.ix[line]` and
+    // Addresses as 32-bit byte offsets from three bases, all shifts of the one pair index: as `L.ix[line]` and
     // `T->pow43[L.ix[line]]` the compiler derived the second LDS address from the first by a 64-bit multiply-add (a quarter-rate
-    // instruction) and sign-extended the table index to 64 bits -- 15 issue slots per term where 10 do (L.ix holds magnitudes).
+    // instruction) and sign-extended the table index to 64 bits (L.ix holds magnitudes).
+    const char *lds = (const char *) &L.xr[0];
+    const unsigned ix_off = (unsigned) ((const char *) &L.ix[0] - (const char *) &L.xr[0]);
+    const char *tab = (const char *) &T->pow43[0];
+    double sum = 0.0;
+    unsigned pr = (unsigned) first >> 1;
+    const unsigned npairs = (unsigned) count >> 1;
+#if !defined(LOOP_NOISE_PAIRS)
+#define LOOP_NOISE_PAIRS 4 /* pairs in flight per step: the jobs of all three rates are at most four pairs long -- one step, no loop */
+#endif
+    for (int k = 0; 2 * k < kmax; k += LOOP_NOISE_PAIRS) {
+        // the quantised values first, then the table entries they select -- the long latency --, the spectrum two pairs at a time behind
+        // them: what is in flight at once decides the kernel's register count
+        unsigned p[LOOP_NOISE_PAIRS], w[LOOP_NOISE_PAIRS];
+        double q43[2 * LOOP_NOISE_PAIRS];
+#pragma unroll
+        for (int u = 0; u < LOOP_NOISE_PAIRS; u++) {
+            p[u] = (unsigned) (k + u) < npairs ? pr + (unsigned) u : 288u;
+            w[u] = *(const unsigned *) (lds + ix_off + 4u * p[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < LOOP_NOISE_PAIRS; u++) {
+            q43[2 * u] = *(const double *) (tab + (size_t) ((w[u] << 3) & 0x7fff8u));
+            q43[2 * u + 1] = *(const double *) (tab + (size_t) ((w[u] >> 13) & 0x7fff8u));
+        }
+        pr += (unsigned) LOOP_NOISE_PAIRS;
+#pragma unroll
+        for (int u = 0; u < LOOP_NOISE_PAIRS; u++) {
+#if !defined(MP3MI_EMU)
+            if ((u & 1) == 0) asm volatile("" ::: "memory"); // (the spectrum's reads stay here, two pairs at a time, behind the table reads)
+#endif
+#if defined(MP3MI_EMU)
+            const double x0 = *(const double *) (lds + 16u * p[u]), x1 = *(const double *) (lds + 16u * p[u] + 8u);
+#else
+            const loop_f64x2 xx = *(const loop_f64x2 *) (lds + 16u * p[u]);
+            const double x0 = xx.x, x1 = xx.y;
+#endif
+            const double t0 = __builtin_fabs(x0) - q43[2 * u] * step, t1 = __builtin_fabs(x1) - q43[2 * u + 1] * step;
+            sum = sum + t0 * t0;
+            sum = sum + t1 * t1;
+        }
+    }
+    return sum;
+}
+// SHORT blocks (one granule in twenty): a job's lines are three apart; line by line, two terms a step (what is in flight here, not the
+// kernel's common path, would otherwise set its register count).
+MP3MI_DEVFN double loop_noise_jobs_short(const mp3mi_tables *T, const loop_lds &L, double step, int first, int count, int kmax)
+{
     const char *lds = (const char *) &L.xr[0];
     const unsigned ix_off = (unsigned) ((const char *) &L.ix[0] - (const char *) &L.xr[0]);
     const char *tab = (const char *) &T->pow43[0];
     double sum = 0.0;
     unsigned line = (unsigned) first;
-    for (int k = 0; k < kmax; k += 4) {
-        double t[4];
+    for (int k = 0; k < kmax; k += 2) {
+        double t[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const unsigned ln = (unsigned) (k + u) < (unsigned) count ? line + (unsigned) (u * stride) : 576u;
+        for (int u = 0; u < 2; u++) {
+            const unsigned ln = (unsigned) (k + u) < (unsigned) count ? line + (unsigned) (3 * u) : 576u;
             const double x = *(const double *) (lds + 8u * ln);
             const unsigned q = *(const uint16_t *) (lds + ix_off + 2u * ln);
             t[u] = __builtin_fabs(x) - *(const double *) (tab + (size_t) (8u * q)) * step;
         }
-        line += (unsigned) (4 * stride);
+        line += 6u;
 #pragma unroll
-        for (int u = 0; u < 4; u++) sum = sum + t[u] * t[u];
+        for (int u = 0; u < 2; u++) sum = sum + t[u] * t[u];
     }
     return sum;
 }
@@ -714,11 +787,45 @@ MP3MI_DEVFN bool loop_noise_close(bool bandlane, double xfsf, double xmin)
     return bandlane && xmin > 0.0 && __builtin_fabs(xfsf - xmin) <= 1e-12 * xmin;
 }
 
-// frames of the chunk [f0, f0 + nf) that a stream with n valid samples per channel still has
-MP3MI_DEVFN int loop_frames_here(const mp3mi_geom &geo, int n)
+// The kernel's arguments as ONE record.  The search needs a dozen pointers and launch constants a few times per granule,
+// per frame or per stream -- and every scalar register matters in between: held in registers across the whole kernel they were
+// what the compiler spilled (131 scalar registers into the lanes of three vector registers, written and read back by vector
+// instructions in the granule's set-up and in every iteration of the distortion loop).  Now the record stays where the launch
+// put it -- the kernel argument segment -- and a value is fetched by a scalar load WHERE IT IS USED (LOOP_ARG: the pointer
+// behind an optimisation barrier, so that the loads are not hoisted to the kernel's top again).
+struct loop_kargs { // (the table block is a kernel argument of its own: a read-only, no-alias pointer, whose loads are scalar loads)
+    mp3mi_geom geo;
+    const double *xr_all;
+    const mp3mi_psy_out *psy;
+    const mp3mi_loop_prep *prep;
+    const int32_t *bits_per_frame;
+    mp3mi_loop_state *state;
+    int16_t *ix_out;
+    mp3mi_frame_side *side_out;
+    unsigned *gate_count;
+    mp3mi_loop_place place;
+};
+#if defined(MP3MI_EMU)
+typedef const loop_kargs *loop_kargs_p;
+#define LOOP_ARG(field) (ka->field)
+#define loop_kargs_ptr(ka) (ka)
+#else
+typedef const __attribute__((address_space(4))) loop_kargs *loop_kargs_p;
+MP3MI_DEVFN loop_kargs_p loop_kargs_here(loop_kargs_p p)
 {
-    const int total = (n + 1151) / 1152, left = total - geo.f0;
-    return left < 0 ? 0 : (left < geo.nf ? left : geo.nf);
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return (loop_kargs_p) ((const __attribute__((address_space(4))) char *) p + z);
+}
+#define LOOP_ARG(field) (loop_kargs_here(ka)->field)
+#define loop_kargs_ptr(ka) loop_kargs_here(ka)
+#endif
+
+// frames of the chunk [f0, f0 + nf) that a stream with n valid samples per channel still has
+MP3MI_DEVFN int loop_frames_here(int f0, int nf, int n)
+{
+    const int total = (n + 1151) / 1152, left = total - f0;
+    return left < 0 ? 0 : (left < nf ? left : nf);
 }
 
 // ---- placement: which stream does this wavefront take? ----
@@ -729,12 +836,16 @@ MP3MI_DEVFN int loop_frames_here(const mp3mi_geom &geo, int n)
 // takes sorted position r*NS + i (r even) or (r+1)*NS - 1 - i (r odd), NS = place.n_simd.
 // Any wavefront that finds its position missing or taken (more streams than slots, an uneven
 // spread) takes the next free one from a scan counter, so every stream is taken exactly once.
-MP3MI_DEVFN int loop_place_stream(const mp3mi_loop_place &pl, int n_streams, int block)
+MP3MI_DEVFN int loop_place_stream(loop_kargs_p ka, int n_streams, int block)
 {
 #if defined(MP3MI_EMU)
-    return pl.order ? pl.order[block] : block;
+    return ka->place.order ? ka->place.order[block] : block;
 #else
+    mp3mi_loop_place pl; // (field by field: the record lives in the kernel argument segment)
+    pl.order = LOOP_ARG(place.order);
     if (!pl.order) return block;
+    pl.taken = LOOP_ARG(place.taken); pl.simd_slots = LOOP_ARG(place.simd_slots); pl.simd_idx = LOOP_ARG(place.simd_idx);
+    pl.ticket = LOOP_ARG(place.ticket); pl.scan = LOOP_ARG(place.scan); pl.n_simd = LOOP_ARG(place.n_simd);
     int pos = -1;
     if (wave_lane() == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
@@ -789,23 +900,21 @@ void mp3mi_launch_rank(const int *cost, int *order, int n, hipStream_t st)
 
 // 80 VGPRs: four resident wavefronts per SIMD leave 192 of its 512 registers to the kernels of the next chunk.
 // One stream, start to end, by one wavefront (k_loop below).
-MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geom &geo,
-                             const double *__restrict__ xr_all, const mp3mi_psy_out *__restrict__ psy,
-                             const mp3mi_loop_prep *__restrict__ prep,
-                             const int32_t *__restrict__ bits_per_frame,
-                             mp3mi_loop_state *__restrict__ state, int16_t *__restrict__ ix_out,
-                             mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count,
-                             const mp3mi_loop_place &place, loop_lds &L, const uint16_t *GL, int block)
+MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, loop_kargs_p ka, loop_lds &L, const uint16_t *GL, int block)
 {
     const int lane = wave_lane();
-    const int s = loop_place_stream(place, geo.n_streams, block), C = geo.channels, G = 2 * geo.nf;
+    const int C = LOOP_ARG(geo.channels), G = 2 * LOOP_ARG(geo.nf);
+    const int s = loop_place_stream(ka, LOOP_ARG(geo.n_streams), block);
     int work = 0; // cost of this stream in this launch: 4 per quantise+count pass, 5 per distortion-loop iteration
-    const int bitsPerFrame = bits_per_frame[s];
-    const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256) + (geo.crc ? 16 : 0))) / 2; // src/musicin.c:729-746
+    const int bitsPerFrame = LOOP_ARG(bits_per_frame)[s];
+    const int mean_bits = (bitsPerFrame - (32 + (C == 1 ? 136 : 256) + (LOOP_ARG(geo.crc) ? 16 : 0))) / 2; // src/musicin.c:729-746
     PROF_DECL;
     // Residency census (batch.cpp, k_gate): every wavefront counts itself in when it starts.  The
     // counter only ever grows; nothing in this kernel waits on it.
-    if (gate_count && lane == 0) atomicAdd(gate_count, 1u);
+    {
+        unsigned *gate_count = LOOP_ARG(gate_count);
+        if (gate_count && lane == 0) atomicAdd(gate_count, 1u);
+    }
 #if !defined(MP3MI_EMU)
     // this wavefront is on the critical path of the whole batch: let it issue ahead of the
     // feed-forward kernels of the next chunk that run beside it (batch.cpp); adjusted
@@ -816,14 +925,14 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
     loop_regs R;
     loop_desc_init(T, lane, &R.desc_a, &R.desc_b);
 
-    for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &state[s])[i];
-    if (lane < 8) L.ix[576 + lane] = 0;
-    if (lane == 0) L.xr[576] = 0.0;
+    for (int i = lane; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &L.st)[i] = ((const int *) &LOOP_ARG(state)[s])[i];
+    L.ix[576 + lane] = 0; L.ix[640 + lane] = 0; // (the padding: pairs that do not exist)
+    if (lane < 2) L.xr[576 + lane] = 0.0;
     wave_sync();
     int ref_abort = __builtin_amdgcn_readfirstlane(L.st.ref_abort); // (sticky: the first event of the stream stands)
 
     // ragged batch: frames of this stream beyond its last (zero-filled) one are not encoded
-    const int nf_s = geo.n_samples ? loop_frames_here(geo, geo.n_samples[s]) : geo.nf;
+    const int nf_s = LOOP_ARG(geo.n_samples) ? loop_frames_here(LOOP_ARG(geo.f0), LOOP_ARG(geo.nf), LOOP_ARG(geo.n_samples)[s]) : LOOP_ARG(geo.nf);
     for (int fl = 0; fl < nf_s; fl++) {
         // ResvFrameBegin (src/reservoir.c:45-93); main_data_begin*8 == ResvSize by construction
         int ResvSize = L.st.ResvSize;
@@ -838,7 +947,9 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 const int lane = wave_lane_here(); // nothing derived from the lane index outlives this granule
                 const int gl = 2 * fl + gr;
                 const size_t rec = ((size_t) s * G + gl) * C + ch;
-                const mp3mi_psy_out *po = &psy[rec];
+                // (the granule's pointers in one go: one laundered base, the scalar loads behind it issue together)
+                loop_kargs_p kg = loop_kargs_ptr(ka);
+                const mp3mi_psy_out *po = &kg->psy[rec];
                 loop_gr g;
                 g.block_type = po->block_type;
                 g.wsf = g.block_type != 0;
@@ -849,20 +960,29 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 g.address2 = L.st.addr[gr][ch][1];
                 g.address3 = L.st.addr[gr][ch][2];
                 const int nband = shortb ? 36 : 21;   // band lanes
-                float y34[9], y34max;
+                float y34[LOOP_NV], y34max;
                 {
-                    double xr[9];
+                    double xr[LOOP_NV];
+                    const double *xr_all = kg->xr_all;
 #pragma unroll
-                    for (int j = 0; j < 9; j++) xr[j] = xr_all[rec * 576 + lane + 64 * j];
+                    for (int k = 0; k < LOOP_SLOTS; k++) { // a pair = 16 bytes per lane
+                        const int pr = loop_pair_of(lane, k);
+                        const bool there = k < 4 || pr < 288;
+                        xr[2 * k] = there ? xr_all[rec * 576 + 2 * pr] : 0.0;
+                        xr[2 * k + 1] = there ? xr_all[rec * 576 + 2 * pr + 1] : 0.0;
+                    }
                     y34max = loop_power34(xr, y34);
 #pragma unroll
-                    for (int j = 0; j < 9; j++) L.xr[lane + 64 * j] = xr[j];
+                    for (int k = 0; k < LOOP_SLOTS; k++) {
+                        const int pr = loop_pair_of(lane, k);
+                        if (k < 4 || pr < 288) { L.xr[2 * pr] = xr[2 * k]; L.xr[2 * pr + 1] = xr[2 * k + 1]; }
+                    }
                 }
 
                 // ---- calc_xmin (src/loop.c:1085-1118) and the values calc_scfsi stores (src/loop.c:631-667)
                 //      were computed by k_mdct's tail (k_prep); only the stateful decision of calc_scfsi happens here ----
                 PROF(0);
-                const mp3mi_loop_prep *pp = &prep[rec];
+                const mp3mi_loop_prep *pp = &kg->prep[rec];
                 // per-band state (allowed distortion, scalefactors): L.band_*
                 if (lane < 36) {
                     L.band_xmin[lane] = lane < nband ? pp->xmin[lane] : 0.0;
@@ -903,7 +1023,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                             scfsi_m |= v << band;
                         }
                     }
-                    if (lane < 4) side_out[(size_t) s * geo.nf + fl].scfsi[ch][lane] = (scfsi_m >> lane) & 1; // (always decided in granule 1)
+                    if (lane < 4) LOOP_ARG(side_out)[(size_t) s * LOOP_ARG(geo.nf) + fl].scfsi[ch][lane] = (scfsi_m >> lane) & 1; // (always decided in granule 1)
                 }
                 wave_sync();
 
@@ -938,11 +1058,12 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 g.region0_count = 0; g.region1_count = 0; g.part2_length = 0; g.preflag = 0;
                 g.count1table_select = 0; g.q = 0;
 #pragma unroll
-                for (int j = 0; j < 9; j++) L.ix[lane + 64 * j] = 0;
+                for (int k = 0; k < LOOP_SLOTS; k++) ((unsigned *) L.ix)[loop_pair_of(lane, k)] = 0u;
                 wave_sync();
 
                 if (nonzero) {
                     g.q = pp->q0; // quantanf_init (src/loop.c:369-402), from k_prep
+                    const int test_flags = LOOP_ARG(geo.test_flags); // (tests: an exact tier only)
 
                     // ---- outer_loop (src/loop.c:415-558) ----
                     int iteration = 0, bits = 0, over, status, save_preflag, save_compress;
@@ -957,7 +1078,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                             // granule's budget and the reference dies.  Without the assert its loop -- and the one below --
                             // would raise the step for ever: no count is <= a negative budget.  The stream is void from
                             // here on; any budget lets the search run out.
-                            LOOP_REF_ABORT(MP3MI_DEV_ABORT_HUFF_BITS, geo.fabs0 + geo.f0 + fl);
+                            LOOP_REF_ABORT(MP3MI_DEV_ABORT_HUFF_BITS, LOOP_ARG(geo.fabs0) + LOOP_ARG(geo.f0) + fl);
                             huff_bits = max_bits;
                         }
                         // bin_search_StepSize (src/loop.c:2119-2140, first iteration only) and inner_loop (src/loop.c:569-606)
@@ -976,11 +1097,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                                     g.q = next;
                                 }
                                 PROF(1);
-                                int tflags = geo.test_flags; // (read where it is used: as a flag held for the whole kernel it ends up in scratch)
-#if !defined(MP3MI_EMU)
-                                asm volatile("" : "+s"(tflags));
-#endif
-                                const bool quant_exact = (tflags & 8) != 0; // MP3MI_QUANT_EXACT=1: the quantiser's exact tier only (tests)
+                                const bool quant_exact = (test_flags & 8) != 0; // MP3MI_QUANT_EXACT=1: the quantiser's exact tier only (tests)
                                 const bool az = !quant_exact && loop_all_zero(y34max, g.q);
                                 work += 4;
                                 const loop_qinfo qi = loop_quantize(T, L, y34, y34max, g.q, az, quant_exact, shortb);
@@ -1004,30 +1121,40 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                         //      and the per-band state comes from / goes back to L.band_*: nothing of it is alive during
                         //      the quantise+count passes above ----
                         const bool bandlane = lane < nband;
-                        const unsigned long long bandpack = T->lane_bands[shortb][lane]; // band of each of this lane's 9 lines
-                        const unsigned long long jobs = T->lane_jobs[shortb][lane];
-                        const int jfirst = (int) (jobs & 1023ull), jcount = (int) ((jobs >> 10) & 255ull), jseg = (int) ((jobs >> 18) & 31ull);
-                        const int pj0 = (int) ((jobs >> 23) & 63ull), scount = (int) ((jobs >> 35) & 255ull), sfirst = (int) ((jobs >> 43) & 1023ull);
+                        // (registers: the partial sums below are where the kernel's register count is set -- ten y34, four terms in
+                        // flight --, so nothing that is only needed behind them is fetched or unpacked in front of them)
+                        unsigned long long jobs = T->lane_jobs[shortb][lane];
+                        const int jfirst = (int) (jobs & 1023ull), jcount = (int) ((jobs >> 10) & 255ull);
                         const int sstride = shortb ? 3 : 1;
                         const int jmax4 = (T->nj_max[shortb] + 3) & ~3; // the longest job, in steps of four terms
-                        double xmin_r = bandlane ? L.band_xmin[lane] : 0.0, xfsf_r = 0.0;
-                        int sf_r = bandlane ? L.band_sf[lane] : 0;
+                        double xfsf_r = 0.0;
                         // calc_noise (src/loop.c:1007-1067).  The noise of a band is only ever COMPARED with the
                         // allowed distortion, and it is a sum of non-negative terms, so any summation order
                         // agrees with the reference's sequential one to within 2(n-1) ulp (n <= 102 lines:
                         // < 2.3e-14 relative).  First tier: every band is cut into parts of ~10 lines summed by
                         // different lanes.  Only if a band lands within 1e-12 of its threshold is the
                         // reference's order used (loop_noise_exact) -- at both places that compare.
-                        bool xfsf_exact = (geo.test_flags & 1) != 0;
-                        double noise_step;
+                        bool xfsf_exact = (test_flags & 1) != 0;
+                        const double noise_step = T->step[g.q - MP3MI_STEP_MIN];
+                        double vjob = 0.0;
+                        if (!xfsf_exact) vjob = shortb ? loop_noise_jobs_short(T, L, noise_step, jfirst, jcount, jmax4) : loop_noise_jobs_long(T, L, noise_step, jfirst, jcount, jmax4);
+                        // band of each of this lane's five PAIRS (a band's edges are even: both lines of a pair are of one band), 6 bits
+                        // each; short blocks: the lines of a pair belong to two windows, i.e. two band lanes: 10 fields of a 64-bit word
+                        // (asked for here: its latency passes under the band sums' reduction)
+                        const unsigned long long bandpack = T->lane_bands[shortb][wave_lane_here()];
+                        // the band lane's state (fetched behind the partial sums, see above)
+                        const int bl = wave_lane_here();
+                        double xmin_r = bandlane ? L.band_xmin[bl] : 0.0;
+                        int sf_r = bandlane ? L.band_sf[bl] : 0;
                         {
-                            noise_step = T->step[g.q - MP3MI_STEP_MIN];
                             if (!xfsf_exact) {
                                 // The jobs of a band sit in consecutive lanes: a segmented sum by doubling (lane l takes
                                 // over the sum of lane l + d where that is a job of the same band: bit of jseg) leaves
                                 // the band's sum in its first job's lane, where the band lane fetches it.  Any order
                                 // of these non-negative terms is as good as another here (see above).
-                                double v = loop_noise_jobs(T, L, noise_step, jfirst, jcount, sstride, jmax4);
+                                double v = vjob;
+                                jobs = wave_opaque_u64(jobs);
+                                const int jseg = (int) ((jobs >> 18) & 31ull), pj0 = (int) ((jobs >> 23) & 63ull), scount = (int) ((jobs >> 35) & 255ull);
                                 // (a band has at most 16 jobs -- tables_host.cpp refuses a table with more -- so four doublings do)
                                 const int lane4 = 4 * lane;
                                 { const double o = wave_down_f64<1>(v, lane4); v = v + ((jseg & 1) ? o : 0.0); }
@@ -1038,7 +1165,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                                 xfsf_r = bandlane ? sum / (double) scount : 0.0;
                                 if (wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) xfsf_exact = true;
                             }
-                            if (xfsf_exact) xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, sfirst, scount, sstride);
+                            if (xfsf_exact) xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, (int) ((jobs >> 43) & 1023ull), (int) ((jobs >> 35) & 255ull), sstride);
                         }
                         if (bandlane) L.band_sfsave[lane] = sf_r; // the result of this iteration stands (src/loop.c:505-519)
                         save_preflag = g.preflag;
@@ -1061,14 +1188,18 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                                     // the thresholds moved: amp_scalefac_bands compares against the new ones
                                     if (!xfsf_exact && wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) {
                                         xfsf_exact = true;
-                                        xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, sfirst, scount, sstride);
+                                        xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, (int) ((jobs >> 43) & 1023ull), (int) ((jobs >> 35) & 255ull), sstride);
                                     }
 #pragma unroll
-                                    for (int j = 0; j < 9; j++) {
-                                        const int b = (int) ((bandpack >> (6 * j)) & 63ull);
+                                    for (int k = 0; k < LOOP_SLOTS; k++) { // (long blocks only: a pair is of one band)
+                                        const int b = (int) (((unsigned) bandpack >> (6 * k)) & 63u); // (63: a pair that does not exist)
+                                        const int line = 2 * loop_pair_of(lane, k);
                                         if (b < g.sfb_lmax) {
-                                            L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * T->pretab_xr[LOOP_PRETAB[b]];
-                                            y34[j] = loop_rescale34(y34[j], LOOP_PRETAB[b]);
+                                            const double f = T->pretab_xr[LOOP_PRETAB[b]];
+                                            L.xr[line] = L.xr[line] * f;
+                                            L.xr[line + 1] = L.xr[line + 1] * f;
+                                            y34[2 * k] = loop_rescale34(y34[2 * k], LOOP_PRETAB[b]);
+                                            y34[2 * k + 1] = loop_rescale34(y34[2 * k + 1], LOOP_PRETAB[b]);
                                         }
                                     }
                                     y34max = y34max * LOOP_Y34MAX_GROW;
@@ -1105,17 +1236,33 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                             const unsigned long long ampmask = __ballot(amp); // bit b = band lane b amplified
                             over = __popcll(ampmask);
                             if (over) {
-                                // The amplified bands are a few runs of consecutive lines, so most of the nine slots of 64
-                                // lines hold none of them: a slot is skipped as a whole,
+                                // The amplified bands are a few runs of consecutive lines, so most of the five slots of 64
+                                // pairs hold none of them: a slot's lines are skipped as a whole,
                                 // and inside a slot only the amplified lines touch the LDS.  ampmask only has bits of
                                 // band lanes, so lines above the last band (b >= nband) find a zero bit.
+                                if (!shortb) { // a pair is of one band; 21 band lanes: the mask is one word
+                                    const unsigned amp32 = (unsigned) ampmask;
 #pragma unroll
-                                for (int j = 0; j < 9; j++) {
-                                    const unsigned b = (unsigned) ((bandpack >> (6 * j)) & 63ull);
-                                    const bool f = ((ampmask >> b) & 1ull) != 0;
-                                    if (f) { // (a slot none of whose lines is amplified: the branch over an empty execution mask)
-                                        L.xr[lane + 64 * j] = L.xr[lane + 64 * j] * ifqstep;
-                                        y34[j] = y34[j] * 1.2968395546510096f; // loop_rescale34(y34, 1)
+                                    for (int k = 0; k < LOOP_SLOTS; k++) {
+                                        const unsigned b = ((unsigned) bandpack >> (6 * k)) & 63u;
+                                        const int line = 2 * loop_pair_of(lane, k);
+                                        if (b < 32u && ((amp32 >> b) & 1u)) { // (a slot none of whose pairs is amplified: the branch over an empty execution mask)
+                                            L.xr[line] = L.xr[line] * ifqstep;
+                                            L.xr[line + 1] = L.xr[line + 1] * ifqstep;
+                                            y34[2 * k] = y34[2 * k] * 1.2968395546510096f; // loop_rescale34(y34, 1)
+                                            y34[2 * k + 1] = y34[2 * k + 1] * 1.2968395546510096f;
+                                        }
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < LOOP_NV; j++) {
+                                        const unsigned b = (unsigned) ((bandpack >> (6 * j)) & 63ull);
+                                        const bool f = ((ampmask >> b) & 1ull) != 0;
+                                        const int line = 2 * loop_pair_of(lane, j >> 1) + (j & 1);
+                                        if (f) {
+                                            L.xr[line] = L.xr[line] * ifqstep;
+                                            y34[j] = y34[j] * 1.2968395546510096f;
+                                        }
                                     }
                                 }
                                 y34max = y34max * LOOP_Y34MAX_AMP;
@@ -1161,18 +1308,25 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                 // ResvAdjust (src/reservoir.c:141-145), global_gain (src/loop.c:357)
                 ResvSize += (mean_bits / C) - g.part2_3_length;
                 const int global_gain = loop_nint((double) g.q + 210.0);
-                if (global_gain >= 256) LOOP_REF_ABORT(MP3MI_DEV_ABORT_GLOBAL_GAIN, geo.fabs0 + geo.f0 + fl); // assert, src/loop.c:358
+                if (global_gain >= 256) LOOP_REF_ABORT(MP3MI_DEV_ABORT_GLOBAL_GAIN, LOOP_ARG(geo.fabs0) + LOOP_ARG(geo.f0) + fl); // assert, src/loop.c:358
 
                 PROF(6);
                 // ---- hand the granule over: signed ix (src/l3bitstream.c:115-125) and side info ----
+                loop_kargs_p ko = loop_kargs_ptr(ka);
+                unsigned *ix_out = (unsigned *) ko->ix_out;
 #pragma unroll
-                for (int j = 0; j < 9; j++) {
-                    int v = L.ix[lane + 64 * j]; // what the last pass (or the reset) left
-                    if (L.xr[lane + 64 * j] < 0 && v > 0) v = -v;
-                    ix_out[rec * 576 + lane + 64 * j] = (int16_t) v;
+                for (int k = 0; k < LOOP_SLOTS; k++) {
+                    const int pr = loop_pair_of(lane, k);
+                    if (k < 4 || pr < 288) {
+                        const unsigned w = ((const unsigned *) L.ix)[pr]; // what the last pass (or the reset) left
+                        int x = (int) (w & 0xffffu), y = (int) (w >> 16);
+                        if (L.xr[2 * pr] < 0 && x > 0) x = -x;
+                        if (L.xr[2 * pr + 1] < 0 && y > 0) y = -y;
+                        ix_out[rec * 288 + pr] = ((unsigned) x & 0xffffu) | ((unsigned) y << 16);
+                    }
                 }
                 {
-                    mp3mi_gr_side *o = &side_out[(size_t) s * geo.nf + fl].gr[gr][ch]; // straight to memory
+                    mp3mi_gr_side *o = &ko->side_out[(size_t) s * ko->geo.nf + fl].gr[gr][ch]; // straight to memory
                     if (lane == 0) {
                         o->part2_3_length = g.part2_3_length; o->big_values = g.big_values; o->count1 = g.count1;
                         o->global_gain = global_gain; o->scalefac_compress = g.scalefac_compress;
@@ -1221,7 +1375,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
                         resvDrain = stuffingBits;
                     }
                 }
-                mp3mi_frame_side *o = &side_out[(size_t) s * geo.nf + fl];
+                mp3mi_frame_side *o = &LOOP_ARG(side_out)[(size_t) s * LOOP_ARG(geo.nf) + fl];
                 if (moved)
                     for (int gr = 0; gr < 2; gr++)
                         for (int ch = 0; ch < C; ch++) o->gr[gr][ch].part2_3_length = L.p23[gr][ch];
@@ -1236,12 +1390,12 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
         // work.  gate_count[1] counts the frames finished by all streams of this launch; a stream
         // behind the average raises its wave priority (it then issues ahead of the three other
         // wavefronts of its SIMD), a stream ahead of it lowers it.  Purely a scheduling hint.
+        unsigned *gate_count = LOOP_ARG(gate_count);
         if (gate_count) {
             const unsigned done_all = __builtin_amdgcn_readfirstlane((int) (lane == 0 ? atomicAdd(gate_count + 1, 1u) + 1u : 0u));
             // (frames per wavefront so far against the average over the wavefronts of the launch: a wavefront on its
             // second stream has that stream's frames on top of the first one's)
-            int n_act = geo.n_streams;
-            asm volatile("" : "+s"(n_act)); // converted here, once per frame, instead of living in a register for the whole kernel
+            const int n_act = LOOP_ARG(geo.n_streams); // (fetched and converted here, once per frame)
             const float lead = (float) (fl + 1) - (float) done_all / (float) n_act;
             if (lead < -1.0f) __builtin_amdgcn_s_setprio(3);
             else if (lead < 0.0f) __builtin_amdgcn_s_setprio(2);
@@ -1254,9 +1408,12 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
         const int ln = wave_lane_here(); // (not the address the state was loaded through, kept alive across the whole kernel)
         if (ln == 0) L.st.ref_abort = ref_abort;
         wave_sync();
-        for (int i = ln; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &state[s])[i] = ((const int *) &L.st)[i];
+        for (int i = ln; i < (int) (sizeof(mp3mi_loop_state) / 4); i += 64) ((int *) &LOOP_ARG(state)[s])[i] = ((const int *) &L.st)[i];
     }
-    if (place.cost && lane == 0) place.cost[s] = work;
+    {
+        int *cost = LOOP_ARG(place.cost);
+        if (cost && lane == 0) cost[s] = work;
+    }
 #if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
     if (lane == 0 && s < 65536) g_loop_work[s] = (unsigned long long) work | ((unsigned long long) __builtin_amdgcn_s_memrealtime() << 20);
 #endif
@@ -1264,11 +1421,6 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
     PROF_END;
 }
 
-#define LOOP_KERNEL_ARGS const mp3mi_tables *__restrict__ T, mp3mi_geom geo, const double *__restrict__ xr_all,                     \
-                         const mp3mi_psy_out *__restrict__ psy, const mp3mi_loop_prep *__restrict__ prep,                      \
-                         const int32_t *__restrict__ bits_per_frame, mp3mi_loop_state *__restrict__ state,                     \
-                         int16_t *__restrict__ ix_out, mp3mi_frame_side *__restrict__ side_out, unsigned *__restrict__ gate_count, \
-                         mp3mi_loop_place place
 // what every wavefront of a workgroup does first: its share of the code-length tables (the workgroup's only barrier;
 // from there on every wavefront is on its own)
 #define LOOP_KERNEL_PROLOGUE                                                                                         \
@@ -1280,11 +1432,18 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, const mp3mi_geo
     __syncthreads()
 
 // As many wavefronts as streams, each takes one.
-__global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP_W) k_loop(LOOP_KERNEL_ARGS)
+__global__ void __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(64 * LOOP_W) k_loop(const mp3mi_tables *__restrict__ T, loop_kargs A)
 {
     LOOP_KERNEL_PROLOGUE;
     const int block = (int) blockIdx.x * LOOP_W + wv;
-    if (block < geo.n_streams) loop_stream(T, geo, xr_all, psy, prep, bits_per_frame, state, ix_out, side_out, gate_count, place, L, GL, block);
+#if defined(MP3MI_EMU)
+    loop_kargs_p ka = &A;
+#else
+    // (the record follows the table pointer in the kernel argument segment)
+    loop_kargs_p ka = (loop_kargs_p) ((const __attribute__((address_space(4))) char *) __builtin_amdgcn_kernarg_segment_ptr() + sizeof(void *));
+    static_assert(alignof(loop_kargs) == 8, "loop_kargs follows an 8-byte argument");
+#endif
+    if (block < A.geo.n_streams) loop_stream(T, ka, L, GL, block);
 }
 
 #if defined(MP3MI_LOOP_PROFILE) && !defined(MP3MI_EMU)
@@ -1336,8 +1495,10 @@ void mp3mi_launch_loop(const mp3mi_tables *T, const mp3mi_geom &g, const double 
                        mp3mi_frame_side *side, unsigned *gate_count, mp3mi_loop_place place, hipStream_t st)
 {
     const int want = (g.n_streams + LOOP_W - 1) / LOOP_W;
-    hipLaunchKernelGGL(k_loop, dim3((unsigned) want), dim3(64 * LOOP_W), 0, st, T, g, xr, psy, prep, bits_per_frame,
-                       (mp3mi_loop_state *) loop_state, ix, side, gate_count, place);
+    loop_kargs A;
+    A.geo = g; A.xr_all = xr; A.psy = psy; A.prep = prep; A.bits_per_frame = bits_per_frame;
+    A.state = (mp3mi_loop_state *) loop_state; A.ix_out = ix; A.side_out = side; A.gate_count = gate_count; A.place = place;
+    hipLaunchKernelGGL(k_loop, dim3((unsigned) want), dim3(64 * LOOP_W), 0, st, T, A);
 }
 
 // Holds the front stream back until the k_loop launch whose census target is `target` has (all but

@@ -101,7 +101,8 @@ typedef struct {
     uint8_t nj_seg[2][64];           /* bit d (1, 2, 4, 8, 16): job j + d belongs to the same band as job j (bands have < 32 jobs) */
     /* what lane l of k_loop needs to know about "its" lines and noise jobs, packed so that one 8-byte load each brings it in
        where it is used (the distortion loop) instead of a dozen registers living through the whole search; [0] long, [1] short:
-       lane_bands: band (= band lane) of line l + 64 j in bits 6j .. 6j+5, j < 9;
+       lane_bands: [0] band (= band lane) of the lane's PAIR k < 5 -- lines 2 (l + 64 k), + 1: one band, k_loop.hip -- in bits 6k .. 6k+5;
+                   [1] of its value j < 10 -- line 2 (l + 64 (j / 2)) + j % 2 -- in bits 6j .. 6j+5 (63: the line does not exist);
        lane_jobs: nj_first (10 bits) | nj_count << 10 (8) | nj_seg << 18 (5) | nj_job0 << 23 (6) | nj_njobs << 29 (6) |
                   lines of band l << 35 (8) | first line of band l << 43 (10; short: l = sfb * 3 + window -> first * 3 + window) */
     uint64_t lane_bands[2][64], lane_jobs[2][64];
@@ -204,11 +205,19 @@ typedef struct {
 #if defined(MP3MI_EMU)
 #define LOOP_FAST_SQRTF(x) __builtin_sqrtf(x)
 #define LOOP_FAST_EXP2F(x) __builtin_exp2f(x)
-#define LOOP_FRACTF(x) ((x) - __builtin_floorf(x)) /* exact for the quantiser's 0.4 <= x < 2048 */
+/* v_cvt_pknorm_u16_f32 as the device executes it (mp3mi_debug_pknorm_bound, k_debug.hip): each operand clamped to [0, 1],
+   times 65535 -- exact in double -- rounded to the nearest integer, ties to even; a | b << 16 */
+static inline unsigned mp3mi_emu_pknorm_u16(float a, float b)
+{
+    const double ca = a > 0.0f ? (a < 1.0f ? (double) a : 1.0) : 0.0, cb = b > 0.0f ? (b < 1.0f ? (double) b : 1.0) : 0.0;
+    return (unsigned) __builtin_rint(ca * 65535.0) | ((unsigned) __builtin_rint(cb * 65535.0) << 16);
+}
+#define LOOP_PKNORM_U16(a, b) mp3mi_emu_pknorm_u16((a), (b))
 #else
-#define LOOP_FRACTF(x) __builtin_amdgcn_fractf(x)  /* v_fract_f32: x - floor(x), exact there */
 #define LOOP_FAST_SQRTF(x) __builtin_amdgcn_sqrtf(x)
 #define LOOP_FAST_EXP2F(x) __builtin_amdgcn_exp2f(x) /* |x| < 80 here: no denormal range to care for */
+typedef unsigned short mp3mi_u16x2 __attribute__((ext_vector_type(2)));
+#define LOOP_PKNORM_U16(a, b) __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16((a), (b)))
 #endif
 
 /* Diagnostic build only (-DMP3MI_ULP_CENSUS, tools/gpu_ulp_census.sh; never the product build): how often does a

@@ -625,9 +625,14 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
     for (int t = 0; t < 2; t++) {
         const int nb = t ? 36 : 21;
         for (int target = 4; target <= 192; target++) {
+            /* long blocks [0]: k_loop sums a job by PAIRS of lines (one 16-byte and one 4-byte LDS read per two terms), so
+               bands -- whose edges are even at every rate, checked here -- are cut into parts of whole pairs: unit = 2 */
+            const int unit = t ? 1 : 2;
+            if (target % unit) continue;
             int jobs = 0;
             for (int b = 0; b < nb; b++) {
                 const int w = t ? SFB_S[ri][b / 3 + 1] - SFB_S[ri][b / 3] : SFB_L[ri][b + 1] - SFB_L[ri][b];
+                if (!t && ((w & 1) || (SFB_L[ri][b] & 1))) return -11;
                 jobs += (w + target - 1) / target;
             }
             if (jobs > 64) continue;
@@ -639,7 +644,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
                 T->nj_job0[t][b] = (uint8_t) j;
                 T->nj_njobs[t][b] = (uint8_t) parts;
                 for (int q = 0, off = 0; q < parts; q++) {
-                    const int cnt = (w - off + (parts - q) - 1) / (parts - q); // even split of what is left
+                    const int cnt = unit * (((w - off) / unit + (parts - q) - 1) / (parts - q)); // even split of what is left, in units
                     T->nj_first[t][j] = (int16_t) (t ? (e0 + off) * 3 + b % 3 : e0 + off);
                     T->nj_count[t][j] = (uint8_t) cnt;
                     if (cnt > T->nj_max[t]) T->nj_max[t] = (uint8_t) cnt;
@@ -662,7 +667,18 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
         const int nb = t ? 36 : 21;
         for (int l = 0; l < 64; l++) {
             uint64_t bp = 0;
-            for (int j = 0; j < 9; j++) bp |= (uint64_t) (t ? T->sfb_of_line_s[l + 64 * j] : T->sfb_of_line_l[l + 64 * j]) << (6 * j);
+            if (t) { /* short blocks: value j of lane l is line 2 (l + 64 (j / 2)) + j % 2 (k_loop.hip, loop_pair_of) */
+                for (int j = 0; j < 10; j++) {
+                    const int line = 2 * (l + 64 * (j / 2)) + j % 2;
+                    bp |= (uint64_t) (line < 576 ? T->sfb_of_line_s[line] : 63) << (6 * j);
+                }
+            } else { /* long blocks: a band's edges are even (checked above), both lines of PAIR l + 64 k are of one band */
+                for (int k = 0; k < 5; k++) {
+                    const int line = 2 * (l + 64 * k);
+                    if (line < 576 && T->sfb_of_line_l[line] != T->sfb_of_line_l[line + 1]) return -12;
+                    bp |= (uint64_t) (line < 576 ? T->sfb_of_line_l[line] : 63) << (6 * k);
+                }
+            }
             T->lane_bands[t][l] = bp;
             uint64_t first = 0, count = 0;
             if (l < nb) {

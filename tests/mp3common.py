@@ -159,6 +159,7 @@ class Mp3mi:
         L.mp3mi_batch_set_test_flags.argtypes = [ctypes.c_void_p, ctypes.c_uint]
         L.mp3mi_synth_pcm_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.mp3mi_debug_fastmath_bounds.argtypes = [ctypes.c_void_p]
+        L.mp3mi_debug_pknorm_bound.argtypes = [ctypes.c_void_p]
         L.mp3mi_batch_encode_next.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_batch_encode_host_async.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.mp3mi_batch_host_io_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

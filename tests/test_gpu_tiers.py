@@ -15,9 +15,9 @@ FLAGS = {"noise": 1, "phase": 2, "psy": 4, "quant": 8, "prep": 16, "cw": 32, "al
 
 
 def test_raw_sqrt_and_exp2_stay_inside_the_guard_band_budget(product):
-    """k_loop.hip loop_quantize: the estimate f of x^(3/4) + 0.4054 is
-         f = fma(y34, exp2_raw(-3q/16), 0.4054f),  y34 = sqrt_raw(a * sqrt_raw(a)) [* up to 17 rescalings]
-    and its guard band budgets 7e-7 relative for everything but the rescalings.  Measured on this device over
+    """k_loop.hip loop_quantize: the two estimates of x^(3/4) + 0.4054 - 0.5 are
+         fma(y34, exp2_raw(-3q/16) * (1 +- 3.5e-6) / 65535, (0.4054 - 0.5 +- 2e-6) / 65535),  y34 = sqrt_raw(a * sqrt_raw(a)) [* up to 17 rescalings]
+    and the band between them budgets 7e-7 relative for everything but the rescalings.  Measured on this device over
     all 2^24 floats of [1, 4) (the error repeats exactly every factor of 4), every step size the search can ask
     for, and 2^24 more exp2 arguments.  2^-24 each: the roundings of the product y34 * cq and of the sum."""
     out = (ctypes.c_double * 3)()
@@ -27,6 +27,17 @@ def test_raw_sqrt_and_exp2_stay_inside_the_guard_band_budget(product):
     assert 0.0 < e_y34 < 3.0e-7      # two 1-ulp roots, the inner one halved, and the rounding of a * sqrt(a)
     assert e_exp_used < 1.5e-7 and 0.0 < e_exp_any < 2.0e-7
     assert e_y34 + max(e_exp_used, e_exp_any) + 2 * 2.0 ** -24 < 7e-7
+
+
+def test_the_quantisers_rounding_instruction_rounds_to_nearest(product):
+    """k_loop.hip loop_quant_pair: v_cvt_pknorm_u16_f32 turns the upper and the lower estimate of x^(3/4) + 0.4054 - 0.5 (scaled
+    by 1 / 65535) into integers, a pair per instruction; the proof that a line whose two roundings agree is settled needs
+    |n - a * 65535| <= 0.5 and a monotone conversion.  Every float of [2^-31, 2048.5 / 65535] (218 M arguments) against double
+    arithmetic, both halves of the instruction, both clamps."""
+    out = (ctypes.c_double * 3)()
+    assert product.lib.mp3mi_debug_pknorm_bound(out) == 0
+    print("v_cvt_pknorm_u16_f32: max |n - a * 65535| = %.9f, non-monotone neighbours %d, half / clamp mismatches %d" % (out[0], out[1], out[2]))
+    assert 0.25 < out[0] <= 0.5 and out[1] == 0 and out[2] == 0
 
 
 @pytest.mark.parametrize("rate,ch,kbps,S,nf,stream0", [(44100, 2, 128, 4096, 24, 0), (48000, 2, 320, 1024, 20, 5000), (32000, 1, 64, 2048, 20, 9000)])
