@@ -23,7 +23,9 @@ The default (--layer 3) is the metric of BASELINE.json.
 
 The default line (N = 1, configs[1], Layer III) also carries `end_to_end` -- the same K steps with PCM and bytes in page-locked
 host memory, crossing PCIe beside the kernels; `value` stays the resident rate -- and `other_workloads`:
-two steps each of configs[3] and configs[4] and one Layer II step, each with its own oracle spot check.
+two steps each of configs[2], configs[3], configs[4] and of the Layer II batch and one Layer I step, each with its own oracle
+spot check.  `collective_backend` says what carried the ranks' barrier / maximum / votes (RCCL, or gloo where RCCL did not come up or
+MP3MI_BENCH_BACKEND=gloo asked for it); `roofline.clock_ghz_measured` is the engine clock the driver reported during the timed region.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, one per GPU, and relays rank 0's line)
@@ -53,6 +55,171 @@ def load_torch():
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class Coll:
+    """The ranks' control traffic: a barrier, a maximum, a vote, a gather -- eight bytes each; the data path has no collective
+    (streams are independent: the reference's loop is one stream in one process, /root/reference/src/musicin.c:585).
+    RCCL (torch.distributed backend "nccl") carries it where it comes up; a rank whose RCCL does not -- or
+    MP3MI_BENCH_BACKEND=gloo, or the one-GPU rehearsal -- falls back to gloo with CPU tensors FOR ALL RANKS: the ranks first
+    meet on gloo (which needs no GPU), try RCCL on a group of its own, and vote.  `backend` says what carried the run."""
+
+    def __init__(self, world, dev, want_nccl):
+        self.world, self.dev, self.dist, self.group, self.backend = world, dev, None, None, "none (one rank)"
+        if world <= 1:
+            return
+        import datetime
+        import torch.distributed as dist
+        self.dist = dist
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+        self.backend = "gloo (asked for)"
+        if not want_nccl:
+            return
+        ok, why = 1, ""
+        try:
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+            t = torch.ones(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(t, group=g)
+            torch.cuda.synchronize()
+            if int(t.item()) != world:
+                ok, why = 0, "a sum over %d ranks came back as %d" % (world, int(t.item()))
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL raises here, the run goes on over gloo
+            ok, why, g = 0, str(e).splitlines()[0][:200], None
+        v = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        if int(v.item()) == 1:
+            self.group, self.backend = g, "nccl (RCCL)"
+        else:
+            self.backend = "gloo (RCCL did not come up on every rank%s)" % ((": " + why) if why else "")
+
+    def _t(self, values, dtype):
+        return torch.tensor(values, dtype=dtype, device=self.dev if self.group is not None else "cpu")
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.all_reduce(self._t([0], torch.int32), group=self.group)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def reduce(self, value, op, dtype=None):
+        if self.dist is None:
+            return value
+        dtype = dtype or (torch.float64 if isinstance(value, float) else torch.int64)
+        t = self._t([value], dtype)
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN, "sum": self.dist.ReduceOp.SUM}[op], group=self.group)
+        return t.item()
+
+    def gather(self, values):
+        """every rank's list of int64 values, by rank"""
+        mine = self._t(values, torch.int64)
+        if self.dist is None:
+            return [mine.tolist()]
+        per = [mine.clone() for _ in range(self.world)]
+        self.dist.all_gather(per, mine, group=self.group)
+        return [t.tolist() for t in per]
+
+    def close(self):
+        if self.dist is not None:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+
+def gpu_numa_cpus(dev_index):
+    """(cpus of the NUMA node the GPU `dev_index` hangs on, description) from the KFD topology and sysfs -- no GPU call, no torch.
+    The ranks of a node then pin themselves to the cores next to their GPU: page-locked buffers (7.9 GB a rank on the end_to_end
+    leg) are allocated there, and eight ranks do not pile onto one socket.  None when the topology does not say."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(l.split() for l in open(os.path.join(base, n, "properties")) if len(l.split()) == 2)
+            if int(props.get("simd_count", "0")) > 0 and int(props.get("vendor_id", "0")) == 0x1002:
+                gpus.append(props)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            gpus = [gpus[int(i)] for i in vis.split(",") if i.strip().isdigit() and int(i) < len(gpus)]
+        pr = gpus[dev_index]
+        loc, dom = int(pr["location_id"]), int(pr.get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None, "GPU %s: no NUMA node recorded" % bdf
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return (cpus or None), "GPU %s on NUMA node %d" % (bdf, node)
+    except Exception as e:  # noqa: BLE001
+        return None, "topology not readable (%s)" % type(e).__name__
+
+
+def pin_to_gpu_numa(dev_index, local_rank, local_world):
+    """Before torch is imported: this rank's threads onto the cores next to its GPU; ranks that share a NUMA node share its
+    cores (not split: the CPU baseline of rank 0 widens its own mask again).  Returns what was done, for the bench line."""
+    if os.environ.get("MP3MI_BENCH_NO_PIN") == "1":
+        return "unchanged (MP3MI_BENCH_NO_PIN=1)"
+    cpus, what = gpu_numa_cpus(dev_index)
+    if not cpus:
+        return "unchanged (%s)" % what
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError as e:
+        return "unchanged (sched_setaffinity: %s)" % e
+    return "%d cpus of %s" % (len(cpus), what)
+
+
+class ClockSampler:
+    """The engine clock while the timed region runs, read from the driver's sysfs table (pp_dpm_sclk: the starred line) every
+    20 ms by a side thread of this process.  `effective_clock_ghz` of the issue roofline is DERIVED (wave cycles over time, pulled
+    down by the loop kernel's tail); this is the clock the hardware reports.  None where the file is not there or not readable."""
+
+    def __init__(self, dev_index):
+        import glob
+        self.samples, self.stop_flag, self.thread, self.path = [], False, None, None
+        try:
+            want = None
+            pr = torch.cuda.get_device_properties(dev_index)
+            if hasattr(pr, "pci_bus_id"):
+                want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+            for c in cards:
+                if want and want in os.path.realpath(os.path.dirname(c)):
+                    self.path = c
+            if self.path is None and len(cards) == 1:
+                self.path = cards[0]
+        except Exception:  # noqa: BLE001
+            self.path = None
+
+    def _run(self):
+        import re
+        while not self.stop_flag:
+            try:
+                for line in open(self.path):
+                    if "*" in line:
+                        m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                        if m:
+                            self.samples.append(int(m.group(1)))
+            except OSError:
+                return
+            time.sleep(0.02)
+
+    def start(self):
+        if self.path is not None:
+            import threading
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+        return self
+
+    def stop(self):
+        self.stop_flag = True
+        if self.thread is not None:
+            self.thread.join(timeout=1)
+        if not self.samples:
+            return None
+        a = np.array(self.samples, dtype=np.float64)
+        return {"mean": round(float(a.mean()) / 1e3, 3), "min": round(float(a.min()) / 1e3, 3), "max": round(float(a.max()) / 1e3, 3), "samples": int(a.size),
+                "source": self.path}
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
 SEED = 0x6D70336D
@@ -241,12 +408,21 @@ L12_KERNEL_BOUND = {
 }
 
 
-def main_l12(args, mp3, dev, cdev, rank, world, distributed):
+def all_host_cores():
+    """The CPU baselines run on ALL host cores: the rank widens the mask it narrowed for its GPU's NUMA node."""
+    n = os.cpu_count() or 1
+    try:
+        os.sched_setaffinity(0, range(n))
+        n = len(os.sched_getaffinity(0))
+    except OSError:
+        n = len(os.sched_getaffinity(0))
+    return max(1, n)
+
+
+def main_l12(args, mp3, dev, coll, rank, world, affinity):
     """The Layer I / II path under the same contract: a step = one mp3mi_l12_batch_encode call over the batch."""
     import hashlib
     from mp3common import Oracle, oracle_l12
-    if distributed:
-        import torch.distributed as dist
     layer = args.layer
     spf = 384 if layer == 1 else 1152
     rate, C, mode = 44100, 2, "s"
@@ -260,11 +436,7 @@ def main_l12(args, mp3, dev, cdev, rank, world, distributed):
     out_len = torch.zeros(S, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    barrier = coll.barrier
     for _ in range(args.warmup):
         batch.encode(pcm, nf, out, out_len)
         batch.sync()
@@ -277,13 +449,10 @@ def main_l12(args, mp3, dev, cdev, rank, world, distributed):
     barrier()
     dt = time.perf_counter() - t0
     k_after = batch.kernel_timing()
-    if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = float(coll.reduce(dt, "max"))
 
-    cores = max(1, min(os.cpu_count() or 1, 64))
     timed_baseline = rank == 0 and not args.no_cpu_baseline
+    cores = all_host_cores() if timed_baseline else 8
     n_sample = max(4, cores * 2) if timed_baseline else 8
     idx = sorted(set(np.linspace(0, S - 1, n_sample).astype(int).tolist()))
     pcm_sample = [pcm[i].cpu().numpy() for i in idx]
@@ -308,13 +477,9 @@ def main_l12(args, mp3, dev, cdev, rank, world, distributed):
             cpu = {"value": round(rfps, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
                    "sample": "%d of this batch's streams x %d frames, oracle/_ref/encode -l %d (unmodified reference, gcc -O2), one process per stream" % (len(idx), nf, layer),
                    "port_value": round(fps, 1)}
-    n_bad = torch.tensor([len(bad)], dtype=torch.int64, device=cdev)
-    mine = torch.tensor([rank, rank * S, S, int(hashlib.md5(b"".join(got)).hexdigest()[:15], 16)], dtype=torch.int64, device=cdev)
-    per_rank = [mine.clone() for _ in range(world)]
-    if distributed:
-        dist.all_reduce(n_bad, op=dist.ReduceOp.SUM)
-        dist.all_gather(per_rank, mine)
-    parity_ok = int(n_bad.item()) == 0
+    n_bad = int(coll.reduce(len(bad), "sum"))
+    per_rank = coll.gather([rank, rank * S, S, int(hashlib.md5(b"".join(got)).hexdigest()[:15], 16)])
+    parity_ok = n_bad == 0
     ranks = [{"rank": int(t[0]), "first_stream": int(t[1]), "streams": int(t[2]), "sample_digest": "%015x" % int(t[3])} for t in per_rank]
     if rank == 0:
         fb = mp3.frame_bytes_l12(layer, rate, kbps)
@@ -357,27 +522,27 @@ def main_l12(args, mp3, dev, cdev, rank, world, distributed):
                          "kernels": {k: {"bound": L12_KERNEL_BOUND.get(k, "?"), "launches_per_step": kt[k][1] // max(args.steps, 1),
                                          "avg_ms_per_launch": round(kt[k][0] / max(kt[k][1], 1), 3)} for k in sorted(kt)},
                          "source_hash": mp3.lib().mp3mi_source_hash().decode()},
-            "cpu_baseline": cpu, "ranks": ranks,
+            "cpu_baseline": cpu, "ranks": ranks, "collective_backend": coll.backend, "cpu_affinity_rank0": affinity,
             "parity_spot_check": {"streams_per_rank": len(idx), "bit_exact": parity_ok, "mismatching_streams_rank0": bad,
                                   "witness": "oracle/liboracle.so" + (" + oracle/_ref/encode" if cpu and cpu["kind"] == "reference" else "")},
         }
         print(json.dumps(result), flush=True)
     batch.close()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    coll.close()
     if not parity_ok:
-        raise SystemExit("bench.py: PARITY FAILURE -- the GPU bitstream differs from the reference on %d sampled streams" % int(n_bad.item()))
+        raise SystemExit("bench.py: PARITY FAILURE -- the GPU bitstream differs from the reference on %d sampled streams" % n_bad)
 
 
 def other_workloads(mp3, dev, steps=2):
-    """configs[3], configs[4] (Layer III) and the Layer II batch, `steps` timed steps each after one warm-up, every one with
-    its own oracle spot check (8 streams spread over the batch, whole files byte for byte).  Short, so that the default
-    bench run carries driver-visible figures for them; tools/full_parity.py and the -m gpu tests hold their parity proper."""
+    """configs[2] (8192 streams: the per-GPU share of the 65 536-stream config, the loop kernel in two parts), configs[3],
+    configs[4] (Layer III) and the Layer II and Layer I batches, `steps` timed steps each (Layer I: one) after one warm-up,
+    every one with its own oracle spot check (8 streams spread over the batch, whole files byte for byte).  Short, so that
+    the default bench run carries driver-visible figures for them; tools/full_parity.py and the -m gpu tests hold their
+    parity proper."""
     from mp3common import Oracle, oracle_l12
     orc = Oracle()
     rows = []
-    for cid in (3, 4):
+    for cid in (2, 3, 4):
         cfg = CONFIGS[cid]
         S, nf, C, rate = cfg["streams"], cfg["frames"], cfg["channels"], cfg["rate"]
         wl = Workload(mp3, cfg, dev, stream0=0)
@@ -402,31 +567,35 @@ def other_workloads(mp3, dev, steps=2):
         wl.close()
         del wl
         torch.cuda.empty_cache()
-    layer, rate, C, kbps, S, nf = 2, 44100, 2, 160, 4096, 383
-    batch = mp3.BatchL12(layer, S, rate, C, kbps, nf)
-    pcm = torch.empty((S, nf * 1152 * C), dtype=torch.int16, device=dev)
-    mp3.synth_pcm_device(pcm, nf * 1152, C, rate, stream0=0, seed=SEED)
-    out = torch.zeros((S, batch.out_stride(nf)), dtype=torch.uint8, device=dev)
-    out_len = torch.zeros(S, dtype=torch.int32, device=dev)
-    batch.encode(pcm, nf, out, out_len)
-    batch.sync()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    for layer, kbps, nf, lsteps in ((2, 160, 383, steps), (1, 288, 1149, 1)):  # (the driver's default bitrates, src/musicin.c:371-372; 10 s of audio)
+        rate, C, S, spf = 44100, 2, 4096, (384 if layer == 1 else 1152)
+        batch = mp3.BatchL12(layer, S, rate, C, kbps, nf)
+        pcm = torch.empty((S, nf * spf * C), dtype=torch.int16, device=dev)
+        mp3.synth_pcm_device(pcm, nf * spf, C, rate, stream0=0, seed=SEED)
+        out = torch.zeros((S, batch.out_stride(nf)), dtype=torch.uint8, device=dev)
+        out_len = torch.zeros(S, dtype=torch.int32, device=dev)
         batch.encode(pcm, nf, out, out_len)
-    batch.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    idx = sorted(set(np.linspace(0, S - 1, 8).astype(int).tolist()))
-    out_h, len_h = out[idx].cpu().numpy(), out_len[idx].cpu().numpy()
-    pcm_h = [pcm[i].cpu().numpy() for i in idx]
-    with ThreadPoolExecutor(max_workers=len(idx)) as ex:
-        refs = list(ex.map(lambda p: oracle_l12(orc, layer, rate, kbps, "s", p)[0], pcm_h))
-    ok = all(out_h[k, : len_h[k]].tobytes() == refs[k] for k in range(len(idx)))
-    rows.append({"layer": 2, "workload": "%d x %d Layer II frames, 44.1 kHz stereo, %d kbps, psychoacoustic model 2 (SURVEY 8(f) row 4)" % (S, nf, kbps),
-                 "value": round(S * nf * steps / dt, 1) if ok else None, "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-                 "algorithmic_bytes_per_frame": 1152 * C * 2 + mp3.frame_bytes_l12(layer, rate, kbps), "bit_exact": ok, "streams_checked": len(idx)})
-    batch.close()
+        batch.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(lsteps):
+            batch.encode(pcm, nf, out, out_len)
+        batch.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        idx = sorted(set(np.linspace(0, S - 1, 8).astype(int).tolist()))
+        out_h, len_h = out[idx].cpu().numpy(), out_len[idx].cpu().numpy()
+        pcm_h = [pcm[i].cpu().numpy() for i in idx]
+        with ThreadPoolExecutor(max_workers=len(idx)) as ex:
+            refs = list(ex.map(lambda p: oracle_l12(orc, layer, rate, kbps, "s", p)[0], pcm_h))
+        ok = all(out_h[k, : len_h[k]].tobytes() == refs[k] for k in range(len(idx)))
+        rows.append({"layer": layer, "workload": "%d x %d Layer %s frames (%d samples), 44.1 kHz stereo, %d kbps, psychoacoustic model 2 (SURVEY 8(f) row 4)"
+                                                 % (S, nf, "I" if layer == 1 else "II", spf, kbps),
+                     "value": round(S * nf * lsteps / dt, 1) if ok else None, "unit": "frames/s", "steps": lsteps, "ms_per_step": round(dt / lsteps * 1e3, 3),
+                     "algorithmic_bytes_per_frame": spf * C * 2 + mp3.frame_bytes_l12(layer, rate, kbps), "bit_exact": ok, "streams_checked": len(idx)})
+        batch.close()
+        del batch, pcm, out, out_len
+        torch.cuda.empty_cache()
     return rows
 
 
@@ -435,41 +604,68 @@ def launch_ranks(n):
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), relay rank 0's
     standard output -- the one JSON line -- and return non-zero if any rank does.  The launcher makes no GPU call and no
     torch.cuda query (it does not even import torch) and is never replaced by another program; a rank that fails takes
-    the others down with it (by their exact PIDs), so that nobody waits at a barrier for ever.
+    the others down with it (by their exact PIDs), so that nobody waits at a barrier for ever -- and so does the launcher's own
+    end: SIGTERM / SIGHUP (a timeout around the command) stop the ranks before the launcher leaves.
     The serial loop this replaces: /root/reference/src/musicin.c:585 (one stream, one process)."""
     import signal
     import socket
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
-        # rank 0's stdout is this process's stdout; the other ranks print nothing there, and what they might goes to stderr
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr, stderr=None))
-    rc = 0
+    import tempfile
+
+    class Stopped(Exception):
+        pass
+
+    def on_signal(signum, frame):  # the launcher is told to stop (a driver's or a test's timeout): the ranks go with it
+        raise Stopped(signum)
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGHUP)}
+    procs, rc = [], 0
+    markdir = tempfile.mkdtemp(prefix="mp3mi_bench_")
     try:
-        alive = set(range(n))
-        while alive:
-            for r in sorted(alive):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                alive.discard(r)
-                if code != 0 and rc == 0:
-                    rc = code if code > 0 else 128 - code
-                    sys.stderr.write("bench.py: rank %d ended with %d: stopping the other ranks\n" % (r, code))
-                    for o in alive:
-                        procs[o].send_signal(signal.SIGTERM)
-            if alive:
-                time.sleep(0.05)
+        for attempt in range(3):
+            # a free port is only known to be free NOW: if the rendezvous fails before every rank has joined (somebody took the port in
+            # between), the ranks are started again on another one
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            mark = os.path.join(markdir, "joined%d" % attempt)
+            base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                        MP3MI_BENCH_RENDEZVOUS_MARK=mark, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs = []
+            for r in range(n):
+                env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+                # rank 0's stdout is this process's stdout; the other ranks print nothing there, and what they might goes to stderr
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                              stdout=None if r == 0 else sys.stderr, stderr=None))
+            rc, alive = 0, set(range(n))
+            while alive:
+                for r in sorted(alive):
+                    code = procs[r].poll()
+                    if code is None:
+                        continue
+                    alive.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 128 - code
+                        sys.stderr.write("bench.py: rank %d ended with %d: stopping the other ranks\n" % (r, code))
+                        for o in alive:
+                            procs[o].send_signal(signal.SIGTERM)
+                if alive:
+                    time.sleep(0.05)
+            # once more only if every rank got as far as the rendezvous and not every rank got through it
+            at = all(os.path.exists(mark + ".at.%d" % r) for r in range(n))
+            joined = all(os.path.exists(mark + ".in.%d" % r) for r in range(n))
+            if rc == 0 or joined or not at or attempt == 2:
+                break
+            sys.stderr.write("bench.py: the ranks did not all join the rendezvous on port %d: once more on another port\n" % port)
     except KeyboardInterrupt:
         rc = 130
+    except Stopped as e:
+        rc = 128 + int(e.args[0])
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
     finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
         deadline = time.time() + 10
         for p in procs:
             if p.poll() is None:
@@ -478,6 +674,8 @@ def launch_ranks(n):
                 except subprocess.TimeoutExpired:
                     p.kill()
                     p.wait()
+        import shutil
+        shutil.rmtree(markdir, ignore_errors=True)
     return rc
 
 
@@ -521,29 +719,30 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to report a line whose n_gpus "
                          "is not what was asked for" % (args.gpus, world))
     distributed = world > 1
-    load_torch()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the encoder has no CPU path")
     # (test hook: MP3MI_BENCH_ONE_GPU=1 runs every rank on device 0 over gloo, so that the multi-rank code path -- stream
     # ranges per rank, barriers, max-over-ranks time, parity vote -- can be exercised on a one-GPU box)
     one_gpu = os.environ.get("MP3MI_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    # the rank's threads next to its GPU -- before torch (and with it the HIP runtime's helper threads) is loaded
+    affinity = pin_to_gpu_numa(dev_index, local_rank, world) if distributed else "unchanged (one rank)"
+    load_torch()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the encoder has no CPU path")
     if not one_gpu and torch.cuda.device_count() < world:
         raise SystemExit("bench.py: --gpus %d but this node shows %d device(s): one rank per GPU, no sharing (MP3MI_BENCH_ONE_GPU=1 is the "
                          "one-GPU rehearsal hook of the tests)" % (world, torch.cuda.device_count()))
-    dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if distributed:
-        import torch.distributed as dist
-        if one_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
-    cdev = torch.device("cpu") if (distributed and one_gpu) else dev  # where the collectives' tensors live
+    mark = os.environ.get("MP3MI_BENCH_RENDEZVOUS_MARK") if distributed else None  # (the launcher's retry looks for these two files)
+    if mark:
+        open(mark + ".at.%d" % rank, "w").close()
+    coll = Coll(world, dev, want_nccl=not one_gpu and os.environ.get("MP3MI_BENCH_BACKEND", "nccl") != "gloo")
+    if mark:
+        open(mark + ".in.%d" % rank, "w").close()
 
     mp3 = importlib.import_module("mp3-enc-bsd_amd")
     if args.layer != 3:
-        return main_l12(args, mp3, dev, cdev, rank, world, distributed)
+        return main_l12(args, mp3, dev, coll, rank, world, affinity)
     cfg_id = args.config
     cfg = dict(CONFIGS[cfg_id])
     default_size = not (args.streams or args.frames or args.kbps)
@@ -556,10 +755,7 @@ def main():
     S, nf, C, rate = cfg["streams"], cfg["frames"], cfg["channels"], cfg["rate"]
     wl = Workload(mp3, cfg, dev, stream0=rank * S)
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = coll.barrier
 
     # A step = one mp3mi_batch_encode call over the whole batch.  The K timed calls are issued back to back, as a
     # service encoding batch after batch would issue them: a call's feed-forward kernels may start beside the last
@@ -571,6 +767,7 @@ def main():
         wl.step()
     barrier()
     t_before = wl.batch.total_timing()
+    clock = ClockSampler(dev_index).start() if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if sync_each:
@@ -580,13 +777,11 @@ def main():
     wl.batch.sync()
     barrier()
     dt = time.perf_counter() - t0
+    clock_ghz = clock.stop() if clock is not None else None
     t_after = wl.batch.total_timing()
     loop_ms, all_ms, launches = t_after[0] - t_before[0], t_after[1] - t_before[1], t_after[2] - t_before[2]
     assert t_after[3] - t_before[3] == args.steps
-    if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = float(coll.reduce(dt, "max"))
 
     # End to end with PCIe (--host-io): the same K steps with the PCM in page-locked host memory and the bytes delivered to it.
     end_to_end = None
@@ -601,10 +796,7 @@ def main():
         except RuntimeError as e:
             print("bench.py: rank %d could not page-lock the host buffers of the end-to-end leg (%s)" % (rank, str(e).splitlines()[0]), file=sys.stderr)
             h_pcm = None
-        have = torch.tensor([1 if h_pcm is not None else 0], dtype=torch.int32, device=cdev)
-        if distributed:
-            dist.all_reduce(have, op=dist.ReduceOp.MIN)
-        if int(have.item()) == 0:
+        if int(coll.reduce(1 if h_pcm is not None else 0, "min")) == 0:
             end_to_end = {"skipped": "a rank could not page-lock its host buffers"}
             h_pcm = None
     else:
@@ -623,10 +815,7 @@ def main():
         barrier()
         dth = time.perf_counter() - th0
         st1 = wl.batch.host_io_stats()
-        if distributed:
-            tmax = torch.tensor([dth], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dth = float(tmax.item())
+        dth = float(coll.reduce(dth, "max"))
         same = bool(torch.equal(h_len, wl.out_len.cpu())) and all(
             torch.equal(h_out[i, : int(h_len[i])], wl.out[i, : int(h_len[i])].cpu()) for i in range(0, S, max(1, S // 256)))
         up_b, dn_b = st1["h2d_bytes"] - st0["h2d_bytes"], st1["d2h_bytes"] - st0["d2h_bytes"]
@@ -649,8 +838,8 @@ def main():
     # parity spot check on the exact device bytes of THIS rank (every rank checks its own streams; the CPU baseline is
     # timed on rank 0 -- at every N, AFTER the timed region: the other ranks do their small check and wait at the
     # parity vote below -- so that every bench line carries it)
-    cores = max(1, min(os.cpu_count() or 1, 64))
     timed_baseline = rank == 0 and not args.no_cpu_baseline
+    cores = all_host_cores() if timed_baseline else 8  # (all of the host's cores, whatever the rank was pinned to for its GPU)
     n_sample = max(4, cores * 2) if timed_baseline else 8
     idx = sorted(set(np.linspace(0, S - 1, n_sample).astype(int).tolist()))
     pcm_sample = [wl.pcm[i].cpu().numpy() for i in idx]
@@ -673,15 +862,11 @@ def main():
             cpu = {"value": round(rfps, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
                    "sample": "%d of this batch's streams x %d frames, oracle/_ref/encode (unmodified reference, gcc -O2), one process per stream" % (len(idx), nf),
                    "port_value": round(fps, 1)}
-    n_bad = torch.tensor([len(bad)], dtype=torch.int64, device=cdev)
     # which streams each rank encoded, and a digest of what it produced (the ranks' ranges must be disjoint, their bytes differ)
     import hashlib
-    mine = torch.tensor([rank, rank * S, S, int(hashlib.md5(b"".join(got)).hexdigest()[:15], 16)], dtype=torch.int64, device=cdev)
-    per_rank = [mine.clone() for _ in range(world)]
-    if distributed:
-        dist.all_reduce(n_bad, op=dist.ReduceOp.SUM)
-        dist.all_gather(per_rank, mine)
-    parity_ok = int(n_bad.item()) == 0
+    n_bad = int(coll.reduce(len(bad), "sum"))
+    per_rank = coll.gather([rank, rank * S, S, int(hashlib.md5(b"".join(got)).hexdigest()[:15], 16)])
+    parity_ok = n_bad == 0
     ranks = [{"rank": int(t[0]), "first_stream": int(t[1]), "streams": int(t[2]), "sample_digest": "%015x" % int(t[3])} for t in per_rank]
 
     frames_total = S * nf * args.steps * world
@@ -736,10 +921,12 @@ def main():
                          # it is only reported where every call was synchronised)
                          "all_kernels_ms_per_step": round(all_ms / max(args.steps, 1), 3) if sync_each else None,
                          "limited_by": "instruction issue of the dominant kernel, not HBM (issue: share of the SIMDs' VALU issue capacity in use; kernels: what bounds each)",
-                         "issue": issue, "pipeline": pipeline, "kernels": kernels, "source_hash": src_hash},
+                         "issue": issue, "clock_ghz_measured": clock_ghz, "pipeline": pipeline, "kernels": kernels, "source_hash": src_hash},
             "cpu_baseline": cpu,
             "end_to_end": end_to_end,
             "ranks": ranks,
+            "collective_backend": coll.backend,
+            "cpu_affinity_rank0": affinity,
             "parity_spot_check": {"streams_per_rank": len(idx), "bit_exact": parity_ok, "mismatching_streams_rank0": bad,
                                   "witness": "oracle/liboracle.so" + (" + oracle/_ref/encode" if cpu and cpu["kind"] == "reference" else "")},
         }
@@ -750,19 +937,23 @@ def main():
         # The other workloads, driver-visible (short runs; the headline above is untouched by them: its batch is closed).
         # Only on the default line: one GPU, configs[1] at its own size.
         if world == 1 and cfg_id == 1 and default_size and not (args.no_other_workloads or args.no_cpu_baseline):
-            torch.cuda.empty_cache()
-            result["other_workloads"] = other_workloads(mp3, dev)
-            others_ok = all(o["bit_exact"] for o in result["other_workloads"])
-            if not others_ok:
-                result["value"] = None
+            # (whatever happens in here -- no memory for a batch of 16 384 streams, an oracle error --, the finished headline
+            # measurement is printed; the failure is recorded in the line and in the exit code)
+            try:
+                torch.cuda.empty_cache()
+                result["other_workloads"] = other_workloads(mp3, dev)
+                others_ok = all(o["bit_exact"] for o in result["other_workloads"])
+                if not others_ok:
+                    result["value"] = None
+            except Exception as e:  # noqa: BLE001
+                result["other_workloads"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+                others_ok = False
         print(json.dumps(result), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    coll.close()
     if not parity_ok:
-        raise SystemExit("bench.py: PARITY FAILURE -- the GPU bitstream differs from the reference on %d sampled streams" % int(n_bad.item()))
+        raise SystemExit("bench.py: PARITY FAILURE -- the GPU bitstream differs from the reference on %d sampled streams" % n_bad)
     if not others_ok:
-        raise SystemExit("bench.py: PARITY FAILURE in other_workloads")
+        raise SystemExit("bench.py: other_workloads failed (see the line's other_workloads)")
 
 
 if __name__ == "__main__":

@@ -79,7 +79,11 @@ typedef struct mp3mi_batch_options {
                                  destroy): calls issued back to back then lose no pipeline fill: -1 default (on), 0, 1 */
     int32_t dropin_stats;     /* the drop-in symbols print, at III_FlushBitstream, the frames they served, the time from the first frame's
                                  first call to the flush and the waits for the device: 0 default, 1 (MP3MI_DROPIN_STATS) */
+    uint32_t abi;             /* MP3MI_OPTIONS_ABI of the header the caller was built against.  The struct's size alone does not tell two
+                                 layouts apart (round 5 replaced a field in the middle and kept the size): a caller built against another layout is
+                                 refused (MP3MI_ERR_ARG) instead of having its fields read as their neighbours */
 } mp3mi_batch_options;
+#define MP3MI_OPTIONS_ABI 6u  /* raised whenever the struct's layout or a field's meaning changes; new fields go at the END */
 /* mp3mi_batch_create_ex returns MP3MI_ERR_ARG for a value outside the ranges named above (the three-state fields take
  * -1, 0, 1; psy_beside -1 .. 2; dropin_lookahead -1 .. 4; loop_part_streams a multiple of 64; unknown test flags). */
 void mp3mi_batch_options_default(mp3mi_batch_options *opt);

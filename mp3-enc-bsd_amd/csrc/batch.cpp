@@ -186,7 +186,10 @@ extern "C" void mp3mi_batch_destroy(mp3mi_batch *b);
 static void hold_release(mp3mi_batch *b)
 {
     if (!b->held) return;
-    __atomic_store_n(b->hold_flag_h + 1, b->hold_seq, __ATOMIC_RELEASE); // (this hold, not the ones before it: k_hold)
+    // (this hold, not the ones before it: k_hold reads the word of ITS ticket -- a ring of eight, so that a release the device
+    // has not looked at yet is not overwritten by the next one: the host runs ahead of the device through chains of calls
+    // that never wait, e.g. encode_next / flush / encode_next / flush)
+    __atomic_store_n(b->hold_flag_h + 1 + (b->hold_seq & 7u), b->hold_seq, __ATOMIC_RELEASE);
     b->held = false;
 }
 
@@ -195,6 +198,7 @@ extern "C" void mp3mi_batch_options_default(mp3mi_batch_options *o)
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->struct_size = (uint32_t) sizeof(*o);
+    o->abi = MP3MI_OPTIONS_ABI;
     o->call_overlap = o->gate = o->placement = o->y_after_loop = o->psy_beside = o->dropin_lookahead = o->call_hold = -1;
 }
 
@@ -311,7 +315,7 @@ static int batch_build(mp3mi_batch *b, int n_streams, int rate_hz, int channels,
     b->hold_calls = opt.call_hold != 0 && opt.call_overlap != 0 && opt.gate != 0;
     if (b->hold_calls) {
         CHK(hipHostMalloc((void **) &b->hold_flag_h, 64, hipHostMallocMapped));
-        b->hold_flag_h[0] = b->hold_flag_h[1] = 0;
+        for (int i = 0; i < 16; i++) b->hold_flag_h[i] = 0;
         CHK(hipHostGetDevicePointer((void **) &b->hold_flag_d, b->hold_flag_h, 0));
     }
     if (opt.gate != 0) {
@@ -405,7 +409,7 @@ extern "C" int mp3mi_batch_create_ex(mp3mi_batch **out, int n_streams, int rate_
     mp3mi_batch_options opt;
     mp3mi_batch_options_default(&opt);
     if (opt_in) {
-        if (opt_in->struct_size != sizeof(opt)) return MP3MI_ERR_ARG; // another version of the header
+        if (opt_in->struct_size != sizeof(opt) || opt_in->abi != MP3MI_OPTIONS_ABI) return MP3MI_ERR_ARG; // another version of the header
         opt = *opt_in;
         auto tri = [](int v) { return v >= -1 && v <= 1; }; // -1 default, 0 off, 1 on
         if ((opt.test_flags & ~(unsigned) (MP3MI_TEST_ALL_EXACT | MP3MI_TEST_PREP_LIST)) || opt.chunk_frames < 0 || opt.loop_part_streams < 0 ||

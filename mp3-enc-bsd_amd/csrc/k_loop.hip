@@ -1528,15 +1528,16 @@ void mp3mi_launch_gate(const unsigned *count, unsigned target, unsigned max_tick
 // for results: batch.cpp, hold_release), or until max_ticks of the 100 MHz counter have passed: the hold only ever
 // changes WHEN the kernel behind it starts, never what it computes, so running out is harmless.  flag[] is host memory
 // mapped into the device's address space; tickets only ever grow.  flag[0]: the highest ticket a NEXT CALL has let go
-// (k_hold_release, on the device, behind that call's first transforms); flag[1]: the ticket the HOST lets go -- that one and
-// no other: the host runs far ahead of the device, and when it waits for the last call it must not let go the holds of the
-// calls before it, which the device has not reached yet and whose successors are already queued.
+// (k_hold_release, on the device, behind that call's first transforms); flag[1 + ticket % 8]: the ticket the HOST lets go -- that
+// one and no other: the host runs far ahead of the device, and when it waits for the last call it must not let go the holds of
+// the calls before it, which the device has not reached yet and whose successors are already queued.  (A ring of eight words:
+// a release the device has not looked at yet survives the next seven.)
 __global__ void __launch_bounds__(64) k_hold(const unsigned *flag, unsigned ticket, unsigned max_ticks)
 {
 #if !defined(MP3MI_EMU)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while ((int) (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - ticket) < 0 &&
-           __hip_atomic_load(flag + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ticket) {
+           __hip_atomic_load(flag + 1 + (ticket & 7u), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ticket) {
         if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long) max_ticks) break;
         __builtin_amdgcn_s_sleep(64);
     }

@@ -113,7 +113,8 @@ class BatchOptions(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("scratch_mb", ctypes.c_uint32), ("chunk_frames", ctypes.c_int32),
                 ("test_flags", ctypes.c_uint32), ("call_overlap", ctypes.c_int32), ("gate", ctypes.c_int32),
                 ("placement", ctypes.c_int32), ("loop_part_streams", ctypes.c_int32),
-                ("y_after_loop", ctypes.c_int32), ("psy_beside", ctypes.c_int32), ("dropin_lookahead", ctypes.c_int32), ("call_hold", ctypes.c_int32), ("dropin_stats", ctypes.c_int32)]
+                ("y_after_loop", ctypes.c_int32), ("psy_beside", ctypes.c_int32), ("dropin_lookahead", ctypes.c_int32), ("call_hold", ctypes.c_int32), ("dropin_stats", ctypes.c_int32),
+                ("abi", ctypes.c_uint32)]
 
 
 class Mp3mi:

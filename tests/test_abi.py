@@ -79,6 +79,11 @@ def test_options_struct(product):
     b = ctypes.c_void_p()
     o.struct_size = 8
     assert product.lib.mp3mi_batch_create_ex(ctypes.byref(b), 4, 44100, 2, None, 128, 8, ctypes.byref(o)) == -1
+    # ... and so is a struct of the right size whose layout is another header's (the size alone does not tell them apart)
+    o = product.options()
+    assert o.abi == 6
+    o.abi = 5
+    assert product.lib.mp3mi_batch_create_ex(ctypes.byref(b), 4, 44100, 2, None, 128, 8, ctypes.byref(o)) == -1
 
 
 def test_product_reads_its_environment_in_one_place_only():

@@ -90,3 +90,46 @@ def test_bench_refuses_a_world_size_other_than_the_flag():
     assert r.returncode != 0 and "--gpus 4" in r.stderr and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
     r = _bench(["--gpus", "1"], RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def _coll_worker(rank, world, port, ret):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    bench.load_torch()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    c = bench.Coll(world, torch.device("cpu"), want_nccl=False)
+    c.barrier()
+    out = (c.backend, c.reduce(float(rank + 1), "max"), c.reduce(rank, "min"), c.reduce(rank + 1, "sum"), c.gather([rank, 10 * rank]))
+    if rank == 0:
+        ret["out"] = out
+    c.close()
+
+
+def test_the_bench_ranks_control_traffic_over_gloo():
+    """bench.py's Coll: barrier, maximum, vote and gather of the ranks over gloo with CPU tensors -- what carries a run where RCCL
+    does not come up on every rank (or MP3MI_BENCH_BACKEND=gloo asks for it); three ranks, no GPU."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_coll_worker, args=(3, 29757, ret), nprocs=3, join=True)
+    backend, tmax, vmin, vsum, per = ret["out"]
+    assert backend.startswith("gloo") and tmax == 3.0 and vmin == 0 and vsum == 6
+    assert per == [[0, 0], [1, 10], [2, 20]]
+
+
+def test_numa_pinning_never_raises_and_says_what_it_did():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    before = os.sched_getaffinity(0)
+    cpus, what = bench.gpu_numa_cpus(0)
+    assert isinstance(what, str) and (cpus is None or cpus <= before)
+    said = bench.pin_to_gpu_numa(0, 0, 2)
+    assert isinstance(said, str) and said
+    os.sched_setaffinity(0, before)
+    assert bench.all_host_cores() >= 1
+    os.sched_setaffinity(0, before)
