@@ -560,7 +560,7 @@ def other_workloads(mp3, dev, steps=2):
         with ThreadPoolExecutor(max_workers=len(idx)) as ex:
             refs = list(ex.map(lambda k: orc.encode(pcm_h[k], rate, wl.kbps[idx[k]], C)[0], range(len(idx))))
         ok = all(out_h[k, : len_h[k]].tobytes() == refs[k] for k in range(len(idx)))
-        rows.append({"config_id": cid, "workload": "%d x %d frames, %.0f kHz %s, %s kbps (%s)" % (S, nf, rate / 1000.0, "stereo" if C == 2 else "mono",
+        rows.append({"config_id": cid, "workload": "%d x %d frames, %.1f kHz %s, %s kbps (%s)" % (S, nf, rate / 1000.0, "stereo" if C == 2 else "mono",
                                                                                                  "64-320 mixed" if cfg["kbps"] == "mix48" else cfg["kbps"], cfg["name"]),
                      "value": round(S * nf * steps / dt, 1) if ok else None, "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
                      "algorithmic_bytes_per_frame": round(wl.alg_bytes_per_frame(), 1), "bit_exact": ok, "streams_checked": len(idx)})

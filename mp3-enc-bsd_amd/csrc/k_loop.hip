@@ -390,12 +390,23 @@ MP3MI_DEVFN int loop_pick_v(int da, int s01, int s2, int *sum)
 // Cost of the pairs of lines [lo, hi) under the candidate tables of one group (descriptor dA/dB), per lane:
 // *a01 = candidate 0 | candidate 1 << 16, *a2 = third candidate.  Walks 64 pairs per step straight out of
 // L.ix.  ESC: the group's tables have linbits (x or y > 14 then costs them); NC3: it has a third candidate.
+// (k15: the constant 15 in a scalar register -- loop_walk_consts --: compiled without the machine-level hoisting of loop
+// invariants, a step would otherwise set it up again, in a vector register)
+struct loop_walk_k { int k15; };
+MP3MI_DEVFN loop_walk_k loop_walk_consts(void)
+{
+    loop_walk_k k = {15};
+#if !defined(MP3MI_EMU)
+    asm volatile("" : "+s"(k.k15));
+#endif
+    return k;
+}
 template <bool ESC, bool NC3, bool LAST>
-MP3MI_DEVFN void loop_walk_step(const uint16_t *GL, const unsigned *ixw, int w, int hi, int ylen2, int dB2, int lb01, int &s01, int &s2)
+MP3MI_DEVFN void loop_walk_step(const uint16_t *GL, const unsigned *ixw, int w, int hi, int ylen2, int dB2, int lb01, const loop_walk_k &K, int &s01, int &s2)
 {
     const unsigned xy = ixw[w];
     const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
-    const int xc = x > 15 ? 15 : x, yc = y > 15 ? 15 : y;
+    const int xc = x > K.k15 ? K.k15 : x, yc = y > K.k15 ? K.k15 : y;
     // (a pair past the end of the region prices some cell of the group all the same -- xc, yc <= 15 keep the index inside the
     // table whatever the padding holds -- and is masked out of the sums: masking the index as well was an instruction per step;
     // the cell's byte address from the doubled descriptor values: a multiply-add and a shift-add)
@@ -403,9 +414,13 @@ MP3MI_DEVFN void loop_walk_step(const uint16_t *GL, const unsigned *ixw, int w, 
 #if !defined(MP3MI_EMU)
     asm volatile("" : "+v"(cell));
 #endif
+#if defined(MP3MI_EMU)
     const int e = *(const uint16_t *) ((const char *) GL + ((unsigned) (xc * ylen2) + cell));
+#else
+    const int e = *(const uint16_t *) ((const char *) GL + ((unsigned) __umul24((unsigned) xc, (unsigned) ylen2) + cell)); // (xc <= 15: a 24-bit multiply-add)
+#endif
     int c = (e & 31) | (((e >> 5) & 31) << 16);
-    if (ESC) c += ((x > 14) + (y > 14)) * lb01;
+    if (ESC) c += ((e >> 10) & 3) * lb01; // (how many of x, y are escapes: in the cell, tables_host.cpp)
     if (LAST) { // only a region's last step of 64 pairs can reach past its end
         const int in = (2 * w - hi) >> 31; // all ones inside the region
         s01 += c & in;
@@ -421,11 +436,12 @@ MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int l
 {
     const int ylen2 = 2 * ((dA >> 15) & 31), dB2 = 2 * dB, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
     int s01 = 0, s2 = 0;
+    const loop_walk_k K = loop_walk_consts();
     int w0 = lo >> 1; // (one to three steps: unrolling only adds scalar bookkeeping)
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
-    for (; 2 * (w0 + 64) <= hi; w0 += 64) loop_walk_step<ESC, NC3, false>(GL, ixw, w0 + lane, hi, ylen2, dB2, lb01, s01, s2);
+    for (; 2 * (w0 + 64) <= hi; w0 += 64) loop_walk_step<ESC, NC3, false>(GL, ixw, w0 + lane, hi, ylen2, dB2, lb01, K, s01, s2);
     // pairs past the end of the region are read all the same (L.ix is padded) and masked out of the sums
-    if (2 * w0 < hi) loop_walk_step<ESC, NC3, true>(GL, ixw, w0 + lane, hi, ylen2, dB2, lb01, s01, s2);
+    if (2 * w0 < hi) loop_walk_step<ESC, NC3, true>(GL, ixw, w0 + lane, hi, ylen2, dB2, lb01, K, s01, s2);
     *a01 = s01;
     *a2 = s2;
 }
@@ -449,6 +465,21 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
 {
     CBPROF_START;
     const int lane = wave_lane_here();
+#if defined(LOOP_EXP_SALU) && !defined(MP3MI_EMU) // experiment (profiles/r06_experiments.txt, F6): what does a pass pay for N more scalar / vector instructions?
+    { int t_ = 0;
+#pragma unroll
+      for (int i_ = 0; i_ < LOOP_EXP_SALU; i_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(t_) : : "scc"); }
+#endif
+#if defined(LOOP_EXP_VALU) && !defined(MP3MI_EMU)
+    { int t_ = lane;
+#pragma unroll
+      for (int i_ = 0; i_ < LOOP_EXP_VALU; i_++) asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(t_)); }
+#endif
+#if defined(LOOP_EXP_VALU3) && !defined(MP3MI_EMU)
+    { int t_ = lane;
+#pragma unroll
+      for (int i_ = 0; i_ < LOOP_EXP_VALU3; i_++) asm volatile("v_add3_u32 %0, %0, %0, 1" : "+v"(t_)); }
+#endif
     const bool shortb = g.wsf && g.block_type == 2;
     const unsigned *ixw = (const unsigned *) L.ix; // (x, y) of pair pr as one word: x | y << 16
     int bits = 0, nslot = 9; // nslot: slots (of 64 lines) that can hold a non-zero value

@@ -377,7 +377,7 @@ void mp3mi_launch_part_wave(const mp3mi_tables *T, const mp3mi_geom &g, const fl
 #define PSY_S3_W 17
 #define PSY_W 4
 template <bool SPARSE>
-__global__ void __launch_bounds__(64 * PSY_W, 4) k_psy(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
+__global__ void __launch_bounds__(64 * PSY_W, 3) k_psy(const mp3mi_tables *__restrict__ T, mp3mi_geom geo,
                                             const double *__restrict__ eb_all, const float *__restrict__ cb_all,
                                             const float *__restrict__ energy_s, const float *__restrict__ hist6,
                                             mp3mi_psy_state *__restrict__ state, mp3mi_psy_out *__restrict__ out)
@@ -677,6 +677,10 @@ void mp3mi_launch_psy(const mp3mi_tables *T, const mp3mi_geom &g, const float *e
     else {
         mp3mi_launch_cw_fix_reset(fix, (unsigned) n_rec, st);
         hipLaunchKernelGGL(k_part, dim3(nblk), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all, fix, 0);
+#if defined(MP3MI_EXP_PART_TWICE) // experiment (profiles/r06_experiments.txt, F5): what does the step pay for k_part's 28 GB of reads?  The same launch once more.
+        mp3mi_launch_cw_fix_reset(fix, (unsigned) n_rec, st);
+        hipLaunchKernelGGL(k_part, dim3(nblk), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all, fix, 0);
+#endif
         mp3mi_launch_cw_fix(g, bins, cw_mid, hist6, fix, st);
         // (as many blocks as the list could need: those beyond its end leave at once)
         hipLaunchKernelGGL(k_part, dim3(nblk), dim3(64), 0, st, T, g, energy_l, cw_mid, hist6, (const mp3mi_psy_state *) psy_state, eb_all, cb_all, fix, 1);

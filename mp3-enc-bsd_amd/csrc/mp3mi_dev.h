@@ -159,7 +159,8 @@ typedef struct {
     uint32_t ht_code[1440];
     /* code lengths grouped the way new_choose_table compares tables: per group and (x,y) cell
        the lengths of its tables INCLUDING the cell's sign bits, 5 bits each.  Groups at offsets 0 {1}, 4 {2,3}, 13 {5,6},
-       29 {7,8,9}, 65 {10,11,12}, 129 {13,15}, 385 {15,24}, 641 {16,24}, 897 {32,33} */
+       29 {7,8,9}, 65 {10,11,12}, 129 {13,15}, 385 {15,24}, 641 {16,24}, 897 {32,33}; the cells of the two groups with linbits
+       carry in bits 10..11 how many of x, y are escapes */
     uint16_t glut[928];
 } mp3mi_tables;
 

@@ -955,6 +955,9 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
                     if (len > 31) return -5;
                     e |= len << (5 * f);
                 }
+                /* the two groups with linbits have no third table: bits 10..11 of their cells hold how many of x, y are escapes
+                   (== 15), so that k_loop's walk prices the linbits without testing the values (k_loop.hip, loop_walk_step) */
+                if (gi == 6 || gi == 7) e |= (unsigned) ((c / 16 == 15) + (c % 16 == 15)) << 10;
                 T->glut[groups[gi][0] + c] = (uint16_t) e;
             }
     }

@@ -129,6 +129,44 @@ def test_a_held_call_ends_without_a_successor(product, oracle):
         run.close()  # destroy with a held call in flight
 
 
+@pytest.mark.gpu
+def test_a_foreign_device_wide_sync_waits_out_the_hold_and_no_more(product, oracle):
+    """An integrator who ends a call with hipDeviceSynchronize (torch.cuda.synchronize) instead of mp3mi_batch_sync does not
+    let go of the hold in front of the call's last k_loop (mp3mi.h, options.call_hold): that launch then starts when the hold's
+    bound runs out -- 0.4 ms per frame of a chunk, at least 20 ms, at most 200 -- and everything is still correct.  Measured
+    here: the same call ended by the library's own sync and by the device-wide one; the difference stays below the bound
+    (plus a margin for the box), and the bytes are the oracle's both times."""
+    import ctypes
+    import time
+    S, nf = 1024, 48  # one chunk of 48 frames: the bound is 20 ms
+    run = BatchRun(product, S, 44100, 2, 128, nf)
+    hip = ctypes.CDLL("libamdhip64.so")
+    try:
+        L = product.lib
+        assert L.mp3mi_batch_encode(run.b, run.d_pcm, nf, run.d_out, run.stride, run.d_len) == 0 and L.mp3mi_batch_sync(run.b) == 0  # warm
+        t = []
+        for how in ("library", "device-wide") * 3:
+            t0 = time.perf_counter()
+            assert L.mp3mi_batch_encode(run.b, run.d_pcm, nf, run.d_out, run.stride, run.d_len) == 0
+            if how == "library":
+                assert L.mp3mi_batch_sync(run.b) == 0
+            else:
+                assert hip.hipDeviceSynchronize() == 0
+            t.append((how, (time.perf_counter() - t0) * 1e3))
+            if how != "library":
+                assert L.mp3mi_batch_sync(run.b) == 0  # (the call is over: nothing left to wait for; keeps the batch's bookkeeping in step)
+            lens = run.mem.download(run.d_len, (S,), np.uint32)
+            out = run.mem.download(run.d_out, (S, run.stride), np.uint8)
+            for s in (0, 511, 1023):
+                assert out[s, :lens[s]].tobytes() == oracle.encode(run.pcm_of(s), 44100, 128, 2)[0], (how, s)
+        lib_ms = min(ms for how, ms in t if how == "library")
+        dev_ms = min(ms for how, ms in t if how != "library")
+        print("one call of %d x %d frames ended by mp3mi_batch_sync: %.1f ms, by hipDeviceSynchronize: %.1f ms (the hold's bound: 20 ms)" % (S, nf, lib_ms, dev_ms))
+        assert dev_ms < lib_ms + 20.0 + 10.0
+    finally:
+        run.close()
+
+
 def test_flush_without_frames_and_argument_errors_emulated(emu):
     """a flush right after create or after a whole-file encode delivers nothing; streaming calls check their arguments"""
     import ctypes
