@@ -422,13 +422,19 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             {
                 typename F::V x[16];
                 fft_reg_long<C>(x, smp, LL.win, LL.regtw + lane, lane);
+#if !defined(MP3MI_FFT_EXP_NO_STORE) // (diagnostic builds, tools/gpu_fft_conflicts.sh: one phase's LDS traffic taken out, results wrong, counters telling)
 #pragma unroll
                 for (int k = 0; k < 16; k++)
                     *(typename F::V *) (L.x + (lane_swz ^ MP3MI_FFT_SWZ(64 * k)) * C) = x[k]; // == SWZ(lane + 64 k): the map is linear
+#else
+                if (lane == 99) L.x[0] = F::get(x[0], 0) + F::get(x[15], 0);
+#endif
             }
             wave_sync();
             PROF(1);
+#if !defined(MP3MI_FFT_EXP_NO_PROG)
             fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, true>)), LL.prog, lane);
+#endif
             PROF(2);
             if (more) load_task(task_of(next), smp);
             // energies of the 513 lines: the read-out words of all nine steps first, then the spectrum, then the stores
@@ -437,8 +443,13 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
 #pragma unroll
             for (int k = 0; k < 9; k++) rdw[k] = LL.rd[lane + 64 * k < MP3MI_HBLK ? lane + 64 * k : 0];
             fft_pair<C> e[9];
+#if !defined(MP3MI_FFT_EXP_NO_READOUT)
 #pragma unroll
             for (int k = 0; k < 9; k++) e[k] = fft_energy<C>(L.x, rdw[k], lane + 64 * k == 0 || lane + 64 * k == 512);
+#else
+#pragma unroll
+            for (int k = 0; k < 9; k++) for (int c = 0; c < C; c++) e[k].c[c] = (float) rdw[k];
+#endif
             if (valid) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) {

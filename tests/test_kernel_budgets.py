@@ -71,6 +71,7 @@ def test_the_kernels_fit_where_the_schedule_puts_them():
     assert k_mdct["VGPRs"] <= 192 and k_mdct["ScratchSize"] == 0, k_mdct           # two per SIMD when alone; beside k_loop as its wavefronts leave
     k_psy, k_part = the(psy, r"^_Z5k_psyILb1E"), the(psy, r"^_Z6k_partPK")
     assert k_psy["VGPRs"] <= beside and k_part["VGPRs"] <= beside, (k_psy, k_part)
+    assert k_psy["ScratchSize"] == 0 and k_part["ScratchSize"] == 0, (k_psy, k_part)   # (round 5: k_psy<true> spilled two registers under a bound of 128)
     assert k_mdct["LDS"] <= 160 * 1024 // 8, k_mdct                                # eight one-wavefront workgroups a CU when alone
     assert k_filter["VGPRs"] <= beside and k_filter["ScratchSize"] == 0 and k_filter["LDS"] <= 10 * 1024, k_filter
     f_long, f_short = the(fft, r"^_Z5k_fftILi2ELi12ELb1E"), the(fft, r"^_Z5k_fftILi2ELi16ELb0E")

@@ -24,7 +24,7 @@ def main(tag):
     for f in sorted(glob.glob(os.path.join(src, "*"))):
         b = os.path.basename(f)
         if b.startswith("bench_") and b.endswith(".json") and b != "bench_under_rocprof.json" or b.startswith("parity_config") and b.endswith(".json") \
-                or b in ("timeline.txt", "loop_profile.txt", "ulp_census.json", "soak.jsonl"):
+                or b in ("timeline.txt", "loop_profile.txt", "loop_profile_383.txt", "ulp_census.json", "soak.jsonl"):
             text = open(f).read()
             assert want in text, "%s does not carry the set's source hash %s" % (b, want)
             shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, b)))

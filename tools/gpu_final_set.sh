@@ -56,6 +56,7 @@ case $stages in *b*)
   for c in 2 3 4; do python3 bench.py --config $c --steps 6 --warmup 1 > $out/bench_config$c.json 2> $out/bench_config$c.err; echo "config $c: rc $?"; stamp $out/bench_config$c.json; done
   for l in 2 1; do python3 bench.py --layer $l --steps 6 --warmup 1 > $out/bench_layer$l.json 2> $out/bench_layer$l.err; echo "layer $l: rc $?"; stamp $out/bench_layer$l.json; done
   MP3MI_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 3 --warmup 1 --streams 2048 > $out/bench_two_ranks_one_gpu.json 2> $out/bench_two_ranks.err; echo "two ranks: rc $?"; stamp $out/bench_two_ranks_one_gpu.json
+  MP3MI_BENCH_ONE_GPU=1 python3 bench.py --gpus 6 --steps 2 --warmup 1 --streams 680 > $out/bench_six_ranks_one_gpu.json 2> $out/bench_six_ranks.err; echo "six ranks: rc $?"; stamp $out/bench_six_ranks_one_gpu.json
   python3 - $out <<'PY'
 import json, sys, glob, os
 for p in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
@@ -66,7 +67,10 @@ for p in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
 PY
 ;; esac
 case $stages in *c*)
-  bash tools/gpu_loop_profile.sh $tag > /dev/null 2>&1; sed -i "1i # sources $hash (diagnostic build -DMP3MI_LOOP_PROFILE)" $out/loop_profile.txt; tail -12 $out/loop_profile.txt
+  bash tools/gpu_loop_profile.sh $tag > /dev/null 2>&1; sed -i "1i # sources $hash (diagnostic build -DMP3MI_LOOP_PROFILE; 4096 x 48 frames = ONE chunk: a launch without a cost history)" $out/loop_profile.txt; tail -12 $out/loop_profile.txt
+  # ... and on the REAL schedule: 383 frames = five chunks, pacing and placement live (the figures are the LAST launch's)
+  MP3MI_LIB=/tmp/libmp3mi_prof.so timeout 300 python3 tools/loop_profile.py 383 > $out/loop_profile_383.txt 2>&1
+  sed -i "1i # sources $hash (diagnostic build -DMP3MI_LOOP_PROFILE; 4096 x 383 frames = five chunks, the last launch's waves; phase cycles include what runs beside k_loop)" $out/loop_profile_383.txt; tail -8 $out/loop_profile_383.txt
   bash tools/gpu_ulp_census.sh $tag 1 3 4 > /dev/null 2>&1
   python3 - $out/ulp_census.json "$hash" <<'PY'
 import json, sys
