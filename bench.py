@@ -151,7 +151,33 @@ def gpu_numa_cpus(dev_index):
         cpus &= os.sched_getaffinity(0)
         return (cpus or None), "GPU %s on NUMA node %d" % (bdf, node)
     except Exception as e:  # noqa: BLE001
-        return None, "topology not readable (%s)" % type(e).__name__
+        kfd_why = type(e).__name__
+    # The KFD topology is not readable for everyone (ordinary users on some hosts).  Second source: the AMD accelerators / display
+    # controllers on the PCI bus, in address order -- the order the HIP runtime lists them in unless *_VISIBLE_DEVICES says otherwise.
+    try:
+        devs = []
+        for d in sorted(os.listdir("/sys/bus/pci/devices")):
+            b = "/sys/bus/pci/devices/" + d
+            if open(b + "/vendor").read().strip() != "0x1002":
+                continue
+            cls = int(open(b + "/class").read().strip(), 16) >> 8
+            if cls in (0x0300, 0x0302, 0x0380, 0x1200) and os.path.exists(b + "/numa_node") and os.path.isdir(b + "/drm"):
+                devs.append(d)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            devs = [devs[int(i)] for i in vis.split(",") if i.strip().isdigit() and int(i) < len(devs)]
+        bdf = devs[dev_index]
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None, "GPU %s: no NUMA node recorded" % bdf
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b2 = part.partition("-")
+            cpus.update(range(int(a), int(b2 or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return (cpus or None), "GPU %s (PCI order) on NUMA node %d" % (bdf, node)
+    except Exception as e:  # noqa: BLE001
+        return None, "topology not readable (kfd: %s, pci: %s)" % (kfd_why, type(e).__name__)
 
 
 def pin_to_gpu_numa(dev_index, local_rank, local_world):

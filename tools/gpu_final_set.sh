@@ -56,7 +56,7 @@ case $stages in *b*)
   for c in 2 3 4; do python3 bench.py --config $c --steps 6 --warmup 1 > $out/bench_config$c.json 2> $out/bench_config$c.err; echo "config $c: rc $?"; stamp $out/bench_config$c.json; done
   for l in 2 1; do python3 bench.py --layer $l --steps 6 --warmup 1 > $out/bench_layer$l.json 2> $out/bench_layer$l.err; echo "layer $l: rc $?"; stamp $out/bench_layer$l.json; done
   MP3MI_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 3 --warmup 1 --streams 2048 > $out/bench_two_ranks_one_gpu.json 2> $out/bench_two_ranks.err; echo "two ranks: rc $?"; stamp $out/bench_two_ranks_one_gpu.json
-  MP3MI_BENCH_ONE_GPU=1 python3 bench.py --gpus 6 --steps 2 --warmup 1 --streams 680 > $out/bench_six_ranks_one_gpu.json 2> $out/bench_six_ranks.err; echo "six ranks: rc $?"; stamp $out/bench_six_ranks_one_gpu.json
+  MP3MI_BENCH_ONE_GPU=1 python3 bench.py --gpus 4 --steps 2 --warmup 1 --streams 1024 > $out/bench_four_ranks_one_gpu.json 2> $out/bench_four_ranks.err; echo "four ranks: rc $?"; stamp $out/bench_four_ranks_one_gpu.json
   python3 - $out <<'PY'
 import json, sys, glob, os
 for p in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
