@@ -39,17 +39,27 @@ struct filter_lds {
 
 // y[i] of filter_subband for this lane's slot, times 32768: sum over k of pcm * enwindow[i + 64 k], in k order
 // (src/encode.c:306-312, 393-397); P: this lane's window in the padded LDS copy
-template <int I> MP3MI_DEVFN double filt_y(const int16_t *P, const mp3mi_tables *T)
+// (FILT_SAMPLE: a sample is read as ONE sign-extending 16-bit LDS read -- ds_read_i16 --; left to itself the compiler fetches two
+// neighbouring samples as a dword and unpacks them with a vector instruction each, 504 per slot in a kernel that is bound by vector
+// issue while its LDS pipe idles: profiles/r06_experiments.txt, F9)
+#if defined(MP3MI_EMU) || defined(FILT_PAIRED_READS)
+typedef const int16_t *filt_pcm_ptr;
+#define FILT_SAMPLE(P, i) ((double) (P)[i])
+#else
+typedef const volatile __attribute__((address_space(3))) int16_t *filt_pcm_ptr; // (an LDS pointer: a volatile generic one would be read through flat loads)
+#define FILT_SAMPLE(P, i) ((double) (P)[i])
+#endif
+template <int I> MP3MI_DEVFN double filt_y(filt_pcm_ptr P, const mp3mi_tables *T)
 {
-    double acc = (double) P[FILT_PAD(511 - I)] * T->enwindow[I];
+    double acc = FILT_SAMPLE(P, FILT_PAD(511 - I)) * T->enwindow[I];
 #pragma unroll
-    for (int k = 1; k < 8; k++) acc = acc + (double) P[FILT_PAD(511 - I - 64 * k)] * T->enwindow[I + 64 * k];
+    for (int k = 1; k < 8; k++) acc = acc + FILT_SAMPLE(P, FILT_PAD(511 - I - 64 * k)) * T->enwindow[I + 64 * k];
     return acc;
 }
 
 // u[0] = y[16], u[1+j] = y[j] + y[32-j] (j < 16), u[17+j] = y[33+j] - y[63-j] (j < 15)   (src/encode.c:398-408);
 // taken in ascending i so that the window taps are read in address order; a + b == b + a bit for bit
-template <int I> MP3MI_DEVFN void filt_fold(double (&u)[32], const int16_t *P, const mp3mi_tables *T)
+template <int I> MP3MI_DEVFN void filt_fold(double (&u)[32], filt_pcm_ptr P, const mp3mi_tables *T)
 {
     if constexpr (I < 64) {
         if constexpr (I != 48) { // (y[48] has no partner: its coefficient is cos(pi/2))
@@ -112,7 +122,7 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
     }
     __syncthreads();
     double u[32];
-    filt_fold<0>(u, &L.pcm[34 * lane], T);
+    filt_fold<0>(u, (filt_pcm_ptr) &L.pcm[34 * lane], T);
     __syncthreads(); // every lane has read its PCM: the results may take its place
 
     // where the slots of this wavefront go: lane >> 4 picks the slot of a group of four, the walk below adds four
