@@ -81,6 +81,7 @@ template <int C, int W, bool LONG> struct fft_lds {
     static constexpr int ROWS = LONG ? MP3MI_FFT_REG_ROWS_L : 1, NRD = LONG ? MP3MI_HBLK : MP3MI_HBLK_S;
     uint32_t prog[PW] __attribute__((aligned(16)));
     uint4 regtw[ROWS * 64];
+    uint4 leaf[64];
     uint32_t rd[(NRD + 63) / 64 * 64];
     float win[LONG ? 1024 : 256];
     fft_wave_lds<C, LONG> w[W];
@@ -93,6 +94,7 @@ template <int C, int W, bool LONG> MP3MI_DEVFN void fft_lds_fill(fft_lds<C, W, L
     for (int i = tid; i < nw4; i += 64 * W) ((uint4 *) LL.prog)[i] = src[i];
     const uint4 *rsrc = (const uint4 *) (LONG ? T->fft_regtw_l : T->fft_regtw_s);
     for (int i = tid; i < fft_lds<C, W, LONG>::ROWS * 64; i += 64 * W) LL.regtw[i] = rsrc[i];
+    if (tid < 64) LL.leaf[tid] = ((const uint4 *) (LONG ? T->fft_leaf_l : T->fft_leaf_s))[tid];
     const uint32_t *dsrc = LONG ? T->fft_rd_l : T->fft_rd_s;
     for (int i = tid; i < fft_lds<C, W, LONG>::NRD; i += 64 * W) LL.rd[i] = dsrc[i];
     const float *wsrc = LONG ? T->window : T->window_s;
@@ -275,6 +277,82 @@ template <int C> MP3MI_DEVFN void fft_reg_long(typename fft_vec<C>::V (&x)[16], 
     fft_reg4<C, 6>(x[0], x[2], x[1], x[3], tw[8]);
 }
 
+// The blocks of 8 points and fewer IN REGISTERS, behind the program (tables_host.cpp, FftGen::in_leaf): a lane takes two runs of 8
+// consecutive elements, A and B -- four 16-byte LDS reads each, a pair of elements (all channels) per read -- and runs what is left
+// of the recursion on them: C(8) with all it spawns (kind 0), the two C(4) of a block C(16) (kind 1), or R(8) and the C(4) beside
+// it (kind 2: one lane a transform).  The same arithmetic as a round of the program (fft_round::compute), with the rotation flags
+// known at compile time; seven rounds of the long program and five of the short one -- two dependent LDS round trips each, on
+// operands that no placement spreads over the banks (profiles/r06_experiments.txt, F10) -- become one.
+template <int C> struct __attribute__((aligned(8 * C))) fft_elem_pair { typename fft_vec<C>::V lo, hi; };
+template <int C, int H, uint32_t FLAGS>
+MP3MI_DEVFN void fft_leaf4(typename fft_vec<C>::V &a, typename fft_vec<C>::V &b, typename fft_vec<C>::V &c, typename fft_vec<C>::V &d)
+{
+    uint4 tw = {0, 0, 0, FLAGS};
+    fft_reg4<C, H>(a, b, c, d, tw);
+}
+template <int C, int H, uint32_t FLAGS>
+MP3MI_DEVFN void fft_leaf8(typename fft_vec<C>::V &r0, typename fft_vec<C>::V &r1, typename fft_vec<C>::V &r2, typename fft_vec<C>::V &r3,
+                           typename fft_vec<C>::V &i0, typename fft_vec<C>::V &i1, typename fft_vec<C>::V &i2, typename fft_vec<C>::V &i3)
+{
+    fft_round<C, H | 1> r;
+    r.v[0] = r0; r.v[1] = r1; r.v[2] = r2; r.v[3] = r3; r.v[4] = i0; r.v[5] = i1; r.v[6] = i2; r.v[7] = i3;
+    r.tw1 = uint4{0, 0, 0, FLAGS};
+    r.tw3 = uint4{0, 0, 0, 0};
+    r.compute();
+    r0 = r.v[0]; r1 = r.v[1]; r2 = r.v[2]; r3 = r.v[3]; i0 = r.v[4]; i1 = r.v[5]; i2 = r.v[6]; i3 = r.v[7];
+}
+template <int C>
+MP3MI_DEVFN void fft_leaves(char *xw, uint32_t woff, const uint4 *leaf_tab, int lane)
+{
+    typedef typename fft_vec<C>::V V;
+    typedef fft_elem_pair<C> P;
+    const uint4 ad = leaf_tab[lane];
+    const uint32_t kind = (ad.x >> 14) & 3u;
+    if (kind == 3u) return; // an idle lane (the three short transforms fill 48)
+    const uint32_t ax = ad.x & 0x3fff3fffu;
+    P *p[8];
+    p[0] = (P *) fft_at<C, 0>(xw, woff, ax);   p[1] = (P *) fft_at<C, 1>(xw, woff, ax);
+    p[2] = (P *) fft_at<C, 0>(xw, woff, ad.y); p[3] = (P *) fft_at<C, 1>(xw, woff, ad.y);
+    p[4] = (P *) fft_at<C, 0>(xw, woff, ad.z); p[5] = (P *) fft_at<C, 1>(xw, woff, ad.z);
+    p[6] = (P *) fft_at<C, 0>(xw, woff, ad.w); p[7] = (P *) fft_at<C, 1>(xw, woff, ad.w);
+    V a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const P pa = *p[j], pb = *p[4 + j];
+        a[2 * j] = pa.lo; a[2 * j + 1] = pa.hi;
+        b[2 * j] = pb.lo; b[2 * j + 1] = pb.hi;
+    }
+    // (the order of FftGen::leaf_ops: what a butterfly reads, the ones before it have written)
+    if (kind == 0u) { // C(8), src/subs.c:288-342 for n = 0 and n = m / 8 = 1
+        fft_leaf8<C, 0, 0u>(a[0], a[4], a[2], a[6], b[0], b[4], b[2], b[6]);
+        fft_leaf8<C, 4, 2u>(a[1], a[5], a[3], a[7], b[1], b[5], b[3], b[7]);
+    } else if (kind == 1u) { // the second C(4)
+        fft_leaf8<C, 0, 0u>(a[4], a[6], a[5], a[7], b[4], b[6], b[5], b[7]);
+    }
+    if (kind <= 1u) {
+        fft_leaf8<C, 0, 0u>(a[0], a[2], a[1], a[3], b[0], b[2], b[1], b[3]); // C(4)
+        fft_leaf4<C, 0, 0u>(a[0], a[1], b[0], b[1]);                         // C(2), src/subs.c:243-250
+        fft_leaf4<C, 0, 0u>(a[4], a[5], b[4], b[5]);
+        if (kind == 0u) fft_leaf4<C, 0, 0u>(a[6], a[7], b[6], b[7]);
+    } else { // R(8) in A (src/subs.c:465-498 for n = 0, 1; then R(4), R(2) and the C(2) of its upper half), C(4) in B
+        fft_leaf4<C, 0, 0x80000000u>(a[0], a[4], a[2], a[6]);
+        fft_leaf4<C, 4, 0x80000002u>(a[1], a[5], a[3], a[7]);
+        fft_leaf4<C, 0, 0x80000000u>(a[0], a[2], a[1], a[3]);
+        { V zc = fft_vec<C>::splat(0.0f), zd = zc; fft_leaf4<C, 0, 0u>(a[0], a[1], zc, zd); } // R(2): its other half is the dummy element
+        fft_leaf4<C, 0, 0u>(a[4], a[5], a[6], a[7]);
+        fft_leaf8<C, 0, 0u>(b[0], b[2], b[1], b[3], b[4], b[6], b[5], b[7]);
+        fft_leaf4<C, 0, 0u>(b[0], b[1], b[4], b[5]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        P pa, pb;
+        pa.lo = a[2 * j]; pa.hi = a[2 * j + 1];
+        pb.lo = b[2 * j]; pb.hi = b[2 * j + 1];
+        *p[j] = pa;
+        *p[4 + j] = pb;
+    }
+}
+
 // The sequence of rounds is a compile-time constant (MP3MI_FFT_HDRS_*, checked against the generator at
 // table build): the program runs as straight-line code, every block a constant offset from the lane's
 // record address, with no per-round dispatch.
@@ -434,6 +512,8 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             PROF(1);
 #if !defined(MP3MI_FFT_EXP_NO_PROG)
             fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, true>)), LL.prog, lane);
+            fft_leaves<C>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, true>)), LL.leaf, lane);
+            wave_sync();
 #endif
             PROF(2);
             if (more) load_task(task_of(next), smp);
@@ -498,6 +578,8 @@ __global__ void __launch_bounds__(64 * W) k_fft(const mp3mi_tables *__restrict__
             wave_sync();
             PROF(5);
             fft_run<C, false, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, false>)), LL.prog, lane);
+            fft_leaves<C>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, false>)), LL.leaf, lane);
+            wave_sync();
             PROF(6);
             if (more) load_task(task_of(next), smp);
             // energies of the three short spectra (bin k of window sb, both channels per LDS read) and the raw
@@ -703,6 +785,8 @@ __global__ void __launch_bounds__(64 * W) k_fft12(const mp3mi_tables *__restrict
         }
         wave_sync();
         fft_run<C, true, 0, 0>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, true>)), LL.prog, lane);
+        fft_leaves<C>((char *) &LL.w[0], (uint32_t) (wv * (int) sizeof(fft_wave_lds<C, true>)), LL.leaf, lane);
+        wave_sync();
         // energy, magnitude and phase of every line straight from the spectrum in LDS (src/subs.c:53-123, src/psy.c:285-286):
         // erp[rec] = {energy, r = (float) sqrt((double) energy), phi}, rows of L12_ROW floats.  The transform is bound by
         // the LDS pipe and leaves the vector pipe idle more than half of the time: the phases' double-precision chain runs

@@ -41,7 +41,7 @@ static inline int mp3mi_fft_swz_rt(int p)
  * constants -- and with them the placement of the butterflies, fft_placement.h -- come out of a search for the
  * fewest LDS bank conflicts of the butterfly programs (tools/exp/fft_swz_search.cpp); the three short transforms
  * are swizzled as ONE 768-element array, so that the same butterfly of two windows does not fall on the same banks. */
-#define MP3MI_FFT_SWZ_COLS 8, 11, 9, 1, 17, 22
+#define MP3MI_FFT_SWZ_COLS 8, 24, 2, 10, 8, 20
 #define MP3MI_FFT_SWZ_PICK(c4, c5, c6, c7, c8, c9, p) \
     ((p) ^ ((((p) >> 4) & 1) * (c4)) ^ ((((p) >> 5) & 1) * (c5)) ^ ((((p) >> 6) & 1) * (c6)) ^ ((((p) >> 7) & 1) * (c7)) ^ \
      ((((p) >> 8) & 1) * (c8)) ^ ((((p) >> 9) & 1) * (c9)))
@@ -53,13 +53,13 @@ static inline int mp3mi_fft_swz_rt(int p)
 #define MP3MI_FFT_DUMMY_S 768     /* the same behind the three 256-point transforms */
 #define MP3MI_FFT_MAX_ROUNDS 48
 #define MP3MI_FFT_REG_ROWS_L 9    /* rows of fft_regtw_l */
-#define MP3MI_FFT_PROG_WORDS 7168 /* capacity of the long program in 32-bit words; checked at table build */
-#define MP3MI_FFT_PROG_WORDS_S 5504 /* capacity of the short program */
+#define MP3MI_FFT_PROG_WORDS 5376 /* capacity of the long program in 32-bit words; checked at table build */
+#define MP3MI_FFT_PROG_WORDS_S 4224 /* capacity of the short program */
 /* the header words of the rounds of the long and of the short program (fft_hdr_* below): k_fft is compiled
    for exactly these sequences -- straight-line code, no per-round dispatch -- and table build checks that the
    generator still produces them (MP3MI_FFT_INFO=1 prints the lists) */
-#define MP3MI_FFT_HDRS_L 15, 6, 15, 6, 15, 6, 15, 6, 15, 4, 1, 13, 0, 9, 0, 8
-#define MP3MI_FFT_HDRS_S 2, 14, 6, 15, 6, 15, 6, 15, 4, 13, 0, 9, 8
+#define MP3MI_FFT_HDRS_L 15, 6, 15, 6, 15, 6, 15, 6, 15
+#define MP3MI_FFT_HDRS_S 2, 14, 6, 15, 6, 15, 6, 15
 #define MP3MI_PCM_HIST 1056   /* samples per channel a call needs from before its first sample: the filterbank of the granule
                                  before the call (k_filter recomputes it: 576 + 480 taps); the FFT window reaches back 768 */
 #define MP3MI_POW43_N 8208
@@ -133,6 +133,10 @@ typedef struct {
     /* the rotations of the butterflies k_fft runs in registers, before the program: [row][lane] {cn, spcn, smcn, flags}
        (tables_host.cpp, FftGen::build) */
     uint32_t fft_regtw_l[MP3MI_FFT_REG_ROWS_L * 256] __attribute__((aligned(16))), fft_regtw_s[256] __attribute__((aligned(16)));
+    /* the blocks of 8 points and fewer, which k_fft finishes in registers behind the program: [lane] the LDS positions of the lane's
+       eight pairs of elements (four of run A, four of run B, 16 bits each), the kind of leaf in bits 14..15 of word 0 (3: an idle
+       lane) (tables_host.cpp, FftGen::in_leaf) */
+    uint32_t fft_leaf_l[256] __attribute__((aligned(16))), fft_leaf_s[256] __attribute__((aligned(16)));
     /* filterbank + MDCT */
     double enwindow[512];
     double filt[32][32];             /* the 31 used columns per subband: 0..15, 33..47  */

@@ -181,6 +181,7 @@ struct FftGen {
     std::vector<Post> post1, post2;
     const std::vector<uint16_t> *(*stored_order)(int logN, int rank, int cls) = NULL;
     void (*schedule_hook)(int logN, const std::vector<FftNode> &nodes, FftSchedule &sched) = NULL; /* the offline search */
+    int leaf_cycles = 0; /* of the last build: LDS cycles of a 16-byte access to every lane's run A plus one to its run B (fft_leaves) */
 
     void add(int rank, const FusedOp &o)
     {
@@ -286,6 +287,30 @@ struct FftGen {
        long: r = 0..3 R(1024) n = lane + 64 r; 4, 5 R(512) n = lane + 64 (r - 4); 6, 7 C(256) n = lane; 8 R(256) n = lane;
        short: r = 0 R(256) n = lane, the same for the three windows. */
     static bool in_registers(const FusedOp &o) { return o.logm >= 8; }
+    /* The other end of the recursion: the blocks of 8 points and fewer are not part of the program either.  Every one of them lies
+       within one or two runs of 8 consecutive elements, 8-aligned: a lane of k_fft.hip takes two such runs A and B (16 elements, four
+       16-byte LDS reads each) after the last round and takes them through the rest of the recursion in its registers (fft_leaves):
+         kind 0   C(8) with its real parts in A and its imaginary parts in B, down to the length-2 butterflies;
+         kind 1   the two C(4) a block C(16) spawns: real parts A[0..3] / A[4..7], imaginary parts B[0..3] / B[4..7];
+         kind 2   the two children of a block R(16): R(8) in A, and in B = A + 8 the C(4) whose imaginary parts follow its real ones.
+       1024 points: 42 + 21 + 1 lanes; the three transforms of 256 points: 3 x (10 + 5 + 1).  leaf_ops lists the butterflies of a kind in
+       the order fft_leaves runs them -- build() checks that they are exactly the recursion's. */
+    static bool in_leaf(const FusedOp &o) { return o.logm <= 3; }
+    struct LeafOp { int cls, logm, kind, neg; int e[8]; /* operand: run (0 = A, 1 = B) * 8 + index; -1 = the dummy element */ };
+    static const std::vector<LeafOp> &leaf_ops(int kind)
+    {
+        enum { A0, A1, A2, A3, A4, A5, A6, A7, B0, B1, B2, B3, B4, B5, B6, B7 };
+        static const std::vector<LeafOp> ops[3] = {
+            {   {1, 3, 0, 0, {A0, A4, A2, A6, B0, B4, B2, B6}}, {1, 3, 2, 0, {A1, A5, A3, A7, B1, B5, B3, B7}},
+                {1, 2, 0, 0, {A0, A2, A1, A3, B0, B2, B1, B3}}, {0, 1, 0, 0, {A0, A1, B0, B1}}, {0, 1, 0, 0, {A4, A5, B4, B5}},
+                {0, 1, 0, 0, {A6, A7, B6, B7}} },
+            {   {1, 2, 0, 0, {A4, A6, A5, A7, B4, B6, B5, B7}},
+                {1, 2, 0, 0, {A0, A2, A1, A3, B0, B2, B1, B3}}, {0, 1, 0, 0, {A0, A1, B0, B1}}, {0, 1, 0, 0, {A4, A5, B4, B5}} },
+            {   {0, 3, 0, 1, {A0, A4, A2, A6}}, {0, 3, 2, 1, {A1, A5, A3, A7}}, {0, 2, 0, 1, {A0, A2, A1, A3}}, {0, 1, 0, 0, {A0, A1, -1, -1}},
+                {0, 1, 0, 0, {A4, A5, A6, A7}}, {1, 2, 0, 0, {B0, B2, B1, B3, B4, B6, B5, B7}}, {0, 1, 0, 0, {B0, B1, B4, B5}} },
+        };
+        return ops[kind];
+    }
     void reg_row(uint32_t *dst, bool cplx_blk, int logm, int n0, int second) const
     {
         const int m = 1 << logm, m8 = m / 8;
@@ -316,7 +341,7 @@ struct FftGen {
         return false;
     }
 
-    int build(int logN, int nwin, uint32_t *hdr, int max_rounds, int32_t *n_rounds, uint32_t *prog, int max_words, uint32_t *rd, uint32_t *regtw)
+    int build(int logN, int nwin, uint32_t *hdr, int max_rounds, int32_t *n_rounds, uint32_t *prog, int max_words, uint32_t *rd, uint32_t *regtw, uint32_t *leaf)
     {
         const int N = 1 << logN;
         const unsigned dummy = logN == 10 ? MP3MI_FFT_DUMMY : MP3MI_FFT_DUMMY_S; /* where the idle lanes of a round work: behind the transforms */
@@ -401,6 +426,108 @@ struct FftGen {
             }
             if (n_reg != (size_t) nwin * (logN == 10 ? 256 + 128 + 64 + 64 : 64)) { fprintf(stderr, "mp3mi: fft register rounds: %zu butterflies\n", n_reg); abort(); }
         }
+        {   /* the lanes of fft_leaves: which two runs of 8 elements each takes, and as what (in_leaf above) */
+            struct Leaf { int kind, a, b; };
+            std::vector<Leaf> leaves;
+            std::vector<char> c8_at((size_t) nwin * (size_t) N, 0), used(nodes.size(), 0);
+            for (size_t i = 0; i < nodes.size(); i++)
+                if (nodes[i].o.cls == 1 && nodes[i].o.logm == 3 && nodes[i].o.kind == 0) c8_at[(size_t) nodes[i].lp[0]] = 1;
+            for (size_t i = 0; i < nodes.size(); i++) {
+                const FusedOp &o = nodes[i].o;
+                const int *lp = nodes[i].lp;
+                if (o.cls == 1 && o.logm == 3 && o.kind == 0) { Leaf l = {0, lp[0], lp[4]}; leaves.push_back(l); }
+                else if (o.cls == 0 && o.logm == 3 && o.kind == 0) { Leaf l = {2, lp[0], lp[0] + 8}; leaves.push_back(l); }
+                else if (o.cls == 1 && o.logm == 2 && lp[0] % 8 == 0 && lp[4] != lp[0] + 4 && !c8_at[(size_t) lp[0]]) { Leaf l = {1, lp[0], lp[4]}; leaves.push_back(l); }
+            }
+            bool ok = leaves.size() <= 64;
+            for (size_t li = 0; ok && li < leaves.size(); li++) {
+                const Leaf &lf = leaves[li];
+                ok = lf.a % 8 == 0 && lf.b % 8 == 0 && lf.a != lf.b;
+                const std::vector<LeafOp> &ops = leaf_ops(lf.kind);
+                for (size_t q = 0; ok && q < ops.size(); q++) {
+                    const LeafOp &lo = ops[q];
+                    int want[8];
+                    for (int k = 0; k < 8; k++) want[k] = (k < (lo.cls ? 8 : 4) && lo.e[k] >= 0) ? (lo.e[k] < 8 ? lf.a + lo.e[k] : lf.b + lo.e[k] - 8) : -1;
+                    bool found = false;
+                    for (size_t i = 0; !found && i < nodes.size(); i++) {
+                        const FusedOp &o = nodes[i].o;
+                        if (used[i] || o.cls != lo.cls || o.logm != lo.logm || o.kind != lo.kind || o.neg != lo.neg) continue;
+                        if (memcmp(nodes[i].lp, want, sizeof(want)) == 0) { used[i] = 1; found = true; }
+                    }
+                    ok = found;
+                }
+            }
+            size_t n_leaf = 0, n_used = 0;
+            for (size_t i = 0; i < nodes.size(); i++) { n_leaf += in_leaf(nodes[i].o) ? 1 : 0; n_used += used[i] ? 1 : 0; ok = ok && (used[i] != 0) == in_leaf(nodes[i].o); }
+            if (!ok) { fprintf(stderr, "mp3mi: fft leaves do not match the butterflies of the recursion (%zu leaves, %zu of %zu butterflies)\n", leaves.size(), n_used, n_leaf); abort(); }
+            /* the lanes: a 16-byte LDS access is served 16 lanes a cycle over the 64 banks -- the runs of the 16 lanes of a group should
+               start in 16 different groups of four banks (position / 2 mod 16; the same for the four accesses of a run) */
+            auto quad = [&](int e) { return (MP3MI_FFT_SWZ(e) >> 1) & 15; };
+            auto cycles = [&](const std::vector<Leaf> &ln) { /* of one access to run A plus one to run B, all lanes */
+                int cyc = 0;
+                for (size_t g = 0; g < ln.size(); g += 16) {
+                    int ca[16] = {0}, cb[16] = {0}, ma = 0, mb = 0;
+                    for (size_t l = g; l < g + 16 && l < ln.size(); l++) { ma = std::max(ma, ++ca[quad(ln[l].a)]); mb = std::max(mb, ++cb[quad(ln[l].b)]); }
+                    cyc += ma + mb;
+                }
+                return cyc;
+            };
+            auto crowding = [&](const std::vector<Leaf> &ln) { /* what the search goes down on: the squares of the lanes per group of banks */
+                int sq = 0;
+                for (size_t g = 0; g < ln.size(); g += 16) {
+                    int ca[16] = {0}, cb[16] = {0};
+                    for (size_t l = g; l < g + 16 && l < ln.size(); l++) { ca[quad(ln[l].a)]++; cb[quad(ln[l].b)]++; }
+                    for (int q = 0; q < 16; q++) sq += ca[q] * ca[q] + cb[q] * cb[q];
+                }
+                return sq;
+            };
+            std::vector<Leaf> lanes; /* greedy by groups of 16 lanes, then swaps of two lanes while they help */
+            std::vector<char> taken(leaves.size(), 0);
+            while (lanes.size() < leaves.size()) {
+                int ua[16] = {0}, ub[16] = {0};
+                for (int g = 0; g < 16 && lanes.size() < leaves.size(); g++) {
+                    size_t best = 0;
+                    int bc = 1 << 30;
+                    for (size_t i = 0; i < leaves.size(); i++) {
+                        if (taken[i]) continue;
+                        const int c = ua[quad(leaves[i].a)] + ub[quad(leaves[i].b)];
+                        if (c < bc) { bc = c; best = i; }
+                    }
+                    taken[best] = 1;
+                    ua[quad(leaves[best].a)]++;
+                    ub[quad(leaves[best].b)]++;
+                    lanes.push_back(leaves[best]);
+                }
+            }
+            for (bool better = true; better;) {
+                better = false;
+                for (size_t i = 0; i < lanes.size(); i++)
+                    for (size_t j = i + 1; j < lanes.size(); j++) {
+                        if (i / 16 == j / 16) continue;
+                        const int before = crowding(lanes);
+                        std::swap(lanes[i], lanes[j]);
+                        if (crowding(lanes) < before) better = true;
+                        else std::swap(lanes[i], lanes[j]);
+                    }
+            }
+            leaf_cycles = cycles(lanes);
+            for (int l = 0; l < 64; l++) {
+                uint32_t w[4] = {3u << 14, 0, 0, 0}; /* kind 3: an idle lane */
+                if ((size_t) l < lanes.size()) {
+                    unsigned pp[8];
+                    for (int j = 0; j < 8; j++) {
+                        const int e = (j < 4 ? lanes[(size_t) l].a : lanes[(size_t) l].b) + 2 * (j & 3);
+                        pp[j] = (unsigned) MP3MI_FFT_SWZ(e);
+                        if ((pp[j] & 1u) || (unsigned) MP3MI_FFT_SWZ(e + 1) != pp[j] + 1u || pp[j] >= (1u << 14)) { fprintf(stderr, "mp3mi: the fft swizzle splits a pair of elements\n"); abort(); }
+                    }
+                    for (int k = 0; k < 4; k++) w[k] = pp[2 * k] | (pp[2 * k + 1] << 16);
+                    w[0] |= (uint32_t) lanes[(size_t) l].kind << 14;
+                }
+                memcpy(leaf + 4 * l, w, 16);
+            }
+            if (MP3MI_FFT_INFO_ON)
+                fprintf(stderr, "mp3mi: fft 2^%d: %zu leaves; a 16-byte access to run A and one to run B of the 64 lanes in %d cycles (conflict-free %zu)\n", logN, lanes.size(), leaf_cycles, 2 * ((lanes.size() + 15) / 16));
+        }
         {
             std::vector<int> last_writer((size_t) nwin * (size_t) N, -1);
             for (size_t i = 0; i < nodes.size(); i++) { /* (rank order: a butterfly's producers come before it) */
@@ -416,12 +543,19 @@ struct FftGen {
                 }
                 for (int k = 0; k < 8; k++) if (nodes[i].lp[k] >= 0) last_writer[(size_t) nodes[i].lp[k]] = (int) i;
             }
-            for (size_t i = nodes.size(); i-- > 0;)
+            for (size_t i = nodes.size(); i-- > 0;) /* (chains of the program: the leaves come behind all of it) */
                 for (size_t j = 0; j < nodes[i].succ.size(); j++)
-                    nodes[i].height = std::max(nodes[i].height, 1 + nodes[(size_t) nodes[i].succ[j]].height);
+                    if (!in_leaf(nodes[(size_t) nodes[i].succ[j]].o)) nodes[i].height = std::max(nodes[i].height, 1 + nodes[(size_t) nodes[i].succ[j]].height);
         }
         FftSchedule sched;
-        size_t n_left = nodes.size();
+        size_t n_left = 0;
+        for (size_t i = 0; i < nodes.size(); i++) {
+            if (in_leaf(nodes[i].o)) {
+                nodes[i].done = true; /* no part of the schedule; nothing of the program waits for a leaf */
+                for (size_t j = 0; j < nodes[i].succ.size(); j++)
+                    if (!in_leaf(nodes[(size_t) nodes[i].succ[j]].o)) { fprintf(stderr, "mp3mi: an fft leaf feeds the program\n"); abort(); }
+            } else n_left++;
+        }
         for (int step = 0; n_left > 0; step++) {
             std::vector<int> ready[2];
             int maxh = 0;
@@ -526,9 +660,12 @@ struct FftGen {
                     ok = id >= 0 && (size_t) id < nodes.size() && step_of[(size_t) id] < 0 && nodes[(size_t) id].o.cls == (int) (li & 1);
                     if (ok) { step_of[(size_t) id] = (int) (li / 2); count++; }
                 }
-            ok = ok && count == nodes.size();
+            size_t n_prog = 0;
+            for (size_t i = 0; i < nodes.size(); i++) n_prog += in_leaf(nodes[i].o) ? 0 : 1;
+            for (size_t i = 0; ok && i < nodes.size(); i++) ok = (step_of[i] >= 0) != in_leaf(nodes[i].o);
+            ok = ok && count == n_prog;
             for (size_t i = 0; ok && i < nodes.size(); i++)
-                for (size_t j = 0; ok && j < nodes[i].pred.size(); j++) ok = step_of[(size_t) nodes[i].pred[j]] < step_of[i];
+                for (size_t j = 0; ok && !in_leaf(nodes[i].o) && j < nodes[i].pred.size(); j++) ok = step_of[(size_t) nodes[i].pred[j]] < step_of[i];
             if (ok) sched = st;
             else if (MP3MI_FFT_INFO_ON) fprintf(stderr, "mp3mi: the stored fft schedule for 2^%d points does not fit, list schedule kept\n", logN);
         }
@@ -780,8 +917,8 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
         FftGen *g = new FftGen();
         g->stored_order = fft_stored_order;
         for (int i = 4; i <= 10; i++) { g->tw_rs[i] = make_twiddle(i, false); g->tw_sr[i] = make_twiddle(i, true); }
-        T->fft_nword_l = g->build(10, 1, T->fft_hdr_l, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_l, T->fft_prog_l, MP3MI_FFT_PROG_WORDS, T->fft_rd_l, T->fft_regtw_l);
-        T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS_S, T->fft_rd_s, T->fft_regtw_s);
+        T->fft_nword_l = g->build(10, 1, T->fft_hdr_l, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_l, T->fft_prog_l, MP3MI_FFT_PROG_WORDS, T->fft_rd_l, T->fft_regtw_l, T->fft_leaf_l);
+        T->fft_nword_s = g->build(8, 3, T->fft_hdr_s, MP3MI_FFT_MAX_ROUNDS, &T->fft_nround_s, T->fft_prog_s, MP3MI_FFT_PROG_WORDS_S, T->fft_rd_s, T->fft_regtw_s, T->fft_leaf_s);
         {   /* the kernel is compiled for exactly this sequence of rounds (k_fft.hip) */
             static const uint8_t hl[] = {MP3MI_FFT_HDRS_L}, hs[] = {MP3MI_FFT_HDRS_S};
             bool same = T->fft_nround_l == (int) sizeof(hl) && T->fft_nround_s == (int) sizeof(hs);
@@ -986,7 +1123,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
     X(nj_seg) X(lane_bands) X(lane_jobs) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
     X(part_s_covered) X(minval) X(qthr_l) X(norm_l) X(qthr_s) X(exp_snr_s) X(s3_l) X(s3_lt) X(s3_lo) X(s3_hi) X(bu_l) X(bo_l) X(bu_s) \
     X(bo_s) X(w1_l) X(w2_l) X(w1_s) X(w2_s) X(fft_nround_l) X(fft_nround_s) X(fft_nword_l) X(fft_nword_s) X(fft_hdr_l) \
-    X(fft_hdr_s) X(fft_prog_l) X(fft_prog_s) X(fft_rd_l) X(fft_rd_s) X(fft_regtw_l) X(fft_regtw_s) X(enwindow) X(filt) X(mdct_win) X(cos_s) X(cos_l) X(ca) \
+    X(fft_hdr_s) X(fft_prog_l) X(fft_prog_s) X(fft_rd_l) X(fft_rd_s) X(fft_regtw_l) X(fft_regtw_s) X(fft_leaf_l) X(fft_leaf_s) X(enwindow) X(filt) X(mdct_win) X(cos_s) X(cos_l) X(ca) \
     X(cs) X(mdct_vidx) X(mdct_nterm) X(mdct_full_row) X(mdct_small_row) X(mdct_g_ops) X(mdct_h_ops) X(mdct_vcoef) \
     X(pow_nint_tab) X(pow43) X(step) X(pretab_xr) X(pretab_xmin) X(sqrt2) X(log2) X(ht_off) X(ht_xlen) X(ht_ylen) \
     X(ht_linbits) X(ht_linmax) X(ht_len) X(ht_code) X(glut)

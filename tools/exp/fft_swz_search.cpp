@@ -24,7 +24,8 @@ static int cost_of(int logN, int nwin, uint32_t *prog, int maxw, uint32_t *rd, i
 {
     int32_t nr = 0;
     static uint32_t regtw[MP3MI_FFT_REG_ROWS_L * 256];
-    const int nw = G->build(logN, nwin, hdr, 256, &nr, prog, 4 * maxw, rd, regtw);
+    static uint32_t leaf[256];
+    const int nw = G->build(logN, nwin, hdr, 256, &nr, prog, 4 * maxw, rd, regtw, leaf);
     int off = 0, tot = (nw > maxw || nr > MP3MI_FFT_MAX_ROUNDS) ? 1000000 : 0; // must fit the product's tables
     for (int r = 0; r < nr; r++) {
         const int h = (int) hdr[r], N = (h & 1) ? 8 : 4;
@@ -66,7 +67,7 @@ static std::mt19937_64 g_rng(20261003);
 static void anneal_hook(int logN, const std::vector<FftNode> &nodes, FftSchedule &sched)
 {
     const size_t NN = nodes.size(), NL = sched.size();
-    std::vector<int> list_of(NN), at(NN);
+    std::vector<int> list_of(NN, -1), at(NN, -1); // (-1: no part of the schedule -- the blocks of 8 points and fewer, FftGen::in_leaf)
     std::vector<size_t> base(NL + 1, 0); // first round of each list
     for (size_t li = 0; li < NL; li++) {
         base[li + 1] = base[li] + (sched[li].size() + 63) / 64;
@@ -94,13 +95,14 @@ static void anneal_hook(int logN, const std::vector<FftNode> &nodes, FftSchedule
     long bestc = cur;
     // pools of interchangeable butterflies
     std::vector<int> pool[2][3];
-    for (size_t i = 0; i < NN; i++) pool[nodes[i].o.cls][nodes[i].o.kind].push_back((int) i);
+    for (size_t i = 0; i < NN; i++) if (list_of[i] >= 0) pool[nodes[i].o.cls][nodes[i].o.kind].push_back((int) i);
     const long tries = g_sweeps * (long) NN;
     std::uniform_real_distribution<double> U(0.0, 1.0);
     long cross = 0;
     for (long t = 0; t < tries && bestc > ideal; t++) {
         const double temp = 0.8 * pow(0.02 / 0.8, (double) t / (double) tries);
         const int a = (int) (g_rng() % NN);
+        if (list_of[(size_t) a] < 0) continue;
         const std::vector<int> &pl = pool[nodes[(size_t) a].o.cls][nodes[(size_t) a].o.kind];
         const int b = pl[g_rng() % pl.size()];
         if (a == b) continue;
@@ -109,7 +111,7 @@ static void anneal_hook(int logN, const std::vector<FftNode> &nodes, FftSchedule
             const int x = la < lb ? a : b, y = la < lb ? b : a; // x moves to the later step, y to the earlier one
             const int s_early = (int) (std::min(la, lb) / 2), s_late = (int) (std::max(la, lb) / 2);
             bool ok = true;
-            for (size_t j = 0; ok && j < nodes[(size_t) x].succ.size(); j++) ok = list_of[(size_t) nodes[(size_t) x].succ[j]] / 2 > s_late;
+            for (size_t j = 0; ok && j < nodes[(size_t) x].succ.size(); j++) ok = list_of[(size_t) nodes[(size_t) x].succ[j]] < 0 || list_of[(size_t) nodes[(size_t) x].succ[j]] / 2 > s_late;
             for (size_t j = 0; ok && j < nodes[(size_t) y].pred.size(); j++) ok = list_of[(size_t) nodes[(size_t) y].pred[j]] / 2 < s_early;
             if (!ok) continue;
         }
@@ -152,20 +154,20 @@ int main(int argc, char **argv)
 {
     G = new FftGen();
     for (int i = 4; i <= 10; i++) { G->tw_rs[i] = make_twiddle(i, false); G->tw_sr[i] = make_twiddle(i, true); }
-    for (int b = 0; b < 10; b++) mp3mi_fft_swz_col[b] = b >= 5 ? 1u << (b - 5) : 0;
+    for (int b = 0; b < 10; b++) mp3mi_fft_swz_col[b] = b >= 5 ? 2u << ((b - 5) & 3) : 0;
     if (argc >= 3 && !strcmp(argv[1], "search")) {
         const double budget = atof(argv[2]);
-        printf("p ^ ((p >> 5) & 31): cost %d\n", total_cost(true));
+        printf("a first even map: cost %d\n", total_cost(true));
         std::mt19937 rng(12345);
         int bestc = 1 << 30;
         const time_t t0 = time(NULL);
         while (difftime(time(NULL), t0) < budget) {
-            for (int b = 4; b < 10; b++) mp3mi_fft_swz_col[b] = rng() & (b == 4 ? 15u : 31u);
+            for (int b = 4; b < 10; b++) mp3mi_fft_swz_col[b] = rng() & (b == 4 ? 14u : 30u); // (even: a pair of elements stays a pair -- fft_leaves reads 16 bytes at a time)
             int c = total_cost();
             for (bool improved = true; improved;) {
                 improved = false;
                 for (int b = 4; b < 10; b++)
-                    for (int bit = 0; bit < (b == 4 ? 4 : 5); bit++) {
+                    for (int bit = 1; bit < (b == 4 ? 4 : 5); bit++) {
                         mp3mi_fft_swz_col[b] ^= 1u << bit;
                         const int c2 = total_cost();
                         if (c2 < c) { c = c2; improved = true; }
@@ -193,12 +195,12 @@ int main(int argc, char **argv)
         int bestc = 1 << 30;
         while (difftime(time(NULL), t0) < budget) {
             if (first) { for (int b = 4; b < 10; b++) mp3mi_fft_swz_col[b] = (unsigned) atoi(argv[5 + b - 4]); first = false; }
-            else for (int b = 4; b < 10; b++) mp3mi_fft_swz_col[b] = rng() & (b == 4 ? 15u : 31u);
+            else for (int b = 4; b < 10; b++) mp3mi_fft_swz_col[b] = rng() & (b == 4 ? 14u : 30u); // (even: a pair of elements stays a pair -- fft_leaves reads 16 bytes at a time)
             g_rng.seed(1); int c = total_cost();
             for (bool improved = true; improved && difftime(time(NULL), t0) < budget;) {
                 improved = false;
                 for (int b = 4; b < 10; b++)
-                    for (int bit = 0; bit < (b == 4 ? 4 : 5); bit++) {
+                    for (int bit = 1; bit < (b == 4 ? 4 : 5); bit++) {
                         mp3mi_fft_swz_col[b] ^= 1u << bit;
                         g_rng.seed(1); const int c2 = total_cost();
                         if (c2 < c) { c = c2; improved = true; }
