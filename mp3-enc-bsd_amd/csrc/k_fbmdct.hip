@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(64, 3) k_filter(const mp3mi_tables *__restrict
                                                   double *__restrict__ sb_dbg)
 {
     __shared__ filter_lds L;
+#if defined(MP3MI_EXP_FILT_PRIO) && !defined(MP3MI_EMU) // (experiment F11: the wave priority of the two kernels that end the chain beside k_loop)
+    __builtin_amdgcn_s_setprio(MP3MI_EXP_FILT_PRIO);
+#endif
     const int lane = wave_lane();
     const int C = geo.channels, G1 = geo.n_gran + 1, NS = G1 * 18, NB = (NS + FILT_SLOTS - 1) / FILT_SLOTS;
     // The two channels of a stereo stream sit interleaved in the same cache lines, and consecutive workgroups go to
@@ -492,6 +495,9 @@ __global__ void __launch_bounds__(64, 3) k_mdct(const mp3mi_tables *__restrict__
                                                 mp3mi_prep_fixlist *__restrict__ fix)
 {
     __shared__ mdct_out_lds L;
+#if defined(MP3MI_EXP_MDCT_PRIO) && !defined(MP3MI_EMU)
+    __builtin_amdgcn_s_setprio(MP3MI_EXP_MDCT_PRIO);
+#endif
     MDCT_PROF_DECL;
     const int lane = wave_lane(), band = lane & 31, h = lane >> 5;
     const int C = geo.channels, G = geo.n_gran, NR = (G + MDCT_RUN - 1) / MDCT_RUN, NT = geo.n_streams * C;

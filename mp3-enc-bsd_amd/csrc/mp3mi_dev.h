@@ -36,7 +36,8 @@ static inline int mp3mi_fft_swz_rt(int p)
 #define MP3MI_FFT_SWZ(p) mp3mi_fft_swz_rt(p)
 #else
 /* LDS index of element p of an FFT array: index bits 4..9 are XORed into the low five bits, bit b with the constant
- * MP3MI_FFT_SWZ_COLS names for it (bit 4's constant stays below 16: the map is a bijection).  GF(2)-linear, so
+ * MP3MI_FFT_SWZ_COLS names for it (bit 4's constant stays below 16: the map is a bijection; all of them even: elements 2 j and
+ * 2 j + 1 stay neighbours, which fft_leaves' 16-byte accesses rely on -- table build checks it).  GF(2)-linear, so
  * SWZ(a ^ b) == SWZ(a) ^ SWZ(b): the kernels split an index into its lane part and a compile-time part.  The
  * constants -- and with them the placement of the butterflies, fft_placement.h -- come out of a search for the
  * fewest LDS bank conflicts of the butterfly programs (tools/exp/fft_swz_search.cpp); the three short transforms
