@@ -299,7 +299,7 @@ class Workload:
 # issued).  A label, not a measurement: the measurements are in the profile the bench line names.
 KERNEL_BOUND = {
     "k_loop": "valu+salu issue (4 wavefronts per SIMD, serial per stream)",
-    "k_fft": "lds pipe (the butterfly program of the blocks below 256 points; the larger ones run in registers)", "k_cw": "valu issue (f64)", "k_cw_fix": "valu issue (f64)",
+    "k_fft": "lds pipe and valu issue, about even (the butterfly program of the blocks of 16 to 128 points; larger and smaller ones run in registers)", "k_cw": "valu issue (f64)", "k_cw_fix": "valu issue (f64)",
     "k_part": "hbm (one lane per record, 2 KB rows)", "k_psy": "latency (one wavefront per track, serial over granules)",
     "k_filter": "valu issue (f64) + hbm", "k_mdct": "hbm + valu issue (the loop's stateless head in its tail)", "k_prep": "idle (the records k_mdct lists: none)", "k_format": "latency (bit scatter)",
 }
