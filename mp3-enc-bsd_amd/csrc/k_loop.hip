@@ -392,43 +392,55 @@ MP3MI_DEVFN int loop_pick_v(int da, int s01, int s2, int *sum)
 // L.ix.  ESC: the group's tables have linbits (x or y > 14 then costs them); NC3: it has a third candidate.
 // (k15: the constant 15 in a scalar register -- loop_walk_consts --: compiled without the machine-level hoisting of loop
 // invariants, a step would otherwise set it up again, in a vector register)
-struct loop_walk_k { int k15; };
+struct loop_walk_k { int k15; unsigned m1f; };
 MP3MI_DEVFN loop_walk_k loop_walk_consts(void)
 {
-    loop_walk_k k = {15};
+    loop_walk_k k = {15, 0x1f001fu};
 #if !defined(MP3MI_EMU)
-    asm volatile("" : "+s"(k.k15));
+    asm volatile("" : "+s"(k.k15), "+s"(k.m1f));
 #endif
     return k;
 }
-template <bool ESC, bool NC3, bool LAST>
-MP3MI_DEVFN void loop_walk_step(const uint16_t *GL, const unsigned *ixw, int w, int hi, int ylen2, int dB2, int lb01, const loop_walk_k &K, int &s01, int &s2)
+// byte address of the cell of pair word xy = x | y << 16 in a group whose values stay below 16: x * ylen2 + 2 y + dB2, as two
+// multiply-adds that read the halves of the word where they lie (no unpacking, no clamp)
+MP3MI_DEVFN unsigned loop_cell_of_word(unsigned xy, int ylen2, int dB2)
 {
-    const unsigned xy = ixw[w];
-    const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
-    const int xc = x > K.k15 ? K.k15 : x, yc = y > K.k15 ? K.k15 : y;
-    // (a pair past the end of the region prices some cell of the group all the same -- xc, yc <= 15 keep the index inside the
-    // table whatever the padding holds -- and is masked out of the sums: masking the index as well was an instruction per step;
-    // the cell's byte address from the doubled descriptor values: a multiply-add and a shift-add)
-    unsigned cell = 2u * (unsigned) yc + (unsigned) dB2; // (kept apart: re-associated, the sum takes three instructions instead of two)
-#if !defined(MP3MI_EMU)
-    asm volatile("" : "+v"(cell));
-#endif
 #if defined(MP3MI_EMU)
-    const int e = *(const uint16_t *) ((const char *) GL + ((unsigned) (xc * ylen2) + cell));
+    return (xy & 0xffffu) * (unsigned) ylen2 + 2u * (xy >> 16) + (unsigned) dB2;
 #else
-    const int e = *(const uint16_t *) ((const char *) GL + ((unsigned) __umul24((unsigned) xc, (unsigned) ylen2) + cell)); // (xc <= 15: a 24-bit multiply-add)
+    unsigned cell, idx;
+    asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(cell) : "v"(xy), "s"(dB2));
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(idx) : "v"(xy), "s"(ylen2), "v"(cell));
+    return idx;
 #endif
-    int c = (e & 31) | (((e >> 5) & 31) << 16);
-    if (ESC) c += ((e >> 10) & 3) * lb01; // (how many of x, y are escapes: in the cell, tables_host.cpp)
-    if (LAST) { // only a region's last step of 64 pairs can reach past its end
-        const int in = (2 * w - hi) >> 31; // all ones inside the region
-        s01 += c & in;
-        if (NC3) s2 += (e >> 10) & 31 & in;
-    } else {
-        s01 += c;
-        if (NC3) s2 += (e >> 10) & 31;
+}
+// One step of a walk: the 64 pairs [w, w + 64) of a region, a pair word xy per lane.  LAST: the region's last step, which can reach past
+// its end -- `inside` says whether this lane's pair still belongs to it; the others are priced as some cell all the same and masked out
+// of the sums (a conditional load costs three scalar instructions and two branches per step).
+template <bool ESC, bool NC3, bool LAST>
+MP3MI_DEVFN void loop_walk_step(const uint16_t *GL, unsigned xy, bool inside, int ylen2, int dB2, int lb01, const loop_walk_k &K, int &s01, int &s2)
+{
+    unsigned at;
+    if (ESC) { // values above 15 occur: clamped (which also keeps a pair past the end inside the table, whatever the padding holds)
+        const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
+        const int xc = x > K.k15 ? K.k15 : x, yc = y > K.k15 ? K.k15 : y;
+        unsigned cell = 2u * (unsigned) yc + (unsigned) dB2; // (kept apart: re-associated, the sum takes three instructions instead of two)
+#if !defined(MP3MI_EMU)
+        asm volatile("" : "+v"(cell));
+        at = (unsigned) __umul24((unsigned) xc, (unsigned) ylen2) + cell; // (xc <= 15: a 24-bit multiply-add)
+#else
+        at = (unsigned) (xc * ylen2) + cell;
+#endif
+    } else { // the region's maximum is below 16: so is every value in it -- only a pair PAST its end can be larger, and counts as (0, 0)
+        if (LAST) xy = inside ? xy : 0u;
+        at = loop_cell_of_word(xy, ylen2, dB2);
     }
+    unsigned e = *(const uint16_t *) ((const char *) GL + at);
+    if (LAST) e = inside ? e : 0u;
+    int c = (int) (((e << 11) | e) & K.m1f); // candidate 0's length | candidate 1's << 16: a shift-or and a mask
+    if (ESC) c += (int) ((e >> 10) & 3u) * lb01; // (how many of x, y are escapes: in the cell, tables_host.cpp)
+    s01 += c;
+    if (NC3) s2 += (int) ((e >> 10) & 31u);
 }
 
 template <bool ESC, bool NC3>
@@ -438,10 +450,11 @@ MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int l
     int s01 = 0, s2 = 0;
     const loop_walk_k K = loop_walk_consts();
     int w0 = lo >> 1; // (one to three steps: unrolling only adds scalar bookkeeping)
+    const unsigned *p = ixw + w0 + lane; // this lane's pair of the step
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
-    for (; 2 * (w0 + 64) <= hi; w0 += 64) loop_walk_step<ESC, NC3, false>(GL, ixw, w0 + lane, hi, ylen2, dB2, lb01, K, s01, s2);
+    for (; 2 * (w0 + 64) <= hi; w0 += 64, p += 64) loop_walk_step<ESC, NC3, false>(GL, *p, true, ylen2, dB2, lb01, K, s01, s2);
     // pairs past the end of the region are read all the same (L.ix is padded) and masked out of the sums
-    if (2 * w0 < hi) loop_walk_step<ESC, NC3, true>(GL, ixw, w0 + lane, hi, ylen2, dB2, lb01, K, s01, s2);
+    if (2 * w0 < hi) loop_walk_step<ESC, NC3, true>(GL, *p, lane < (hi >> 1) - w0, ylen2, dB2, lb01, K, s01, s2);
     *a01 = s01;
     *a2 = s2;
 }
@@ -600,25 +613,19 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     // zero.  (Written out per region: arrays indexed by the region would live in scratch memory.)
     const int nzend = 64 * nslot;
     auto region_max = [&](int lo, int hi) {        hi = hi < nzend ? hi : nzend; // both even
-        int m = 0;
+        mp3mi_u16x2 m = {0, 0}; // the maxima of the x and of the y of this lane's pairs: one packed instruction a step
         int w0 = lo >> 1; // pair index of lane 0
+        const unsigned *p = ixw + w0 + lane;
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
-        for (; 2 * (w0 + 64) <= hi; w0 += 64) { // whole steps of 64 pairs: nothing to mask
-            const unsigned xy = ixw[w0 + lane];
-            const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
-            const int v = x > y ? x : y;
-            m = v > m ? v : m;
-        }
+        for (; 2 * (w0 + 64) <= hi; w0 += 64, p += 64) // whole steps of 64 pairs: nothing to mask
+            m = LOOP_PK_MAX_U16(m, __builtin_bit_cast(mp3mi_u16x2, *p));
         if (2 * w0 < hi) {
-            const int w = w0 + lane;
             // read unconditionally (L.ix is padded: pairs past the end exist) and mask: a conditional load costs
             // three scalar instructions and two branches per step
-            const unsigned xy = ixw[w] & (unsigned) ((2 * w - hi) >> 31);
-            const int x = (int) (xy & 0xffffu), y = (int) (xy >> 16);
-            const int v = x > y ? x : y;
-            m = v > m ? v : m;
+            const unsigned xy = lane < (hi >> 1) - w0 ? *p : 0u;
+            m = LOOP_PK_MAX_U16(m, __builtin_bit_cast(mp3mi_u16x2, xy));
         }
-        return m; // this lane's part
+        return (int) (m.x > m.y ? m.x : m.y); // this lane's part
     };
     // the three region maxima and the count1 region's two bit sums: four reductions in lock-step
     int red[4] = {c1part, region_max(0, a1), region_max(a1, a2), region_max(a2, e2)};
