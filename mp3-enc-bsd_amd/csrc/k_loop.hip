@@ -781,8 +781,11 @@ MP3MI_DEVFN double loop_noise_jobs_long(const mp3mi_tables *T, const loop_lds &L
             const double x0 = xx.x, x1 = xx.y;
 #endif
             const double t0 = __builtin_fabs(x0) - q43[2 * u] * step, t1 = __builtin_fabs(x1) - q43[2 * u + 1] * step;
-            sum = sum + t0 * t0;
-            sum = sum + t1 * t1;
+            // (this is the FIRST tier: its sum only has to lie within 1e-12 of the reference's -- loop_noise_close -- and a fused
+            // square-and-add differs from the reference's two roundings by an ulp of the running sum per term, < 2.2e-14 over the
+            // 192 terms of the widest band; the difference itself stays two roundings: fused, a value of 8000 could move a term by 1.6e-12)
+            sum = __builtin_fma(t0, t0, sum);
+            sum = __builtin_fma(t1, t1, sum);
         }
     }
     return sum;
@@ -807,7 +810,7 @@ MP3MI_DEVFN double loop_noise_jobs_short(const mp3mi_tables *T, const loop_lds &
         }
         line += 6u;
 #pragma unroll
-        for (int u = 0; u < 2; u++) sum = sum + t[u] * t[u];
+        for (int u = 0; u < 2; u++) sum = __builtin_fma(t[u], t[u], sum); // (first tier: see loop_noise_jobs_long)
     }
     return sum;
 }
@@ -1169,7 +1172,8 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, loop_kargs_p ka
                         // calc_noise (src/loop.c:1007-1067).  The noise of a band is only ever COMPARED with the
                         // allowed distortion, and it is a sum of non-negative terms, so any summation order
                         // agrees with the reference's sequential one to within 2(n-1) ulp (n <= 102 lines:
-                        // < 2.3e-14 relative).  First tier: every band is cut into parts of ~10 lines summed by
+                        // < 2.3e-14 relative; the fused square-and-add of the partial sums adds an ulp per term, the
+                        // multiplication by 1 / n in place of the division 1.5).  First tier: every band is cut into parts of ~10 lines summed by
                         // different lanes.  Only if a band lands within 1e-12 of its threshold is the
                         // reference's order used (loop_noise_exact) -- at both places that compare.
                         bool xfsf_exact = (test_flags & 1) != 0;
@@ -1180,6 +1184,7 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, loop_kargs_p ka
                         // each; short blocks: the lines of a pair belong to two windows, i.e. two band lanes: 10 fields of a 64-bit word
                         // (asked for here: its latency passes under the band sums' reduction)
                         const unsigned long long bandpack = T->lane_bands[shortb][wave_lane_here()];
+                        const double inv_lines = T->lane_inv_lines[shortb][wave_lane_here()]; // 1 / (lines of this band lane's band)
                         // the band lane's state (fetched behind the partial sums, see above)
                         const int bl = wave_lane_here();
                         double xmin_r = bandlane ? L.band_xmin[bl] : 0.0;
@@ -1200,7 +1205,8 @@ MP3MI_DEVFN void loop_stream(const mp3mi_tables *__restrict__ T, loop_kargs_p ka
                                 { const double o = wave_down_f64<4>(v, lane4); v = v + ((jseg & 4) ? o : 0.0); }
                                 { const double o = wave_down_f64<8>(v, lane4); v = v + ((jseg & 8) ? o : 0.0); }
                                 const double sum = __shfl(v, pj0);
-                                xfsf_r = bandlane ? sum / (double) scount : 0.0;
+                                (void) scount;
+                                xfsf_r = bandlane ? sum * inv_lines : 0.0; // (first tier: within 1.5 ulp of the reference's quotient; the exact tier divides)
                                 if (wave_any(loop_noise_close(bandlane, xfsf_r, xmin_r))) xfsf_exact = true;
                             }
                             if (xfsf_exact) xfsf_r = loop_noise_exact(T, L, noise_step, bandlane, (int) ((jobs >> 43) & 1023ull), (int) ((jobs >> 35) & 255ull), sstride);

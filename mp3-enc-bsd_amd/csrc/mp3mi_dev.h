@@ -107,6 +107,9 @@ typedef struct {
        lane_jobs: nj_first (10 bits) | nj_count << 10 (8) | nj_seg << 18 (5) | nj_job0 << 23 (6) | nj_njobs << 29 (6) |
                   lines of band l << 35 (8) | first line of band l << 43 (10; short: l = sfb * 3 + window -> first * 3 + window) */
     uint64_t lane_bands[2][64], lane_jobs[2][64];
+    /* 1 / (lines of band l): the first tier of calc_noise (k_loop.hip) takes a band's mean by a multiplication -- its value only has to
+       lie within 1e-12 of the reference's quotient --, the exact tier divides */
+    double lane_inv_lines[2][64];
     /* subdivide (src/loop.c:1596-1706) for blocks without window switching, by big_values:
        region0_count | region1_count << 4 | address1 << 8 | address2 << 18 (tables_host.cpp) */
     uint32_t subdiv_lut[289];

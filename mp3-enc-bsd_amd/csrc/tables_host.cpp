@@ -826,6 +826,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
             T->lane_jobs[t][l] = (uint64_t) T->nj_first[t][l] | ((uint64_t) T->nj_count[t][l] << 10) | ((uint64_t) (T->nj_seg[t][l] & 31) << 18) |
                                  ((uint64_t) (l < nb ? T->nj_job0[t][l] : 0) << 23) | ((uint64_t) (l < nb ? T->nj_njobs[t][l] : 0) << 29) |
                                  (count << 35) | (first << 43);
+            T->lane_inv_lines[t][l] = count ? 1.0 / (double) count : 0.0; /* (an IEEE division: the same on every host) */
         }
     }
 
@@ -1120,7 +1121,7 @@ static int build_tables_unpinned(mp3mi_tables *T, int rate_idx)
  * loudly (MP3MI_ERR_TABLES) instead of emitting a different stream.  There is no switch to turn the check off. */
 #define MP3MI_TABLE_MEMBERS(X) \
     X(rate_idx) X(sfb_l) X(sfb_s) X(sfb_of_line_l) X(sfb_of_line_s) X(nj_first) X(nj_count) X(nj_job0) X(nj_njobs) X(nj_max) \
-    X(nj_seg) X(lane_bands) X(lane_jobs) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
+    X(nj_seg) X(lane_bands) X(lane_jobs) X(lane_inv_lines) X(subdiv_lut) X(window) X(window_s) X(numlines_pe) X(part_l_start) X(part_s_start) X(part_l_covered) \
     X(part_s_covered) X(minval) X(qthr_l) X(norm_l) X(qthr_s) X(exp_snr_s) X(s3_l) X(s3_lt) X(s3_lo) X(s3_hi) X(bu_l) X(bo_l) X(bu_s) \
     X(bo_s) X(w1_l) X(w2_l) X(w1_s) X(w2_s) X(fft_nround_l) X(fft_nround_s) X(fft_nword_l) X(fft_nword_s) X(fft_hdr_l) \
     X(fft_hdr_s) X(fft_prog_l) X(fft_prog_s) X(fft_rd_l) X(fft_rd_s) X(fft_regtw_l) X(fft_regtw_s) X(fft_leaf_l) X(fft_leaf_s) X(enwindow) X(filt) X(mdct_win) X(cos_s) X(cos_l) X(ca) \
