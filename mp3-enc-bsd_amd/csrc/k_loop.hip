@@ -279,14 +279,17 @@ MP3MI_DEVFN loop_qinfo loop_quantize(const mp3mi_tables *T, loop_lds &L, const f
             qi.m2 = (!low && v > qi.m2) ? v : qi.m2;
         }
     } else {
-        // min(x | y, 2) of the lane's five pairs as 2-bit fields of one word, slot k in bits 2k, 2k + 1: its highest set bit
+        // min(x, 2) | min(y, 2) of the lane's five pairs as 2-bit fields of one word, slot k in bits 2k, 2k + 1: its highest set bit
         // names the lane's last non-zero pair, the highest set ODD bit its last pair with a value above 1.
-        unsigned w = 0;
+        // (both halves of a pair word clamped to 2 by ONE packed instruction, the five words shifted together while x and y are
+        // still apart -- the x codes in bits 0..9, the y codes in bits 16..25 --, then one OR of the halves: a field reads 0, 1, 2 or 3,
+        // 3 = one value 1 beside one above 1, which the two questions below answer as they answer 2)
+        const mp3mi_u16x2 two2 = {2, 2};
+        unsigned wp = __builtin_bit_cast(unsigned, LOOP_PK_MIN_U16(__builtin_bit_cast(mp3mi_u16x2, pw[0]), two2));
 #pragma unroll
-        for (int k = 0; k < LOOP_SLOTS; k++) {
-            const unsigned o = (pw[k] & 0xffffu) | (pw[k] >> 16);
-            w |= (o < 2u ? o : 2u) << (2 * k);
-        }
+        for (int k = 1; k < LOOP_SLOTS; k++)
+            wp |= __builtin_bit_cast(unsigned, LOOP_PK_MIN_U16(__builtin_bit_cast(mp3mi_u16x2, pw[k]), two2)) << (2 * k);
+        const unsigned w = (wp & 0xffffu) | (wp >> 16);
         // ONE reduction -- the OR of the words names the last slot that holds a non-zero pair / a pair with a value above 1 -- and a
         // lane mask per run length for the last lane of that slot.
         const unsigned wo = wave_or_u32(w);

@@ -226,12 +226,15 @@ static inline unsigned mp3mi_emu_pknorm_u16(float a, float b)
 struct mp3mi_u16x2 { unsigned short x, y; };
 static inline mp3mi_u16x2 mp3mi_emu_pk_max_u16(mp3mi_u16x2 a, mp3mi_u16x2 b) { mp3mi_u16x2 r = {a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y}; return r; }
 #define LOOP_PK_MAX_U16(a, b) mp3mi_emu_pk_max_u16((a), (b))
+static inline mp3mi_u16x2 mp3mi_emu_pk_min_u16(mp3mi_u16x2 a, mp3mi_u16x2 b) { mp3mi_u16x2 r = {a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y}; return r; }
+#define LOOP_PK_MIN_U16(a, b) mp3mi_emu_pk_min_u16((a), (b))
 #else
 #define LOOP_FAST_SQRTF(x) __builtin_amdgcn_sqrtf(x)
 #define LOOP_FAST_EXP2F(x) __builtin_amdgcn_exp2f(x) /* |x| < 80 here: no denormal range to care for */
 typedef unsigned short mp3mi_u16x2 __attribute__((ext_vector_type(2)));
 #define LOOP_PKNORM_U16(a, b) __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16((a), (b)))
 #define LOOP_PK_MAX_U16(a, b) __builtin_elementwise_max((a), (b))
+#define LOOP_PK_MIN_U16(a, b) __builtin_elementwise_min((a), (b))
 #endif
 
 /* Diagnostic build only (-DMP3MI_ULP_CENSUS, tools/gpu_ulp_census.sh; never the product build): how often does a
