@@ -411,9 +411,8 @@ MP3MI_DEVFN unsigned loop_cell_of_word(unsigned xy, int ylen2, int dB2)
 #if defined(MP3MI_EMU)
     return (xy & 0xffffu) * (unsigned) ylen2 + 2u * (xy >> 16) + (unsigned) dB2;
 #else
-    unsigned cell, idx;
-    asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(cell) : "v"(xy), "s"(dB2));
-    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(idx) : "v"(xy), "s"(ylen2), "v"(cell));
+    unsigned idx; // (one statement: between two the compiler puts a wait state it cannot know to be unnecessary)
+    asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]\n\tv_mad_u32_u16 %0, %1, %3, %0" : "=&v"(idx) : "v"(xy), "s"(dB2), "s"(ylen2));
     return idx;
 #endif
 }
@@ -447,11 +446,10 @@ MP3MI_DEVFN void loop_walk_step(const uint16_t *GL, unsigned xy, bool inside, in
 }
 
 template <bool ESC, bool NC3>
-MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int lane, int lo, int hi, int dA, int dB, int *a01, int *a2)
+MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int lane, int lo, int hi, int dA, int dB, const loop_walk_k &K, int *a01, int *a2)
 {
     const int ylen2 = 2 * ((dA >> 15) & 31), dB2 = 2 * dB, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
     int s01 = 0, s2 = 0;
-    const loop_walk_k K = loop_walk_consts();
     int w0 = lo >> 1; // (one to three steps: unrolling only adds scalar bookkeeping)
     const unsigned *p = ixw + w0 + lane; // this lane's pair of the step
 #pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
@@ -462,15 +460,15 @@ MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int l
     *a2 = s2;
 }
 
-MP3MI_DEVFN void loop_region_cost(const uint16_t *GL, const unsigned *ixw, int lane, int lo, int hi, int m, int dA, int dB, int *a01, int *a2)
+MP3MI_DEVFN void loop_region_cost(const uint16_t *GL, const unsigned *ixw, int lane, int lo, int hi, int m, int dA, int dB, const loop_walk_k &K, int *a01, int *a2)
 {
     *a01 = 0;
     *a2 = 0;
     if (m == 0) return; // no table, no bits (src/loop.c:1771-1777)
     const bool esc = (dA >> 20) != 0, nc3 = ((dA >> 10) & 31) != 0; // tables with linbits never come in threes
-    if (esc) loop_region_walk<true, false>(GL, ixw, lane, lo, hi, dA, dB, a01, a2);
-    else if (nc3) loop_region_walk<false, true>(GL, ixw, lane, lo, hi, dA, dB, a01, a2);
-    else loop_region_walk<false, false>(GL, ixw, lane, lo, hi, dA, dB, a01, a2);
+    if (esc) loop_region_walk<true, false>(GL, ixw, lane, lo, hi, dA, dB, K, a01, a2);
+    else if (nc3) loop_region_walk<false, true>(GL, ixw, lane, lo, hi, dA, dB, K, a01, a2);
+    else loop_region_walk<false, false>(GL, ixw, lane, lo, hi, dA, dB, K, a01, a2);
 }
 
 // calc_runlen + count1_bitcount + subdivide + bigv_tab_select + bigv_bitcount
@@ -654,9 +652,10 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     // Per region two partial sums per lane: candidates 0 and 1 in the halves of one word (the layout the
     // reduction wants), the third candidate -- only the groups {7,8,9} and {10,11,12} have one -- in another.
     int s01p[3], s2p[3];
-    loop_region_cost(GL, ixw, lane, 0, a1, m0, da[0], db[0], &s01p[0], &s2p[0]);
-    loop_region_cost(GL, ixw, lane, a1, a2, m1, da[1], db[1], &s01p[1], &s2p[1]);
-    loop_region_cost(GL, ixw, lane, a2, e2, m2, da[2], db[2], &s01p[2], &s2p[2]);
+    const loop_walk_k K = loop_walk_consts(); // (once a pass, not once a region)
+    loop_region_cost(GL, ixw, lane, 0, a1, m0, da[0], db[0], K, &s01p[0], &s2p[0]);
+    loop_region_cost(GL, ixw, lane, a1, a2, m1, da[1], db[1], K, &s01p[1], &s2p[1]);
+    loop_region_cost(GL, ixw, lane, a2, e2, m2, da[2], db[2], K, &s01p[2], &s2p[2]);
     CBPROF(3); // descriptors + region walks
     const bool third = (((da[0] | da[1] | da[2]) >> 10) & 31) != 0; // (descriptors of empty regions are zero)
     // The sums stay where the reduction leaves them -- lane 63 of a vector register -- and new_choose_table's decision
