@@ -64,7 +64,7 @@ def test_the_kernels_fit_where_the_schedule_puts_them():
     assert k_loop["VGPRs"] <= 88 and k_loop["ScratchSize"] == 0, k_loop            # four per SIMD (allocated by eights), 160 registers left beside them
     assert k_loop["LDS"] <= 32 * 1024 + 256, k_loop                                # four 4-wavefront workgroups a CU (63 LDS granules of 512 bytes each), ~31 KB left
     # scalar registers the compiler parks in vector-register lanes: every access is a VECTOR instruction in an issue-bound kernel
-    # (round 5: 131, 355 lane moves in the listing; round 6: the kernel's arguments are fetched where they are used)
+    # (round 5: 131, 355 lane moves in the listing; round 6: the kernel's arguments are fetched where they are used: 86 .. 89)
     assert k_loop["SGPRSpill"] <= 90, k_loop
     beside = 512 - 4 * 88
     k_mdct, k_filter = the(fbm, r"^_Z6k_mdctPK"), the(fbm, r"^_Z8k_filterPK")
