@@ -442,7 +442,7 @@ MP3MI_DEVFN void loop_walk_step(const uint16_t *GL, unsigned xy, bool inside, in
     int c = (int) (((e << 11) | e) & K.m1f); // candidate 0's length | candidate 1's << 16: a shift-or and a mask
     if (ESC) c += (int) ((e >> 10) & 3u) * lb01; // (how many of x, y are escapes: in the cell, tables_host.cpp)
     s01 += c;
-    if (NC3) s2 += (int) ((e >> 10) & 31u);
+    if (NC3) s2 += (int) (e >> 10); // (a cell's bit 15 is clear: the third length needs no mask)
 }
 
 template <bool ESC, bool NC3>
@@ -450,12 +450,22 @@ MP3MI_DEVFN void loop_region_walk(const uint16_t *GL, const unsigned *ixw, int l
 {
     const int ylen2 = 2 * ((dA >> 15) & 31), dB2 = 2 * dB, lb01 = ((dA >> 20) & 15) | (((dA >> 24) & 15) << 16);
     int s01 = 0, s2 = 0;
-    int w0 = lo >> 1; // (one to three steps: unrolling only adds scalar bookkeeping)
-    const unsigned *p = ixw + w0 + lane; // this lane's pair of the step
-#pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
-    for (; 2 * (w0 + 64) <= hi; w0 += 64, p += 64) loop_walk_step<ESC, NC3, false>(GL, *p, true, ylen2, dB2, lb01, K, s01, s2);
+    // Up to four whole steps of 64 pairs (a region holds at most 288) and a last, partial one: written out, every step at a constant
+    // offset from the lane's first pair -- as a loop each step paid a pointer increment and two scalar additions of bookkeeping.
+    const unsigned *p = ixw + (lo >> 1) + lane; // this lane's pair of the first step
+    const int span = hi > lo ? hi - lo : 0, nfull = span >> 7, rest = (span & 127) >> 1; // (lo, hi even; a walk only runs on a region that holds a value: lo < hi)
+    if (nfull > 0) {
+        loop_walk_step<ESC, NC3, false>(GL, p[0], true, ylen2, dB2, lb01, K, s01, s2);
+        if (nfull > 1) {
+            loop_walk_step<ESC, NC3, false>(GL, p[64], true, ylen2, dB2, lb01, K, s01, s2);
+            if (nfull > 2) {
+                loop_walk_step<ESC, NC3, false>(GL, p[128], true, ylen2, dB2, lb01, K, s01, s2);
+                if (nfull > 3) loop_walk_step<ESC, NC3, false>(GL, p[192], true, ylen2, dB2, lb01, K, s01, s2);
+            }
+        }
+    }
     // pairs past the end of the region are read all the same (L.ix is padded) and masked out of the sums
-    if (2 * w0 < hi) loop_walk_step<ESC, NC3, true>(GL, *p, lane < (hi >> 1) - w0, ylen2, dB2, lb01, K, s01, s2);
+    if (rest) loop_walk_step<ESC, NC3, true>(GL, p[64 * nfull], lane < rest, ylen2, dB2, lb01, K, s01, s2);
     *a01 = s01;
     *a2 = s2;
 }
@@ -615,15 +625,22 @@ MP3MI_DEVFN int loop_count_bits(const mp3mi_tables *T, const loop_regs &R, loop_
     const int nzend = 64 * nslot;
     auto region_max = [&](int lo, int hi) {        hi = hi < nzend ? hi : nzend; // both even
         mp3mi_u16x2 m = {0, 0}; // the maxima of the x and of the y of this lane's pairs: one packed instruction a step
-        int w0 = lo >> 1; // pair index of lane 0
-        const unsigned *p = ixw + w0 + lane;
-#pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
-        for (; 2 * (w0 + 64) <= hi; w0 += 64, p += 64) // whole steps of 64 pairs: nothing to mask
-            m = LOOP_PK_MAX_U16(m, __builtin_bit_cast(mp3mi_u16x2, *p));
-        if (2 * w0 < hi) {
+        const unsigned *p = ixw + (lo >> 1) + lane;
+        const int span = hi > lo ? hi - lo : 0, nfull = span >> 7, rest = (span & 127) >> 1; // whole steps of 64 pairs (nothing to mask), and a last one
+        if (nfull > 0) {
+            m = LOOP_PK_MAX_U16(m, __builtin_bit_cast(mp3mi_u16x2, p[0]));
+            if (nfull > 1) {
+                m = LOOP_PK_MAX_U16(m, __builtin_bit_cast(mp3mi_u16x2, p[64]));
+                if (nfull > 2) {
+                    m = LOOP_PK_MAX_U16(m, __builtin_bit_cast(mp3mi_u16x2, p[128]));
+                    if (nfull > 3) m = LOOP_PK_MAX_U16(m, __builtin_bit_cast(mp3mi_u16x2, p[192]));
+                }
+            }
+        }
+        if (rest) {
             // read unconditionally (L.ix is padded: pairs past the end exist) and mask: a conditional load costs
             // three scalar instructions and two branches per step
-            const unsigned xy = lane < (hi >> 1) - w0 ? *p : 0u;
+            const unsigned xy = lane < rest ? p[64 * nfull] : 0u;
             m = LOOP_PK_MAX_U16(m, __builtin_bit_cast(mp3mi_u16x2, xy));
         }
         return (int) (m.x > m.y ? m.x : m.y); // this lane's part
