@@ -301,6 +301,15 @@ MP3MI_DEVFN void fft_leaf8(typename fft_vec<C>::V &r0, typename fft_vec<C>::V &r
     r.compute();
     r0 = r.v[0]; r1 = r.v[1]; r2 = r.v[2]; r3 = r.v[3]; i0 = r.v[4]; i1 = r.v[5]; i2 = r.v[6]; i3 = r.v[7];
 }
+// (a pair of elements is read as ONE aligned access: the wavefronts' arrays must start and repeat on multiples of its size)
+static_assert(sizeof(fft_wave_lds<2, true>) % 16 == 0 && sizeof(fft_wave_lds<2, false>) % 16 == 0 && sizeof(fft_wave_lds<1, true>) % 8 == 0 &&
+              sizeof(fft_wave_lds<1, false>) % 8 == 0, "fft_leaves: a wavefront's array is not a whole number of element pairs");
+typedef fft_lds<2, 12, true> fft_lds_2l;
+typedef fft_lds<2, 16, false> fft_lds_2s;
+typedef fft_lds<1, 16, true> fft_lds_1l;
+typedef fft_lds<1, 16, false> fft_lds_1s;
+static_assert(__builtin_offsetof(fft_lds_2l, w) % 16 == 0 && __builtin_offsetof(fft_lds_2s, w) % 16 == 0 && __builtin_offsetof(fft_lds_1l, w) % 8 == 0 &&
+              __builtin_offsetof(fft_lds_1s, w) % 8 == 0, "fft_leaves: the wavefronts' arrays do not start on a pair boundary");
 template <int C>
 MP3MI_DEVFN void fft_leaves(char *xw, uint32_t woff, const uint4 *leaf_tab, int lane)
 {
